@@ -1,0 +1,99 @@
+"""ctypes binding of libd3m_raster.so (include/d3m_raster.h).  There is no fallback: if the HIP
+library is missing or a call fails, this module raises."""
+import ctypes
+import os
+
+import torch
+
+from .build import LIB_PATH
+
+_c_f32p = ctypes.c_void_p      # device pointers travel as integers
+_I, _F, _SZ, _L = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
+_P = ctypes.c_void_p
+
+
+class D3MCamera(ctypes.Structure):
+    _fields_ = [("mode", _I), ("perspective", _I), ("tan_half_width", _F), ("orig_size", _F),
+                ("rot", _P), ("eye_or_t", _P), ("K", _P), ("dist", _P),
+                ("rot_batch", _I), ("eye_batch", _I), ("K_batch", _I), ("dist_batch", _I)]
+
+
+CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
+
+_SIGNATURES = {
+    "d3m_version": (ctypes.c_char_p, []),
+    "d3m_last_hip_error": (_I, []),
+    "d3m_error_string": (ctypes.c_char_p, [_I]),
+    "d3m_forward_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_forward_workspace_min_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
+    "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P]),
+    "d3m_backward_textures": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "d3m_backward_depth_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_camera_basis": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
+    "d3m_camera_forward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _I, _I, _P]),
+    "d3m_camera_backward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _P, _I, _I, _P]),
+    "d3m_gather_faces": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "d3m_scatter_face_grads": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "d3m_lighting_forward": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
+    "d3m_lighting_backward": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
+    "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/d3m_raster.h declares."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m deep3dmap_amd.build`). "
+                "deep3dmap_amd has no CPU / eager fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)     # AttributeError if the build is stale
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise RuntimeError(f"{what} failed: {L.d3m_error_string(rc).decode()} (code {rc}, hip error "
+                           f"{L.d3m_last_hip_error()})")
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream on the current device."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def require_device(*tensors, names=None):
+    """The reference's CHECK_INPUT (rasterize_cuda.cpp:66-68): CUDA + contiguous, else RuntimeError."""
+    for i, t in enumerate(tensors):
+        if t is None:
+            continue
+        n = names[i] if names else f"argument {i}"
+        if not t.is_cuda:
+            raise RuntimeError(f"{n} must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{n} must be contiguous")

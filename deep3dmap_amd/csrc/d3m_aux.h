@@ -1,0 +1,464 @@
+// d3m_aux.h -- the steps either side of the rasterizer kernels that the reference runs as chains of
+// eager torch ops: camera transforms (+ adjoint), vertices_to_faces gather / scatter-add, the output
+// epilogue of rasterize_rgbad, and the losses.  Each is one pass over its data.
+#pragma once
+#include "d3m_device.h"
+#include "../../include/d3m_raster.h"
+
+namespace d3m {
+
+// Camera block as the kernels see it (a by-value copy of the host struct).
+struct Cam {
+    int mode, perspective;
+    float width, orig;
+    const float *rot, *eye_or_t, *K, *dist;
+    int rot_b, eye_b, K_b, dist_b;
+};
+
+__device__ __forceinline__ const float* cam_ptr(const float* p, int nb, int b, int stride) {
+    return p + (size_t)(nb > 1 ? b : 0) * stride;
+}
+
+// look_at / look basis: rows (x, y, z) = normalise(cross(up, z)), normalise(cross(z, x)), z with
+// z = normalise(at - eye) or normalise(direction); F.normalize semantics v / max(|v|, 1e-5)
+// (neural_renderer/look_at.py:48-53, look.py:39-44).  One lane per view.
+__device__ __forceinline__ void normalize3(float* v) {
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float d = fmaxf(n, 1e-5f);
+    v[0] /= d; v[1] /= d; v[2] /= d;
+}
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__global__ void k_camera_basis(const float* __restrict__ eye, int eye_b, const float* __restrict__ at_or_dir, int at_b,
+                               const float* __restrict__ up, int up_b, int is_look_at, float* __restrict__ rot, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* e = cam_ptr(eye, eye_b, b, 3);
+    const float* a = cam_ptr(at_or_dir, at_b, b, 3);
+    const float* u = cam_ptr(up, up_b, b, 3);
+    float z[3], x[3], y[3];
+    for (int k = 0; k < 3; k++) z[k] = is_look_at ? a[k] - e[k] : a[k];
+    normalize3(z);
+    cross3(u, z, x);
+    normalize3(x);
+    cross3(z, x, y);
+    normalize3(y);
+    for (int k = 0; k < 3; k++) { rot[b * 9 + k] = x[k]; rot[b * 9 + 3 + k] = y[k]; rot[b * 9 + 6 + k] = z[k]; }
+}
+
+// Intermediate values of the projection chain that both directions need.
+struct ProjTmp {
+    float cx, cy, cz, zz, x_, y_, r2, radial, dr;
+};
+
+__device__ __forceinline__ void camera_point(const Cam& c, int b, const float* v, float* o, ProjTmp* tmp) {
+    if (c.mode == D3M_CAMERA_NONE) {
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        return;
+    }
+    const float* r = cam_ptr(c.rot, c.rot_b, b, 9);
+    const float* e = cam_ptr(c.eye_or_t, c.eye_b, b, 3);
+    if (c.mode == D3M_CAMERA_LOOK_AT || c.mode == D3M_CAMERA_LOOK) {
+        const float d0 = v[0] - e[0], d1 = v[1] - e[1], d2 = v[2] - e[2];
+        float x = d0 * r[0] + d1 * r[1] + d2 * r[2];
+        float y = d0 * r[3] + d1 * r[4] + d2 * r[5];
+        const float z = d0 * r[6] + d1 * r[7] + d2 * r[8];
+        if (c.perspective) {            // perspective.py:18-19: x / z / width
+            x = x / z / c.width;
+            y = y / z / c.width;
+        }
+        o[0] = x; o[1] = y; o[2] = z;
+        return;
+    }
+    // projection.py:19-42
+    const float* K = cam_ptr(c.K, c.K_b, b, 9);
+    const float* dc = cam_ptr(c.dist, c.dist_b, b, 5);
+    const float cx = v[0] * r[0] + v[1] * r[1] + v[2] * r[2] + e[0];
+    const float cy = v[0] * r[3] + v[1] * r[4] + v[2] * r[5] + e[1];
+    const float cz = v[0] * r[6] + v[1] * r[7] + v[2] * r[8] + e[2];
+    const float zz = cz + 1e-9f;
+    const float x_ = cx / zz, y_ = cy / zz;
+    const float k1 = dc[0], k2 = dc[1], p1 = dc[2], p2 = dc[3], k3 = dc[4];
+    const float rr = sqrtf(x_ * x_ + y_ * y_);
+    const float r2 = rr * rr, r4 = r2 * r2, r6 = r4 * r2;
+    const float radial = 1 + k1 * r2 + k2 * r4 + k3 * r6;
+    const float x__ = x_ * radial + 2 * p1 * x_ * y_ + p2 * (r2 + 2 * x_ * x_);
+    const float y__ = y_ * radial + p1 * (r2 + 2 * y_ * y_) + 2 * p2 * x_ * y_;
+    float u = x__ * K[0] + y__ * K[1] + K[2];
+    float vv = x__ * K[3] + y__ * K[4] + K[5];
+    vv = c.orig - vv;
+    o[0] = 2 * (u - c.orig / 2.f) / c.orig;
+    o[1] = 2 * (vv - c.orig / 2.f) / c.orig;
+    o[2] = cz;
+    if (tmp) {
+        tmp->cx = cx; tmp->cy = cy; tmp->cz = cz; tmp->zz = zz; tmp->x_ = x_; tmp->y_ = y_;
+        tmp->r2 = r2; tmp->radial = radial; tmp->dr = k1 + 2 * k2 * r2 + 3 * k3 * r4;
+    }
+}
+
+// adjoint of camera_point at v: g (wrt output) -> gv (wrt input vertex)
+__device__ __forceinline__ void camera_point_adjoint(const Cam& c, int b, const float* v, const float* g, float* gv) {
+    if (c.mode == D3M_CAMERA_NONE) {
+        gv[0] = g[0]; gv[1] = g[1]; gv[2] = g[2];
+        return;
+    }
+    const float* r = cam_ptr(c.rot, c.rot_b, b, 9);
+    const float* e = cam_ptr(c.eye_or_t, c.eye_b, b, 3);
+    float gc[3];
+    if (c.mode == D3M_CAMERA_LOOK_AT || c.mode == D3M_CAMERA_LOOK) {
+        if (c.perspective) {
+            const float d0 = v[0] - e[0], d1 = v[1] - e[1], d2 = v[2] - e[2];
+            const float x = d0 * r[0] + d1 * r[1] + d2 * r[2];
+            const float y = d0 * r[3] + d1 * r[4] + d2 * r[5];
+            const float z = d0 * r[6] + d1 * r[7] + d2 * r[8];
+            const float izw = 1.0f / (z * c.width);
+            gc[0] = g[0] * izw;
+            gc[1] = g[1] * izw;
+            gc[2] = g[2] - (g[0] * x + g[1] * y) * izw / z;
+        } else {
+            gc[0] = g[0]; gc[1] = g[1]; gc[2] = g[2];
+        }
+    } else {
+        ProjTmp t;
+        float o[3];
+        camera_point(c, b, v, o, &t);
+        const float* K = cam_ptr(c.K, c.K_b, b, 9);
+        const float* dc = cam_ptr(c.dist, c.dist_b, b, 5);
+        const float p1 = dc[2], p2 = dc[3];
+        const float gu = g[0] * 2.f / c.orig, gvp = -g[1] * 2.f / c.orig;
+        const float gx2 = K[0] * gu + K[3] * gvp, gy2 = K[1] * gu + K[4] * gvp;
+        const float x_ = t.x_, y_ = t.y_;
+        const float dxx = t.radial + 2 * x_ * x_ * t.dr + 2 * p1 * y_ + 6 * p2 * x_;
+        const float dxy = 2 * x_ * y_ * t.dr + 2 * p1 * x_ + 2 * p2 * y_;
+        const float dyx = 2 * x_ * y_ * t.dr + 2 * p1 * x_ + 2 * p2 * y_;
+        const float dyy = t.radial + 2 * y_ * y_ * t.dr + 6 * p1 * y_ + 2 * p2 * x_;
+        const float gx1 = gx2 * dxx + gy2 * dyx, gy1 = gx2 * dxy + gy2 * dyy;
+        gc[0] = gx1 / t.zz;
+        gc[1] = gy1 / t.zz;
+        gc[2] = g[2] - (gx1 * x_ + gy1 * y_) / t.zz;
+    }
+    gv[0] = r[0] * gc[0] + r[3] * gc[1] + r[6] * gc[2];
+    gv[1] = r[1] * gc[0] + r[4] * gc[1] + r[7] * gc[2];
+    gv[2] = r[2] * gc[0] + r[5] * gc[1] + r[8] * gc[2];
+}
+
+__global__ void __launch_bounds__(256) k_camera_forward(const float* __restrict__ vertices, int vb, Cam c,
+                                                       float* __restrict__ out, int B, int V) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * V) return;
+    const int b = (int)(i / V), v = (int)(i % V);
+    const float* p = vertices + ((size_t)(vb > 1 ? b : 0) * V + v) * 3;
+    const float in[3] = {p[0], p[1], p[2]};
+    float o[3];
+    camera_point(c, b, in, o, nullptr);
+    out[i * 3 + 0] = o[0];
+    out[i * 3 + 1] = o[1];
+    out[i * 3 + 2] = o[2];
+}
+
+// One lane per (mesh vertex); with a shared mesh (vb == 1) the lane loops over the B views and sums,
+// so the multi-view reduction needs no atomics and is deterministic.
+__global__ void __launch_bounds__(256) k_camera_backward(const float* __restrict__ vertices, int vb, Cam c,
+                                                        const float* __restrict__ grad_out,
+                                                        float* __restrict__ grad_vertices, int B, int V) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)(vb > 1 ? B : 1) * V;
+    if (i >= n) return;
+    const int v = (int)(i % V);
+    const int b_lo = vb > 1 ? (int)(i / V) : 0, b_hi = vb > 1 ? b_lo + 1 : B;
+    const float* p = vertices + (size_t)i * 3;
+    const float in[3] = {p[0], p[1], p[2]};
+    float acc[3] = {0, 0, 0};
+    for (int b = b_lo; b < b_hi; b++) {
+        const float* gp = grad_out + ((size_t)b * V + v) * 3;
+        const float g[3] = {gp[0], gp[1], gp[2]};
+        float gv[3];
+        camera_point_adjoint(c, b, in, g, gv);
+        acc[0] += gv[0]; acc[1] += gv[1]; acc[2] += gv[2];
+    }
+    grad_vertices[i * 3 + 0] = acc[0];
+    grad_vertices[i * 3 + 1] = acc[1];
+    grad_vertices[i * 3 + 2] = acc[2];
+}
+
+// vertices_to_faces.py:16-22 + fill_back (renderer.py:86): one lane per output float, coalesced stores
+__global__ void __launch_bounds__(256) k_gather_faces(IndexedFaces fs, float* __restrict__ faces_out, int B) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Fp = fs.num_faces();
+    if (i >= (long)B * Fp * 9) return;
+    const int c = (int)(i % 3), n = (int)((i / 3) % 3);
+    const long bf = i / 9;
+    const int b = (int)(bf / Fp), f = (int)(bf % Fp);
+    int ids[3];
+    fs.vertex_ids(b, f, ids);
+    faces_out[i] = fs.verts[((size_t)b * fs.V + ids[n]) * 3 + c];
+}
+
+// Backward of the gather: grad_vertices[b, id, c] += grad_faces[b, f, n, c].  One lane per input float
+// (coalesced loads); the three components of a vertex sit in adjacent lanes so one atomic
+// wave-instruction touches ~21 vertices' 12-byte records.  Zero entries (culled faces) are skipped.
+__global__ void __launch_bounds__(256) k_scatter_face_grads(IndexedFaces fs, const float* __restrict__ grad_faces,
+                                                           float* __restrict__ grad_vertices, int B) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Fp = fs.num_faces();
+    if (i >= (long)B * Fp * 9) return;
+    const float g = grad_faces[i];
+    if (g == 0.0f) return;
+    const int c = (int)(i % 3), n = (int)((i / 3) % 3);
+    const long bf = i / 9;
+    const int b = (int)(bf / Fp), f = (int)(bf % Fp);
+    int ids[3];
+    fs.vertex_ids(b, f, ids);
+    atomicAdd(&grad_vertices[((size_t)b * fs.V + ids[n]) * 3 + c], g);
+}
+
+// ---- lighting (neural_renderer/lighting.py:33-56) ---------------------------------------------------------
+// light[b,f,:] = ia*ca + id*cd*relu(normal . direction), normal = normalise(cross(v0-v1, v2-v1), eps 1e-5);
+// textures[b,f,...,:] *= light.  A block owns 256 consecutive faces: phase 1 one lane per face computes the
+// light into LDS, phase 2 all lanes sweep the block's contiguous texel range (coalesced).
+struct LightParams {
+    float ia, id;
+    float ca[3], cd[3], dir[3];
+};
+
+__device__ __forceinline__ void face_light(const float* f, const LightParams& lp, float* light, float* nrm, float* len,
+                                           float* cosv) {
+    const float a[3] = {f[0] - f[3], f[1] - f[4], f[2] - f[5]};     // v10 = v0 - v1
+    const float b[3] = {f[6] - f[3], f[7] - f[4], f[8] - f[5]};     // v12 = v2 - v1
+    float c[3];
+    cross3(a, b, c);
+    const float n = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const float d = fmaxf(n, 1e-5f);
+    const float nx = c[0] / d, ny = c[1] / d, nz = c[2] / d;
+    const float cs = nx * lp.dir[0] + ny * lp.dir[1] + nz * lp.dir[2];
+    const float r = fmaxf(cs, 0.0f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float l = 0.0f;
+        if (lp.ia != 0) l += lp.ia * lp.ca[k];
+        if (lp.id != 0) l += lp.id * (lp.cd[k] * r);
+        light[k] = l;
+    }
+    if (nrm) { nrm[0] = nx; nrm[1] = ny; nrm[2] = nz; *len = n; *cosv = cs; }
+}
+
+__global__ void __launch_bounds__(256) k_lighting_forward(const float* __restrict__ faces, const float* __restrict__ tex_in,
+                                                         float* __restrict__ tex_out, LightParams lp, long n_faces,
+                                                         int texels3 /* ts^3*3 */) {
+    __shared__ float s_light[256][3];
+    const long f0 = (long)blockIdx.x * 256;
+    const long f = f0 + threadIdx.x;
+    if (f < n_faces) {
+        float fc[9], l[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) fc[k] = faces[f * 9 + k];
+        face_light(fc, lp, l, nullptr, nullptr, nullptr);
+        s_light[threadIdx.x][0] = l[0]; s_light[threadIdx.x][1] = l[1]; s_light[threadIdx.x][2] = l[2];
+    }
+    __syncthreads();
+    const long nf_blk = min((long)256, n_faces - f0);
+    const long n_el = nf_blk * texels3;
+    const long base = f0 * texels3;
+    for (long e = threadIdx.x; e < n_el; e += 256) {
+        const int lf = (int)(e / texels3), ch = (int)(e % 3);
+        tex_out[base + e] = tex_in[base + e] * s_light[lf][ch];
+    }
+}
+
+// Adjoint: grad_tex_in = g * light;  grad_light[c] = sum_texels g*tex_in  -> chain rule through the normal.
+__global__ void __launch_bounds__(256) k_lighting_backward(const float* __restrict__ faces, const float* __restrict__ tex_in,
+                                                          const float* __restrict__ g_out, float* __restrict__ g_tex,
+                                                          float* __restrict__ g_faces, LightParams lp, long n_faces,
+                                                          int texels3) {
+    __shared__ float s_light[256][3];
+    __shared__ float s_gl[256][3];
+    const long f0 = (long)blockIdx.x * 256;
+    const long f = f0 + threadIdx.x;
+    float fc[9], nrm[3], len = 0, cs = 0;
+    if (f < n_faces) {
+        float l[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) fc[k] = faces[f * 9 + k];
+        face_light(fc, lp, l, nrm, &len, &cs);
+        s_light[threadIdx.x][0] = l[0]; s_light[threadIdx.x][1] = l[1]; s_light[threadIdx.x][2] = l[2];
+    }
+    s_gl[threadIdx.x][0] = 0; s_gl[threadIdx.x][1] = 0; s_gl[threadIdx.x][2] = 0;
+    __syncthreads();
+    const long nf_blk = min((long)256, n_faces - f0);
+    const long n_el = nf_blk * texels3;
+    const long base = f0 * texels3;
+    for (long e = threadIdx.x; e < n_el; e += 256) {
+        const int lf = (int)(e / texels3), ch = (int)(e % 3);
+        const float g = g_out[base + e];
+        if (g_tex) g_tex[base + e] = g * s_light[lf][ch];
+        if (g_faces) atomicAdd(&s_gl[lf][ch], g * tex_in[base + e]);
+    }
+    __syncthreads();
+    if (!g_faces || f >= n_faces) return;
+    float gf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (lp.id != 0 && cs > 0) {
+        const float g_cos = lp.id * (lp.cd[0] * s_gl[threadIdx.x][0] + lp.cd[1] * s_gl[threadIdx.x][1] +
+                                     lp.cd[2] * s_gl[threadIdx.x][2]);
+        const float gn[3] = {g_cos * lp.dir[0], g_cos * lp.dir[1], g_cos * lp.dir[2]};
+        float gc[3];
+        if (len > 1e-5f) {      // n = c/|c| : (I - n n^T)/|c| ; below the clamp n = c/eps
+            const float dot = nrm[0] * gn[0] + nrm[1] * gn[1] + nrm[2] * gn[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) gc[k] = (gn[k] - nrm[k] * dot) / len;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) gc[k] = gn[k] / 1e-5f;
+        }
+        const float a[3] = {fc[0] - fc[3], fc[1] - fc[4], fc[2] - fc[5]};
+        const float b[3] = {fc[6] - fc[3], fc[7] - fc[4], fc[8] - fc[5]};
+        float ga[3], gb[3];
+        cross3(b, gc, ga);      // c = a x b : dc/da^T g = b x g
+        cross3(gc, a, gb);      //             dc/db^T g = g x a
+#pragma unroll
+        for (int k = 0; k < 3; k++) { gf[k] = ga[k]; gf[6 + k] = gb[k]; gf[3 + k] = -(ga[k] + gb[k]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) g_faces[f * 9 + k] = gf[k];
+}
+
+// ---- output epilogue (rasterize.py:181-195, 305-326) -------------------------------------------------
+// One lane per OUTPUT pixel.  Internal row r is output row S-1-r (vertical flip); with anti-aliasing
+// the output pixel is the mean of its 2x2 internal pixels.
+__global__ void __launch_bounds__(256) k_output_epilogue(const int32_t* __restrict__ face_index_map,
+                                                        const float* __restrict__ rgb_map,
+                                                        const float* __restrict__ depth_map,
+                                                        const float* __restrict__ background, int bg_b,
+                                                        float* __restrict__ rgb_blended, float* __restrict__ alpha_map,
+                                                        float* __restrict__ rgb_out, float* __restrict__ alpha_out,
+                                                        float* __restrict__ depth_out, int B, int S, int aa) {
+    const int s = aa ? S / 2 : S;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * s * s) return;
+    const int b = (int)(i / ((long)s * s));
+    const int yo = (int)((i / s) % s), xo = (int)(i % s);
+    const int n = aa ? 2 : 1;
+    float acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
+    const float* bg = background ? cam_ptr(background, bg_b, b, 3) : nullptr;
+    for (int dy = 0; dy < n; dy++) {
+        for (int dx = 0; dx < n; dx++) {
+            const int yi = S - 1 - (yo * n + dy), xi = xo * n + dx;
+            const size_t p = ((size_t)b * S + yi) * S + xi;
+            const float mask = face_index_map[p] >= 0 ? 1.0f : 0.0f;
+            if (rgb_map) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float v = rgb_map[3 * p + k] * mask + (1 - mask) * bg[k];     // rasterize.py:192
+                    if (rgb_blended) rgb_blended[3 * p + k] = v;
+                    acc_rgb[k] += v;
+                }
+            }
+            if (alpha_map) alpha_map[p] = mask;
+            acc_a += mask;
+            if (depth_map) acc_d += depth_map[p];
+        }
+    }
+    const float inv = aa ? 0.25f : 1.0f;
+    if (rgb_out) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] = acc_rgb[k] * inv;
+    }
+    if (alpha_out) alpha_out[i] = acc_a * inv;
+    if (depth_out) depth_out[i] = acc_d * inv;
+}
+
+// Adjoint: one lane per INTERNAL pixel.  No coverage mask is applied: the reference blends the
+// background inside RasterizeFunction.forward, so its backward kernels see the gradient wrt the
+// blended image at every pixel (rasterize.py:83, 141-147).
+__global__ void __launch_bounds__(256) k_output_epilogue_backward(const float* __restrict__ g_rgb_out,
+                                                                 const float* __restrict__ g_alpha_out,
+                                                                 const float* __restrict__ g_depth_out,
+                                                                 float* __restrict__ g_rgb_map, float* __restrict__ g_alpha_map,
+                                                                 float* __restrict__ g_depth_map, int B, int S, int aa) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)B * S * S) return;
+    const int s = aa ? S / 2 : S;
+    const int b = (int)(p / ((long)S * S));
+    const int yi = (int)((p / S) % S), xi = (int)(p % S);
+    const int yo = aa ? (S - 1 - yi) / 2 : S - 1 - yi, xo = aa ? xi / 2 : xi;
+    const float sc = aa ? 0.25f : 1.0f;
+    const size_t o = ((size_t)b * s + yo) * s + xo;
+    if (g_rgb_map) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) g_rgb_map[3 * p + k] = g_rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] * sc;
+    }
+    if (g_alpha_map) g_alpha_map[p] = g_alpha_out[o] * sc;
+    if (g_depth_map) g_depth_map[p] = g_depth_out[o] * sc;
+}
+
+// ---- losses ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* s_part) {
+    v = wave_sum(v);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 0) s_part[wv] = v;
+    __syncthreads();
+    float r = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    return r;
+}
+
+// photometric_loss (deep3dmap/core/utils/utils.py:105-114): pass 1 accumulates
+// scratch[0] = sum(|a-b| [*sqrt2/(sigma+EPS) + log(sigma+EPS)] * mask), scratch[1] = sum(mask over C)
+__global__ void __launch_bounds__(256) k_photometric_reduce(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ mask,
+                                                           const float* __restrict__ sigma, float* __restrict__ scratch,
+                                                           long n, int C, long hw) {
+    __shared__ float s_part[4];
+    float num = 0, den = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long pix = (i / (hw * C)) * hw + (i % hw);
+        float l = fabsf(a[i] - b[i]);
+        if (sigma) {
+            const float sg = sigma[pix] + 1e-7f;
+            l = l * 1.41421356237309515f / sg + logf(sg);
+        }
+        const float m = mask ? mask[pix] : 1.0f;
+        num += l * m;
+        den += m;
+    }
+    num = block_sum_256(num, s_part);
+    den = block_sum_256(den, s_part);
+    if (threadIdx.x == 0) {
+        atomicAdd(&scratch[0], num);
+        atomicAdd(&scratch[1], den);
+    }
+}
+__global__ void __launch_bounds__(256) k_photometric_finish(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ mask,
+                                                           const float* __restrict__ sigma,
+                                                           const float* __restrict__ scratch, float* __restrict__ loss,
+                                                           float* __restrict__ grad_a, long n, int C, long hw) {
+    const float den = scratch[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = scratch[0] / den;
+    if (!grad_a) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long pix = (i / (hw * C)) * hw + (i % hw);
+        const float d = a[i] - b[i];
+        float g = d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f);
+        if (sigma) g = g * 1.41421356237309515f / (sigma[pix] + 1e-7f);
+        const float m = mask ? mask[pix] : 1.0f;
+        grad_a[i] = g * m / den;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sum_squared_error(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ loss, float* __restrict__ grad_a, long n) {
+    __shared__ float s_part[4];
+    float acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+        if (grad_a) grad_a[i] = 2.0f * d;
+    }
+    acc = block_sum_256(acc, s_part);
+    if (threadIdx.x == 0) atomicAdd(loss, acc);
+}
+
+}  // namespace d3m

@@ -1,0 +1,149 @@
+// d3m_device.h -- device-side building blocks shared by the gfx950 rasterizer kernels.
+//
+// The per-(pixel, face) arithmetic below is the contract with the reference
+// (pnpmodules/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu, "KCU"): the same f32
+// operations in the same order, with the same points of promotion to double, so that coverage
+// decisions, barycentrics and depth come out bit-identical to a brute-force evaluation.  This file is
+// compiled with -ffp-contract=off for that reason (no FMA contraction: every operation rounds once).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d3m {
+
+constexpr int TILE = 8;          // screen tile = 8x8 pixels = one wave64, lane = (y&7)*8 + (x&7)
+constexpr int WAVE = 64;
+
+// ---- small helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// v_cvt_i32_f32 / v_cvt_i32_f64 saturate and map NaN to 0, which is also what the reference's
+// CUDA float->int conversions do (KCU:312-321, 427-429).
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+__device__ __forceinline__ int d2i(double v) { return (int)v; }
+
+// order-preserving map f32 -> u32 (so that a u64 (key<<32 | face) min is a (depth, index) lexicographic min)
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+    uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// ---- the reference's per-face / per-pixel arithmetic ----------------------------------------------
+// back-face predicate, KCU:40 / :111 / :270
+__device__ __forceinline__ bool backside(const float* f) {
+    return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
+}
+
+// NDC -> pixel coordinate, KCU:47 / :282 (the 0.5 literal makes the product double; it is exact)
+__device__ __forceinline__ float to_pixel(float v, int is) {
+    return (float)(0.5 * (double)(v * (float)is + (float)is - 1.0f));
+}
+
+// pixel centre in NDC, KCU:96-97 (double arithmetic, rounded once to f32)
+__device__ __forceinline__ float pixel_center(int i, int is) { return (float)((2. * i + 1 - is) / is); }
+
+// inverse of [[x0,x1,x2],[y0,y1,y2],[1,1,1]] in pixel space, KCU:44-62
+__device__ __forceinline__ void face_inverse(const float* face, int is, float* out) {
+    float p[3][2];
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+        p[n][0] = to_pixel(face[3 * n + 0], is);
+        p[n][1] = to_pixel(face[3 * n + 1], is);
+    }
+    const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]));
+    out[0] = (p[1][1] - p[2][1]) / den;
+    out[1] = (p[2][0] - p[1][0]) / den;
+    out[2] = (p[1][0] * p[2][1] - p[2][0] * p[1][1]) / den;
+    out[3] = (p[2][1] - p[0][1]) / den;
+    out[4] = (p[0][0] - p[2][0]) / den;
+    out[5] = (p[2][0] * p[0][1] - p[0][0] * p[2][1]) / den;
+    out[6] = (p[0][1] - p[1][1]) / den;
+    out[7] = (p[1][0] - p[0][0]) / den;
+    out[8] = (p[0][0] * p[1][1] - p[1][0] * p[0][1]) / den;
+}
+
+// three half-plane tests at the pixel centre, KCU:115-117 (a '<' rejects: edges are inclusive)
+__device__ __forceinline__ bool inside_face(const float* face, float xp, float yp) {
+    return !(((yp - face[1]) * (face[3] - face[0]) < (xp - face[0]) * (face[4] - face[1])) ||
+             ((yp - face[4]) * (face[6] - face[3]) < (xp - face[3]) * (face[7] - face[4])) ||
+             ((yp - face[7]) * (face[0] - face[6]) < (xp - face[6]) * (face[1] - face[7])));
+}
+
+// barycentrics (clamped, renormalised) and perspective-correct depth, KCU:120-139.
+// Returns false when the depth falls outside (near, far) -- NaN depths (zero-area faces) also fail.
+__device__ __forceinline__ bool weights_depth(const float* face, const float* finv, int xi, int yi, float near,
+                                              float far, float* w, float& zp) {
+    const float fx = (float)xi, fy = (float)yi;
+    w[0] = finv[0] * fx + finv[1] * fy + finv[2];
+    w[1] = finv[3] * fx + finv[4] * fy + finv[5];
+    w[2] = finv[6] * fx + finv[7] * fy + finv[8];
+    float w_sum = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);   // fmax/fmin drop a NaN operand, as in CUDA
+        w_sum += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) w[k] /= w_sum;
+    zp = (float)(1. / (double)(w[0] / face[2] + w[1] / face[5] + w[2] / face[8]));
+    return !(zp <= near || far <= zp) && (zp == zp);
+}
+
+// ---- face sources ----------------------------------------------------------------------------
+// Dense: faces [B,F,3,3] as the reference extension receives them.
+struct DenseFaces {
+    const float* faces;
+    int F;
+    __host__ __device__ __forceinline__ int num_faces() const { return F; }
+    __device__ __forceinline__ void load(int b, int f, float* out) const {
+        const float* p = faces + ((size_t)b * F + f) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[k] = p[k];
+    }
+};
+
+// Indexed: projected vertices [B,V,3] + index triples [Bt,Ft,3]; the fill_back copy (face Ft+f =
+// face f with vertex order reversed, renderer.py:86) is generated on the fly.
+struct IndexedFaces {
+    const float* verts;
+    const int32_t* tri;
+    int V, Ft, tri_batch, fill_back;
+    __host__ __device__ __forceinline__ int num_faces() const { return fill_back ? 2 * Ft : Ft; }
+    __device__ __forceinline__ void vertex_ids(int b, int f, int* ids) const {
+        const bool back = f >= Ft;
+        const int32_t* t = tri + ((size_t)(tri_batch > 1 ? b : 0) * Ft + (back ? f - Ft : f)) * 3;
+        const int i0 = t[0], i1 = t[1], i2 = t[2];
+        ids[0] = back ? i2 : i0;
+        ids[1] = i1;
+        ids[2] = back ? i0 : i2;
+    }
+    __device__ __forceinline__ void load(int b, int f, float* out) const {
+        int ids[3];
+        vertex_ids(b, f, ids);
+#pragma unroll
+        for (int n = 0; n < 3; n++) {
+            const float* p = verts + ((size_t)b * V + ids[n]) * 3;
+            out[3 * n + 0] = p[0];
+            out[3 * n + 1] = p[1];
+            out[3 * n + 2] = p[2];
+        }
+    }
+};
+
+// ---- wave-level primitives -----------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+}  // namespace d3m

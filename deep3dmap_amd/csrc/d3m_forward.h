@@ -1,0 +1,301 @@
+// d3m_forward.h -- forward coverage for gfx950: bin faces to 8x8 screen tiles, then one wave64 per tile.
+//
+// Replaces the reference's brute-force pair of kernels (KCU:24-169: every pixel streams every face)
+// with:  k_bin_count -> k_bin_alloc -> k_bin_fill -> k_raster_tiles.
+// The per-(pixel, face) arithmetic is d3m_device.h's restatement of KCU:110-139, so as long as the
+// binning is conservative the selected face, weights and depth are bit-identical to brute force; the
+// reference's "strict < in ascending face order" (KCU:142) is reproduced as a lexicographic minimum of
+// (depth, face index) taken with 64-bit LDS atomics, which makes the result independent of list order.
+#pragma once
+#include "d3m_device.h"
+
+namespace d3m {
+
+struct BinBuffers {
+    int B, F, S, tiles_x, T, kcap;
+    uint2* rect;        // [B*F]  tile rectangle of each face (x = tx0 | ty0<<16, y = tx1 | ty1<<16), x = ~0u: none
+    int* tile_count;    // [B*T]  zeroed per call
+    int* tile_cursor;   // [B*T]  zeroed per call
+    int* big_count;     // [B]    zeroed per call
+    int* alloc_cursor;  // [1]    zeroed per call
+    int* tile_offset;   // [B*T]
+    int* big_list;      // [B*F]  faces covering more than kcap tiles: scanned by every tile of the view
+    int* pairs;         // [kcap*B*F] concatenated per-tile face lists
+};
+
+constexpr uint32_t RECT_NONE = 0xFFFFFFFFu;
+
+// Conservative pixel bounding box of a face, in the raster's pixel grid.  NDC -> pixel is
+// p = (v*S + S - 1)/2 (KCU:47).  The box is dilated by a rounding margin so that no pixel that passes
+// the f32 half-plane tests of KCU:115-117 can fall outside it (DESIGN.md "Binning is conservative").
+// Returns false when the face cannot cover any pixel.
+__device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& x1, int& y0, int& y1) {
+    // three coincident xy: every entry of the face inverse is 0/0, weights are NaN, never selected
+    if (f[0] == f[3] && f[3] == f[6] && f[1] == f[4] && f[4] == f[7]) return false;
+    const bool finite = __builtin_isfinite(f[0]) && __builtin_isfinite(f[1]) && __builtin_isfinite(f[3]) &&
+                        __builtin_isfinite(f[4]) && __builtin_isfinite(f[6]) && __builtin_isfinite(f[7]);
+    if (!finite) {  // comparisons with NaN are false -> such a face "covers" everything; evaluate it everywhere
+        x0 = 0; y0 = 0; x1 = S - 1; y1 = S - 1;
+        return true;
+    }
+    const float xmn = fminf(f[0], fminf(f[3], f[6])), xmx = fmaxf(f[0], fmaxf(f[3], f[6]));
+    const float ymn = fminf(f[1], fminf(f[4], f[7])), ymx = fmaxf(f[1], fmaxf(f[4], f[7]));
+    const double m = 4e-6 * ((double)fmaxf(fmaxf(fabsf(xmn), fabsf(xmx)), fmaxf(fabsf(ymn), fabsf(ymx))) + 1.0);
+    const double lx = ceil((((double)xmn - m) * S + S - 1) * 0.5), hx = floor((((double)xmx + m) * S + S - 1) * 0.5);
+    const double ly = ceil((((double)ymn - m) * S + S - 1) * 0.5), hy = floor((((double)ymx + m) * S + S - 1) * 0.5);
+    if (lx > S - 1 || hx < 0 || ly > S - 1 || hy < 0 || lx > hx || ly > hy) return false;
+    x0 = d2i(fmax(lx, 0.0));
+    y0 = d2i(fmax(ly, 0.0));
+    x1 = d2i(fmin(hx, (double)(S - 1)));
+    y1 = d2i(fmin(hy, (double)(S - 1)));
+    return true;
+}
+
+// ---- pass 1: one lane per (view, face): cull, tile rectangle, per-tile counts ---------------------
+// Also fills the reference's faces_inv scratch (KCU:24-67) when the caller passes it.
+template <class FS>
+__global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = bb.F;
+    if (i >= (long)bb.B * F) return;
+    const int b = (int)(i / F), f = (int)(i % F);
+    float face[9];
+    fs.load(b, f, face);
+    uint2 r = make_uint2(RECT_NONE, 0);
+    if (!backside(face)) {
+        if (faces_inv) {
+            float fi[9];
+            face_inverse(face, bb.S, fi);
+#pragma unroll
+            for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = fi[k];
+        }
+        int x0, x1, y0, y1;
+        if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
+            const int tx0 = x0 / TILE, tx1 = x1 / TILE, ty0 = y0 / TILE, ty1 = y1 / TILE;
+            r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+            const int nt = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            if (nt <= bb.kcap) {
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&bb.tile_count[(size_t)b * bb.T + ty * bb.tiles_x + tx], 1);
+            } else {
+                const int pos = atomicAdd(&bb.big_count[b], 1);
+                bb.big_list[(size_t)b * F + pos] = f;
+            }
+        }
+    }
+    bb.rect[i] = r;
+}
+
+// ---- pass 2: give every tile a slice of `pairs` (one atomic per 256 tiles; order is irrelevant) ---
+__global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int n = bb.B * bb.T;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c = i < n ? bb.tile_count[i] : 0;
+    const int incl = wave_inclusive_scan(c);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3];
+        s_base = atomicAdd(bb.alloc_cursor, t0 + t1 + t2 + t3);
+        s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
+    }
+    __syncthreads();
+    if (i < n) bb.tile_offset[i] = s_base + s_wave[wv] + incl - c;
+}
+
+// ---- pass 3: scatter face ids into the per-tile lists ------------------------------------------
+__global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)bb.B * bb.F) return;
+    const uint2 r = bb.rect[i];
+    if (r.x == RECT_NONE) return;
+    const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > bb.kcap) return;   // lives in big_list
+    const int b = (int)(i / bb.F), f = (int)(i % bb.F);
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+            const size_t t = (size_t)b * bb.T + ty * bb.tiles_x + tx;
+            const int pos = atomicAdd(&bb.tile_cursor[t], 1);
+            bb.pairs[(size_t)bb.tile_offset[t] + pos] = f;
+        }
+}
+
+// ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------
+// Per chunk of 64 listed faces: lane j stages face j (NDC vertices, pixel-space inverse, its bounding
+// box clipped to the tile) in LDS; the (face, pixel) candidates of the whole chunk are then flattened
+// over the 64 lanes, so a chunk of sub-pixel triangles costs a few iterations and a tile-filling
+// triangle costs one iteration per face.  Winners are kept in a 64-entry LDS z-buffer of
+// (ordered depth bits << 32 | face index).
+struct RasterOut {
+    int32_t* face_index_map;
+    float* weight_map;
+    float* depth_map;
+    float* face_inv_map;   // NULL unless the caller wants the reference's [B,S,S,3,3] map
+};
+
+template <class FS>
+__global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
+    __shared__ float s_face[9][WAVE];
+    __shared__ float s_finv[9][WAVE];
+    __shared__ int s_fid[WAVE];
+    __shared__ uint32_t s_box[WAVE];
+    __shared__ int s_pre[WAVE + 1];
+    __shared__ unsigned long long s_z[WAVE];
+    __shared__ float s_cx[TILE], s_cy[TILE];
+
+    // XCD-aware order: consecutive blocks are dealt round-robin to the 8 XCDs, so give XCD x the
+    // contiguous tile range [x*per, (x+1)*per): neighbouring tiles (shared faces, shared vertex
+    // lines) stay within one L2.
+    const int n_tiles = bb.B * bb.T;
+    const int per = (n_tiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int b = tile / bb.T, t = tile % bb.T;
+    const int px0 = (t % bb.tiles_x) * TILE, py0 = (t / bb.tiles_x) * TILE;
+    const int S = bb.S;
+    const int lane = lane_id();
+
+    if (lane < TILE) s_cx[lane] = pixel_center(px0 + lane, S);
+    else if (lane < 2 * TILE) s_cy[lane - TILE] = pixel_center(py0 + lane - TILE, S);
+    s_z[lane] = ~0ull;
+    if (lane == 0) s_pre[0] = 0;
+    __syncthreads();
+
+    for (int which = 0; which < 2; which++) {
+        const int* list = which == 0 ? bb.pairs + bb.tile_offset[tile] : bb.big_list + (size_t)b * bb.F;
+        const int n = which == 0 ? bb.tile_count[tile] : bb.big_count[b];
+        for (int base = 0; base < n; base += WAVE) {
+            int cnt = 0;
+            if (base + lane < n) {
+                const int fid = list[base + lane];
+                float face[9];
+                fs.load(b, fid, face);
+                int x0, x1, y0, y1;
+                if (pixel_bbox(face, S, x0, x1, y0, y1)) {
+                    x0 = max(x0, px0); x1 = min(x1, px0 + TILE - 1);
+                    y0 = max(y0, py0); y1 = min(y1, py0 + TILE - 1);
+                    if (x0 <= x1 && y0 <= y1) {
+                        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+                        cnt = bw * bh;
+                        float finv[9];
+                        face_inverse(face, S, finv);
+#pragma unroll
+                        for (int k = 0; k < 9; k++) { s_face[k][lane] = face[k]; s_finv[k][lane] = finv[k]; }
+                        s_fid[lane] = fid;
+                        // x | y<<4 | width<<8 | ceil(65536/width)<<12  (exact floor(c/width) for c < 64)
+                        s_box[lane] = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 4) | ((uint32_t)bw << 8) |
+                                      ((uint32_t)((65536 + bw - 1) / bw) << 12);
+                    }
+                }
+            }
+            const int incl = wave_inclusive_scan(cnt);
+            s_pre[lane + 1] = incl;
+            const int total = __shfl(incl, 63, 64);
+            __syncthreads();
+            for (int c = lane; c < total; c += WAVE) {
+                int lo = 0, hi = WAVE;                 // s_pre[lo] <= c < s_pre[hi]
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= c) lo = mid; else hi = mid;
+                }
+                const int local = c - s_pre[lo];
+                const uint32_t box = s_box[lo];
+                const int bw = (box >> 8) & 15;
+                const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
+                const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
+                float face[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) face[k] = s_face[k][lo];
+                if (inside_face(face, s_cx[lx], s_cy[ly])) {
+                    float finv[9], w[3], zp;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) finv[k] = s_finv[k][lo];
+                    if (weights_depth(face, finv, px0 + lx, py0 + ly, near, far, w, zp)) {
+                        const unsigned long long key = ((unsigned long long)ordered_bits(zp) << 32) | (uint32_t)s_fid[lo];
+                        atomicMin(&s_z[ly * TILE + lx], key);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store
+    const unsigned long long key = s_z[lane];
+    const int xi = px0 + (lane & 7), yi = py0 + (lane >> 3);
+    if (key != ~0ull && xi < S && yi < S) {
+        const int fid = (int)(uint32_t)(key & 0xFFFFFFFFull);
+        float face[9], finv[9], w[3], zp;
+        fs.load(b, fid, face);
+        face_inverse(face, S, finv);
+        weights_depth(face, finv, xi, yi, near, far, w, zp);
+        const size_t i = ((size_t)b * S + yi) * S + xi;
+        out.depth_map[i] = zp;
+        out.face_index_map[i] = fid;
+        out.weight_map[3 * i + 0] = w[0];
+        out.weight_map[3 * i + 1] = w[1];
+        out.weight_map[3 * i + 2] = w[2];
+        if (out.face_inv_map) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
+        }
+    }
+}
+
+// ---- texture sampling (KCU:172-242), one lane per pixel ---------------------------------------------
+// ts == 1 makes KCU:229-233 index texels 1..3 of a one-texel cube (the following faces' texels, with
+// weights ~ -eps); that in-buffer bleed is reproduced, reads past the end of the buffer yield 0.
+__global__ void __launch_bounds__(256) k_texture_sampling(const float* __restrict__ faces, const float* __restrict__ textures,
+                                                         const int32_t* __restrict__ face_index_map,
+                                                         const float* __restrict__ weight_map,
+                                                         const float* __restrict__ depth_map, float* __restrict__ rgb_map,
+                                                         int32_t* __restrict__ sampling_index_map,
+                                                         float* __restrict__ sampling_weight_map, int B, int F, int S, int ts,
+                                                         float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S * S) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int bn = (int)(i / ((long)S * S));
+    const float* face = faces + ((size_t)bn * F + fi) * 9;
+    const size_t tex_base = ((size_t)bn * F + fi) * ts * ts * ts * 3;
+    const size_t tex_total = (size_t)B * F * ts * ts * ts * 3;
+    const float depth = depth_map[i];
+    float tif[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float t = weight_map[3 * i + k] * (float)(ts - 1) * (depth / face[3 * k + 2]);
+        t = (float)fmax((double)t, 0.);
+        t = fminf(t, (float)(ts - 1) - eps);
+        tif[k] = t;
+    }
+    float px[3] = {0, 0, 0};
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float w = 1;
+        int tii[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int fl = f2i(tif[k]);
+            if (((pn >> k) & 1) == 0) { w *= 1 - (tif[k] - (float)fl); tii[k] = fl; }
+            else                      { w *= tif[k] - (float)fl;       tii[k] = fl + 1; }
+        }
+        const int isc = tii[0] * ts * ts + tii[1] * ts + tii[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const size_t ti = tex_base + (size_t)((long)isc * 3 + k);
+            px[k] += w * (ti < tex_total ? textures[ti] : 0.0f);
+        }
+        if (sampling_index_map) sampling_index_map[i * 8 + pn] = isc;
+        if (sampling_weight_map) sampling_weight_map[i * 8 + pn] = w;
+    }
+    rgb_map[3 * i + 0] = px[0];
+    rgb_map[3 * i + 1] = px[1];
+    rgb_map[3 * i + 2] = px[2];
+}
+
+}  // namespace d3m

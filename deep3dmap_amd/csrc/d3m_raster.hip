@@ -1,0 +1,385 @@
+// d3m_raster.hip -- extern "C" entry points of libd3m_raster.so (see include/d3m_raster.h).
+// gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/d3m_raster.h"
+#include "d3m_aux.h"
+#include "d3m_backward.h"
+#include "d3m_device.h"
+#include "d3m_edge_grad.h"
+#include "d3m_forward.h"
+
+using namespace d3m;
+
+#define D3M_EXPORT extern "C" __attribute__((visibility("default")))
+
+static thread_local int g_last_hip_error = 0;
+
+static inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return D3M_ERR_LAUNCH;
+    }
+    return D3M_OK;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e__ = (expr);                        \
+        if (e__ != hipSuccess) {                        \
+            g_last_hip_error = (int)e__;                \
+            return D3M_ERR_LAUNCH;                      \
+        }                                               \
+    } while (0)
+
+static inline unsigned blocks_for(long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+D3M_EXPORT const char* d3m_version(void) { return "d3m_raster 0.1 (gfx950)"; }
+D3M_EXPORT int d3m_last_hip_error(void) { return g_last_hip_error; }
+D3M_EXPORT const char* d3m_error_string(int code) {
+    switch (code) {
+        case D3M_OK: return "ok";
+        case D3M_ERR_INVALID: return "invalid argument";
+        case D3M_ERR_WORKSPACE: return "workspace missing or too small";
+        case D3M_ERR_LAUNCH: return "HIP call failed";
+        default: return "unknown error";
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace carving for the binned forward
+// ---------------------------------------------------------------------------------------------------
+static const int KCAP_DEFAULT = 16;   // a face covering more tiles than this is "large"
+static const int KCAP_MAX = 64;
+
+struct FwdLayout {
+    size_t zero_bytes;   // prefix that must be zeroed per call
+    size_t off_count, off_cursor, off_big_count, off_alloc, off_offset, off_rect, off_big, off_pairs;
+    size_t fixed_bytes;  // everything but pairs
+};
+
+static FwdLayout fwd_layout(int B, int F, int S) {
+    const int tiles_x = (S + TILE - 1) / TILE;
+    const size_t nt = (size_t)B * tiles_x * tiles_x;
+    FwdLayout L;
+    size_t o = 0;
+    L.off_count = o;     o += align_up(nt * 4, 256);
+    L.off_cursor = o;    o += align_up(nt * 4, 256);
+    L.off_big_count = o; o += align_up((size_t)B * 4, 256);
+    L.off_alloc = o;     o += 256;
+    L.zero_bytes = o;
+    L.off_offset = o;    o += align_up(nt * 4, 256);
+    L.off_rect = o;      o += align_up((size_t)B * F * 8, 256);
+    L.off_big = o;       o += align_up((size_t)B * F * 4, 256);
+    L.off_pairs = o;
+    L.fixed_bytes = o;
+    return L;
+}
+
+D3M_EXPORT size_t d3m_forward_workspace_bytes(int B, int F, int S) {
+    if (B <= 0 || F <= 0 || S <= 0) return 0;
+    return fwd_layout(B, F, S).fixed_bytes + (size_t)KCAP_DEFAULT * B * F * 4;
+}
+D3M_EXPORT size_t d3m_forward_workspace_min_bytes(int B, int F, int S) {
+    if (B <= 0 || F <= 0 || S <= 0) return 0;
+    return fwd_layout(B, F, S).fixed_bytes + (size_t)B * F * 4;
+}
+
+static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_bytes) {
+    if (!ws) return D3M_ERR_WORKSPACE;
+    const FwdLayout L = fwd_layout(B, F, S);
+    if (ws_bytes < L.fixed_bytes + (size_t)B * F * 4) return D3M_ERR_WORKSPACE;
+    long kcap = (long)((ws_bytes - L.fixed_bytes) / ((size_t)B * F * 4));
+    if (kcap > KCAP_MAX) kcap = KCAP_MAX;
+    char* p = (char*)ws;
+    bb.B = B; bb.F = F; bb.S = S;
+    bb.tiles_x = (S + TILE - 1) / TILE;
+    bb.T = bb.tiles_x * bb.tiles_x;
+    bb.kcap = (int)kcap;
+    bb.tile_count = (int*)(p + L.off_count);
+    bb.tile_cursor = (int*)(p + L.off_cursor);
+    bb.big_count = (int*)(p + L.off_big_count);
+    bb.alloc_cursor = (int*)(p + L.off_alloc);
+    bb.tile_offset = (int*)(p + L.off_offset);
+    bb.rect = (uint2*)(p + L.off_rect);
+    bb.big_list = (int*)(p + L.off_big);
+    bb.pairs = (int*)(p + L.off_pairs);
+    return D3M_OK;
+}
+
+template <class FS>
+static int run_forward(FS fs, int B, int F, int S, float near, float far, RasterOut out, float* faces_inv, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    if (S > 8 * 65535) return D3M_ERR_INVALID;
+    BinBuffers bb;
+    int rc = make_bins(bb, B, F, S, ws, ws_bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ws, 0, fwd_layout(B, F, S).zero_bytes, st));
+    const long nf = (long)B * F;
+    hipLaunchKernelGGL(k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), 0, st, fs, bb, faces_inv);
+    hipLaunchKernelGGL(k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), 0, st, bb);
+    hipLaunchKernelGGL(k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), 0, st, bb);
+    const int n_tiles = B * bb.T;
+    const int per = (n_tiles + 7) / 8;
+    hipLaunchKernelGGL(k_raster_tiles<FS>, dim3(per * 8), dim3(64), 0, st, fs, bb, out, near, far);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A. the five operators
+// ---------------------------------------------------------------------------------------------------
+D3M_EXPORT int d3m_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+                                          float* depth_map, float* face_inv_map, float* faces_inv, int batch_size,
+                                          int num_faces, int image_size, float near, float far, int return_rgb,
+                                          int return_alpha, int return_depth, void* workspace, size_t workspace_bytes,
+                                          d3m_stream_t stream) {
+    (void)return_rgb; (void)return_alpha;
+    if (!faces || !face_index_map || !weight_map || !depth_map || batch_size <= 0 || num_faces <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    DenseFaces fs{faces, num_faces};
+    RasterOut out{face_index_map, weight_map, depth_map, return_depth ? face_inv_map : nullptr};
+    return run_forward(fs, batch_size, num_faces, image_size, near, far, out, faces_inv, workspace, workspace_bytes,
+                       (hipStream_t)stream);
+}
+
+D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* textures, const int32_t* face_index_map,
+                                            const float* weight_map, const float* depth_map, float* rgb_map,
+                                            int32_t* sampling_index_map, float* sampling_weight_map, int batch_size,
+                                            int num_faces, int image_size, int texture_size, float eps,
+                                            d3m_stream_t stream) {
+    if (!faces || !textures || !face_index_map || !weight_map || !depth_map || !rgb_map || batch_size <= 0 ||
+        num_faces <= 0 || image_size <= 0 || texture_size <= 0)
+        return D3M_ERR_INVALID;
+    const long n = (long)batch_size * image_size * image_size;
+    hipLaunchKernelGGL(k_texture_sampling, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, faces, textures,
+                       face_index_map, weight_map, depth_map, rgb_map, sampling_index_map, sampling_weight_map,
+                       batch_size, num_faces, image_size, texture_size, eps);
+    return check_launch();
+}
+
+D3M_EXPORT size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size) {
+    return edge_grad_workspace_bytes(batch_size, num_faces, image_size);
+}
+
+D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
+                                      const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
+                                      float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
+                                      int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
+                                      d3m_stream_t stream) {
+    if (!faces || !face_index_map || !grad_faces || batch_size <= 0 || num_faces <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    if (return_rgb && (!rgb_map || !grad_rgb_map)) return D3M_ERR_INVALID;
+    if (return_alpha && (!alpha_map || !grad_alpha_map)) return D3M_ERR_INVALID;
+    if (!return_rgb && !return_alpha) return D3M_OK;    // rasterize.py:200-201
+    DenseFaces fs{faces, num_faces};
+    PixelMaps m{face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb != 0,
+                return_alpha != 0};
+    return run_edge_grad(fs, m, grad_faces, batch_size, eps, workspace, workspace_bytes, (hipStream_t)stream,
+                         &g_last_hip_error);
+}
+
+D3M_EXPORT int d3m_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+                                     const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
+                                     int batch_size, int num_faces, int image_size, int texture_size,
+                                     d3m_stream_t stream) {
+    if (!face_index_map || !sampling_weight_map || !sampling_index_map || !grad_rgb_map || !grad_textures ||
+        batch_size <= 0 || num_faces <= 0 || image_size <= 0 || texture_size <= 0)
+        return D3M_ERR_INVALID;
+    const long n = (long)batch_size * image_size * image_size;
+    hipLaunchKernelGGL(k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, face_index_map,
+                       sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, batch_size, num_faces,
+                       image_size, texture_size);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                                      const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
+                                      float* grad_faces, int batch_size, int num_faces, int image_size,
+                                      d3m_stream_t stream) {
+    if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !grad_faces || batch_size <= 0 ||
+        num_faces <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    DenseFaces fs{faces, num_faces};
+    const long n = (long)batch_size * image_size * image_size;
+    hipLaunchKernelGGL(k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs,
+                       depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, batch_size,
+                       image_size);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// B. camera, gather / scatter, epilogue
+// ---------------------------------------------------------------------------------------------------
+static int to_cam(const d3m_camera* h, int B, Cam& c) {
+    if (!h) return D3M_ERR_INVALID;
+    c.mode = h->mode; c.perspective = h->perspective; c.width = h->tan_half_width; c.orig = h->orig_size;
+    c.rot = h->rot; c.eye_or_t = h->eye_or_t; c.K = h->K; c.dist = h->dist;
+    c.rot_b = h->rot_batch; c.eye_b = h->eye_batch; c.K_b = h->K_batch; c.dist_b = h->dist_batch;
+    if (c.mode == D3M_CAMERA_NONE) return D3M_OK;
+    if (c.mode != D3M_CAMERA_LOOK_AT && c.mode != D3M_CAMERA_LOOK && c.mode != D3M_CAMERA_PROJECTION) return D3M_ERR_INVALID;
+    if (!c.rot || !c.eye_or_t) return D3M_ERR_INVALID;
+    if ((c.rot_b != 1 && c.rot_b != B) || (c.eye_b != 1 && c.eye_b != B)) return D3M_ERR_INVALID;
+    if (c.mode == D3M_CAMERA_PROJECTION) {
+        if (!c.K || !c.dist) return D3M_ERR_INVALID;
+        if ((c.K_b != 1 && c.K_b != B) || (c.dist_b != 1 && c.dist_b != B)) return D3M_ERR_INVALID;
+    }
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_camera_basis(const float* eye, int eye_batch, const float* at_or_direction, int at_batch,
+                                const float* up, int up_batch, int is_look_at, float* rot_out, int batch_size,
+                                d3m_stream_t stream) {
+    if (!eye || !at_or_direction || !up || !rot_out || batch_size <= 0) return D3M_ERR_INVALID;
+    hipLaunchKernelGGL(k_camera_basis, dim3(blocks_for(batch_size, 64)), dim3(64), 0, (hipStream_t)stream, eye, eye_batch,
+                       at_or_direction, at_batch, up, up_batch, is_look_at, rot_out, batch_size);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_camera_forward(const float* vertices, int vertices_batch, const d3m_camera* cam, float* out,
+                                  int batch_size, int num_vertices, d3m_stream_t stream) {
+    if (!vertices || !out || batch_size <= 0 || num_vertices <= 0) return D3M_ERR_INVALID;
+    if (vertices_batch != 1 && vertices_batch != batch_size) return D3M_ERR_INVALID;
+    Cam c;
+    int rc = to_cam(cam, batch_size, c);
+    if (rc) return rc;
+    const long n = (long)batch_size * num_vertices;
+    hipLaunchKernelGGL(k_camera_forward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, vertices,
+                       vertices_batch, c, out, batch_size, num_vertices);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam,
+                                   const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
+                                   d3m_stream_t stream) {
+    if (!vertices || !grad_out || !grad_vertices || batch_size <= 0 || num_vertices <= 0) return D3M_ERR_INVALID;
+    if (vertices_batch != 1 && vertices_batch != batch_size) return D3M_ERR_INVALID;
+    Cam c;
+    int rc = to_cam(cam, batch_size, c);
+    if (rc) return rc;
+    const long n = (long)(vertices_batch > 1 ? batch_size : 1) * num_vertices;
+    hipLaunchKernelGGL(k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, vertices,
+                       vertices_batch, c, grad_out, grad_vertices, batch_size, num_vertices);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_gather_faces(const float* vertices, const int32_t* tri, int tri_batch, float* faces_out,
+                                int batch_size, int num_vertices, int num_tri, int fill_back, d3m_stream_t stream) {
+    if (!vertices || !tri || !faces_out || batch_size <= 0 || num_vertices <= 0 || num_tri <= 0) return D3M_ERR_INVALID;
+    if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
+    const long n = (long)batch_size * fs.num_faces() * 9;
+    hipLaunchKernelGGL(k_gather_faces, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs, faces_out,
+                       batch_size);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_scatter_face_grads(const float* grad_faces, const int32_t* tri, int tri_batch, float* grad_vertices,
+                                      int batch_size, int num_vertices, int num_tri, int fill_back,
+                                      d3m_stream_t stream) {
+    if (!grad_faces || !tri || !grad_vertices || batch_size <= 0 || num_vertices <= 0 || num_tri <= 0)
+        return D3M_ERR_INVALID;
+    if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
+    IndexedFaces fs{nullptr, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
+    const long n = (long)batch_size * fs.num_faces() * 9;
+    hipLaunchKernelGGL(k_scatter_face_grads, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs, grad_faces,
+                       grad_vertices, batch_size);
+    return check_launch();
+}
+
+static LightParams to_light(float ia, float id, const float* ca, const float* cd, const float* dir) {
+    LightParams lp;
+    lp.ia = ia; lp.id = id;
+    for (int k = 0; k < 3; k++) { lp.ca[k] = ca[k]; lp.cd[k] = cd[k]; lp.dir[k] = dir[k]; }
+    return lp;
+}
+
+D3M_EXPORT int d3m_lighting_forward(const float* faces, const float* textures_in, float* textures_out,
+                                    float intensity_ambient, float intensity_directional, const float* color_ambient,
+                                    const float* color_directional, const float* direction, long num_faces_total,
+                                    int texture_size, d3m_stream_t stream) {
+    if (!faces || !textures_in || !textures_out || !color_ambient || !color_directional || !direction ||
+        num_faces_total <= 0 || texture_size <= 0)
+        return D3M_ERR_INVALID;
+    const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    hipLaunchKernelGGL(k_lighting_forward, dim3(blocks_for(num_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
+                       textures_in, textures_out, lp, num_faces_total, texture_size * texture_size * texture_size * 3);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_lighting_backward(const float* faces, const float* textures_in, const float* grad_out,
+                                     float* grad_textures, float* grad_faces, float intensity_ambient,
+                                     float intensity_directional, const float* color_ambient,
+                                     const float* color_directional, const float* direction, long num_faces_total,
+                                     int texture_size, d3m_stream_t stream) {
+    if (!faces || !textures_in || !grad_out || !color_ambient || !color_directional || !direction ||
+        num_faces_total <= 0 || texture_size <= 0)
+        return D3M_ERR_INVALID;
+    const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    hipLaunchKernelGGL(k_lighting_backward, dim3(blocks_for(num_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
+                       textures_in, grad_out, grad_textures, grad_faces, lp, num_faces_total,
+                       texture_size * texture_size * texture_size * 3);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_output_epilogue(const int32_t* face_index_map, const float* rgb_map, const float* depth_map,
+                                   const float* background, int background_batch, float* rgb_blended,
+                                   float* alpha_map, float* rgb_out, float* alpha_out, float* depth_out, int batch_size,
+                                   int image_size, int anti_aliasing, d3m_stream_t stream) {
+    if (!face_index_map || batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
+    if (rgb_map && !background) return D3M_ERR_INVALID;
+    if (background && background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
+    const int s = anti_aliasing ? image_size / 2 : image_size;
+    const long n = (long)batch_size * s * s;
+    hipLaunchKernelGGL(k_output_epilogue, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, face_index_map,
+                       rgb_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
+                       depth_out, batch_size, image_size, anti_aliasing ? 1 : 0);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_output_epilogue_backward(const float* grad_rgb_out, const float* grad_alpha_out,
+                                            const float* grad_depth_out, float* grad_rgb_map, float* grad_alpha_map,
+                                            float* grad_depth_map, int batch_size, int image_size, int anti_aliasing,
+                                            d3m_stream_t stream) {
+    if (batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if ((grad_rgb_map && !grad_rgb_out) || (grad_alpha_map && !grad_alpha_out) || (grad_depth_map && !grad_depth_out))
+        return D3M_ERR_INVALID;
+    const long n = (long)batch_size * image_size * image_size;
+    hipLaunchKernelGGL(k_output_epilogue_backward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_rgb_out, grad_alpha_out, grad_depth_out, grad_rgb_map, grad_alpha_map, grad_depth_map,
+                       batch_size, image_size, anti_aliasing ? 1 : 0);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C. losses
+// ---------------------------------------------------------------------------------------------------
+D3M_EXPORT int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, const float* conf_sigma,
+                                    float* loss, float* grad_im1, float* scratch, int batch_size, int channels,
+                                    int height, int width, d3m_stream_t stream) {
+    if (!im1 || !im2 || !loss || !scratch || batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0)
+        return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long hw = (long)height * width, n = (long)batch_size * channels * hw;
+    HIP_TRY(hipMemsetAsync(scratch, 0, 3 * sizeof(float), st));
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_photometric_reduce, dim3(grid), dim3(256), 0, st, im1, im2, mask, conf_sigma, scratch, n,
+                       channels, hw);
+    hipLaunchKernelGGL(k_photometric_finish, dim3(grad_im1 ? grid : 1), dim3(256), 0, st, im1, im2, mask, conf_sigma,
+                       scratch, loss, grad_im1, n, channels, hw);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, long n,
+                                     d3m_stream_t stream) {
+    if (!a || !b || !loss || n <= 0) return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_sum_squared_error, dim3(grid), dim3(256), 0, st, a, b, loss, grad_a, n);
+    return check_launch();
+}

@@ -1,0 +1,100 @@
+"""Stand-in for the pybind module `neural_renderer.cuda.rasterize`
+(pnpmodules/neural_renderer/neural_renderer/cuda/rasterize_cuda.cpp:193-199): the same five functions,
+same argument order, same ownership rule (caller allocates and pre-fills, callee mutates in place and
+returns the same tensors), same errors (non-CUDA / non-contiguous -> RuntimeError).  Each call is one
+entry point of libd3m_raster.so; kernels run on torch's current stream."""
+import torch
+
+from .. import _lib
+
+_workspaces = {}
+
+
+def _workspace(key, nbytes, device):
+    """Scratch buffers are cached per (kind, device) and only ever grow."""
+    buf = _workspaces.get((key, device))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[(key, device)] = buf
+    return buf
+
+
+def _opt(t):
+    """The reference passes 1-element dummies for disabled outputs (rasterize.py:46,59-69)."""
+    return None if (t is None or t.numel() <= 1) else t
+
+
+def forward_face_index_map(faces, face_index_map, weight_map, depth_map, face_inv_map, faces_inv, image_size,
+                           near, far, return_rgb, return_alpha, return_depth):
+    _lib.require_device(faces, face_index_map, weight_map, depth_map, face_inv_map, faces_inv,
+                        names=["faces", "face_index_map", "weight_map", "depth_map", "face_inv_map", "faces_inv"])
+    L = _lib.lib()
+    B, F = faces.shape[:2]
+    ws = _workspace("fwd", L.d3m_forward_workspace_bytes(B, F, image_size), faces.device)
+    rc = L.d3m_forward_face_index_map(_lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(weight_map),
+                                      _lib.ptr(depth_map), _lib.ptr(_opt(face_inv_map) if return_depth else None),
+                                      _lib.ptr(_opt(faces_inv)), B, F, int(image_size), float(near), float(far),
+                                      int(bool(return_rgb)), int(bool(return_alpha)), int(bool(return_depth)),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "forward_face_index_map")
+    return [face_index_map, weight_map, depth_map, face_inv_map]
+
+
+def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
+                             sampling_weight_map, image_size, eps):
+    _lib.require_device(faces, textures, face_index_map, weight_map, depth_map, rgb_map, sampling_index_map,
+                        sampling_weight_map,
+                        names=["faces", "textures", "face_index_map", "weight_map", "depth_map", "rgb_map",
+                               "sampling_index_map", "sampling_weight_map"])
+    B, F = faces.shape[:2]
+    rc = _lib.lib().d3m_forward_texture_sampling(
+        _lib.ptr(faces), _lib.ptr(textures), _lib.ptr(face_index_map), _lib.ptr(weight_map), _lib.ptr(depth_map),
+        _lib.ptr(rgb_map), _lib.ptr(_opt(sampling_index_map)), _lib.ptr(_opt(sampling_weight_map)), B, F,
+        int(image_size), int(textures.shape[2]), float(eps), _lib.stream_ptr())
+    _lib.check(rc, "forward_texture_sampling")
+    return [rgb_map, sampling_index_map, sampling_weight_map]
+
+
+def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
+                       image_size, eps, return_rgb, return_alpha):
+    _lib.require_device(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
+                        names=["faces", "face_index_map", "rgb_map", "alpha_map", "grad_rgb_map", "grad_alpha_map",
+                               "grad_faces"])
+    L = _lib.lib()
+    B, F = faces.shape[:2]
+    ws = _workspace("edge", L.d3m_backward_pixel_map_workspace_bytes(B, F, image_size), faces.device)
+    rc = L.d3m_backward_pixel_map(
+        _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(rgb_map if return_rgb else None),
+        _lib.ptr(alpha_map if return_alpha else None), _lib.ptr(grad_rgb_map if return_rgb else None),
+        _lib.ptr(grad_alpha_map if return_alpha else None), _lib.ptr(grad_faces), B, F, int(image_size), float(eps),
+        int(bool(return_rgb)), int(bool(return_alpha)), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "backward_pixel_map")
+    return grad_faces
+
+
+def backward_textures(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures,
+                      num_faces):
+    _lib.require_device(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures,
+                        names=["face_index_map", "sampling_weight_map", "sampling_index_map", "grad_rgb_map",
+                               "grad_textures"])
+    B, S = face_index_map.shape[:2]
+    rc = _lib.lib().d3m_backward_textures(
+        _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map), _lib.ptr(sampling_index_map),
+        _lib.ptr(grad_rgb_map), _lib.ptr(grad_textures), B, int(num_faces), S, int(grad_textures.shape[2]),
+        _lib.stream_ptr())
+    _lib.check(rc, "backward_textures")
+    return grad_textures
+
+
+def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
+                       image_size):
+    _lib.require_device(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
+                        names=["faces", "depth_map", "face_index_map", "face_inv_map", "weight_map",
+                               "grad_depth_map", "grad_faces"])
+    B, F = faces.shape[:2]
+    rc = _lib.lib().d3m_backward_depth_map(
+        _lib.ptr(faces), _lib.ptr(depth_map), _lib.ptr(face_index_map), _lib.ptr(_opt(face_inv_map)),
+        _lib.ptr(weight_map), _lib.ptr(grad_depth_map), _lib.ptr(grad_faces), B, F, int(image_size),
+        _lib.stream_ptr())
+    _lib.check(rc, "backward_depth_map")
+    return grad_faces

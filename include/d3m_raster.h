@@ -1,0 +1,207 @@
+/*
+ * d3m_raster.h -- C ABI of libd3m_raster.so, the MI355X (gfx950) differentiable mesh rasterizer.
+ *
+ * This is the drop-in boundary for the rasterization hot path of achao2013/deep3dmap.  Plain
+ * pointers and sizes only: every pointer is a DEVICE pointer unless it says "host"; `stream` is a
+ * hipStream_t passed as void* (NULL = the legacy default stream, which is what the reference's
+ * `<<<blocks, threads>>>` launches use, rasterize_cuda_kernel.cu:615).  No ATen / torch types.
+ *
+ * Conventions kept from the reference extension (pnpmodules/neural_renderer/neural_renderer/cuda/
+ * rasterize_cuda.cpp, "KCPP" below; kernels in rasterize_cuda_kernel.cu, "KCU"):
+ *   - the caller allocates AND pre-fills every output (face_index -1, weight 0, depth = far, rgb 0,
+ *     sampling maps 0, face_inv 0, grad buffers 0: neural_renderer/rasterize.py:50-69,111-115);
+ *     entry points mutate in place;
+ *   - tensors are contiguous f32 / i32 in the layouts named per argument;
+ *   - disabled outputs may be NULL (the reference passes 1-element dummies, rasterize.py:46,59-69);
+ *   - nothing here synchronises the device; errors detected on the host are returned at once,
+ *     launch failures surface as D3M_ERR_LAUNCH with hipGetLastError() kept in d3m_last_hip_error().
+ *
+ * Return value of every int function: 0 on success, one of the D3M_ERR_* codes otherwise.
+ */
+#ifndef D3M_RASTER_H
+#define D3M_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* d3m_stream_t; /* hipStream_t */
+
+enum {
+    D3M_OK = 0,
+    D3M_ERR_INVALID = 1,   /* bad size / NULL where data is required / unsupported value */
+    D3M_ERR_WORKSPACE = 2, /* workspace missing or smaller than d3m_*_workspace_bytes() */
+    D3M_ERR_LAUNCH = 3     /* a HIP call failed; see d3m_last_hip_error() */
+};
+
+/* camera_mode values of d3m_camera_* (neural_renderer/renderer.py:88-112) */
+enum { D3M_CAMERA_NONE = 0, D3M_CAMERA_LOOK_AT = 1, D3M_CAMERA_LOOK = 2, D3M_CAMERA_PROJECTION = 3 };
+
+const char* d3m_version(void);
+int d3m_last_hip_error(void);         /* hipError_t of the most recent failed HIP call, 0 if none */
+const char* d3m_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * A. The five operators of `neural_renderer.cuda.rasterize` (KCPP:193-199), same argument order.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch d3m_forward_face_index_map needs for (batch_size, num_faces, image_size):
+ * per-tile face lists built on the device.  A smaller buffer is accepted down to
+ * d3m_forward_workspace_min_bytes(); it only lowers the size above which a face is handled as
+ * "large" (scanned by every tile of its view).  Contents need no initialisation. */
+size_t d3m_forward_workspace_bytes(int batch_size, int num_faces, int image_size);
+size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_size);
+
+/* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
+ *   faces          [B,F,3,3] f32 in   NDC x,y in [-1,1] (+y up), z = depth
+ *   face_index_map [B,S,S]   i32 i/o  index of the nearest covering face, untouched where uncovered
+ *   weight_map     [B,S,S,3] f32 i/o  clamped+renormalised barycentrics of that face
+ *   depth_map      [B,S,S]   f32 i/o  perspective-correct depth
+ *   face_inv_map   [B,S,S,3,3] f32 i/o, written only if return_depth != 0 (may be NULL otherwise)
+ *   faces_inv      [B,F,3,3] f32 i/o  scratch the reference fills for front-facing faces (may be NULL)
+ * Row 0 of the maps is the BOTTOM of the image (the flip happens in Python, rasterize.py:305-317). */
+int d3m_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
+                               float* depth_map, float* face_inv_map, float* faces_inv, int batch_size,
+                               int num_faces, int image_size, float near, float far, int return_rgb,
+                               int return_alpha, int return_depth, void* workspace, size_t workspace_bytes,
+                               d3m_stream_t stream);
+
+/* Replaces forward_texture_sampling (KCPP:97-124 -> KCU:172-242).
+ *   textures [B,F,ts,ts,ts,3] f32 in; rgb_map [B,S,S,3] f32 i/o; sampling_index_map [B,S,S,8] i32 i/o;
+ *   sampling_weight_map [B,S,S,8] f32 i/o (the last two may be NULL: they are recomputable). */
+int d3m_forward_texture_sampling(const float* faces, const float* textures, const int32_t* face_index_map,
+                                 const float* weight_map, const float* depth_map, float* rgb_map,
+                                 int32_t* sampling_index_map, float* sampling_weight_map, int batch_size,
+                                 int num_faces, int image_size, int texture_size, float eps,
+                                 d3m_stream_t stream);
+
+/* Replaces backward_pixel_map (KCPP:126-150 -> KCU:245-503).  OVERWRITES the 9 entries of every
+ * front-facing face in grad_faces [B,F,3,3] (x,y components carry the gradient, z is set to 0);
+ * culled faces are left untouched.  rgb_map/grad_rgb_map may be NULL when return_rgb == 0, alpha
+ * likewise.  workspace: d3m_backward_pixel_map_workspace_bytes() bytes of scratch (no init needed). */
+size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size);
+int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
+                           const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
+                           float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
+                           int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
+                           d3m_stream_t stream);
+
+/* Replaces backward_textures (KCPP:152-168 -> KCU:506-540): grad_textures [B,F,ts,ts,ts,3] += . */
+int d3m_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+                          const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
+                          int batch_size, int num_faces, int image_size, int texture_size,
+                          d3m_stream_t stream);
+
+/* Replaces backward_depth_map (KCPP:170-191 -> KCU:543-592): grad_faces += (after backward_pixel_map).
+ * face_inv_map may be NULL: the face inverse is then recomputed from `faces` (bit-identical values). */
+int d3m_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                           const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
+                           float* grad_faces, int batch_size, int num_faces, int image_size,
+                           d3m_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * B. The eager-torch steps either side of those operators, as single HIP passes.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Camera parameter block, HOST memory, copied by value into the launch.
+ *   LOOK_AT / LOOK : rot = rows (x_axis, y_axis, z_axis) per view, eye per view
+ *                    (neural_renderer/look_at.py:48-60, look.py:39-51), then, if perspective != 0,
+ *                    x,y /= z * tan(viewing_angle) (perspective.py:13-20; `inv_width`= 1/tan is NOT
+ *                    used: the divisions are kept as the reference writes them).
+ *   PROJECTION     : v*R^T + t, x/(z+1e-9), distortion (k1,k2,p1,p2,k3), K, v = orig-v, map to
+ *                    [-1,1] (projection.py:19-42).
+ * Per-view arrays live on the DEVICE: rot [Bc,3,3], eye_or_t [Bc,3], K [Bc,3,3], dist [Bc,5]; Bc is
+ * either 1 (broadcast) or batch_size. */
+typedef struct d3m_camera {
+    int mode;              /* D3M_CAMERA_* */
+    int perspective;       /* look / look_at only */
+    float tan_half_width;  /* tan(viewing_angle), look / look_at only */
+    float orig_size;       /* projection only */
+    const float* rot;      /* device: look/look_at basis rows, or projection R */
+    const float* eye_or_t; /* device: look/look_at eye, or projection t */
+    const float* K;        /* device: projection only */
+    const float* dist;     /* device: projection only */
+    int rot_batch, eye_batch, K_batch, dist_batch; /* 1 or batch_size each */
+} d3m_camera;
+
+/* look_at / look basis on the device (look_at.py:48-53, look.py:39-44): rot_out [B,3,3] rows
+ * (x_axis, y_axis, z_axis); eye/at_or_direction/up are [n,3] device arrays with n = 1 or B.
+ * is_look_at != 0: z = normalise(at - eye); else z = normalise(direction). */
+int d3m_camera_basis(const float* eye, int eye_batch, const float* at_or_direction, int at_batch, const float* up,
+                     int up_batch, int is_look_at, float* rot_out, int batch_size, d3m_stream_t stream);
+
+/* vertices [Bv,V,3] (Bv = 1 broadcasts one mesh to every view) -> out [B,V,3] in NDC + depth. */
+int d3m_camera_forward(const float* vertices, int vertices_batch, const d3m_camera* cam, float* out,
+                       int batch_size, int num_vertices, d3m_stream_t stream);
+/* grad_vertices [Bv,V,3] = d(out)/d(vertices)^T grad_out; with Bv == 1 the B views are summed. */
+int d3m_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam,
+                        const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
+                        d3m_stream_t stream);
+
+/* vertices_to_faces (neural_renderer/vertices_to_faces.py:16-22) with the fill_back copy made on the
+ * fly (renderer.py:86): faces_out [B,F',3,3], F' = 2F if fill_back else F; face F+f is face f with
+ * vertex order reversed.  tri [Bt,F,3] i32, Bt = 1 or B. */
+int d3m_gather_faces(const float* vertices, const int32_t* tri, int tri_batch, float* faces_out,
+                     int batch_size, int num_vertices, int num_tri, int fill_back, d3m_stream_t stream);
+/* Its backward: the per-vertex scatter-add.  grad_vertices [B,V,3] += ; wave-level pre-reduction of
+ * lanes that hit the same vertex, then float atomics. */
+int d3m_scatter_face_grads(const float* grad_faces, const int32_t* tri, int tri_batch, float* grad_vertices,
+                           int batch_size, int num_vertices, int num_tri, int fill_back,
+                           d3m_stream_t stream);
+
+/* lighting (neural_renderer/lighting.py:33-56): light = ia*ca + id*cd*relu(normal . direction) per face,
+ * normal = normalise(cross(v0-v1, v2-v1)) with F.normalize's eps 1e-5, on WORLD-space faces
+ * (renderer.py:159); textures_out = textures_in * light (may alias for the reference's in-place form).
+ *   faces [N,3,3], textures [N,ts,ts,ts,3] with N = num_faces_total (= B*F'); the three colour /
+ *   direction vectors are HOST arrays of 3 floats. */
+int d3m_lighting_forward(const float* faces, const float* textures_in, float* textures_out,
+                         float intensity_ambient, float intensity_directional, const float* color_ambient,
+                         const float* color_directional, const float* direction, long num_faces_total,
+                         int texture_size, d3m_stream_t stream);
+/* grad_textures [N,ts,ts,ts,3] = grad_out*light (NULL to skip); grad_faces [N,3,3] = gradient through
+ * the face normal (NULL to skip; written, not accumulated). */
+int d3m_lighting_backward(const float* faces, const float* textures_in, const float* grad_out,
+                          float* grad_textures, float* grad_faces, float intensity_ambient,
+                          float intensity_directional, const float* color_ambient, const float* color_directional,
+                          const float* direction, long num_faces_total, int texture_size, d3m_stream_t stream);
+
+/* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
+ * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.
+ *   in : face_index_map [B,S,S], rgb_map [B,S,S,3] (sampled, NOT yet blended; NULL if !rgb),
+ *        depth_map [B,S,S] (NULL if !depth); background [Bb,3] device, Bb = 1 or B.
+ *   out: rgb_out [B,3,s,s], alpha_out [B,s,s], depth_out [B,s,s]  (s = S/2 if anti_aliasing else S);
+ *        rgb_blended [B,S,S,3] and alpha_map [B,S,S] are the internal-resolution maps the backward
+ *        needs (either may be NULL when the mode does not use it). */
+int d3m_output_epilogue(const int32_t* face_index_map, const float* rgb_map, const float* depth_map,
+                        const float* background, int background_batch, float* rgb_blended, float* alpha_map,
+                        float* rgb_out, float* alpha_out, float* depth_out, int batch_size, int image_size,
+                        int anti_aliasing, d3m_stream_t stream);
+/* Its adjoint: output-resolution grads -> internal maps grad_rgb_map [B,S,S,3], grad_alpha_map [B,S,S],
+ * grad_depth_map [B,S,S] (un-pool, un-flip, CHW->HWC).  No coverage mask is applied: the reference
+ * blends the background inside RasterizeFunction.forward, so its backward kernels receive the
+ * gradient wrt the blended image at every pixel (rasterize.py:83,141-147).  NULL pairs are skipped. */
+int d3m_output_epilogue_backward(const float* grad_rgb_out, const float* grad_alpha_out,
+                                 const float* grad_depth_out, float* grad_rgb_map, float* grad_alpha_map,
+                                 float* grad_depth_map, int batch_size, int image_size, int anti_aliasing,
+                                 d3m_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * C. Losses on the path (deep3dmap/core/utils/utils.py:82-114; examples/example2.py:43-47).
+ *    Each writes ONE f32 to `loss` (device) and, if grad_* != NULL, the gradient for d(loss) = 1.
+ * ---------------------------------------------------------------------------------------------- */
+/* photometric_loss(im1, im2, mask, conf_sigma): im [B,C,H,W]; mask/conf_sigma [B,1,H,W] or NULL.
+ * scratch: 3 floats of device memory, zero-initialised by the call itself. */
+int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, const float* conf_sigma,
+                         float* loss, float* grad_im1, float* scratch, int batch_size, int channels,
+                         int height, int width, d3m_stream_t stream);
+/* sum((a-b)^2) over n elements (silhouette loss of the examples). */
+int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, long n,
+                          d3m_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D3M_RASTER_H */

@@ -1,0 +1,130 @@
+"""GPU parity tests of the five drop-in operators (section A of include/d3m_raster.h), called through
+the C ABI, against the committed golden vectors (= the reference's kernels) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_case
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["rand_b2_f24_s32_ts2", "rand_b1_f64_s64_ts4", "rand_b3_f12_s16_ts1", "nearfar_b1_f32_s32",
+         "ties_zero_batch_b2_f32_s32", "fillback_small_b2_f80_s48", "grid_on_pixel_centres_b1_f128_s32"]
+
+# Tolerances.  north_star: 1e-4 on depth/barycentrics, 1e-3 on backward gradients.  The forward is
+# built to be bit-identical (same f32 operations, no FMA contraction), so it is held to exact equality
+# on indices and 1e-6 on floats; gradients are float-atomic / re-associated sums.
+FWD_ATOL = 1e-6
+GRAD_RTOL = 1e-3
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _grad_close(got, ref):
+    scale = max(1.0, float(np.abs(ref).max()))
+    return np.abs(got - ref).max() <= GRAD_RTOL * scale
+
+
+def _forward(c):
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    faces, tex = _dev(c["faces"]), _dev(c["textures"])
+    B, F = faces.shape[:2]
+    S = int(c["image_size"])
+    fi = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
+    wm = torch.zeros(B, S, S, 3, device="cuda")
+    dm = torch.full((B, S, S), float(c["far"]), device="cuda")
+    fim = torch.zeros(B, S, S, 3, 3, device="cuda")
+    finv = torch.zeros_like(faces)
+    ops.forward_face_index_map(faces, fi, wm, dm, fim, finv, S, float(c["near"]), float(c["far"]), 1, 1, 1)
+    rgb = torch.zeros(B, S, S, 3, device="cuda")
+    si = torch.zeros(B, S, S, 8, dtype=torch.int32, device="cuda")
+    sw = torch.zeros(B, S, S, 8, device="cuda")
+    ops.forward_texture_sampling(faces, tex, fi, wm, dm, rgb, si, sw, S, float(c["eps"]))
+    return dict(faces=faces, textures=tex, face_index_map=fi, weight_map=wm, depth_map=dm, face_inv_map=fim,
+                faces_inv=finv, rgb_sampled=rgb, sampling_index_map=si, sampling_weight_map=sw)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_ops_match_reference_vectors(golden, name):
+    c = golden_case(golden, name)
+    m = _forward(c)
+    assert np.array_equal(m["face_index_map"].cpu().numpy(), c["face_index_map"])
+    assert np.array_equal(m["sampling_index_map"].cpu().numpy(), c["sampling_index_map"])
+    for key in ("weight_map", "depth_map", "face_inv_map", "faces_inv", "sampling_weight_map"):
+        got, ref = m[key].cpu().numpy(), c[key]
+        assert np.allclose(got, ref, rtol=0, atol=FWD_ATOL, equal_nan=True), (key, np.nanmax(np.abs(got - ref)))
+    # the golden rgb_map is after the background blend; compare covered pixels only
+    cov = c["face_index_map"] >= 0
+    assert np.allclose(m["rgb_sampled"].cpu().numpy()[cov], c["rgb_map"][cov], rtol=0, atol=FWD_ATOL)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_backward_ops_match_reference_vectors(golden, name):
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    c = golden_case(golden, name)
+    m = _forward(c)
+    S = int(c["image_size"])
+    rgb, alpha = _dev(c["rgb_map"]), _dev(c["alpha_map"])
+    g_rgb, g_alpha, g_depth = _dev(c["grad_rgb_map"]), _dev(c["grad_alpha_map"]), _dev(c["grad_depth_map"])
+    eps = float(c["eps"])
+    # K4 alone, rgb + alpha
+    gf = torch.zeros_like(m["faces"])
+    ops.backward_pixel_map(m["faces"], m["face_index_map"], rgb, alpha, g_rgb, g_alpha, gf, S, eps, 1, 1)
+    assert _grad_close(gf.cpu().numpy(), c["grad_faces_pixel_rgba"])
+    # K4 alone, alpha only (rgb tensors are 1-element dummies as in rasterize.py:59)
+    gf = torch.zeros_like(m["faces"])
+    dummy = torch.zeros(1, device="cuda")
+    ops.backward_pixel_map(m["faces"], m["face_index_map"], dummy, alpha, dummy, g_alpha, gf, S, eps, 0, 1)
+    assert _grad_close(gf.cpu().numpy(), c["grad_faces_pixel_alpha"])
+    # K6 alone, with the stored face_inv_map and with it recomputed
+    for fim in (m["face_inv_map"], dummy):
+        gf = torch.zeros_like(m["faces"])
+        ops.backward_depth_map(m["faces"], m["depth_map"], m["face_index_map"], fim, m["weight_map"], g_depth, gf, S)
+        assert _grad_close(gf.cpu().numpy(), c["grad_faces_depth"])
+    # composed order K4 -> K5 -> K6 (rasterize.py:141-151)
+    gf = torch.zeros_like(m["faces"])
+    gt = torch.zeros_like(m["textures"])
+    ops.backward_pixel_map(m["faces"], m["face_index_map"], rgb, alpha, g_rgb, g_alpha, gf, S, eps, 1, 1)
+    ops.backward_textures(m["face_index_map"], m["sampling_weight_map"], m["sampling_index_map"], g_rgb, gt,
+                          m["faces"].shape[1])
+    ops.backward_depth_map(m["faces"], m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
+                           g_depth, gf, S)
+    assert _grad_close(gf.cpu().numpy(), c["grad_faces_all"])
+    assert _grad_close(gt.cpu().numpy(), c["grad_textures"])
+
+
+def test_ops_reject_cpu_and_noncontiguous_tensors():
+    """rasterize_cuda.cpp:66-68: CHECK_CUDA / CHECK_CONTIGUOUS raise RuntimeError."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    f = torch.zeros(1, 2, 3, 3)
+    with pytest.raises(RuntimeError):
+        ops.forward_face_index_map(f, f, f, f, f, f, 8, 0.1, 100.0, 0, 0, 0)
+    fc = torch.zeros(1, 2, 3, 6, device="cuda")[..., ::2]
+    with pytest.raises(RuntimeError):
+        ops.forward_face_index_map(fc, fc, fc, fc, fc, fc, 8, 0.1, 100.0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("S,F,size", [(64, 500, 0.05), (100, 300, 0.3), (37, 64, 1.5)])
+def test_forward_equals_oracle_bruteforce_on_random_scenes(S, F, size):
+    """Binned tile raster vs the oracle's brute-force loop: tiny, medium and screen-filling triangles,
+    image sizes that are not multiples of the 8-pixel tile."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    rng = np.random.default_rng(S * 1000 + F)
+    B = 2
+    xy = rng.uniform(-1.2, 1.2, (B, F, 1, 2)) + rng.uniform(-size, size, (B, F, 3, 2))
+    faces = np.concatenate([xy, rng.uniform(0.3, 4.0, (B, F, 3, 1))], -1).astype(np.float32)
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()             # fill_back pairs
+    ref = O.raster_forward(faces, None, S, 0.5, 3.5, 1e-3, None, False, True, True)
+    fd = _dev(faces)
+    fi = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
+    wm = torch.zeros(B, S, S, 3, device="cuda")
+    dm = torch.full((B, S, S), 3.5, device="cuda")
+    fim = torch.zeros(B, S, S, 3, 3, device="cuda")
+    ops.forward_face_index_map(fd, fi, wm, dm, fim, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
+    assert np.array_equal(fi.cpu().numpy(), ref["face_index_map"])
+    assert np.array_equal(wm.cpu().numpy(), ref["weight_map"])
+    assert np.array_equal(dm.cpu().numpy(), ref["depth_map"])
+    assert np.array_equal(fim.cpu().numpy(), ref["face_inv_map"])
