@@ -1,0 +1,159 @@
+"""Camera / viewpoint transforms of neural_renderer, each a single HIP pass with an analytic adjoint
+(d3m_camera_forward / d3m_camera_backward in include/d3m_raster.h).
+
+Reference (NR = pnpmodules/neural_renderer/neural_renderer): NR/look_at.py:6-62, NR/look.py:6-53,
+NR/perspective.py:6-21, NR/projection.py:6-43, NR/get_points_from_angles.py:6-24.
+"""
+import ctypes
+import math
+
+import torch
+
+from .. import _lib
+from ._util import as_device_f32, const_tensor, f32c
+
+
+class _CameraFunction(torch.autograd.Function):
+    """vertices [Bv,V,3] -> [B,V,3].  `params` is a dict of plain values / device tensors; gradients
+    flow to the vertices only (camera parameters are treated as constants)."""
+
+    @staticmethod
+    def forward(ctx, vertices, params):
+        v = f32c(vertices)
+        B = params["batch"]
+        cam, keep = _camera_struct(params, v.device)
+        out = torch.empty(B, v.shape[1], 3, dtype=torch.float32, device=v.device)
+        rc = _lib.lib().d3m_camera_forward(_lib.ptr(v), v.shape[0], ctypes.byref(cam), _lib.ptr(out), B, v.shape[1],
+                                           _lib.stream_ptr())
+        _lib.check(rc, "d3m_camera_forward")
+        ctx.save_for_backward(v)
+        ctx.params, ctx.keep = params, keep
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (v,) = ctx.saved_tensors
+        params = ctx.params
+        g = f32c(grad_out)
+        cam, keep = _camera_struct(params, v.device)
+        gv = torch.empty_like(v)
+        rc = _lib.lib().d3m_camera_backward(_lib.ptr(v), v.shape[0], ctypes.byref(cam), _lib.ptr(g), _lib.ptr(gv),
+                                            params["batch"], v.shape[1], _lib.stream_ptr())
+        _lib.check(rc, "d3m_camera_backward")
+        return gv, None
+
+
+def _camera_struct(p, device):
+    cam = _lib.D3MCamera()
+    cam.mode = p["mode"]
+    cam.perspective = int(bool(p.get("perspective", False)))
+    cam.tan_half_width = float(p.get("width", 1.0))
+    cam.orig_size = float(p.get("orig_size", 1.0))
+    keep = []
+    for field, key in (("rot", "rot"), ("eye_or_t", "eye_or_t"), ("K", "K"), ("dist", "dist")):
+        t = p.get(key)
+        if t is not None:
+            keep.append(t)
+            setattr(cam, field, t.data_ptr())
+            setattr(cam, field + "_batch" if field != "eye_or_t" else "eye_batch", t.shape[0])
+    return cam, keep
+
+
+def _no_grad_param(t, name):
+    if torch.is_tensor(t) and t.requires_grad:
+        raise NotImplementedError(f"gradient with respect to the camera parameter `{name}` is not implemented in "
+                                  "the HIP path (DESIGN.md, 'Out of scope this round')")
+
+
+def _tan_width(angle):
+    # perspective.py:15-17: the angle is rounded to f32 before tan
+    return float(torch.tan(torch.tensor(angle / 180 * math.pi, dtype=torch.float32)))
+
+
+def _basis(eye, at_or_dir, up, is_look_at, batch, device):
+    """rows (x, y, z) of the camera frame, computed on the device (d3m_camera_basis)."""
+    rot = torch.empty(batch, 3, 3, dtype=torch.float32, device=device)
+    rc = _lib.lib().d3m_camera_basis(_lib.ptr(eye), eye.shape[0], _lib.ptr(at_or_dir), at_or_dir.shape[0],
+                                     _lib.ptr(up), up.shape[0], int(is_look_at), _lib.ptr(rot), batch,
+                                     _lib.stream_ptr())
+    _lib.check(rc, "d3m_camera_basis")
+    return rot
+
+
+def _vec_param(x, device):
+    t = as_device_f32(x, device)
+    return t[None, :].contiguous() if t.dim() == 1 else t
+
+
+def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
+    """"Look at" transformation of vertices (NR/look_at.py:6-62).
+    `eye`, `at`, `up`: list / tuple / ndarray / tensor of shape [3] or [batch, 3]."""
+    if vertices.ndimension() != 3:
+        raise ValueError('vertices Tensor should have 3 dimensions')
+    _no_grad_param(eye, "eye")
+    device = vertices.device
+    B = vertices.shape[0]
+    eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
+    nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
+    rot = _basis(eye_t, at_t, up_t, True, nb, device)
+    params = dict(mode=_lib.CAMERA_LOOK_AT, batch=B, rot=rot, eye_or_t=eye_t,
+                  perspective=_perspective_angle is not None,
+                  width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+    return _CameraFunction.apply(vertices, params)
+
+
+def look(vertices, eye, direction=[0, 1, 0], up=None, _perspective_angle=None):
+    """"Look" transformation of vertices (NR/look.py:6-53); `up` defaults to [0, 1, 0]."""
+    if vertices.ndimension() != 3:
+        raise ValueError('vertices Tensor should have 3 dimensions')
+    _no_grad_param(eye, "eye")
+    device = vertices.device
+    B = vertices.shape[0]
+    eye_t, dir_t = _vec_param(eye, device), _vec_param(direction, device)
+    up_t = _vec_param([0, 1, 0] if up is None else up, device)
+    nb = max(eye_t.shape[0], dir_t.shape[0], up_t.shape[0])
+    rot = _basis(eye_t, dir_t, up_t, False, nb, device)
+    params = dict(mode=_lib.CAMERA_LOOK, batch=B, rot=rot, eye_or_t=eye_t,
+                  perspective=_perspective_angle is not None,
+                  width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+    return _CameraFunction.apply(vertices, params)
+
+
+def perspective(vertices, angle=30.):
+    """Perspective distortion x,y /= z*tan(angle) (NR/perspective.py:6-21)."""
+    if vertices.ndimension() != 3:
+        raise ValueError('vertices Tensor should have 3 dimensions')
+    device = vertices.device
+    params = dict(mode=_lib.CAMERA_LOOK_AT, batch=vertices.shape[0],
+                  rot=const_tensor([[1, 0, 0], [0, 1, 0], [0, 0, 1]], device, (1, 3, 3)),
+                  eye_or_t=const_tensor([0, 0, 0], device, (1, 3)), perspective=True, width=_tan_width(angle))
+    return _CameraFunction.apply(vertices, params)
+
+
+def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
+    """Projective transformation with lens distortion (NR/projection.py:6-43).
+    K [b,3,3], R [b,3,3], t [b,1,3] (or [b,3]), dist_coeffs [b,5]; b is 1 or the batch size."""
+    if eps != 1e-9:
+        raise NotImplementedError("projection: only the reference's default eps=1e-9 is supported")
+    for name, p in (("K", K), ("R", R), ("t", t), ("dist_coeffs", dist_coeffs)):
+        _no_grad_param(p, name)
+    device = vertices.device
+    tt = as_device_f32(t, device).reshape(-1, 3)
+    params = dict(mode=_lib.CAMERA_PROJECTION, batch=vertices.shape[0], rot=as_device_f32(R, device).reshape(-1, 3, 3),
+                  eye_or_t=tt, K=as_device_f32(K, device).reshape(-1, 3, 3),
+                  dist=as_device_f32(dist_coeffs, device).reshape(-1, 5), orig_size=float(orig_size))
+    return _CameraFunction.apply(vertices, params)
+
+
+def get_points_from_angles(distance, elevation, azimuth, degrees=True):
+    """Spherical -> cartesian eye position (NR/get_points_from_angles.py:6-24).  Host-side scalar form, or
+    tensor form ([n] tensors -> [n,3])."""
+    if isinstance(distance, (float, int)):
+        if degrees:
+            elevation, azimuth = math.radians(elevation), math.radians(azimuth)
+        return (distance * math.cos(elevation) * math.sin(azimuth), distance * math.sin(elevation),
+                -distance * math.cos(elevation) * math.cos(azimuth))
+    if degrees:
+        elevation, azimuth = math.pi / 180. * elevation, math.pi / 180. * azimuth
+    return torch.stack([distance * torch.cos(elevation) * torch.sin(azimuth), distance * torch.sin(elevation),
+                        -distance * torch.cos(elevation) * torch.cos(azimuth)]).transpose(1, 0)

@@ -1,0 +1,264 @@
+"""Differentiable rasterization: RasterizeFunction / Rasterize / rasterize_rgbad and friends, same
+signatures and semantics as pnpmodules/neural_renderer/neural_renderer/rasterize.py (NR/rasterize.py),
+running on the HIP operators of libd3m_raster.so.  CUDA(=HIP)-device tensors only, like the reference."""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import rasterize_ops as ops
+from ._util import const_tensor, f32c
+
+DEFAULT_IMAGE_SIZE = 256
+DEFAULT_ANTI_ALIASING = True
+DEFAULT_NEAR = 0.1
+DEFAULT_FAR = 100
+DEFAULT_EPS = 1e-4
+DEFAULT_BACKGROUND_COLOR = (0, 0, 0)
+
+
+def _background_tensor(background_color, device):
+    """[1,3] or [B,3] device tensor (NR/rasterize.py:189-194 accepts a colour or one colour per batch entry)."""
+    if background_color is None:
+        background_color = DEFAULT_BACKGROUND_COLOR
+    if torch.is_tensor(background_color):
+        t = background_color.to(device=device, dtype=torch.float32)
+    else:
+        t = const_tensor(background_color, device)
+    return (t[None, :] if t.dim() == 1 else t).contiguous()
+
+
+def _raster_forward(faces, textures, image_size, near, far, eps, background, return_rgb, return_alpha,
+                    return_depth, keep_reference_maps):
+    """Kernels 1+2 (+3), background blend and alpha: the body of NR/rasterize.py:50-84.
+    keep_reference_maps: also materialise the reference's face_inv_map / faces_inv scratch."""
+    dev = faces.device
+    B, F = faces.shape[:2]
+    S = int(image_size)
+    m = {}
+    m["face_index_map"] = torch.full((B, S, S), -1, dtype=torch.int32, device=dev)
+    m["weight_map"] = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
+    m["depth_map"] = torch.full((B, S, S), float(far), dtype=torch.float32, device=dev)
+    dummy = torch.zeros(1, dtype=torch.float32, device=dev)
+    want_finv = return_depth and keep_reference_maps
+    face_inv_map = torch.zeros(B, S, S, 3, 3, dtype=torch.float32, device=dev) if want_finv else dummy
+    faces_inv = torch.zeros_like(faces) if keep_reference_maps else dummy
+    ops.forward_face_index_map(faces, m["face_index_map"], m["weight_map"], m["depth_map"], face_inv_map, faces_inv,
+                               S, near, far, return_rgb, return_alpha, want_finv)
+    m["face_inv_map"] = face_inv_map
+    rgb_sampled = None
+    if return_rgb:
+        rgb_sampled = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
+        m["sampling_index_map"] = torch.zeros(B, S, S, 8, dtype=torch.int32, device=dev)
+        m["sampling_weight_map"] = torch.zeros(B, S, S, 8, dtype=torch.float32, device=dev)
+        ops.forward_texture_sampling(faces, textures, m["face_index_map"], m["weight_map"], m["depth_map"],
+                                     rgb_sampled, m["sampling_index_map"], m["sampling_weight_map"], S, eps)
+    return m, rgb_sampled
+
+
+def _epilogue(m, rgb_sampled, background, B, S, anti_aliasing, return_rgb, return_alpha, return_depth, outputs):
+    """d3m_output_epilogue: blend + alpha at internal resolution and, when `outputs`, the flipped / pooled
+    CHW output images of rasterize_rgbad in the same pass."""
+    dev = m["face_index_map"].device
+    s = S // 2 if anti_aliasing else S
+    m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev) if return_rgb else None
+    m["alpha_map"] = torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None
+    rgb_out = alpha_out = depth_out = None
+    if outputs:
+        rgb_out = torch.empty(B, 3, s, s, dtype=torch.float32, device=dev) if return_rgb else None
+        alpha_out = torch.empty(B, s, s, dtype=torch.float32, device=dev) if return_alpha else None
+        depth_out = torch.empty(B, s, s, dtype=torch.float32, device=dev) if return_depth else None
+    rc = _lib.lib().d3m_output_epilogue(
+        _lib.ptr(m["face_index_map"]), _lib.ptr(rgb_sampled), _lib.ptr(m["depth_map"] if (outputs and return_depth) else None),
+        _lib.ptr(background if return_rgb else None), background.shape[0] if return_rgb else 1,
+        _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(rgb_out), _lib.ptr(alpha_out), _lib.ptr(depth_out),
+        B, S, int(bool(anti_aliasing and outputs)), _lib.stream_ptr())
+    _lib.check(rc, "d3m_output_epilogue")
+    return rgb_out, alpha_out, depth_out
+
+
+def _raster_backward(faces, textures, m, S, eps, grad_rgb_map, grad_alpha_map, grad_depth_map, return_rgb,
+                     return_alpha, return_depth, need_textures_grad):
+    """NR/rasterize.py:109-156: K4 (overwrite) -> K5 -> K6 (add)."""
+    dev = faces.device
+    dummy = torch.zeros(1, dtype=torch.float32, device=dev)
+    grad_faces = torch.zeros_like(faces, dtype=torch.float32)
+    grad_textures = None
+    if return_rgb or return_alpha:
+        ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"] if return_rgb else dummy,
+                               m["alpha_map"] if return_alpha else dummy, grad_rgb_map if return_rgb else dummy,
+                               grad_alpha_map if return_alpha else dummy, grad_faces, S, eps, return_rgb, return_alpha)
+    if return_rgb and need_textures_grad:
+        grad_textures = torch.zeros_like(textures, dtype=torch.float32)
+        ops.backward_textures(m["face_index_map"], m["sampling_weight_map"], m["sampling_index_map"], grad_rgb_map,
+                              grad_textures, faces.shape[1])
+    if return_depth:
+        ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
+                               grad_depth_map, grad_faces, S)
+    return grad_faces, grad_textures
+
+
+class RasterizeFunction(torch.autograd.Function):
+    '''
+    Definition of differentiable rasterize operation (NR/rasterize.py:15-226): internal-resolution maps,
+    row 0 = bottom of the image.  Returns (rgb_map [B,S,S,3], alpha_map [B,S,S], depth_map [B,S,S]);
+    disabled outputs are empty tensors.
+    '''
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, near, far, eps, background_color,
+                return_rgb=False, return_alpha=False, return_depth=False):
+        faces = f32c(faces)
+        if return_rgb:
+            textures = f32c(textures)
+        dev = faces.device
+        B = faces.shape[0]
+        S = int(image_size)
+        background = _background_tensor(background_color, dev) if return_rgb else None
+        m, rgb_sampled = _raster_forward(faces, textures if return_rgb else None, S, float(near), float(far), float(eps),
+                                         background, return_rgb, return_alpha, return_depth, True)
+        if return_rgb or return_alpha:
+            _epilogue(m, rgb_sampled, background, B, S, False, return_rgb, return_alpha, return_depth, False)
+        ctx.cfg = (S, float(eps), bool(return_rgb), bool(return_alpha), bool(return_depth))
+        ctx.maps = m
+        ctx.save_for_backward(faces, textures if return_rgb else None)
+        ctx.tex_needs_grad = bool(return_rgb and ctx.needs_input_grad[1])
+        rgb_r = m["rgb_map"] if return_rgb else torch.tensor([])
+        alpha_r = m["alpha_map"].clone() if return_alpha else torch.tensor([])
+        depth_r = m["depth_map"].clone() if return_depth else torch.tensor([])
+        return rgb_r, alpha_r, depth_r
+
+    @staticmethod
+    def backward(ctx, grad_rgb_map, grad_alpha_map, grad_depth_map):
+        faces, textures = ctx.saved_tensors
+        S, eps, rr, ra, rd = ctx.cfg
+        g_rgb = f32c(grad_rgb_map) if rr else None
+        g_alpha = f32c(grad_alpha_map) if ra else None
+        g_depth = f32c(grad_depth_map) if rd else None
+        gf, gt = _raster_backward(faces, textures, ctx.maps, S, eps, g_rgb, g_alpha, g_depth, rr, ra, rd,
+                                  ctx.tex_needs_grad)
+        return gf, gt, None, None, None, None, None, None, None, None
+
+
+class Rasterize(nn.Module):
+    '''
+    Wrapper around the autograd function RasterizeFunction (NR/rasterize.py:228-251).
+    '''
+    def __init__(self, image_size, near, far, eps, background_color,
+                 return_rgb=False, return_alpha=False, return_depth=False):
+        super(Rasterize, self).__init__()
+        self.image_size = image_size
+        self.near = near
+        self.far = far
+        self.eps = eps
+        self.background_color = background_color
+        self.return_rgb = return_rgb
+        self.return_alpha = return_alpha
+        self.return_depth = return_depth
+
+    def forward(self, faces, textures):
+        if not faces.is_cuda or (textures is not None and not textures.is_cuda):
+            raise TypeError('Rasterize module supports only cuda Tensors')
+        return RasterizeFunction.apply(faces, textures, self.image_size, self.near, self.far,
+                                       self.eps, self.background_color,
+                                       self.return_rgb, self.return_alpha, self.return_depth)
+
+
+class _RasterizeImages(torch.autograd.Function):
+    """rasterize_rgbad in one autograd node: RasterizeFunction + vertical flip + CHW + 2x2 pooling
+    (NR/rasterize.py:297-326), with the epilogue and its adjoint as single kernels."""
+
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, anti_aliasing, near, far, eps, background_color, return_rgb,
+                return_alpha, return_depth):
+        faces = f32c(faces)
+        if return_rgb:
+            textures = f32c(textures)
+        dev = faces.device
+        B = faces.shape[0]
+        S = int(image_size) * 2 if anti_aliasing else int(image_size)
+        background = _background_tensor(background_color, dev) if return_rgb else None
+        m, rgb_sampled = _raster_forward(faces, textures if return_rgb else None, S, float(near), float(far), float(eps),
+                                         background, return_rgb, return_alpha, return_depth, False)
+        rgb, alpha, depth = _epilogue(m, rgb_sampled, background, B, S, anti_aliasing, return_rgb, return_alpha,
+                                      return_depth, True)
+        ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_rgb), bool(return_alpha), bool(return_depth))
+        ctx.maps = m
+        ctx.save_for_backward(faces, textures if return_rgb else None)
+        ctx.tex_needs_grad = bool(return_rgb and ctx.needs_input_grad[1])
+        empty = torch.tensor([])
+        return (rgb if return_rgb else empty, alpha if return_alpha else empty, depth if return_depth else empty)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth):
+        faces, textures = ctx.saved_tensors
+        S, eps, aa, rr, ra, rd = ctx.cfg
+        dev, B = faces.device, faces.shape[0]
+        g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev) if rr else None
+        g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
+        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
+        rc = _lib.lib().d3m_output_epilogue_backward(
+            _lib.ptr(f32c(g_rgb) if rr else None), _lib.ptr(f32c(g_alpha) if ra else None),
+            _lib.ptr(f32c(g_depth) if rd else None), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map),
+            B, S, int(aa), _lib.stream_ptr())
+        _lib.check(rc, "d3m_output_epilogue_backward")
+        gf, gt = _raster_backward(faces, textures, ctx.maps, S, eps, g_rgb_map, g_alpha_map, g_depth_map, rr, ra, rd,
+                                  ctx.tex_needs_grad)
+        return (gf, gt) + (None,) * 9
+
+
+def rasterize_rgbad(
+        faces,
+        textures=None,
+        image_size=DEFAULT_IMAGE_SIZE,
+        anti_aliasing=DEFAULT_ANTI_ALIASING,
+        near=DEFAULT_NEAR,
+        far=DEFAULT_FAR,
+        eps=DEFAULT_EPS,
+        background_color=DEFAULT_BACKGROUND_COLOR,
+        return_rgb=True,
+        return_alpha=True,
+        return_depth=True,
+):
+    """
+    Generate RGB, alpha channel, and depth images from faces and textures (NR/rasterize.py:253-334).
+
+    Args:
+        faces (torch.Tensor): [batch size, number of faces, 3 (vertices), 3 (XYZ)].
+        textures (torch.Tensor): [batch size, number of faces, ts, ts, ts, 3 (RGB)].
+        image_size (int): width and height of rendered images.
+        anti_aliasing (bool): 2x super-sampling.
+        near, far (float): depth range that is drawn.
+        eps (float): epsilon of the approximate edge gradient.
+        background_color: colour (3) or one colour per batch entry (B, 3).
+
+    Returns:
+        dict: 'rgb' [B,3,s,s], 'alpha' [B,s,s], 'depth' [B,s,s] (None for disabled outputs); row 0 is the
+        TOP of the image.
+    """
+    if not faces.is_cuda or (textures is not None and not textures.is_cuda):
+        raise TypeError('Rasterize module supports only cuda Tensors')
+    rgb, alpha, depth = _RasterizeImages.apply(faces, textures, image_size, anti_aliasing, near, far, eps,
+                                               background_color, return_rgb, return_alpha, return_depth)
+    return {
+        'rgb': rgb if return_rgb else None,
+        'alpha': alpha if return_alpha else None,
+        'depth': depth if return_depth else None,
+    }
+
+
+def rasterize(faces, textures, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING,
+              near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR):
+    """RGB images [B,3,s,s] (NR/rasterize.py:367-394)."""
+    return rasterize_rgbad(
+        faces, textures, image_size, anti_aliasing, near, far, eps, background_color, True, False, False)['rgb']
+
+
+def rasterize_silhouettes(faces, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING,
+                          near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS):
+    """Alpha channels [B,s,s] (NR/rasterize.py:397-420)."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, True, False)['alpha']
+
+
+def rasterize_depth(faces, image_size=DEFAULT_IMAGE_SIZE, anti_aliasing=DEFAULT_ANTI_ALIASING,
+                    near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS):
+    """Depth images [B,s,s] (NR/rasterize.py:423-446)."""
+    return rasterize_rgbad(faces, None, image_size, anti_aliasing, near, far, eps, None, False, False, True)['depth']

@@ -1,0 +1,128 @@
+"""`Renderer`: the nn.Module deep3dmap drives (pnpmodules/neural_renderer/neural_renderer/renderer.py:11-246),
+same constructor, attributes (plain, mutable, read at call time) and render_* methods."""
+from __future__ import division
+
+import math
+
+import numpy
+import torch
+import torch.nn as nn
+
+from . import cameras, mesh_ops
+from .rasterize import rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes
+
+
+class Renderer(nn.Module):
+    def __init__(self, image_size=256, anti_aliasing=True, background_color=[0, 0, 0],
+                 fill_back=True, camera_mode='projection',
+                 K=None, R=None, t=None, dist_coeffs=None, orig_size=1024,
+                 perspective=True, viewing_angle=30, camera_direction=[0, 0, 1],
+                 near=0.1, far=100,
+                 light_intensity_ambient=0.5, light_intensity_directional=0.5,
+                 light_color_ambient=[1, 1, 1], light_color_directional=[1, 1, 1],
+                 light_direction=[0, 1, 0]):
+        super(Renderer, self).__init__()
+        # rendering
+        self.image_size = image_size
+        self.anti_aliasing = anti_aliasing
+        self.background_color = background_color
+        self.fill_back = fill_back
+
+        # camera
+        self.camera_mode = camera_mode
+        if self.camera_mode == 'projection':
+            as_dev = lambda a: torch.as_tensor(a, dtype=torch.float32).cuda() if isinstance(a, numpy.ndarray) else a
+            self.K, self.R, self.t = as_dev(K), as_dev(R), as_dev(t)
+            self.dist_coeffs = dist_coeffs
+            if dist_coeffs is None:
+                self.dist_coeffs = torch.zeros(1, 5, dtype=torch.float32).cuda()
+            self.orig_size = orig_size
+        elif self.camera_mode in ['look', 'look_at']:
+            self.perspective = perspective
+            self.viewing_angle = viewing_angle
+            self.eye = [0, 0, -(1. / math.tan(math.radians(self.viewing_angle)) + 1)]
+            self.camera_direction = [0, 0, 1]
+        else:
+            raise ValueError('Camera mode has to be one of projection, look or look_at')
+
+        self.near = near
+        self.far = far
+
+        # light
+        self.light_intensity_ambient = light_intensity_ambient
+        self.light_intensity_directional = light_intensity_directional
+        self.light_color_ambient = light_color_ambient
+        self.light_color_directional = light_color_directional
+        self.light_direction = light_direction
+
+        # rasterization
+        self.rasterizer_eps = 1e-3
+
+    def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
+                orig_size=None):
+        '''
+        mode: None -> render (rgb, depth, alpha); 'rgb'; 'silhouettes'; 'depth'  (NR/renderer.py:65-80)
+        '''
+        if mode is None:
+            return self.render(vertices, faces, textures, K, R, t, dist_coeffs, orig_size)
+        elif mode == 'rgb':
+            return self.render_rgb(vertices, faces, textures, K, R, t, dist_coeffs, orig_size)
+        elif mode == 'silhouettes':
+            return self.render_silhouettes(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        elif mode == 'depth':
+            return self.render_depth(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        else:
+            raise ValueError("mode should be one of None, 'silhouettes' or 'depth'")
+
+    # ---- the stages shared by the four render methods -------------------------------------------------
+    def _transform(self, vertices, K, R, t, dist_coeffs, orig_size):
+        """viewpoint transformation, NR/renderer.py:88-112; any other camera_mode leaves the vertices alone
+        (the reference's tests rely on that: tests/test_rasterize_depth.py:67)."""
+        if self.camera_mode == 'look_at':
+            return cameras.look_at(vertices, self.eye,
+                                   _perspective_angle=self.viewing_angle if self.perspective else None)
+        if self.camera_mode == 'look':
+            return cameras.look(vertices, self.eye, self.camera_direction,
+                                _perspective_angle=self.viewing_angle if self.perspective else None)
+        if self.camera_mode == 'projection':
+            return cameras.projection(vertices, self.K if K is None else K, self.R if R is None else R,
+                                      self.t if t is None else t,
+                                      self.dist_coeffs if dist_coeffs is None else dist_coeffs,
+                                      self.orig_size if orig_size is None else orig_size)
+        return vertices
+
+    def _lit_textures(self, vertices, faces, textures):
+        """fill_back of the textures (NR/renderer.py:156) + lighting on world-space faces (:159-167)."""
+        if self.fill_back:
+            textures = torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)
+        faces_lighting = mesh_ops.gather_faces(vertices, faces, self.fill_back)
+        return mesh_ops.lighting(faces_lighting, textures, self.light_intensity_ambient,
+                                 self.light_intensity_directional, self.light_color_ambient,
+                                 self.light_color_directional, self.light_direction)
+
+    def _screen_faces(self, vertices, faces, K, R, t, dist_coeffs, orig_size):
+        vertices = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+        return mesh_ops.gather_faces(vertices, faces, self.fill_back)
+
+    # ---- public render methods ------------------------------------------------------------------------
+    def render_silhouettes(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        # rasterizer defaults, not self.near / self.far (NR/renderer.py:114)
+        return rasterize_silhouettes(f, self.image_size, self.anti_aliasing)
+
+    def render_depth(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        return rasterize_depth(f, self.image_size, self.anti_aliasing)          # NR/renderer.py:149
+
+    def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        textures = self._lit_textures(vertices, faces, textures)
+        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
+                              self.rasterizer_eps, self.background_color)
+
+    def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        textures = self._lit_textures(vertices, faces, textures)
+        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        out = rasterize_rgbad(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
+                                   self.rasterizer_eps, self.background_color)
+        return out['rgb'], out['depth'], out['alpha']
