@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered Mpix/s (forward + backward) of the multi-view fit on a 100k-triangle mesh at
+512x512 (BASELINE.json metric), one rank per GPU, camera-sharded (weak scaling: 8 views per GPU).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = render (rgb+depth+alpha) of this rank's views of the shared mesh, the loss against fixed
+targets, the backward to per-vertex / per-texel gradients and (N > 1) one RCCL all-reduce of them.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def algorithmic_bytes(V, F, S, s, ts, alpha=1, depth=1, rgb=1, tex_grad=1):
+    """compulsory HBM bytes per view, forward and backward."""
+    P, Po = S * S, s * s
+    T = F * ts ** 3 * 12 if rgb else 0
+    Tg = T if tex_grad else 0
+    a_fwd = 12 * V + 12 * F + T + 20 * P + Po * (4 * alpha + 4 * depth + 12 * rgb)
+    a_bwd = (Po * (4 * alpha + 4 * depth + 12 * rgb) + 20 * P + P * (4 * alpha + 12 * rgb) * (1 if (alpha or rgb) else 0)
+             + 12 * V + 12 * F + 12 * V + Tg)
+    return a_fwd, a_bwd
+
+
+# Per-kernel share of that byte count (DESIGN.md "Kernels and their rooflines"): bytes per view.
+def kernel_bytes(name, V, F, S, ts):
+    P = S * S
+    table = {
+        # reads faces of both windings' gather (verts+indices), writes the 20 B/px saved maps
+        "k_raster_tiles": 12 * V + 12 * F + 20 * P,
+        "k_bin_count": 12 * V + 12 * F,
+        "k_bin_fill": 12 * F,
+        "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
+        # edge gradient: face_index + alpha + rgb maps + their grads, verts+indices, writes x,y grads
+        "k_backward_pixel_map": P * (4 + 4 + 12) + P * (4 + 12) + 12 * V + 12 * F + 12 * V,
+        "k_backward_textures": P * (4 + 12) + F * ts ** 3 * 12,
+        "k_backward_depth_map": P * (20 + 4) + 12 * V + 12 * F + 12 * V,
+    }
+    return table.get(name)
+
+
+def cpu_baseline(n, image_size, ts, budget_s=25.0):
+    """The oracle (this repo's C restatement of the reference algorithm, 'port') timed on the host cores
+    on ONE view of the same workload: bounding-box forward + texture sampling + the three backward kernels."""
+    from deep3dmap_amd import synthetic
+    from oracle import nr_oracle as O
+    v, tri = synthetic.grid_mesh(n)
+    tex = synthetic.random_textures(tri.shape[0], ts)
+    eye = synthetic.camera_ring(8)[1]
+    O.OracleRasterizeFunction.backend, O.OracleRasterizeFunction.bbox = "port", True
+    r = O.Renderer(camera_mode="look_at", image_size=image_size, anti_aliasing=False)
+    r.eye = [float(x) for x in eye]
+    vt, trit, text = torch.from_numpy(v)[None], torch.from_numpy(tri)[None], torch.from_numpy(tex)[None]
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and time.perf_counter() - t_all < budget_s:
+        vv = vt.clone().requires_grad_(True)
+        tt = text.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        rgb, depth, alpha = r(vv, trit, tt)
+        (rgb.sum() + alpha.sum() + depth.sum()).backward()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(image_size * image_size / best / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(),
+            "kind": "port",
+            "sample": f"1 view of the same mesh @ {image_size}x{image_size}, render+backward, best of {len(times)} "
+                      f"({best:.2f} s each), OpenMP over {O.num_threads()} threads, per-face bounding-box forward"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views-per-gpu", type=int, default=8)
+    ap.add_argument("--mesh-n", type=int, default=225, help="grid_mesh(n): 225 -> 100,352 triangles")
+    ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--texture-size", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from deep3dmap_amd import _lib, synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+
+    n_views = args.views_per_gpu * world
+    v, tri = synthetic.grid_mesh(args.mesh_n)
+    tex = synthetic.random_textures(tri.shape[0], args.texture_size)
+    eyes = synthetic.camera_ring(n_views)
+    fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
+                       world_size=world, device=f"cuda:{local_rank}")
+    fit.set_targets_from(synthetic.perturb(v))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fit.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, gv, gt = fit.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
+
+    # instrumented pass (not part of `value`): per-kernel HIP-event durations on the launch stream
+    _lib.kernel_timing(True)
+    n_inst = max(3, min(args.steps, 10))
+    for _ in range(n_inst):
+        fit.step()
+    ktimes = _lib.collect_kernel_times()
+    _lib.kernel_timing(False)
+
+    if rank == 0:
+        V, F, S, ts = v.shape[0], tri.shape[0], args.image_size, args.texture_size
+        ms_per_step = elapsed / args.steps * 1e3
+        pix = n_views * S * S
+        value = pix / (elapsed / args.steps) / 1e6
+        a_fwd, a_bwd = algorithmic_bytes(V, F, S, S, ts)
+        step_bytes = (a_fwd + a_bwd) * args.views_per_gpu
+        # dominant kernel = largest summed duration in the instrumented pass
+        per_kernel = {k: (c, ms) for k, (c, ms) in ktimes.items()}
+        dom = max(per_kernel, key=lambda k: per_kernel[k][1])
+        dom_count, dom_ms = per_kernel[dom]
+        dom_avg_s = dom_ms / dom_count / 1e3
+        kb = kernel_bytes(dom, V, F, S, ts)
+        roof = None
+        if kb is not None:
+            ach = kb * args.views_per_gpu / dom_avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_count / n_inst,
+                    "algorithmic_bytes_per_launch": kb * args.views_per_gpu}
+        out = {
+            "metric": "rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512", "value": round(value, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
+                                   f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "
+                                   f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
+                                   + (", RCCL all-reduce of grads" if world > 1 else ""),
+                       "views_per_gpu": args.views_per_gpu, "triangles": int(F), "image_size": S,
+                       "texture_size": ts, "fill_back": True, "anti_aliasing": False,
+                       "parallelism": f"camera-sharded x{world}"},
+            "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
+            "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.mesh_n, S, ts)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,8 @@ _SIGNATURES = {
     "d3m_version": (ctypes.c_char_p, []),
     "d3m_last_hip_error": (_I, []),
     "d3m_error_string": (ctypes.c_char_p, [_I]),
+    "d3m_timing_enable": (None, [_I]),
+    "d3m_timing_collect": (_I, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I), ctypes.POINTER(_F), _I]),
     "d3m_forward_workspace_bytes": (_SZ, [_I, _I, _I]),
     "d3m_forward_workspace_min_bytes": (_SZ, [_I, _I, _I]),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
@@ -97,3 +99,16 @@ def require_device(*tensors, names=None):
             raise RuntimeError(f"{n} must be a CUDA tensor")
         if not t.is_contiguous():
             raise RuntimeError(f"{n} must be contiguous")
+
+
+def kernel_timing(enable):
+    lib().d3m_timing_enable(int(bool(enable)))
+
+
+def collect_kernel_times(max_entries=64):
+    """{kernel name: (launches, total ms)} since timing was enabled / last collected (synchronises)."""
+    names = (ctypes.c_char_p * max_entries)()
+    counts = (_I * max_entries)()
+    ms = (_F * max_entries)()
+    n = lib().d3m_timing_collect(names, counts, ms, max_entries)
+    return {names[i].decode(): (counts[i], ms[i]) for i in range(n)}

@@ -1,0 +1,86 @@
+"""Losses evaluated on renderer outputs (deep3dmap/core/utils/utils.py:82-114 and the silhouette loss of
+pnpmodules/neural_renderer/examples/example2.py:43-47), as HIP reduction kernels with fused gradients."""
+import torch
+
+from .. import _lib
+from ..neural_renderer._util import f32c
+
+EPS = 1e-7
+
+
+class _Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im1, im2, mask, conf_sigma):
+        a, b = f32c(im1), f32c(im2)
+        B, C, H, W = a.shape
+        m = f32c(mask) if mask is not None else None
+        s = f32c(conf_sigma) if conf_sigma is not None else None
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        need = ctx.needs_input_grad[0]
+        grad = torch.empty_like(a) if need else None
+        scratch = torch.empty(3, dtype=torch.float32, device=a.device)
+        rc = _lib.lib().d3m_photometric_loss(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), _lib.ptr(s), _lib.ptr(loss),
+                                             _lib.ptr(grad), _lib.ptr(scratch), B, C, H, W, _lib.stream_ptr())
+        _lib.check(rc, "d3m_photometric_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g if grad is not None else None), None, None, None
+
+
+def photometric_loss(im1, im2, mask=None, conf_sigma=None):
+    """Masked mean L1, optionally the Laplacian NLL with per-pixel sigma (utils.py:105-114).
+    im1/im2 [B,C,H,W]; mask / conf_sigma [B,1,H,W] (broadcast over channels).  Gradient flows to im1."""
+    if im1.dim() == 3:
+        im1, im2 = im1[:, None], im2[:, None]
+    if mask is not None and mask.dim() == 3:
+        mask = mask[:, None]
+    if mask is not None and mask.shape[1] != 1:
+        raise NotImplementedError("photometric_loss: mask must have one channel")
+    return _Photometric.apply(im1, im2, mask, conf_sigma)
+
+
+class _SumSquaredError(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = f32c(a), f32c(b)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)
+        grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        rc = _lib.lib().d3m_sum_squared_error(_lib.ptr(a), _lib.ptr(b), _lib.ptr(loss), _lib.ptr(grad), a.numel(),
+                                              _lib.stream_ptr())
+        _lib.check(rc, "d3m_sum_squared_error")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g if grad is not None else None), None
+
+
+def silhouette_loss(image, image_ref):
+    """sum((image - image_ref)^2) (examples/example2.py:46)."""
+    return _SumSquaredError.apply(image, image_ref.expand_as(image))
+
+
+def smooth_loss(pred_map):
+    """Second-order smoothness over a (pyramid of) map(s) (utils.py:82-102): sum of mean |dxx|, |dxy|, |dyx|,
+    |dyy|, weights 1, 1/2.3, ... per level.  Acts on the network's depth maps, not on rasterizer output; kept
+    as a short eager composition (listed under "next" for a fused kernel)."""
+    def gradient(pred):
+        if pred.dim() == 4:
+            pred = pred.reshape(-1, pred.size(2), pred.size(3))
+        return pred[:, :, 1:] - pred[:, :, :-1], pred[:, 1:] - pred[:, :-1]
+
+    maps = pred_map if type(pred_map) in (tuple, list) else [pred_map]
+    loss, weight = 0, 1.
+    for scaled_map in maps:
+        dx, dy = gradient(scaled_map)
+        dx2, dxdy = gradient(dx)
+        dydx, dy2 = gradient(dy)
+        loss = loss + (dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() + dy2.abs().mean()) * weight
+        weight /= 2.3
+    return loss

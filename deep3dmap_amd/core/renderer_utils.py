@@ -1,0 +1,82 @@
+"""Helpers of deep3dmap's NrRenderer (deep3dmap/core/renderer/utils.py:22-107): pixel grids, Euler
+rotations, view vectors -> (R, t), the implicit grid topology and image -> texture cubes.  Host-side
+index/constant construction and small tensor algebra; the heavy lifting happens in the renderer."""
+import torch
+
+_face_idx_cache = {}
+
+
+def get_grid(b, H, W, normalize=True):
+    """[b,H,W,2] grid in (x, y) order (utils.py:22-31)."""
+    if normalize:
+        h_range, w_range = torch.linspace(-1, 1, H), torch.linspace(-1, 1, W)
+    else:
+        h_range, w_range = torch.arange(0, H), torch.arange(0, W)
+    gy, gx = torch.meshgrid(h_range, w_range, indexing="ij")
+    return torch.stack((gx, gy), -1)[None].repeat(b, 1, 1, 1).float()
+
+
+def get_rotation_matrix(tx, ty, tz):
+    """Rz @ Ry @ Rx for batched Euler angles (utils.py:34-51)."""
+    n, dev = len(tx), tx.device
+    one, zero = torch.ones(n, device=dev), torch.zeros(n, device=dev)
+    cx, sx, cy, sy, cz, sz = tx.cos(), tx.sin(), ty.cos(), ty.sin(), tz.cos(), tz.sin()
+    m_x = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], 1).reshape(n, 3, 3)
+    m_y = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], 1).reshape(n, 3, 3)
+    m_z = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], 1).reshape(n, 3, 3)
+    return torch.matmul(m_z, torch.matmul(m_y, m_x))
+
+
+def get_transform_matrices(view):
+    """view [b,6|5|3] = (rx, ry, rz[, tx, ty[, tz]]) -> (rot [b,3,3], trans [b,1,3]) (utils.py:54-71)."""
+    b = view.size(0)
+    if view.size(1) == 6:
+        trans_xyz = view[:, 3:].reshape(b, 1, 3)
+    elif view.size(1) == 5:
+        trans_xyz = torch.cat([view[:, 3:].reshape(b, 1, 2), torch.zeros(b, 1, 1).to(view.device)], 2)
+    elif view.size(1) == 3:
+        trans_xyz = torch.zeros(b, 1, 3).to(view.device)
+    else:
+        raise ValueError("view must have 3, 5 or 6 components")
+    return get_rotation_matrix(view[:, 0], view[:, 1], view[:, 2]), trans_xyz
+
+
+def get_face_idx(b, h, w, device=None):
+    """int32 [b, 2(h-1)(w-1), 3]: two triangles per grid cell, (tl,bl,tr) then (tr,bl,br) (utils.py:74-78).
+    With `device`, the single-batch topology is built once per (h, w, device) and expanded -- the reference
+    rebuilds it on the CPU and uploads it on every call (renderer_nr.py:119)."""
+    key = (h, w, str(device))
+    base = _face_idx_cache.get(key)
+    if base is None:
+        idx_map = torch.arange(h * w).reshape(h, w)
+        faces1 = torch.stack([idx_map[:h - 1, :w - 1], idx_map[1:, :w - 1], idx_map[:h - 1, 1:]], -1).reshape(-1, 3)
+        faces2 = torch.stack([idx_map[:h - 1, 1:], idx_map[1:, :w - 1], idx_map[1:, 1:]], -1).reshape(-1, 3)
+        base = torch.cat([faces1, faces2], 0).int()
+        if device is not None:
+            base = base.to(device)
+        _face_idx_cache[key] = base
+    return base[None].repeat(b, 1, 1)
+
+
+_CUBE = [[0.5, 0.5, 0.5], [0., 0., 1.], [0., 1., 0.], [-0.5, 0.5, 0.5],
+         [1., 0., 0.], [0.5, -0.5, 0.5], [0.5, 0.5, -0.5], [0., 0., 0.]]
+
+
+def vcolor_to_texture_cube(vcolors):
+    """[b,c,n,3] vertex colours -> [b,n,2,2,2,c] texture cubes (utils.py:81-94)."""
+    b, c, n, f = vcolors.shape
+    coeffs = torch.tensor(_CUBE, dtype=torch.float32, device=vcolors.device)
+    return coeffs.matmul(vcolors.permute(0, 2, 3, 1)).reshape(b, n, 2, 2, 2, c)
+
+
+def get_textures_from_im(im, tx_size=1):
+    """Per-face textures of the implicit grid mesh from an image [b,c,h,w] (utils.py:97-107)."""
+    b, c, h, w = im.shape
+    if tx_size == 1:
+        textures = torch.cat([im[:, :, :h - 1, :w - 1].reshape(b, c, -1), im[:, :, 1:, 1:].reshape(b, c, -1)], 2)
+        return textures.transpose(2, 1).reshape(b, -1, 1, 1, 1, c)
+    if tx_size == 2:
+        t1 = torch.stack([im[:, :, :h - 1, :w - 1], im[:, :, :h - 1, 1:], im[:, :, 1:, :w - 1]], -1).reshape(b, c, -1, 3)
+        t2 = torch.stack([im[:, :, 1:, :w - 1], im[:, :, :h - 1, 1:], im[:, :, 1:, 1:]], -1).reshape(b, c, -1, 3)
+        return vcolor_to_texture_cube(torch.cat([t1, t2], 2))
+    raise NotImplementedError("Currently support texture size of 1 or 2 only.")

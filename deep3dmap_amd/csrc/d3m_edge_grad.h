@@ -1,6 +1,7 @@
 // d3m_edge_grad.h -- host dispatch of the edge / silhouette gradient (KCU:245-503).
 #pragma once
 #include "d3m_backward.h"
+#include "d3m_launch.h"
 
 namespace d3m {
 
@@ -14,7 +15,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
                   int* last_err) {
     (void)ws; (void)ws_bytes;
     const long n = (long)B * fs.num_faces();
-    hipLaunchKernelGGL(k_backward_pixel_map<FS>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fs, m, grad_faces, B, eps);
+    LAUNCH("k_backward_pixel_map", k_backward_pixel_map<FS>, dim3((unsigned)((n + 255) / 256)), dim3(256), st, fs, m, grad_faces, B, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

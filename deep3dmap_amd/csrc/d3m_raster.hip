@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/d3m_raster.h"
+#include "d3m_launch.h"
 #include "d3m_aux.h"
 #include "d3m_backward.h"
 #include "d3m_device.h"
@@ -37,6 +38,36 @@ static inline int check_launch() {
 
 static inline unsigned blocks_for(long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+D3M_EXPORT void d3m_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timing = on != 0;
+}
+// Synchronises the device, folds the recorded launches into per-kernel (count, total ms) and clears the
+// record.  Writes up to max_entries rows; names are static strings.  Returns the number of rows.
+D3M_EXPORT int d3m_timing_collect(const char** names, int* counts, float* total_ms, int max_entries) {
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    std::map<std::string, std::pair<int, double>> agg;
+    std::map<std::string, const char*> keep;
+    for (auto& t : g_timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            auto& e = agg[t.name];
+            e.first += 1; e.second += ms;
+            keep[t.name] = t.name;
+        }
+        (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop);
+    }
+    g_timed.clear();
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n >= max_entries) break;
+        names[n] = keep[kv.first]; counts[n] = kv.second.first; total_ms[n] = (float)kv.second.second;
+        n++;
+    }
+    return n;
+}
 
 D3M_EXPORT const char* d3m_version(void) { return "d3m_raster 0.1 (gfx950)"; }
 D3M_EXPORT int d3m_last_hip_error(void) { return g_last_hip_error; }
@@ -120,12 +151,12 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ws, 0, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    hipLaunchKernelGGL(k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), 0, st, fs, bb, faces_inv);
-    hipLaunchKernelGGL(k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), 0, st, bb);
-    hipLaunchKernelGGL(k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), 0, st, bb);
+    LAUNCH("k_bin_count", k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv);
+    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
-    hipLaunchKernelGGL(k_raster_tiles<FS>, dim3(per * 8), dim3(64), 0, st, fs, bb, out, near, far);
+    LAUNCH("k_raster_tiles", k_raster_tiles<FS>, dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
@@ -155,7 +186,7 @@ D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* tex
         num_faces <= 0 || image_size <= 0 || texture_size <= 0)
         return D3M_ERR_INVALID;
     const long n = (long)batch_size * image_size * image_size;
-    hipLaunchKernelGGL(k_texture_sampling, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, faces, textures,
+    LAUNCH("k_texture_sampling", k_texture_sampling, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, faces, textures,
                        face_index_map, weight_map, depth_map, rgb_map, sampling_index_map, sampling_weight_map,
                        batch_size, num_faces, image_size, texture_size, eps);
     return check_launch();
@@ -190,7 +221,7 @@ D3M_EXPORT int d3m_backward_textures(const int32_t* face_index_map, const float*
         batch_size <= 0 || num_faces <= 0 || image_size <= 0 || texture_size <= 0)
         return D3M_ERR_INVALID;
     const long n = (long)batch_size * image_size * image_size;
-    hipLaunchKernelGGL(k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, face_index_map,
+    LAUNCH("k_backward_textures", k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, face_index_map,
                        sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, batch_size, num_faces,
                        image_size, texture_size);
     return check_launch();
@@ -205,7 +236,7 @@ D3M_EXPORT int d3m_backward_depth_map(const float* faces, const float* depth_map
         return D3M_ERR_INVALID;
     DenseFaces fs{faces, num_faces};
     const long n = (long)batch_size * image_size * image_size;
-    hipLaunchKernelGGL(k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs,
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs,
                        depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, batch_size,
                        image_size);
     return check_launch();
@@ -234,7 +265,7 @@ D3M_EXPORT int d3m_camera_basis(const float* eye, int eye_batch, const float* at
                                 const float* up, int up_batch, int is_look_at, float* rot_out, int batch_size,
                                 d3m_stream_t stream) {
     if (!eye || !at_or_direction || !up || !rot_out || batch_size <= 0) return D3M_ERR_INVALID;
-    hipLaunchKernelGGL(k_camera_basis, dim3(blocks_for(batch_size, 64)), dim3(64), 0, (hipStream_t)stream, eye, eye_batch,
+    LAUNCH("k_camera_basis", k_camera_basis, dim3(blocks_for(batch_size, 64)), dim3(64), (hipStream_t)stream, eye, eye_batch,
                        at_or_direction, at_batch, up, up_batch, is_look_at, rot_out, batch_size);
     return check_launch();
 }
@@ -247,7 +278,7 @@ D3M_EXPORT int d3m_camera_forward(const float* vertices, int vertices_batch, con
     int rc = to_cam(cam, batch_size, c);
     if (rc) return rc;
     const long n = (long)batch_size * num_vertices;
-    hipLaunchKernelGGL(k_camera_forward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, vertices,
+    LAUNCH("k_camera_forward", k_camera_forward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, vertices,
                        vertices_batch, c, out, batch_size, num_vertices);
     return check_launch();
 }
@@ -261,7 +292,7 @@ D3M_EXPORT int d3m_camera_backward(const float* vertices, int vertices_batch, co
     int rc = to_cam(cam, batch_size, c);
     if (rc) return rc;
     const long n = (long)(vertices_batch > 1 ? batch_size : 1) * num_vertices;
-    hipLaunchKernelGGL(k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, vertices,
+    LAUNCH("k_camera_backward", k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, vertices,
                        vertices_batch, c, grad_out, grad_vertices, batch_size, num_vertices);
     return check_launch();
 }
@@ -272,7 +303,7 @@ D3M_EXPORT int d3m_gather_faces(const float* vertices, const int32_t* tri, int t
     if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
     IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
     const long n = (long)batch_size * fs.num_faces() * 9;
-    hipLaunchKernelGGL(k_gather_faces, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs, faces_out,
+    LAUNCH("k_gather_faces", k_gather_faces, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, faces_out,
                        batch_size);
     return check_launch();
 }
@@ -285,7 +316,7 @@ D3M_EXPORT int d3m_scatter_face_grads(const float* grad_faces, const int32_t* tr
     if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
     IndexedFaces fs{nullptr, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
     const long n = (long)batch_size * fs.num_faces() * 9;
-    hipLaunchKernelGGL(k_scatter_face_grads, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, fs, grad_faces,
+    LAUNCH("k_scatter_face_grads", k_scatter_face_grads, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, grad_faces,
                        grad_vertices, batch_size);
     return check_launch();
 }
@@ -305,7 +336,7 @@ D3M_EXPORT int d3m_lighting_forward(const float* faces, const float* textures_in
         num_faces_total <= 0 || texture_size <= 0)
         return D3M_ERR_INVALID;
     const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
-    hipLaunchKernelGGL(k_lighting_forward, dim3(blocks_for(num_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
+    LAUNCH("k_lighting_forward", k_lighting_forward, dim3(blocks_for(num_faces_total, 256)), dim3(256), (hipStream_t)stream, faces,
                        textures_in, textures_out, lp, num_faces_total, texture_size * texture_size * texture_size * 3);
     return check_launch();
 }
@@ -319,7 +350,7 @@ D3M_EXPORT int d3m_lighting_backward(const float* faces, const float* textures_i
         num_faces_total <= 0 || texture_size <= 0)
         return D3M_ERR_INVALID;
     const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
-    hipLaunchKernelGGL(k_lighting_backward, dim3(blocks_for(num_faces_total, 256)), dim3(256), 0, (hipStream_t)stream, faces,
+    LAUNCH("k_lighting_backward", k_lighting_backward, dim3(blocks_for(num_faces_total, 256)), dim3(256), (hipStream_t)stream, faces,
                        textures_in, grad_out, grad_textures, grad_faces, lp, num_faces_total,
                        texture_size * texture_size * texture_size * 3);
     return check_launch();
@@ -335,7 +366,7 @@ D3M_EXPORT int d3m_output_epilogue(const int32_t* face_index_map, const float* r
     if (background && background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
     const int s = anti_aliasing ? image_size / 2 : image_size;
     const long n = (long)batch_size * s * s;
-    hipLaunchKernelGGL(k_output_epilogue, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, face_index_map,
+    LAUNCH("k_output_epilogue", k_output_epilogue, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, face_index_map,
                        rgb_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
                        depth_out, batch_size, image_size, anti_aliasing ? 1 : 0);
     return check_launch();
@@ -349,7 +380,7 @@ D3M_EXPORT int d3m_output_epilogue_backward(const float* grad_rgb_out, const flo
     if ((grad_rgb_map && !grad_rgb_out) || (grad_alpha_map && !grad_alpha_out) || (grad_depth_map && !grad_depth_out))
         return D3M_ERR_INVALID;
     const long n = (long)batch_size * image_size * image_size;
-    hipLaunchKernelGGL(k_output_epilogue_backward, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    LAUNCH("k_output_epilogue_backward", k_output_epilogue_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream,
                        grad_rgb_out, grad_alpha_out, grad_depth_out, grad_rgb_map, grad_alpha_map, grad_depth_map,
                        batch_size, image_size, anti_aliasing ? 1 : 0);
     return check_launch();
@@ -367,9 +398,9 @@ D3M_EXPORT int d3m_photometric_loss(const float* im1, const float* im2, const fl
     const long hw = (long)height * width, n = (long)batch_size * channels * hw;
     HIP_TRY(hipMemsetAsync(scratch, 0, 3 * sizeof(float), st));
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_photometric_reduce, dim3(grid), dim3(256), 0, st, im1, im2, mask, conf_sigma, scratch, n,
+    LAUNCH("k_photometric_reduce", k_photometric_reduce, dim3(grid), dim3(256), st, im1, im2, mask, conf_sigma, scratch, n,
                        channels, hw);
-    hipLaunchKernelGGL(k_photometric_finish, dim3(grad_im1 ? grid : 1), dim3(256), 0, st, im1, im2, mask, conf_sigma,
+    LAUNCH("k_photometric_finish", k_photometric_finish, dim3(grad_im1 ? grid : 1), dim3(256), st, im1, im2, mask, conf_sigma,
                        scratch, loss, grad_im1, n, channels, hw);
     return check_launch();
 }
@@ -380,6 +411,6 @@ D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
     const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_sum_squared_error, dim3(grid), dim3(256), 0, st, a, b, loss, grad_a, n);
+    LAUNCH("k_sum_squared_error", k_sum_squared_error, dim3(grid), dim3(256), st, a, b, loss, grad_a, n);
     return check_launch();
 }

@@ -44,6 +44,12 @@ const char* d3m_version(void);
 int d3m_last_hip_error(void);         /* hipError_t of the most recent failed HIP call, 0 if none */
 const char* d3m_error_string(int code);
 
+/* Per-kernel timing with HIP events recorded on each launch's own stream (used by bench.py for the
+ * live roofline figure; off by default).  d3m_timing_collect synchronises the device, returns one row
+ * per kernel name (static strings) with its launch count and summed duration, and clears the record. */
+void d3m_timing_enable(int on);
+int d3m_timing_collect(const char** names, int* counts, float* total_ms, int max_entries);
+
 /* ------------------------------------------------------------------------------------------------
  * A. The five operators of `neural_renderer.cuda.rasterize` (KCPP:193-199), same argument order.
  * ---------------------------------------------------------------------------------------------- */
