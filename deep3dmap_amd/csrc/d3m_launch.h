@@ -33,3 +33,8 @@ struct LaunchTimer {
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
     } while (0)
 
+#define LAUNCH_SMEM(name, kernel, grid, block, smem, stream, ...)               \
+    do {                                                                        \
+        LaunchTimer lt__(name, stream);                                         \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
+    } while (0)
