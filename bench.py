@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +122,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loss_eager, gv_eager, _ = fit.step()
+    gv_eager = gv_eager.clone()
+    if not args.no_graph:
+        fit.capture_graph()
     for _ in range(args.warmup):
         fit.step()
     barrier()
@@ -134,8 +139,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
+    # the replayed graph must reproduce the eager step (same inputs every step: no optimiser in the loop)
+    rel = float(torch.linalg.norm(gv - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
+    assert rel < 1e-3 and abs(float(loss) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)) + 1e-7, (rel, loss, loss_eager)
 
-    # instrumented pass (not part of `value`): per-kernel HIP-event durations on the launch stream
+    # instrumented pass (not part of `value`), eager: per-kernel HIP-event durations on the launch stream
+    fit._graph = None
     _lib.kernel_timing(True)
     n_inst = max(3, min(args.steps, 10))
     for _ in range(n_inst):
@@ -172,7 +181,7 @@ def main():
                                    f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
                        "views_per_gpu": args.views_per_gpu, "triangles": int(F), "image_size": S,
-                       "texture_size": ts, "fill_back": True, "anti_aliasing": False,
+                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": not args.no_graph,
                        "parallelism": f"camera-sharded x{world}"},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},

@@ -32,8 +32,9 @@ _SIGNATURES = {
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
     "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P]),
-    "d3m_backward_textures": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "d3m_backward_depth_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_backward_faces_workspace_bytes": (_SZ, [_I, _I]),
+    "d3m_backward_textures": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
+    "d3m_backward_depth_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
     "d3m_camera_basis": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
     "d3m_camera_forward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _I, _I, _P]),
     "d3m_camera_backward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _P, _I, _I, _P]),
@@ -44,7 +45,7 @@ _SIGNATURES = {
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _L, _P]),
+    "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _P, _L, _P]),
 }
 
 _lib = None

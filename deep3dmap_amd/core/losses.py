@@ -18,7 +18,7 @@ class _Photometric(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         need = ctx.needs_input_grad[0]
         grad = torch.empty_like(a) if need else None
-        scratch = torch.empty(3, dtype=torch.float32, device=a.device)
+        scratch = torch.empty(2048, dtype=torch.float32, device=a.device)
         rc = _lib.lib().d3m_photometric_loss(_lib.ptr(a), _lib.ptr(b), _lib.ptr(m), _lib.ptr(s), _lib.ptr(loss),
                                              _lib.ptr(grad), _lib.ptr(scratch), B, C, H, W, _lib.stream_ptr())
         _lib.check(rc, "d3m_photometric_loss")
@@ -49,8 +49,9 @@ class _SumSquaredError(torch.autograd.Function):
         a, b = f32c(a), f32c(b)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
-        rc = _lib.lib().d3m_sum_squared_error(_lib.ptr(a), _lib.ptr(b), _lib.ptr(loss), _lib.ptr(grad), a.numel(),
-                                              _lib.stream_ptr())
+        scratch = torch.empty(1024, dtype=torch.float32, device=a.device)
+        rc = _lib.lib().d3m_sum_squared_error(_lib.ptr(a), _lib.ptr(b), _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(scratch),
+                                              a.numel(), _lib.stream_ptr())
         _lib.check(rc, "d3m_sum_squared_error")
         ctx.save_for_backward(grad)
         return loss

@@ -405,51 +405,68 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_part) {
 }
 
 // photometric_loss (deep3dmap/core/utils/utils.py:105-114): pass 1 accumulates
-// scratch[0] = sum(|a-b| [*sqrt2/(sigma+EPS) + log(sigma+EPS)] * mask), scratch[1] = sum(mask over C)
+// per workgroup: scratch[2k] = sum(|a-b| [*sqrt2/(sigma+EPS) + log(sigma+EPS)] * mask), scratch[2k+1] = sum(mask).
+// grid.y runs over the B*C image planes, so the per-element index math has no division.
 __global__ void __launch_bounds__(256) k_photometric_reduce(const float* __restrict__ a, const float* __restrict__ b,
                                                            const float* __restrict__ mask,
                                                            const float* __restrict__ sigma, float* __restrict__ scratch,
-                                                           long n, int C, long hw) {
+                                                           int C, int hw) {
     __shared__ float s_part[4];
+    const int plane = blockIdx.y, bn = plane / C;
+    const float* pa = a + (size_t)plane * hw;
+    const float* pb = b + (size_t)plane * hw;
+    const float* pm = mask ? mask + (size_t)bn * hw : nullptr;
+    const float* ps = sigma ? sigma + (size_t)bn * hw : nullptr;
     float num = 0, den = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const long pix = (i / (hw * C)) * hw + (i % hw);
-        float l = fabsf(a[i] - b[i]);
-        if (sigma) {
-            const float sg = sigma[pix] + 1e-7f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        float l = fabsf(pa[i] - pb[i]);
+        if (ps) {
+            const float sg = ps[i] + 1e-7f;
             l = l * 1.41421356237309515f / sg + logf(sg);
         }
-        const float m = mask ? mask[pix] : 1.0f;
+        const float m = pm ? pm[i] : 1.0f;
         num += l * m;
         den += m;
     }
     num = block_sum_256(num, s_part);
     den = block_sum_256(den, s_part);
-    if (threadIdx.x == 0) {
-        atomicAdd(&scratch[0], num);
-        atomicAdd(&scratch[1], den);
+    if (threadIdx.x == 0) {      // one partial pair per workgroup: deterministic, no same-address atomics
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        scratch[2 * blk + 0] = num;
+        scratch[2 * blk + 1] = den;
     }
 }
 __global__ void __launch_bounds__(256) k_photometric_finish(const float* __restrict__ a, const float* __restrict__ b,
                                                            const float* __restrict__ mask,
                                                            const float* __restrict__ sigma,
-                                                           const float* __restrict__ scratch, float* __restrict__ loss,
-                                                           float* __restrict__ grad_a, long n, int C, long hw) {
-    const float den = scratch[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = scratch[0] / den;
+                                                           const float* __restrict__ scratch, int n_partials,
+                                                           float* __restrict__ loss, float* __restrict__ grad_a, int C,
+                                                           int hw) {
+    __shared__ float s_part[4];
+    float num = 0, den = 0;      // every workgroup re-sums the (<= 1024) partial pairs in the same order
+    for (int i = threadIdx.x; i < n_partials; i += 256) { num += scratch[2 * i]; den += scratch[2 * i + 1]; }
+    num = block_sum_256(num, s_part);
+    den = block_sum_256(den, s_part);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *loss = num / den;
     if (!grad_a) return;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const long pix = (i / (hw * C)) * hw + (i % hw);
-        const float d = a[i] - b[i];
+    const int plane = blockIdx.y, bn = plane / C;
+    const float* pa = a + (size_t)plane * hw;
+    const float* pb = b + (size_t)plane * hw;
+    const float* pm = mask ? mask + (size_t)bn * hw : nullptr;
+    const float* ps = sigma ? sigma + (size_t)bn * hw : nullptr;
+    float* pg = grad_a + (size_t)plane * hw;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const float d = pa[i] - pb[i];
         float g = d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f);
-        if (sigma) g = g * 1.41421356237309515f / (sigma[pix] + 1e-7f);
-        const float m = mask ? mask[pix] : 1.0f;
-        grad_a[i] = g * m / den;
+        if (ps) g = g * 1.41421356237309515f / (ps[i] + 1e-7f);
+        const float m = pm ? pm[i] : 1.0f;
+        pg[i] = g * m / den;
     }
 }
 
+// sum((a-b)^2): per-workgroup partials, then one small workgroup adds them (no same-address atomics)
 __global__ void __launch_bounds__(256) k_sum_squared_error(const float* __restrict__ a, const float* __restrict__ b,
-                                                          float* __restrict__ loss, float* __restrict__ grad_a, long n) {
+                                                          float* __restrict__ partials, float* __restrict__ grad_a, long n) {
     __shared__ float s_part[4];
     float acc = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -458,7 +475,14 @@ __global__ void __launch_bounds__(256) k_sum_squared_error(const float* __restri
         if (grad_a) grad_a[i] = 2.0f * d;
     }
     acc = block_sum_256(acc, s_part);
-    if (threadIdx.x == 0) atomicAdd(loss, acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ partials, int n, float* __restrict__ out) {
+    __shared__ float s_part[4];
+    float acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    acc = block_sum_256(acc, s_part);
+    if (threadIdx.x == 0) *out = acc;
 }
 
 }  // namespace d3m

@@ -24,12 +24,14 @@ __global__ void __launch_bounds__(256) k_backward_textures(const int32_t* __rest
                                                           const float* __restrict__ sampling_weight_map,
                                                           const int32_t* __restrict__ sampling_index_map,
                                                           const float* __restrict__ grad_rgb_map,
-                                                          float* __restrict__ grad_textures, int B, int F, int S, int ts) {
+                                                          float* __restrict__ grad_textures, int B, int F, int S, int ts,
+                                                          const int* __restrict__ only_large) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fi = face_index_map[i];
     if (fi < 0) return;
     const int bn = (int)(i / ((long)S * S));
+    if (only_large && only_large[(size_t)bn * F + fi] != 2) return;   // the rest was gathered per face
     const size_t tex_base = ((size_t)bn * F + fi) * ts * ts * ts * 3;
     const size_t tex_total = (size_t)B * F * ts * ts * ts * 3;   // ts == 1 bleed guard, see k_texture_sampling
     const float g[3] = {grad_rgb_map[3 * i + 0], grad_rgb_map[3 * i + 1], grad_rgb_map[3 * i + 2]};
@@ -52,13 +54,15 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            const float* __restrict__ face_inv_map,
                                                            const float* __restrict__ weight_map,
                                                            const float* __restrict__ grad_depth_map,
-                                                           float* __restrict__ grad_faces, int B, int S) {
+                                                           float* __restrict__ grad_faces, int B, int S,
+                                                           const int* __restrict__ only_large) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fn = face_index_map[i];
     if (fn < 0) return;
     const int bn = (int)(i / ((long)S * S));
     const int F = fs.num_faces();
+    if (only_large && only_large[(size_t)bn * F + fn] != 2) return;   // the rest was gathered per face
     float face[9], finv[9];
     fs.load(bn, fn, face);
     if (face_inv_map) {

@@ -24,6 +24,7 @@
 // inside the walk use v_rcp_f32 (1 ulp), far inside the 1e-3 gradient tolerance.
 #pragma once
 #include "d3m_backward.h"
+#include "d3m_face_major.h"
 #include "d3m_launch.h"
 
 namespace d3m {
@@ -48,6 +49,7 @@ struct EdgeGradArgs {
 };
 
 struct EdgeWork {
+    int* visible;        // [B*F]   1 if the face owns a pixel (zeroed per call, set by k_mark_visible)
     int* face_count;     // [B*F]   long segments per face (zeroed per call)
     int* face_offset;    // [B*F]
     int* line_count;     // [B*2*S] long segments per line (zeroed per call)
@@ -172,15 +174,25 @@ __device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, boo
     }
 }
 
+// A face that owns no pixel cannot contribute: the outward walk needs the in-pixel to be its own
+// (KCU:354) and the inward walk only counts its own pixels (KCU:470).  `visible` makes that a 4-byte test.
 template <class FS>
-__device__ __forceinline__ bool load_face_pixels(const FS& fs, long gi, int B, int is, int& bn, int& fn, float* pp) {
+__device__ __forceinline__ bool load_face_pixels(const FS& fs, const int* visible, long gi, int B, int is, int& bn,
+                                                 int& fn, float* pp, float* zero_out) {
     const int F = fs.num_faces();
     if (gi >= (long)B * F) return false;
     bn = (int)(gi / F);
     fn = (int)(gi % F);
+    const bool vis = visible[gi] != 0;
+    if (!vis && !zero_out) return false;
     float face[9];
     fs.load(bn, fn, face);
     if (backside(face)) return false;                      // KCU:270: culled faces are left untouched
+    if (!vis) {                                            // front-facing but hidden: the reference stores zeros
+#pragma unroll
+        for (int k = 0; k < 9; k++) zero_out[(size_t)gi * 9 + k] = 0.0f;
+        return false;
+    }
 #pragma unroll
     for (int n = 0; n < 3; n++) {
         pp[2 * n + 0] = to_pixel(face[3 * n + 0], is);     // KCU:282
@@ -197,7 +209,7 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
     const long gi = (long)blockIdx.x * 256 + threadIdx.x;
     int bn, fn;
     float pp[6];
-    if (!load_face_pixels(fs, gi, B, a.S, bn, fn, pp)) return;
+    if (!load_face_pixels(fs, w.visible, gi, B, a.S, bn, fn, pp, nullptr)) return;
     const int is = a.S;
     const size_t base = (size_t)bn * is * is;
     int n = 0;
@@ -240,7 +252,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     const long gi = (long)blockIdx.x * 256 + threadIdx.x;
     int bn, fn;
     float pp[6];
-    if (!load_face_pixels(fs, gi, B, a.S, bn, fn, pp)) return;
+    if (!load_face_pixels(fs, w.visible, gi, B, a.S, bn, fn, pp, grad_faces)) return;
     const int is = a.S;
     const float two_over_is = 2.0f / (float)is;
     const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
@@ -414,7 +426,7 @@ __global__ void __launch_bounds__(256) k_transpose_map(const uint32_t* __restric
 struct EdgeLayout {
     size_t off_fiT, off_alphaT, off_galphaT, off_rgbT, off_grgbT;
     size_t off_zero, zero_bytes;   // face_count | line_count | line_cursor | alloc
-    size_t off_face_count, off_line_count, off_line_cursor, off_alloc, off_face_offset, off_line_offset;
+    size_t off_visible, off_face_count, off_line_count, off_line_cursor, off_alloc, off_face_offset, off_line_offset;
     size_t off_items;              // items | line_items | results follow, sized by capacity
     size_t fixed_bytes;
 };
@@ -431,6 +443,7 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.off_rgbT = o;     o += eg_align(px * 12);
     L.off_grgbT = o;    o += eg_align(px * 12);
     L.off_zero = o;
+    L.off_visible = o;      o += eg_align(nf * 4);
     L.off_face_count = o;   o += eg_align(nf * 4);
     L.off_line_count = o;   o += eg_align(nl * 4);
     L.off_line_cursor = o;  o += eg_align(nl * 4);
@@ -462,6 +475,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     cap = cap > 256 ? cap - 128 : 0;                            // slack for the two 256-byte alignments below
     if (cap > 0x7FFFFF00) cap = 0x7FFFFF00;
     EdgeWork w;
+    w.visible = (int*)(p + L.off_visible);
     w.face_count = (int*)(p + L.off_face_count);
     w.line_count = (int*)(p + L.off_line_count);
     w.line_cursor = (int*)(p + L.off_line_cursor);
@@ -498,6 +512,8 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps;
     const long nf = (long)B * F, nl = (long)B * 2 * S;
     const dim3 gf((unsigned)((nf + 255) / 256)), gl((unsigned)((nl + 255) / 256));
+    LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
+           m.face_index_map, w.visible, B, F, S);
     LAUNCH("k_edge_count", k_edge_count<FS>, gf, dim3(256), st, fs, a, w, B);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gf, dim3(256), st, (const int*)w.face_count, w.face_offset, w.alloc, nf);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);

@@ -1,0 +1,115 @@
+// d3m_face_major.h -- atomic-free forms of the texture and depth backward passes.
+//
+// The reference scatters from pixels with float atomics: 24 per covered pixel for the texture cube
+// (KCU:531-538), 9 for the depth gradient (KCU:573-590).  A face owns only the pixels inside its
+// bounding box, so the sums can instead be GATHERED: one lane per visible face walks its (small)
+// bounding box, keeps the sums in registers / LDS and stores them once.  Faces that own no pixel
+// (culled, hidden or off screen: ~95% of the 2F' faces of a closed mesh) are skipped via a visibility
+// flag; faces with a large bounding box fall back to the per-pixel atomic kernels.
+#pragma once
+#include "d3m_backward.h"
+#include "d3m_forward.h"
+
+namespace d3m {
+
+constexpr int FM_MAX_BBOX_AREA = 1024;   // larger faces are left to the per-pixel atomic kernels
+constexpr int FLAG_HIDDEN = 0, FLAG_VISIBLE = 1, FLAG_LARGE = 2;
+
+// flags[b*F + f] = 1 for every face that owns at least one pixel (plain stores of the same value)
+__global__ void __launch_bounds__(256) k_mark_visible(const int32_t* __restrict__ face_index_map, int* __restrict__ flags,
+                                                     int B, int F, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * S * S) return;
+    const int fi = face_index_map[i];
+    if (fi >= 0) flags[(size_t)(i / ((long)S * S)) * F + fi] = FLAG_VISIBLE;
+}
+
+// Depth backward, gathered: KCU:543-592 summed over the pixels a face owns.  grad_faces += .
+template <class FS>
+__global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float* __restrict__ depth_map,
+                                                             const int32_t* __restrict__ face_index_map,
+                                                             const float* __restrict__ weight_map,
+                                                             const float* __restrict__ grad_depth_map,
+                                                             float* __restrict__ grad_faces, int* __restrict__ flags, int B,
+                                                             int S) {
+    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const int F = fs.num_faces();
+    if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;
+    const int bn = (int)(gi / F), fn = (int)(gi % F);
+    float face[9], finv[9];
+    fs.load(bn, fn, face);
+    int x0, x1, y0, y1;
+    if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    face_inverse(face, S, finv);
+    float tmp[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / face[3 * l + 2];     // KCU:582
+    }
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const size_t base = (size_t)bn * S * S;
+    for (int y = y0; y <= y1; y++) {
+        for (int x = x0; x <= x1; x++) {
+            const size_t p = base + (size_t)y * S + x;
+            if (face_index_map[p] != fn) continue;
+            const float depth = depth_map[p], g = grad_depth_map[p];
+            const float depth2 = depth * depth;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float wk = weight_map[3 * p + k], z_k = face[3 * k + 2];
+                acc[3 * k + 0] += -g * tmp[0] * wk * depth2 * (float)S / 2.0f;          // KCU:588
+                acc[3 * k + 1] += -g * tmp[1] * wk * depth2 * (float)S / 2.0f;
+                acc[3 * k + 2] += g * wk * depth2 / (z_k * z_k);                        // KCU:575
+            }
+        }
+    }
+    float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) gf[k] += acc[k];
+}
+
+// Texture backward for ts == 2, gathered: 8 texels x 3 channels per face kept in LDS.  grad_textures += .
+template <class FS>
+__global__ void __launch_bounds__(256) k_backward_textures_faces(FS fs, const int32_t* __restrict__ face_index_map,
+                                                                const float* __restrict__ sampling_weight_map,
+                                                                const int32_t* __restrict__ sampling_index_map,
+                                                                const float* __restrict__ grad_rgb_map,
+                                                                float* __restrict__ grad_textures, int* __restrict__ flags,
+                                                                int B, int S) {
+    __shared__ float s_acc[24][256];
+    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const int F = fs.num_faces();
+    if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;
+    const int bn = (int)(gi / F), fn = (int)(gi % F);
+    float face[9];
+    fs.load(bn, fn, face);
+    int x0, x1, y0, y1;
+    if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int l = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
+    const size_t base = (size_t)bn * S * S;
+    for (int y = y0; y <= y1; y++) {
+        for (int x = x0; x <= x1; x++) {
+            const size_t p = base + (size_t)y * S + x;
+            if (face_index_map[p] != fn) continue;
+            const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
+#pragma unroll
+            for (int pn = 0; pn < 8; pn++) {
+                const float w = sampling_weight_map[p * 8 + pn];
+                const int isc = sampling_index_map[p * 8 + pn] & 7;                     // ts == 2: 0..7
+                s_acc[isc * 3 + 0][l] += w * g0;                                        // KCU:537
+                s_acc[isc * 3 + 1][l] += w * g1;
+                s_acc[isc * 3 + 2][l] += w * g2;
+            }
+        }
+    }
+    float* gt = grad_textures + (size_t)gi * 24;
+#pragma unroll
+    for (int t = 0; t < 24; t++) gt[t] += s_acc[t][l];
+}
+
+}  // namespace d3m

@@ -57,33 +57,42 @@ template <class FS>
 __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int F = bb.F;
-    if (i >= (long)bb.B * F) return;
-    const int b = (int)(i / F), f = (int)(i % F);
-    float face[9];
-    fs.load(b, f, face);
+    const bool in_range = i < (long)bb.B * F;
+    const int b = in_range ? (int)(i / F) : 0, f = in_range ? (int)(i % F) : 0;
     uint2 r = make_uint2(RECT_NONE, 0);
-    if (!backside(face)) {
-        if (faces_inv) {
-            float fi[9];
-            face_inverse(face, bb.S, fi);
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;     // empty
+    bool small = false;
+    if (in_range) {
+        float face[9];
+        fs.load(b, f, face);
+        if (!backside(face)) {
+            if (faces_inv) {
+                float fi[9];
+                face_inverse(face, bb.S, fi);
 #pragma unroll
-            for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = fi[k];
-        }
-        int x0, x1, y0, y1;
-        if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
-            const int tx0 = x0 / TILE, tx1 = x1 / TILE, ty0 = y0 / TILE, ty1 = y1 / TILE;
-            r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
-            const int nt = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
-            if (nt <= bb.kcap) {
-                for (int ty = ty0; ty <= ty1; ty++)
-                    for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&bb.tile_count[(size_t)b * bb.T + ty * bb.tiles_x + tx], 1);
-            } else {
-                const int pos = atomicAdd(&bb.big_count[b], 1);
-                bb.big_list[(size_t)b * F + pos] = f;
+                for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = fi[k];
+            }
+            int x0, x1, y0, y1;
+            if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
+                tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE;
+                r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+                small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
+                if (!small) {
+                    const int pos = atomicAdd(&bb.big_count[b], 1);
+                    bb.big_list[(size_t)b * F + pos] = f;
+                }
             }
         }
+        bb.rect[i] = r;
     }
-    bb.rect[i] = r;
+    // Neighbouring faces land in the same tiles: walk the (at most kcap) tiles of every small face in
+    // lock step and merge equal tile ids within the wave into one atomic.
+    const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
+    for (int s = 0; __any(s < nt); s++) {
+        const bool has = s < nt;
+        const int tx = has ? tx0 + s % w : 0, ty = has ? ty0 + s / w : 0;
+        wave_grouped_add(bb.tile_count, (size_t)b * bb.T + ty * bb.tiles_x + tx, has, false);
+    }
 }
 
 // ---- pass 2: give every tile a slice of `pairs` (one atomic per 256 tiles; order is irrelevant) ---
@@ -109,18 +118,25 @@ __global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
 // ---- pass 3: scatter face ids into the per-tile lists ------------------------------------------
 __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)bb.B * bb.F) return;
-    const uint2 r = bb.rect[i];
-    if (r.x == RECT_NONE) return;
-    const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > bb.kcap) return;   // lives in big_list
-    const int b = (int)(i / bb.F), f = (int)(i % bb.F);
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const size_t t = (size_t)b * bb.T + ty * bb.tiles_x + tx;
-            const int pos = atomicAdd(&bb.tile_cursor[t], 1);
-            bb.pairs[(size_t)bb.tile_offset[t] + pos] = f;
+    int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
+    if (i < (long)bb.B * bb.F) {
+        const uint2 r = bb.rect[i];
+        if (r.x != RECT_NONE) {
+            tx0 = r.x & 0xFFFF; ty0 = r.x >> 16;
+            const int tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
+            w = tx1 - tx0 + 1;
+            nt = w * (ty1 - ty0 + 1);
+            if (nt > bb.kcap) nt = 0;                 // lives in big_list
+            b = (int)(i / bb.F); f = (int)(i % bb.F);
         }
+    }
+    for (int s = 0; __any(s < nt); s++) {
+        const bool has = s < nt;
+        const int tx = has ? tx0 + s % w : 0, ty = has ? ty0 + s / w : 0;
+        const size_t t = (size_t)b * bb.T + ty * bb.tiles_x + tx;
+        const int pos = wave_grouped_add(bb.tile_cursor, t, has, true);
+        if (has) bb.pairs[(size_t)bb.tile_offset[t] + pos] = f;
+    }
 }
 
 // ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------

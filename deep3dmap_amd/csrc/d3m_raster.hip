@@ -11,6 +11,7 @@
 #include "d3m_backward.h"
 #include "d3m_device.h"
 #include "d3m_edge_grad.h"
+#include "d3m_face_major.h"
 #include "d3m_forward.h"
 
 using namespace d3m;
@@ -213,33 +214,80 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                          &g_last_hip_error);
 }
 
-D3M_EXPORT int d3m_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+// scratch of the gathered (face-major) backward passes: one int per face
+D3M_EXPORT size_t d3m_backward_faces_workspace_bytes(int batch_size, int num_faces) {
+    if (batch_size <= 0 || num_faces <= 0) return 0;
+    return (size_t)batch_size * num_faces * 4;
+}
+
+template <class FS>
+static int run_backward_textures(FS fs, const float* faces_dummy, const int32_t* face_index_map, const float* sw,
+                                 const int32_t* si, const float* grad_rgb_map, float* grad_textures, int B, int F, int S,
+                                 int ts, int* flags, bool flags_ready, hipStream_t st) {
+    (void)faces_dummy;
+    const long n = (long)B * S * S, nf = (long)B * F;
+    if (flags && ts == 2) {
+        if (!flags_ready) {
+            HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+            LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
+        }
+        LAUNCH("k_backward_textures_faces", k_backward_textures_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs,
+               face_index_map, sw, si, grad_rgb_map, grad_textures, flags, B, S);
+        LAUNCH("k_backward_textures", k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, sw, si,
+               grad_rgb_map, grad_textures, B, F, S, ts, (const int*)flags);
+    } else {
+        LAUNCH("k_backward_textures", k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, sw, si,
+               grad_rgb_map, grad_textures, B, F, S, ts, (const int*)nullptr);
+    }
+    return check_launch();
+}
+
+template <class FS>
+static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face_index_map, const float* face_inv_map,
+                              const float* weight_map, const float* grad_depth_map, float* grad_faces, int B, int S,
+                              int* flags, bool flags_ready, hipStream_t st) {
+    const int F = fs.num_faces();
+    const long n = (long)B * S * S, nf = (long)B * F;
+    if (flags) {
+        if (!flags_ready) {
+            HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+            LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
+        }
+        LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, depth_map,
+               face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S);
+    }
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(blocks_for(n, 256)), dim3(256), st, fs, depth_map,
+           face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_backward_textures(const float* faces, const int32_t* face_index_map, const float* sampling_weight_map,
                                      const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
-                                     int batch_size, int num_faces, int image_size, int texture_size,
-                                     d3m_stream_t stream) {
+                                     int batch_size, int num_faces, int image_size, int texture_size, void* workspace,
+                                     size_t workspace_bytes, d3m_stream_t stream) {
     if (!face_index_map || !sampling_weight_map || !sampling_index_map || !grad_rgb_map || !grad_textures ||
         batch_size <= 0 || num_faces <= 0 || image_size <= 0 || texture_size <= 0)
         return D3M_ERR_INVALID;
-    const long n = (long)batch_size * image_size * image_size;
-    LAUNCH("k_backward_textures", k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, face_index_map,
-                       sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, batch_size, num_faces,
-                       image_size, texture_size);
-    return check_launch();
+    int* flags = nullptr;
+    if (faces && workspace && workspace_bytes >= (size_t)batch_size * num_faces * 4) flags = (int*)workspace;
+    DenseFaces fs{faces, num_faces};
+    return run_backward_textures(fs, faces, face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map,
+                                 grad_textures, batch_size, num_faces, image_size, texture_size, flags, false,
+                                 (hipStream_t)stream);
 }
 
 D3M_EXPORT int d3m_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
                                       const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
-                                      float* grad_faces, int batch_size, int num_faces, int image_size,
-                                      d3m_stream_t stream) {
+                                      float* grad_faces, int batch_size, int num_faces, int image_size, void* workspace,
+                                      size_t workspace_bytes, d3m_stream_t stream) {
     if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !grad_faces || batch_size <= 0 ||
         num_faces <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
+    int* flags = nullptr;
+    if (workspace && workspace_bytes >= (size_t)batch_size * num_faces * 4) flags = (int*)workspace;
     DenseFaces fs{faces, num_faces};
-    const long n = (long)batch_size * image_size * image_size;
-    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs,
-                       depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, batch_size,
-                       image_size);
-    return check_launch();
+    return run_backward_depth(fs, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
+                              batch_size, image_size, flags, false, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -395,22 +443,27 @@ D3M_EXPORT int d3m_photometric_loss(const float* im1, const float* im2, const fl
     if (!im1 || !im2 || !loss || !scratch || batch_size <= 0 || channels <= 0 || height <= 0 || width <= 0)
         return D3M_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const long hw = (long)height * width, n = (long)batch_size * channels * hw;
-    HIP_TRY(hipMemsetAsync(scratch, 0, 3 * sizeof(float), st));
-    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    LAUNCH("k_photometric_reduce", k_photometric_reduce, dim3(grid), dim3(256), st, im1, im2, mask, conf_sigma, scratch, n,
-                       channels, hw);
-    LAUNCH("k_photometric_finish", k_photometric_finish, dim3(grad_im1 ? grid : 1), dim3(256), st, im1, im2, mask, conf_sigma,
-                       scratch, loss, grad_im1, n, channels, hw);
+    const long hw = (long)height * width;
+    if (hw > 0x7FFFFFFF || (long)batch_size * channels > 65535) return D3M_ERR_INVALID;
+    const unsigned planes = (unsigned)(batch_size * channels);
+    unsigned gx = (unsigned)((hw + 2047) / 2048);
+    const unsigned gx_cap = planes >= 1024 ? 1 : 1024 / planes;      // at most 1024 partial pairs (2048 floats)
+    if (gx > gx_cap) gx = gx_cap;
+    if (planes * gx > 1024) return D3M_ERR_INVALID;
+    const dim3 grid(gx, planes);
+    LAUNCH("k_photometric_reduce", k_photometric_reduce, grid, dim3(256), st, im1, im2, mask, conf_sigma, scratch, channels,
+           (int)hw);
+    LAUNCH("k_photometric_finish", k_photometric_finish, grad_im1 ? grid : dim3(1, 1), dim3(256), st, im1, im2, mask,
+           conf_sigma, (const float*)scratch, (int)(planes * gx), loss, grad_im1, channels, (int)hw);
     return check_launch();
 }
 
-D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, long n,
+D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, float* scratch, long n,
                                      d3m_stream_t stream) {
-    if (!a || !b || !loss || n <= 0) return D3M_ERR_INVALID;
+    if (!a || !b || !loss || !scratch || n <= 0) return D3M_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(loss, 0, sizeof(float), st));
-    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    LAUNCH("k_sum_squared_error", k_sum_squared_error, dim3(grid), dim3(256), st, a, b, loss, grad_a, n);
+    const unsigned grid = (unsigned)((n + 2047) / 2048 < 1024 ? (n + 2047) / 2048 : 1024);
+    LAUNCH("k_sum_squared_error", k_sum_squared_error, dim3(grid), dim3(256), st, a, b, scratch, grad_a, n);
+    LAUNCH("k_sum_partials", k_sum_partials, dim3(1), dim3(256), st, (const float*)scratch, (int)grid, loss);
     return check_launch();
 }

@@ -58,6 +58,7 @@ class MultiViewFit:
         self.renderer.eye = self.eyes
         self.image_size = image_size
         self.targets = None
+        self._graph = None
 
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices
@@ -79,12 +80,39 @@ class MultiViewFit:
         return (photometric_loss(rgb, rgb_t, mask=mask) + silhouette_loss(alpha, alpha_t) / pixels +
                 photometric_loss(depth[:, None], depth_t[:, None], mask=mask))
 
-    def step(self):
-        """forward + loss + backward + gradient all-reduce.  Returns (loss, grad_vertices, grad_textures)."""
+    def _forward_backward(self):
         self.vertices.grad = None
         self.textures.grad = None
         loss = self.loss(*self.render())
         loss.backward()
+        return loss.detach()
+
+    def capture_graph(self, warmup=3):
+        """Capture forward + loss + backward of one step into a HIP graph (torch.cuda.CUDAGraph): the step is
+        ~50 short kernels, so eager launches are host-bound (~1 ms of Python per step).  Every kernel of
+        libd3m_raster.so goes to torch's current stream and none allocates or synchronises, so the whole step
+        is capturable.  Vertices / textures / targets are updated IN PLACE between replays."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._forward_backward()
+        torch.cuda.current_stream().wait_stream(side)
+        self.vertices.grad = None
+        self.textures.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._graph_loss = self._forward_backward()
+        self._graph = graph
+        return self
+
+    def step(self):
+        """forward + loss + backward + gradient all-reduce.  Returns (loss, grad_vertices, grad_textures)."""
+        if self._graph is not None:
+            self._graph.replay()
+            loss = self._graph_loss
+        else:
+            loss = self._forward_backward()
         grads = [self.vertices.grad] + ([self.textures.grad] if self.textures.requires_grad else [])
         grads = allreduce_flat(grads)
-        return loss.detach(), grads[0], (grads[1] if len(grads) > 1 else None)
+        return loss, grads[0], (grads[1] if len(grads) > 1 else None)

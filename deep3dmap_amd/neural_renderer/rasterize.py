@@ -90,7 +90,7 @@ def _raster_backward(faces, textures, m, S, eps, grad_rgb_map, grad_alpha_map, g
     if return_rgb and need_textures_grad:
         grad_textures = torch.zeros_like(textures, dtype=torch.float32)
         ops.backward_textures(m["face_index_map"], m["sampling_weight_map"], m["sampling_index_map"], grad_rgb_map,
-                              grad_textures, faces.shape[1])
+                              grad_textures, faces.shape[1], faces=faces)
     if return_depth:
         ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                grad_depth_map, grad_faces, S)

@@ -73,15 +73,20 @@ def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, 
 
 
 def backward_textures(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures,
-                      num_faces):
-    _lib.require_device(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures,
+                      num_faces, faces=None):
+    """`faces` is optional and not part of the reference signature: with it the texel sums are gathered per
+    visible face instead of scattered with float atomics."""
+    _lib.require_device(face_index_map, sampling_weight_map, sampling_index_map, grad_rgb_map, grad_textures, faces,
                         names=["face_index_map", "sampling_weight_map", "sampling_index_map", "grad_rgb_map",
-                               "grad_textures"])
+                               "grad_textures", "faces"])
+    L = _lib.lib()
     B, S = face_index_map.shape[:2]
-    rc = _lib.lib().d3m_backward_textures(
-        _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map), _lib.ptr(sampling_index_map),
+    ws = _workspace("faces", L.d3m_backward_faces_workspace_bytes(B, int(num_faces)), face_index_map.device) \
+        if faces is not None else None
+    rc = L.d3m_backward_textures(
+        _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(sampling_weight_map), _lib.ptr(sampling_index_map),
         _lib.ptr(grad_rgb_map), _lib.ptr(grad_textures), B, int(num_faces), S, int(grad_textures.shape[2]),
-        _lib.stream_ptr())
+        _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
     _lib.check(rc, "backward_textures")
     return grad_textures
 
@@ -91,10 +96,12 @@ def backward_depth_map(faces, depth_map, face_index_map, face_inv_map, weight_ma
     _lib.require_device(faces, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
                         names=["faces", "depth_map", "face_index_map", "face_inv_map", "weight_map",
                                "grad_depth_map", "grad_faces"])
+    L = _lib.lib()
     B, F = faces.shape[:2]
-    rc = _lib.lib().d3m_backward_depth_map(
+    ws = _workspace("faces", L.d3m_backward_faces_workspace_bytes(B, F), faces.device)
+    rc = L.d3m_backward_depth_map(
         _lib.ptr(faces), _lib.ptr(depth_map), _lib.ptr(face_index_map), _lib.ptr(_opt(face_inv_map)),
         _lib.ptr(weight_map), _lib.ptr(grad_depth_map), _lib.ptr(grad_faces), B, F, int(image_size),
-        _lib.stream_ptr())
+        _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "backward_depth_map")
     return grad_faces

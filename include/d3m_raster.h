@@ -95,18 +95,25 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
                            int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
                            d3m_stream_t stream);
 
-/* Replaces backward_textures (KCPP:152-168 -> KCU:506-540): grad_textures [B,F,ts,ts,ts,3] += . */
-int d3m_backward_textures(const int32_t* face_index_map, const float* sampling_weight_map,
+/* Scratch for the two entry points below: one int per face.  With it the sums are GATHERED per visible
+ * face (no atomics; faces with a very large bounding box still use the per-pixel atomic kernel);
+ * without it (NULL) the reference's per-pixel float atomics are used throughout. */
+size_t d3m_backward_faces_workspace_bytes(int batch_size, int num_faces);
+
+/* Replaces backward_textures (KCPP:152-168 -> KCU:506-540): grad_textures [B,F,ts,ts,ts,3] += .
+ * `faces` [B,F,3,3] is an ADDITION to the reference's argument list (needed to gather per face; pass
+ * NULL to force the atomic form). */
+int d3m_backward_textures(const float* faces, const int32_t* face_index_map, const float* sampling_weight_map,
                           const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
-                          int batch_size, int num_faces, int image_size, int texture_size,
-                          d3m_stream_t stream);
+                          int batch_size, int num_faces, int image_size, int texture_size, void* workspace,
+                          size_t workspace_bytes, d3m_stream_t stream);
 
 /* Replaces backward_depth_map (KCPP:170-191 -> KCU:543-592): grad_faces += (after backward_pixel_map).
  * face_inv_map may be NULL: the face inverse is then recomputed from `faces` (bit-identical values). */
 int d3m_backward_depth_map(const float* faces, const float* depth_map, const int32_t* face_index_map,
                            const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
-                           float* grad_faces, int batch_size, int num_faces, int image_size,
-                           d3m_stream_t stream);
+                           float* grad_faces, int batch_size, int num_faces, int image_size, void* workspace,
+                           size_t workspace_bytes, d3m_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * B. The eager-torch steps either side of those operators, as single HIP passes.
@@ -199,12 +206,13 @@ int d3m_output_epilogue_backward(const float* grad_rgb_out, const float* grad_al
  *    Each writes ONE f32 to `loss` (device) and, if grad_* != NULL, the gradient for d(loss) = 1.
  * ---------------------------------------------------------------------------------------------- */
 /* photometric_loss(im1, im2, mask, conf_sigma): im [B,C,H,W]; mask/conf_sigma [B,1,H,W] or NULL.
- * scratch: 3 floats of device memory, zero-initialised by the call itself. */
+ * scratch: 2048 floats of device memory (per-workgroup partial sums; no initialisation needed);
+ * batch_size * channels must not exceed 1024. */
 int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, const float* conf_sigma,
                          float* loss, float* grad_im1, float* scratch, int batch_size, int channels,
                          int height, int width, d3m_stream_t stream);
-/* sum((a-b)^2) over n elements (silhouette loss of the examples). */
-int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, long n,
+/* sum((a-b)^2) over n elements (silhouette loss of the examples).  scratch: 1024 floats. */
+int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, float* scratch, long n,
                           d3m_stream_t stream);
 
 #ifdef __cplusplus

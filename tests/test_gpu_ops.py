@@ -89,6 +89,11 @@ def test_backward_ops_match_reference_vectors(golden, name):
     ops.backward_pixel_map(m["faces"], m["face_index_map"], rgb, alpha, g_rgb, g_alpha, gf, S, eps, 1, 1)
     ops.backward_textures(m["face_index_map"], m["sampling_weight_map"], m["sampling_index_map"], g_rgb, gt,
                           m["faces"].shape[1])
+    # the same sums gathered per visible face (optional `faces` argument) instead of scattered atomically
+    gt2 = torch.zeros_like(m["textures"])
+    ops.backward_textures(m["face_index_map"], m["sampling_weight_map"], m["sampling_index_map"], g_rgb, gt2,
+                          m["faces"].shape[1], faces=m["faces"])
+    assert _grad_close(gt2.cpu().numpy(), c["grad_textures"])
     ops.backward_depth_map(m["faces"], m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                            g_depth, gf, S)
     assert _grad_close(gf.cpu().numpy(), c["grad_faces_all"])

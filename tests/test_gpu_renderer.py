@@ -225,3 +225,24 @@ def test_rasterize_module_matches_reference_layout():
     assert r2[0].numel() == 0 and r2[2].numel() == 0 and r2[1].shape == (1, 32, 32)
     with pytest.raises(TypeError):
         nr.Rasterize(32, 0.1, 100.0, 1e-3, [0, 0, 0], False, True, False)(torch.from_numpy(faces), None)
+
+
+def test_loss_kernels_match_reference_losses(golden):
+    """photometric_loss / silhouette loss kernels vs vectors produced by the reference's utils.py."""
+    from deep3dmap_amd.core import photometric_loss, silhouette_loss
+    g = golden
+    a, b, m, s = (_t(g, k) for k in ("loss/a", "loss/b", "loss/mask", "loss/sigma"))
+    assert np.allclose(photometric_loss(a, b).item(), g["loss/photometric"], rtol=1e-5)
+    assert np.allclose(photometric_loss(a, b, mask=m).item(), g["loss/photometric_mask"], rtol=1e-5)
+    assert np.allclose(photometric_loss(a, b, mask=m, conf_sigma=s).item(), g["loss/photometric_mask_sigma"], rtol=1e-5)
+    # gradients against torch autograd of the oracle's restatement
+    from oracle import nr_oracle as O
+    ag = a.clone().requires_grad_(True)
+    (photometric_loss(ag, b, mask=m, conf_sigma=s) * 3.0).backward()
+    ac = a.cpu().clone().requires_grad_(True)
+    (O.photometric_loss(ac, b.cpu(), mask=m.cpu(), conf_sigma=s.cpu()) * 3.0).backward()
+    assert torch.allclose(ag.grad.cpu(), ac.grad, rtol=1e-4, atol=1e-7)
+    ag = a.clone().requires_grad_(True)
+    silhouette_loss(ag[:, 0], b[:, 0]).backward()
+    assert np.allclose(silhouette_loss(a[:, 0], b[:, 0]).item(), ((a[:, 0] - b[:, 0]) ** 2).sum().item(), rtol=1e-5)
+    assert torch.allclose(ag.grad, 2 * (a - b) * torch.tensor([1., 0, 0], device="cuda").view(1, 3, 1, 1), atol=1e-6)
