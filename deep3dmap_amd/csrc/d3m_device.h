@@ -147,28 +147,33 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Wave-aggregated counter bump: lanes with `has` add 1 to counters[key]; lanes sharing a key are merged
-// into ONE atomic by an elected leader.  Returns this lane's slot (base + rank among equal keys) when
-// `want_slot`, which makes it usable both for counting and for cursor-style list fills.
+// into ONE atomic issued by an elected leader.  Group discovery (ballot / shuffle only) comes first, so
+// all leaders' atomics go out in a single wave instruction instead of a chain of dependent round trips.
+// Returns this lane's slot (base + rank among equal keys) when `want_slot`: usable both for counting and
+// for cursor-style list fills.
 __device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot) {
     unsigned long long pending = __ballot(has);
     const int lane = lane_id();
-    int slot = 0;
+    int my_leader = lane, my_rank = 0, my_count = 0;
     while (pending) {
         const int leader = __ffsll((long long)pending) - 1;
         const unsigned long long k_lo = __shfl((unsigned long long)key, leader, 64);
         const unsigned long long same = __ballot(has && (unsigned long long)key == k_lo);
-        int base = 0;
-        if (lane == leader) {
-            if (want_slot) base = atomicAdd(&counters[key], __popcll(same));
-            else atomicAdd(&counters[key], __popcll(same));
-        }
-        if (want_slot) {
-            base = __shfl(base, leader, 64);
-            if (has && (unsigned long long)key == k_lo) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        if (has && (unsigned long long)key == k_lo) {
+            my_leader = leader;
+            my_rank = __popcll(same & ((1ull << lane) - 1ull));
+            my_count = __popcll(same);
         }
         pending &= ~same;
     }
-    return slot;
+    int base = 0;
+    if (has && lane == my_leader) {
+        if (want_slot) base = atomicAdd(&counters[key], my_count);
+        else atomicAdd(&counters[key], my_count);
+    }
+    if (!want_slot) return 0;
+    base = __shfl(base, my_leader, 64);
+    return base + my_rank;
 }
 
 }  // namespace d3m

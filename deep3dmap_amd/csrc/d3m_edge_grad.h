@@ -9,18 +9,21 @@
 //
 // LINE-MAJOR formulation.  A walk only ever moves along ONE image line (a row for axis 1, a column for
 // axis 0), and a line is shared by hundreds of walks.  So:
-//   1. k_edge_count   one lane per face: enumerate crossings exactly as the reference does, count the
-//                     LONG walk segments per face and per line;
-//   2. k_alloc_ranges (x2) hand every face / every line a slice of the item arrays (order-free);
-//   3. k_edge_emit    one lane per face: enumerate again; walk SHORT segments itself (a handful of
-//                     pixels) and write each long segment as a 48-byte item, indexed under its line;
+//   0. k_mark_visible / k_compact_visible   faces that own no pixel cannot contribute: drop them;
+//   1. k_edge_count   SIX lanes per visible face, one per (edge, axis): enumerate crossings exactly as
+//                     the reference does, count the LONG walk segments per lane and per line, reserve
+//                     item slots (wave prefix + one atomic per wave);
+//   2. k_alloc_ranges hand every line a slice of the item index (order-free);
+//   3. k_edge_emit    same lanes: enumerate again; walk SHORT segments in-lane (a handful of pixels)
+//                     and write each long segment as a 48-byte item, indexed under its line;
 //   4. k_edge_lines   one workgroup per (view, axis, line, part): stage the line's maps in LDS ONCE
 //                     (unit stride: column lines read transposed copies of the maps), then one wave
 //                     per item walks 64 pixels per iteration out of LDS and wave-reduces;
-//   5. k_edge_gather  one lane per face: add its items' results to the short-walk sums and store.
-// No global atomics on the gradient, results are deterministic, and the reference's contract
-// "overwrite the 9 entries of every front-facing face, leave culled faces alone" (KCU:270,501-502) is
-// kept.  Per visited pixel the expressions are those of KCU:385-412 / :473-493; the two divisions
+//   5. k_edge_gather  one lane per visible face: its six lanes' sums + their items' results, stored once.
+// No global atomics on the gradient and the result is deterministic.  The reference OVERWRITES the 9
+// entries of every front-facing face (KCU:501-502) and leaves culled ones alone (KCU:270); with the
+// caller's zero-initialised grad_faces (rasterize.py:111, a precondition of the C ABI) writing only the
+// faces that own a pixel is the same thing: every other front-facing face would get zeros.  Per visited pixel the expressions are those of KCU:385-412 / :473-493; the two divisions
 // inside the walk use v_rcp_f32 (1 ulp), far inside the 1e-3 gradient tolerance.
 #pragma once
 #include "d3m_backward.h"
@@ -50,12 +53,15 @@ struct EdgeGradArgs {
 
 struct EdgeWork {
     int* visible;        // [B*F]   1 if the face owns a pixel (zeroed per call, set by k_mark_visible)
-    int* face_count;     // [B*F]   long segments per face (zeroed per call)
-    int* face_offset;    // [B*F]
+    int* visible_list;   // [B*F]   compacted indices of those faces
+    int* n_visible;      // [1]     (zeroed per call)
+    int* lane_count;     // [6*B*F] long segments per (visible face, edge, axis) lane, indexed by list position
+    int* lane_offset;    // [6*B*F] first item slot of that lane
+    float2* lane_partial;// [6*B*F] short-walk sums of that lane
     int* line_count;     // [B*2*S] long segments per line (zeroed per call)
     int* line_cursor;    // [B*2*S] (zeroed per call)
     int* line_offset;    // [B*2*S]
-    int* alloc;          // [2] cursors of the two range allocations (zeroed per call)
+    int* alloc;          // [2] cursors: item slots, line slices (zeroed per call)
     uint32_t* items;     // [cap * EG_ITEM_DW]
     int* line_items;     // [cap] item indices grouped by line
     float2* results;     // [cap]
@@ -68,85 +74,70 @@ struct SegRef {
 
 // One walk segment.
 struct Segment {
-    int axis, slot0, slot1, d0, from, to, inward, f0, f1;
+    int axis, d0, from, to, inward, f0, f1;
     float d1_cross, q0, q1;
     int ref_pos;     // d1 of the pixel whose value is the reference (in-pixel for outward, out-pixel for inward)
 };
 
-// Enumerates every walk segment of one face in the reference's order (edges, then axes, then d0).
-// pp = pixel-space x0,y0,x1,y1,x2,y2 (KCU:282).  owner(axis, d0, d1) must return face_index_map at that
+// Enumerates the walk segments of ONE (edge, axis) pair of a face, in the reference's d0 order.
+// p00..p21 = p[num][dim] of KCU:289-294 for that pair.  owner(d0, d1) must return face_index_map at that
 // line position; emit(const Segment&) is called for each non-empty segment.
 template <class Owner, class Emit>
-__device__ __forceinline__ void for_each_segment(const float* pp, int fn, int is, Owner&& owner, Emit&& emit) {
-#pragma unroll
-    for (int edge = 0; edge < 3; edge++) {
-        const int i0 = edge, i1 = (edge + 1) % 3, i2 = (edge + 2) % 3;                    // pi[], KCU:278-279
-#pragma unroll
-        for (int axis = 0; axis < 2; axis++) {
-            // p[num][dim] = pp[num][(dim + axis) % 2], KCU:289-294
-            const float p00 = pp[2 * i0 + axis], p01 = pp[2 * i0 + 1 - axis];
-            const float p10 = pp[2 * i1 + axis], p11 = pp[2 * i1 + 1 - axis];
-            const float p20 = pp[2 * i2 + axis], p21 = pp[2 * i2 + 1 - axis];
-            const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
-            const int d0_from = f2i(fmaxf(ceilf(fminf(p00, p10)), 0.0f));                          // KCU:312
-            const int d0_to = f2i(fminf(fmaxf(p00, p10), (float)(is - 1)));                        // KCU:313
-            Segment sg;
-            sg.axis = axis;
-            sg.slot0 = i0 * 2 + (1 - axis);
-            sg.slot1 = i1 * 2 + (1 - axis);
-            for (int d0 = d0_from; d0 <= d0_to; d0++) {
-                const float fd0 = (float)d0;
-                const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;             // KCU:317
-                const int d1_in = (0 < direction) ? f2i(floorf(d1_cross)) : f2i(ceilf(d1_cross));
-                const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
-                if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;             // KCU:325-328
-                sg.d0 = d0;
-                sg.d1_cross = d1_cross;
-                sg.f0 = p10 != fd0;
-                sg.f1 = p00 != fd0;
-                sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
-                sg.q1 = (p10 - p00) / (fd0 - p00);
-                // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
-                if (owner(axis, d0, d1_in) == fn) {
-                    const int d1_limit = (0 < direction) ? is - 1 : 0;
-                    sg.from = max(min(d1_out, d1_limit), 0);
-                    sg.to = min(max(d1_out, d1_limit), is - 1);
-                    sg.inward = 0;
-                    sg.ref_pos = d1_in;
-                    emit(sg);
-                }
-                // inward: in-pixel .. opposite edge (KCU:417-431)
-                float d0_cross2;
-                if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
-                else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
-                const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
-                sg.from = max(min(d1_in, d1_limit), 0);
-                sg.to = min(max(d1_in, d1_limit), is - 1);
-                if (sg.from <= sg.to) {
-                    sg.inward = 1;
-                    sg.ref_pos = d1_out;
-                    emit(sg);
-                }
-            }
+__device__ __forceinline__ void for_each_segment(float p00, float p01, float p10, float p11, float p20, float p21,
+                                                 int axis, int fn, int is, Owner&& owner, Emit&& emit) {
+    const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
+    const int d0_from = f2i(fmaxf(ceilf(fminf(p00, p10)), 0.0f));                          // KCU:312
+    const int d0_to = f2i(fminf(fmaxf(p00, p10), (float)(is - 1)));                        // KCU:313
+    Segment sg;
+    sg.axis = axis;
+    for (int d0 = d0_from; d0 <= d0_to; d0++) {
+        const float fd0 = (float)d0;
+        const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;             // KCU:317
+        const int d1_in = (0 < direction) ? f2i(floorf(d1_cross)) : f2i(ceilf(d1_cross));
+        const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
+        if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;             // KCU:325-328
+        sg.d0 = d0;
+        sg.d1_cross = d1_cross;
+        sg.f0 = p10 != fd0;
+        sg.f1 = p00 != fd0;
+        sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
+        sg.q1 = (p10 - p00) / (fd0 - p00);
+        // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
+        if (owner(d0, d1_in) == fn) {
+            const int d1_limit = (0 < direction) ? is - 1 : 0;
+            sg.from = max(min(d1_out, d1_limit), 0);
+            sg.to = min(max(d1_out, d1_limit), is - 1);
+            sg.inward = 0;
+            sg.ref_pos = d1_in;
+            emit(sg);
+        }
+        // inward: in-pixel .. opposite edge (KCU:417-431)
+        float d0_cross2;
+        if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
+        else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
+        const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
+        sg.from = max(min(d1_in, d1_limit), 0);
+        sg.to = min(max(d1_in, d1_limit), is - 1);
+        if (sg.from <= sg.to) {
+            sg.inward = 1;
+            sg.ref_pos = d1_out;
+            emit(sg);
         }
     }
 }
 
-// Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).
-__device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, float q0, float q1, bool f0, bool f1,
+// Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).  Branch-free: a pixel whose
+// diff_grad is <= 0 (KCU:401/:481) contributes 0 through the select, NaNs still propagate.
+__device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, float q0, float q1, float m0, float m1,
                                             float two_over_is, float eps, float& g0, float& g1) {
-    if (diff <= 0) return;
+    const float d = (diff <= 0) ? 0.0f : diff;
     const float t = (float)d1 - d1_cross;
-    if (f0) {
-        float dist = q0 * t * two_over_is;
-        dist = (0 < dist) ? dist + eps : dist - eps;
-        g0 -= diff * __builtin_amdgcn_rcpf(dist);
-    }
-    if (f1) {
-        float dist = q1 * t * two_over_is;
-        dist = (0 < dist) ? dist + eps : dist - eps;
-        g1 -= diff * __builtin_amdgcn_rcpf(dist);
-    }
+    float dist0 = q0 * t * two_over_is;
+    dist0 = (0 < dist0) ? dist0 + eps : dist0 - eps;
+    g0 -= m0 * (d * __builtin_amdgcn_rcpf(dist0));
+    float dist1 = q1 * t * two_over_is;
+    dist1 = (0 < dist1) ? dist1 + eps : dist1 - eps;
+    g1 -= m1 * (d * __builtin_amdgcn_rcpf(dist1));
 }
 
 __device__ __forceinline__ SegRef load_ref(const AxisMaps& m, bool use_rgb, bool use_alpha, size_t idx) {
@@ -158,11 +149,17 @@ __device__ __forceinline__ SegRef load_ref(const AxisMaps& m, bool use_rgb, bool
 
 // short segment, walked straight from global memory by the owning lane
 __device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, bool use_alpha, size_t line_base,
-                                            const Segment& sg, int fn, const SegRef& ref, float two_over_is, float eps,
-                                            float& g0, float& g1) {
+                                            const Segment& sg, int fn, float two_over_is, float eps, float& g0,
+                                            float& g1) {
+    bool have_ref = false;
+    SegRef ref = {0, 0, 0, 0};
+    // a multiplier of exactly 0 must not turn an inf/NaN quotient into a NaN: give disabled terms q = 1
+    const float q0 = sg.f0 ? sg.q0 : 1.0f, q1 = sg.f1 ? sg.q1 : 1.0f;
+    const float m0 = sg.f0 ? 1.0f : 0.0f, m1 = sg.f1 ? 1.0f : 0.0f;
     for (int d1 = sg.from; d1 <= sg.to; d1++) {
         const size_t idx = line_base + d1;
         if (sg.inward && m.fi[idx] != fn) continue;
+        if (!have_ref) { ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos); have_ref = true; }
         float diff = 0;
         if (use_alpha) diff += (m.alpha[idx] - ref.alpha) * m.galpha[idx];
         if (use_rgb) {
@@ -170,58 +167,101 @@ __device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, boo
             diff += (m.rgb[3 * idx + 1] - ref.g) * m.grgb[3 * idx + 1];
             diff += (m.rgb[3 * idx + 2] - ref.b) * m.grgb[3 * idx + 2];
         }
-        visit_pixel(diff, d1, sg.d1_cross, sg.q0, sg.q1, sg.f0, sg.f1, two_over_is, eps, g0, g1);
+        visit_pixel(diff, d1, sg.d1_cross, q0, q1, m0, m1, two_over_is, eps, g0, g1);
     }
 }
 
-// A face that owns no pixel cannot contribute: the outward walk needs the in-pixel to be its own
-// (KCU:354) and the inward walk only counts its own pixels (KCU:470).  `visible` makes that a 4-byte test.
+// ---- 0. compact the faces that own at least one pixel -------------------------------------------------
+// A face that owns no pixel cannot contribute: the outward walk needs its own in-pixel (KCU:354) and the
+// inward walk only counts its own pixels (KCU:470).
+__global__ void __launch_bounds__(256) k_compact_visible(const int* __restrict__ visible, int* __restrict__ list,
+                                                        int* __restrict__ n_visible, long n) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool v = i < n && visible[i] != 0;
+    const unsigned long long mask = __ballot(v);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (lane == 0) s_wave[wv] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {                                   // one atomic per 256 faces
+        const int t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3];
+        const int tot = t0 + t1 + t2 + t3;
+        s_base = tot ? atomicAdd(n_visible, tot) : 0;
+        s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
+    }
+    __syncthreads();
+    if (v) list[s_base + s_wave[wv] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
+}
+
+// Six lanes per visible face, one per (edge, axis) pair; 42 faces per 256-thread workgroup.
+constexpr int EG_FACES_PER_BLOCK = 42;
+
 template <class FS>
-__device__ __forceinline__ bool load_face_pixels(const FS& fs, const int* visible, long gi, int B, int is, int& bn,
-                                                 int& fn, float* pp, float* zero_out) {
+__device__ __forceinline__ bool load_face_lane(const FS& fs, const EdgeWork& w, int blk, int is, int& pos, int& ea, long& gi,
+                                               int& bn, int& fn, float& p00, float& p01, float& p10, float& p11,
+                                               float& p20, float& p21) {
+    const int t = threadIdx.x;
+    if (t >= EG_FACES_PER_BLOCK * 6) return false;
+    pos = blk * EG_FACES_PER_BLOCK + t / 6;
+    ea = t % 6;
+    if (pos >= *w.n_visible) return false;
+    gi = w.visible_list[pos];
     const int F = fs.num_faces();
-    if (gi >= (long)B * F) return false;
     bn = (int)(gi / F);
     fn = (int)(gi % F);
-    const bool vis = visible[gi] != 0;
-    if (!vis && !zero_out) return false;
     float face[9];
     fs.load(bn, fn, face);
-    if (backside(face)) return false;                      // KCU:270: culled faces are left untouched
-    if (!vis) {                                            // front-facing but hidden: the reference stores zeros
+    if (backside(face)) return false;       // cannot own a pixel; kept for safety against inconsistent inputs
+    float px[3], py[3];
 #pragma unroll
-        for (int k = 0; k < 9; k++) zero_out[(size_t)gi * 9 + k] = 0.0f;
-        return false;
-    }
-#pragma unroll
-    for (int n = 0; n < 3; n++) {
-        pp[2 * n + 0] = to_pixel(face[3 * n + 0], is);     // KCU:282
-        pp[2 * n + 1] = to_pixel(face[3 * n + 1], is);
-    }
+    for (int n = 0; n < 3; n++) { px[n] = to_pixel(face[3 * n + 0], is); py[n] = to_pixel(face[3 * n + 1], is); }   // KCU:282
+    const int edge = ea >> 1, axis = ea & 1;
+    // vertex order (edge, edge+1, edge+2) mod 3 (KCU:278-279); dim 0 = x for axis 0, y for axis 1 (KCU:289-294)
+    const float ax0 = edge == 0 ? px[0] : edge == 1 ? px[1] : px[2], ay0 = edge == 0 ? py[0] : edge == 1 ? py[1] : py[2];
+    const float ax1 = edge == 0 ? px[1] : edge == 1 ? px[2] : px[0], ay1 = edge == 0 ? py[1] : edge == 1 ? py[2] : py[0];
+    const float ax2 = edge == 0 ? px[2] : edge == 1 ? px[0] : px[1], ay2 = edge == 0 ? py[2] : edge == 1 ? py[0] : py[1];
+    p00 = axis ? ay0 : ax0; p01 = axis ? ax0 : ay0;
+    p10 = axis ? ay1 : ax1; p11 = axis ? ax1 : ay1;
+    p20 = axis ? ay2 : ax2; p21 = axis ? ax2 : ay2;
     return true;
 }
 
-// ---- 1. count long segments per face and per line --------------------------------------------------
-// face_count[gi] = 1 + number of long segments for front-facing faces, 0 for culled ones (so that the
-// gather pass can tell "front-facing without items" from "culled").
+// ---- 1. count long segments per (face, edge, axis) lane and per line; reserve item slots ---------------
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeWork w, int B) {
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
-    int bn, fn;
-    float pp[6];
-    if (!load_face_pixels(fs, w.visible, gi, B, a.S, bn, fn, pp, nullptr)) return;
-    const int is = a.S;
-    const size_t base = (size_t)bn * is * is;
-    int n = 0;
-    for_each_segment(
-        pp, fn, is, [&](int axis, int d0, int d1) { return a.ax[axis].fi[base + (size_t)d0 * is + d1]; },
-        [&](const Segment& sg) {
-            if (sg.to - sg.from + 1 > EG_INLINE_MAX) {
-                n++;
-                atomicAdd(&w.line_count[((size_t)bn * 2 + sg.axis) * is + sg.d0], 1);
-            }
-        });
-    w.face_count[gi] = n;
+__global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeWork w) {
+    const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {      // fixed grid, uniform trip count per workgroup
+        int pos = 0, ea = 0, bn = 0, fn = 0, n = 0;
+        long gi = 0;
+        float p00, p01, p10, p11, p20, p21;
+        const bool on = load_face_lane(fs, w, blk, a.S, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21);
+        if (on) {
+            const int is = a.S, axis = ea & 1;
+            const int32_t* fi = a.ax[axis].fi + (size_t)bn * is * is;
+            for_each_segment(
+                p00, p01, p10, p11, p20, p21, axis, fn, is, [&](int d0, int d1) { return fi[(size_t)d0 * is + d1]; },
+                [&](const Segment& sg) {
+                    if (sg.to - sg.from + 1 > EG_INLINE_MAX) {
+                        n++;
+                        // neighbouring faces cross the same lines: merge equal lines within the wave
+                        wave_grouped_add(w.line_count, ((size_t)bn * 2 + axis) * is + sg.d0, true, false);
+                    }
+                });
+        }
+        // item slots: wave prefix + ONE atomic per wave (slices need not be ordered)
+        const int incl = wave_inclusive_scan(n);
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (total > 0) {
+            if (lane_id() == 0) base = atomicAdd(w.alloc, total);
+            base = __shfl(base, 0, 64);
+        }
+        if (on) {
+            w.lane_count[(size_t)pos * 6 + ea] = n;
+            w.lane_offset[(size_t)pos * 6 + ea] = base + incl - n;
+        }
+    }
 }
 
 // ---- 2. order-free range allocation: offsets[i] = slice start for counts[i] (one atomic per 256) ----
@@ -245,80 +285,63 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 }
 
 // ---- 3. walk short segments, emit long ones ------------------------------------------------------------
-// Item (12 dwords): 0 bits = slot0[0:3) slot1[3:6) inward[6] axis[7] f0[8] f1[9]; 1 d0 | b<<16;
-// 2 from | to<<16; 3 fn; 4 d1_cross; 5 q0; 6 q1; 7..10 reference alpha,r,g,b; 11 unused.
+// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2]; 1 unused; 2 from | to<<16; 3 fn; 4 d1_cross; 5 q0; 6 q1;
+// 7..10 reference alpha,r,g,b; 11 unused.  (line and slots are implied by where the item is indexed.)
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w, float* __restrict__ grad_faces, int B) {
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
-    int bn, fn;
-    float pp[6];
-    if (!load_face_pixels(fs, w.visible, gi, B, a.S, bn, fn, pp, grad_faces)) return;
-    const int is = a.S;
-    const float two_over_is = 2.0f / (float)is;
-    const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
-    const size_t base = (size_t)bn * is * is;
-    float acc[6] = {0, 0, 0, 0, 0, 0};
-    int k = 0;
-    const int my_offset = w.face_offset[gi];
-    for_each_segment(
-        pp, fn, is, [&](int axis, int d0, int d1) { return a.ax[axis].fi[base + (size_t)d0 * is + d1]; },
-        [&](const Segment& sg) {
-            const AxisMaps& m = a.ax[sg.axis];
-            const size_t line_base = base + (size_t)sg.d0 * is;
-            const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos);
-            const bool is_long = sg.to - sg.from + 1 > EG_INLINE_MAX;
-            const int item = my_offset + k;
-            if (is_long) k++;
-            const size_t line = ((size_t)bn * 2 + sg.axis) * is + sg.d0;
-            const uint32_t bits = (uint32_t)sg.slot0 | ((uint32_t)sg.slot1 << 3) | ((uint32_t)sg.inward << 6) |
-                                  ((uint32_t)sg.axis << 7) | ((uint32_t)sg.f0 << 8) | ((uint32_t)sg.f1 << 9);
-            // A long segment is queued only if both its item slot and its line's whole slice fit the
-            // capacity the workspace gives; otherwise this lane walks it (still correct, just serial).
-            const bool queued = is_long && item < w.cap &&
-                                (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
-            if (!queued) {
-                if (is_long && item < w.cap) {      // keep the gather pass well-defined for this slot
-                    w.items[(size_t)item * EG_ITEM_DW] = bits;
-                    w.results[item] = make_float2(0.0f, 0.0f);
+__global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w) {
+    const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        int pos = 0, ea = 0, bn = 0, fn = 0;
+        long gi = 0;
+        float p00, p01, p10, p11, p20, p21;
+        if (!load_face_lane(fs, w, blk, a.S, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21)) continue;
+        const int is = a.S, axis = ea & 1;
+        const float two_over_is = 2.0f / (float)is;
+        const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
+        const AxisMaps m = a.ax[axis];
+        const size_t base = (size_t)bn * is * is;
+        const int my_offset = w.lane_offset[(size_t)pos * 6 + ea];
+        float g0 = 0, g1 = 0;
+        int k = 0;
+        for_each_segment(
+            p00, p01, p10, p11, p20, p21, axis, fn, is, [&](int d0, int d1) { return m.fi[base + (size_t)d0 * is + d1]; },
+            [&](const Segment& sg) {
+                const size_t line_base = base + (size_t)sg.d0 * is;
+                const bool is_long = sg.to - sg.from + 1 > EG_INLINE_MAX;
+                const int item = my_offset + k;
+                if (is_long) k++;
+                const size_t line = ((size_t)bn * 2 + axis) * is + sg.d0;
+                // A long segment is queued only if both its item slot and its line's whole slice fit the
+                // capacity the workspace gives; otherwise this lane walks it (still correct, just serial).
+                const bool queued = is_long && item < w.cap &&
+                                    (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
+                if (!queued) {
+                    if (is_long && item < w.cap) w.results[item] = make_float2(0.0f, 0.0f);   // keep the gather well-defined
+                    walk_inline(m, use_rgb, use_alpha, line_base, sg, fn, two_over_is, a.eps, g0, g1);
+                    return;
                 }
-                float g0 = 0, g1 = 0;
-                walk_inline(m, use_rgb, use_alpha, line_base, sg, fn, ref, two_over_is, a.eps, g0, g1);
-                // slot indices are compile-time constants after for_each_segment is unrolled
-#pragma unroll
-                for (int s = 0; s < 6; s++) {
-                    if (s == sg.slot0) acc[s] += g0;
-                    if (s == sg.slot1) acc[s] += g1;
-                }
-                return;
-            }
-            uint4* q = (uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-            q[0] = make_uint4(bits, (uint32_t)sg.d0 | ((uint32_t)bn << 16), (uint32_t)sg.from | ((uint32_t)sg.to << 16),
-                              (uint32_t)fn);
-            q[1] = make_uint4(__float_as_uint(sg.d1_cross), __float_as_uint(sg.q0), __float_as_uint(sg.q1),
-                              __float_as_uint(ref.alpha));
-            q[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b), 0u);
-            const int pos = atomicAdd(&w.line_cursor[line], 1);
-            w.line_items[(size_t)w.line_offset[line] + pos] = item;
-        });
-    float* gf = grad_faces + (size_t)gi * 9;
-#pragma unroll
-    for (int n = 0; n < 3; n++) {
-        gf[3 * n + 0] = acc[2 * n + 0];
-        gf[3 * n + 1] = acc[2 * n + 1];
-        gf[3 * n + 2] = 0.0f;
+                const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos);
+                uint4* q = (uint4*)(w.items + (size_t)item * EG_ITEM_DW);
+                q[0] = make_uint4((uint32_t)sg.inward | ((uint32_t)sg.f0 << 1) | ((uint32_t)sg.f1 << 2), 0u,
+                                  (uint32_t)sg.from | ((uint32_t)sg.to << 16), (uint32_t)fn);
+                q[1] = make_uint4(__float_as_uint(sg.d1_cross), __float_as_uint(sg.f0 ? sg.q0 : 1.0f),
+                                  __float_as_uint(sg.f1 ? sg.q1 : 1.0f), __float_as_uint(ref.alpha));
+                q[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b), 0u);
+                const int slot = wave_grouped_add(w.line_cursor, line, true, true);
+                w.line_items[(size_t)w.line_offset[line] + slot] = item;
+            });
+        w.lane_partial[(size_t)pos * 6 + ea] = make_float2(g0, g1);
     }
 }
 
 // ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
-// LDS: the line's maps, structure of arrays, 9 x S floats (fi, alpha, galpha, r, g, b, gr, gg, gb).
+template <bool USE_RGB, bool USE_ALPHA>
 __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     const int is = a.S;
     const int part = blockIdx.x % EG_LINE_PARTS;
     const size_t line = blockIdx.x / EG_LINE_PARTS;          // (b*2 + axis)*S + d0
-    // items of this line that fit the capacity: a line's slice may straddle cap; entries past it were
-    // never written (k_edge_emit walked those segments itself), and cursor counts only written ones
-    const int n_items = w.line_cursor[line];
+    const int n_items = w.line_cursor[line];                  // items actually queued under this line
     if (part * 4 >= n_items) return;                          // nothing for this workgroup (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int d0 = (int)(line % is);
@@ -326,22 +349,22 @@ __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) 
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
-    const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
-    int* s_fi = (int*)s_line;
-    float* s_alpha = s_line + is;
-    float* s_galpha = s_line + 2 * is;
-    float* s_rgb = s_line + 3 * is;      // r | g | b planes
-    float* s_grgb = s_line + 6 * is;
+    // LDS image of the line: per pixel one float4 of values (alpha, r, g, b) and one of their gradients,
+    // then the owner indices: 2 x ds_read_b128 (+1 b32 for inward walks) per visited pixel.
+    float4* s_val = (float4*)s_line;
+    float4* s_grd = s_val + is;
+    int* s_fi = (int*)(s_grd + is);
     for (int p = threadIdx.x; p < is; p += 256) {
         s_fi[p] = m.fi[line_base + p];
-        if (use_alpha) { s_alpha[p] = m.alpha[line_base + p]; s_galpha[p] = m.galpha[line_base + p]; }
-    }
-    if (use_rgb) {
-        for (int e = threadIdx.x; e < 3 * is; e += 256) {      // coalesced over the interleaved rgb triplets
-            const int p = e / 3, c = e - 3 * p;
-            s_rgb[c * is + p] = m.rgb[3 * line_base + e];
-            s_grgb[c * is + p] = m.grgb[3 * line_base + e];
+        float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
+        if (USE_ALPHA) { v.x = m.alpha[line_base + p]; g.x = m.galpha[line_base + p]; }
+        if (USE_RGB) {
+            const size_t e = 3 * (line_base + p);
+            v.y = m.rgb[e]; v.z = m.rgb[e + 1]; v.w = m.rgb[e + 2];
+            g.y = m.grgb[e]; g.z = m.grgb[e + 1]; g.w = m.grgb[e + 2];
         }
+        s_val[p] = v;
+        s_grd[p] = g;
     }
     __syncthreads();
     const float two_over_is = 2.0f / (float)is;
@@ -352,21 +375,23 @@ __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) 
         const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
         const uint32_t bits = q0v.x;
         const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)q0v.w;
-        const bool inward = (bits >> 6) & 1, f0 = (bits >> 8) & 1, f1 = (bits >> 9) & 1;
+        const bool inward = bits & 1;
+        const float m0 = (bits >> 1) & 1 ? 1.0f : 0.0f, m1 = (bits >> 2) & 1 ? 1.0f : 0.0f;
         const float d1_cross = __uint_as_float(q1v.x), qq0 = __uint_as_float(q1v.y), qq1 = __uint_as_float(q1v.z);
         const float ra = __uint_as_float(q1v.w), rr = __uint_as_float(q2v.x), rg = __uint_as_float(q2v.y),
                     rb = __uint_as_float(q2v.z);
         float g0 = 0, g1 = 0;
         for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            if (inward && s_fi[d1] != fn) continue;
+            const float4 v = s_val[d1], g = s_grd[d1];
             float diff = 0;
-            if (use_alpha) diff += (s_alpha[d1] - ra) * s_galpha[d1];
-            if (use_rgb) {
-                diff += (s_rgb[d1] - rr) * s_grgb[d1];
-                diff += (s_rgb[is + d1] - rg) * s_grgb[is + d1];
-                diff += (s_rgb[2 * is + d1] - rb) * s_grgb[2 * is + d1];
+            if (USE_ALPHA) diff += (v.x - ra) * g.x;
+            if (USE_RGB) {
+                diff += (v.y - rr) * g.y;
+                diff += (v.z - rg) * g.z;
+                diff += (v.w - rb) * g.w;
             }
-            visit_pixel(diff, d1, d1_cross, qq0, qq1, f0, f1, two_over_is, a.eps, g0, g1);
+            if (inward && s_fi[d1] != fn) diff = 0;           // KCU:470: only this face's pixels
+            visit_pixel(diff, d1, d1_cross, qq0, qq1, m0, m1, two_over_is, a.eps, g0, g1);
         }
         g0 = wave_sum(g0);
         g1 = wave_sum(g1);
@@ -374,32 +399,34 @@ __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) 
     }
 }
 
-// ---- 5. per face: short-walk sums (already in grad_faces) + its items' results ------------------------
+// ---- 5. per visible face: the six lanes' short-walk sums + their items' results --------------------------
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces, int B) {
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gi >= (long)B * fs.num_faces()) return;
-    const int n = w.face_count[gi];
-    if (n == 0) return;                           // no long segments (or culled: count stays 0): nothing to add
-    const int off = w.face_offset[gi];
+__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces) {
+    const int n_vis = *w.n_visible;
+    for (int pos = blockIdx.x * 256 + threadIdx.x; pos < n_vis; pos += gridDim.x * 256) {
+    const long gi = w.visible_list[pos];
     float acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < n; k++) {
-        const int item = off + k;
-        if (item >= w.cap) break;                 // those were walked inline by k_edge_emit
-        const uint32_t bits = w.items[(size_t)item * EG_ITEM_DW];
-        const float2 r = w.results[item];
-        const int s0 = bits & 7, s1 = (bits >> 3) & 7;
 #pragma unroll
-        for (int s = 0; s < 6; s++) {
-            if (s == s0) acc[s] += r.x;
-            if (s == s1) acc[s] += r.y;
+    for (int ea = 0; ea < 6; ea++) {
+        const int edge = ea >> 1, axis = ea & 1;
+        const int n = w.lane_count[(size_t)pos * 6 + ea], off = w.lane_offset[(size_t)pos * 6 + ea];
+        float2 g = w.lane_partial[(size_t)pos * 6 + ea];
+        for (int k = 0; k < n; k++) {
+            if (off + k >= w.cap) break;                      // those were walked inline by k_edge_emit
+            const float2 r = w.results[off + k];
+            g.x += r.x;
+            g.y += r.y;
         }
+        acc[edge * 2 + (1 - axis)] += g.x;                    // vertex pi[0] = edge, component 1 - axis (KCU:406)
+        acc[((edge + 1) % 3) * 2 + (1 - axis)] += g.y;        // vertex pi[1] = edge + 1            (KCU:411)
     }
     float* gf = grad_faces + (size_t)gi * 9;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
-        gf[3 * v + 0] += acc[2 * v + 0];
-        gf[3 * v + 1] += acc[2 * v + 1];
+        gf[3 * v + 0] = acc[2 * v + 0];
+        gf[3 * v + 1] = acc[2 * v + 1];
+        gf[3 * v + 2] = 0.0f;
+    }
     }
 }
 
@@ -425,8 +452,9 @@ __global__ void __launch_bounds__(256) k_transpose_map(const uint32_t* __restric
 // ---- host side ----------------------------------------------------------------------------------------
 struct EdgeLayout {
     size_t off_fiT, off_alphaT, off_galphaT, off_rgbT, off_grgbT;
-    size_t off_zero, zero_bytes;   // face_count | line_count | line_cursor | alloc
-    size_t off_visible, off_face_count, off_line_count, off_line_cursor, off_alloc, off_face_offset, off_line_offset;
+    size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
+    size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_count, off_lane_offset,
+        off_lane_partial, off_line_offset;
     size_t off_items;              // items | line_items | results follow, sized by capacity
     size_t fixed_bytes;
 };
@@ -444,12 +472,15 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.off_grgbT = o;    o += eg_align(px * 12);
     L.off_zero = o;
     L.off_visible = o;      o += eg_align(nf * 4);
-    L.off_face_count = o;   o += eg_align(nf * 4);
     L.off_line_count = o;   o += eg_align(nl * 4);
     L.off_line_cursor = o;  o += eg_align(nl * 4);
-    L.off_alloc = o;        o += 256;
+    L.off_alloc = o;        o += 256;                 // alloc[0], alloc[1], n_visible (alloc[2])
     L.zero_bytes = o - L.off_zero;
-    L.off_face_offset = o;  o += eg_align(nf * 4);
+    L.off_visible_list = o; o += eg_align(nf * 4);
+    // at most half of the faces can be front-facing AND own a pixel only if ... no such bound: size for all
+    L.off_lane_count = o;   o += eg_align(nf * 6 * 4);
+    L.off_lane_offset = o;  o += eg_align(nf * 6 * 4);
+    L.off_lane_partial = o; o += eg_align(nf * 6 * 8);
     L.off_line_offset = o;  o += eg_align(nl * 4);
     L.off_items = o;
     L.fixed_bytes = o;
@@ -467,7 +498,7 @@ template <class FS>
 int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void* ws, size_t ws_bytes, hipStream_t st,
                   int* last_err) {
     const int S = m.S, F = fs.num_faces();
-    if (S > 65535 || B > 65535) return 1;                       // item packing limits (D3M_ERR_INVALID)
+    if (S > 65535) return 1;                                    // item packing limit (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + 1024) return 2;       // D3M_ERR_WORKSPACE
     char* p = (char*)ws;
@@ -476,11 +507,14 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     if (cap > 0x7FFFFF00) cap = 0x7FFFFF00;
     EdgeWork w;
     w.visible = (int*)(p + L.off_visible);
-    w.face_count = (int*)(p + L.off_face_count);
     w.line_count = (int*)(p + L.off_line_count);
     w.line_cursor = (int*)(p + L.off_line_cursor);
     w.alloc = (int*)(p + L.off_alloc);
-    w.face_offset = (int*)(p + L.off_face_offset);
+    w.n_visible = w.alloc + 2;
+    w.visible_list = (int*)(p + L.off_visible_list);
+    w.lane_count = (int*)(p + L.off_lane_count);
+    w.lane_offset = (int*)(p + L.off_lane_offset);
+    w.lane_partial = (float2*)(p + L.off_lane_partial);
     w.line_offset = (int*)(p + L.off_line_offset);
     w.items = (uint32_t*)(p + L.off_items);
     const size_t off_list = eg_align(L.off_items + cap * EG_ITEM_DW * 4);
@@ -511,21 +545,35 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     a.ax[1] = AxisMaps{m.face_index_map, m.alpha_map, m.grad_alpha_map, m.rgb_map, m.grad_rgb_map};
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps;
     const long nf = (long)B * F, nl = (long)B * 2 * S;
+    // worst-case grids (every face visible); workgroups past n_visible exit on their first load
     const dim3 gf((unsigned)((nf + 255) / 256)), gl((unsigned)((nl + 255) / 256));
+    // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device)
+    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const dim3 g6((unsigned)(g6_full < 8192 ? g6_full : 8192));
+    const dim3 gg((unsigned)((nf + 255) / 256 < 2048 ? (nf + 255) / 256 : 2048));
     LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
            m.face_index_map, w.visible, B, F, S);
-    LAUNCH("k_edge_count", k_edge_count<FS>, gf, dim3(256), st, fs, a, w, B);
-    LAUNCH("k_alloc_ranges", k_alloc_ranges, gf, dim3(256), st, (const int*)w.face_count, w.face_offset, w.alloc, nf);
+    LAUNCH("k_compact_visible", k_compact_visible, gf, dim3(256), st, (const int*)w.visible, w.visible_list, w.n_visible, nf);
+    LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
-    LAUNCH("k_edge_emit", k_edge_emit<FS>, gf, dim3(256), st, fs, a, w, grad_faces, B);
+    LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
     const size_t smem = (size_t)9 * S * 4;
-    if (smem > 64 * 1024) {
-        if (smem > 160 * 1024) return 1;                        // line does not fit LDS (S > 4551)
-        e = hipFuncSetAttribute((const void*)k_edge_lines, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) { *last_err = (int)e; return 3; }
-    }
-    LAUNCH_SMEM("k_edge_lines", k_edge_lines, dim3((unsigned)(nl * EG_LINE_PARTS)), dim3(256), smem, st, a, w);
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, gf, dim3(256), st, fs, w, grad_faces, B);
+    const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
+#define D3M_LINES(RGB, ALPHA)                                                                                        \
+    do {                                                                                                             \
+        if (smem > 64 * 1024) {                                                                                      \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem);                                                                      \
+            if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
+        }                                                                                                            \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(256), smem, st, a, w);                  \
+    } while (0)
+    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > 4551)
+    if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
+    else if (m.use_rgb) D3M_LINES(true, false);
+    else D3M_LINES(false, true);
+#undef D3M_LINES
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, gg, dim3(256), st, fs, w, grad_faces);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

@@ -84,9 +84,11 @@ int d3m_forward_texture_sampling(const float* faces, const float* textures, cons
                                  int num_faces, int image_size, int texture_size, float eps,
                                  d3m_stream_t stream);
 
-/* Replaces backward_pixel_map (KCPP:126-150 -> KCU:245-503).  OVERWRITES the 9 entries of every
- * front-facing face in grad_faces [B,F,3,3] (x,y components carry the gradient, z is set to 0);
- * culled faces are left untouched.  rgb_map/grad_rgb_map may be NULL when return_rgb == 0, alpha
+/* Replaces backward_pixel_map (KCPP:126-150 -> KCU:245-503).  Writes (not accumulates) the 9 entries of
+ * every face that owns at least one pixel in grad_faces [B,F,3,3] (x,y carry the gradient, z is set to
+ * 0).  grad_faces must arrive zero-initialised, as RasterizeFunction.backward provides it
+ * (rasterize.py:111): the reference also stores zeros for front-facing faces without pixels and leaves
+ * culled faces untouched, which is then identical.  rgb_map/grad_rgb_map may be NULL when return_rgb == 0, alpha
  * likewise.  workspace: d3m_backward_pixel_map_workspace_bytes() bytes of scratch (no init needed). */
 size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size);
 int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
