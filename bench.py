@@ -37,21 +37,38 @@ def algorithmic_bytes(V, F, S, s, ts, alpha=1, depth=1, rgb=1, tex_grad=1):
     return a_fwd, a_bwd
 
 
-# Per-kernel share of that byte count (DESIGN.md "Kernels and their rooflines"): bytes per view.
+# Per-kernel share of that byte count: the section-8(d) terms each kernel must touch, per view.
 def kernel_bytes(name, V, F, S, ts):
     P = S * S
+    maps = P * (4 + 4 + 12)            # face_index + alpha + rgb values
+    grads = P * (4 + 12)               # their gradients
     table = {
-        # reads faces of both windings' gather (verts+indices), writes the 20 B/px saved maps
         "k_raster_tiles": 12 * V + 12 * F + 20 * P,
         "k_bin_count": 12 * V + 12 * F,
         "k_bin_fill": 12 * F,
         "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
-        # edge gradient: face_index + alpha + rgb maps + their grads, verts+indices, writes x,y grads
-        "k_backward_pixel_map": P * (4 + 4 + 12) + P * (4 + 12) + 12 * V + 12 * F + 12 * V,
+        "k_edge_lines": maps + grads,
+        "k_edge_emit": 12 * V + 12 * F + maps + 12 * V,
+        "k_edge_count": 12 * V + 12 * F + 4 * P,
+        "k_backward_textures_faces": 12 * V + 12 * F + P * (4 + 12 + 12) + F * ts ** 3 * 12,
         "k_backward_textures": P * (4 + 12) + F * ts ** 3 * 12,
+        "k_backward_depth_faces": 12 * V + 12 * F + P * (20 + 4) + 12 * V,
         "k_backward_depth_map": P * (20 + 4) + 12 * V + 12 * F + 12 * V,
+        "k_lighting_forward": 12 * V + 12 * F + 2 * F * ts ** 3 * 12,
+        "k_lighting_backward": 12 * V + 12 * F + 2 * F * ts ** 3 * 12 + 12 * V,
     }
     return table.get(name)
+
+
+def measured_traffic(name):
+    """HBM bytes per launch of `name` from the newest committed PMC summary (profiles/*pmc_traffic*.json, made by
+    profiles/pmc_traffic.py from two rocprofv3 --pmc passes of this same command), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(name)
+    return k["hbm_bytes_per_launch"] if k else None
 
 
 def cpu_baseline(n, image_size, ts, budget_s=25.0):
@@ -169,7 +186,7 @@ def main():
         if kb is not None:
             ach = kb * args.views_per_gpu / dom_avg_s / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom),
                     "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_count / n_inst,
                     "algorithmic_bytes_per_launch": kb * args.views_per_gpu}
         out = {

@@ -33,7 +33,8 @@
 namespace d3m {
 
 constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are walked by the owning lane
-constexpr int EG_LINE_PARTS = 4;   // workgroups per line (items are dealt round-robin to the parts)
+constexpr int EG_LINE_PARTS = 2;   // workgroups per line (items are dealt round-robin to the parts)
+constexpr int EG_LINE_WAVES = 8;   // waves per workgroup: parts x waves walk one line's items concurrently
 constexpr int EG_ITEM_DW = 12;     // dwords per item
 
 // Maps as one scan axis sees them: element (line d0, position d1) lives at b*S*S + d0*S + d1.
@@ -49,6 +50,7 @@ struct EdgeGradArgs {
     AxisMaps ax[2];   // [0]: axis 0 = column walks (transposed maps); [1]: axis 1 = row walks (original maps)
     int S, use_rgb, use_alpha;
     float eps;
+    unsigned n_lines;   // B*2*S
 };
 
 struct EdgeWork {
@@ -336,13 +338,15 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
 
 // ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
 template <bool USE_RGB, bool USE_ALPHA>
-__global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
+__global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     const int is = a.S;
+    // (Keeping a line's parts on one XCD for L2 reuse was measured SLOWER: it piles a heavy line's work
+    //  onto one XCD.  Parts of a line are consecutive workgroups, i.e. spread over the XCDs.)
     const int part = blockIdx.x % EG_LINE_PARTS;
     const size_t line = blockIdx.x / EG_LINE_PARTS;          // (b*2 + axis)*S + d0
     const int n_items = w.line_cursor[line];                  // items actually queued under this line
-    if (part * 4 >= n_items) return;                          // nothing for this workgroup (uniform exit)
+    if (part * EG_LINE_WAVES >= n_items) return;              // nothing for this workgroup (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int d0 = (int)(line % is);
     const int axis = (int)((line / is) & 1);
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) 
     float4* s_val = (float4*)s_line;
     float4* s_grd = s_val + is;
     int* s_fi = (int*)(s_grd + is);
-    for (int p = threadIdx.x; p < is; p += 256) {
+    for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
         s_fi[p] = m.fi[line_base + p];
         float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
         if (USE_ALPHA) { v.x = m.alpha[line_base + p]; g.x = m.galpha[line_base + p]; }
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(256) k_edge_lines(EdgeGradArgs a, EdgeWork w) 
     __syncthreads();
     const float two_over_is = 2.0f / (float)is;
     const int* list = w.line_items + w.line_offset[line];
-    for (int it = part * 4 + wv; it < n_items; it += 4 * EG_LINE_PARTS) {
+    for (int it = part * EG_LINE_WAVES + wv; it < n_items; it += EG_LINE_WAVES * EG_LINE_PARTS) {
         const int item = list[it];
         const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
         const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
@@ -543,7 +547,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     EdgeGradArgs a;
     a.ax[0] = AxisMaps{fiT, alphaT, galphaT, rgbT, grgbT};
     a.ax[1] = AxisMaps{m.face_index_map, m.alpha_map, m.grad_alpha_map, m.rgb_map, m.grad_rgb_map};
-    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps;
+    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
     const long nf = (long)B * F, nl = (long)B * 2 * S;
     // worst-case grids (every face visible); workgroups past n_visible exit on their first load
     const dim3 gf((unsigned)((nf + 255) / 256)), gl((unsigned)((nl + 255) / 256));
@@ -566,7 +570,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
                                     (int)smem);                                                                      \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(256), smem, st, a, w);                  \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_WAVES * 64), smem, st, a, w);                  \
     } while (0)
     if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > 4551)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
