@@ -23,10 +23,15 @@ class MeshViewRenderer:
         n = len(azimuths)
         return self.renderer(vertices[None].expand(n, -1, -1), faces[None].expand(n, -1, -1), mode="silhouettes")
 
-    def fit_step(self, vertices, faces, target, azimuths, lr=0.01):
-        """One gradient step of sum((silhouette - target)^2); returns the loss before the step."""
-        loss = silhouette_loss(self.silhouettes(vertices, faces, azimuths), target)
-        (g,) = torch.autograd.grad(loss, vertices)
-        with torch.no_grad():
-            vertices -= lr * g
-        return float(loss)
+    def fit(self, vertices, faces, target, azimuths, steps=50, lr=0.01):
+        """Silhouette fit with Adam, as pnpmodules/neural_renderer/examples/example2.py:43-47,62 does:
+        minimise sum((silhouette - target)^2) over the vertices.  Returns the loss history."""
+        opt = torch.optim.Adam([vertices], lr=lr)
+        history = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = silhouette_loss(self.silhouettes(vertices, faces, azimuths), target)
+            loss.backward()
+            opt.step()
+            history.append(float(loss))
+        return history
