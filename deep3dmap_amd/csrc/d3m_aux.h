@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) k_gather_faces(IndexedFaces fs, float* __
     const int b = (int)(bf / Fp), f = (int)(bf % Fp);
     int ids[3];
     fs.vertex_ids(b, f, ids);
-    faces_out[i] = fs.verts[((size_t)b * fs.V + ids[n]) * 3 + c];
+    faces_out[i] = fs.verts[((size_t)(fs.vert_batch > 1 ? b : 0) * fs.V + ids[n]) * 3 + c];
 }
 
 // Backward of the gather: grad_vertices[b, id, c] += grad_faces[b, f, n, c].  One lane per input float

@@ -108,6 +108,7 @@ struct IndexedFaces {
     const float* verts;
     const int32_t* tri;
     int V, Ft, tri_batch, fill_back;
+    int vert_batch;   // 1: one vertex array shared by every view (stride 0), otherwise one per view
     __host__ __device__ __forceinline__ int num_faces() const { return fill_back ? 2 * Ft : Ft; }
     __device__ __forceinline__ void vertex_ids(int b, int f, int* ids) const {
         const bool back = f >= Ft;
@@ -122,7 +123,7 @@ struct IndexedFaces {
         vertex_ids(b, f, ids);
 #pragma unroll
         for (int n = 0; n < 3; n++) {
-            const float* p = verts + ((size_t)b * V + ids[n]) * 3;
+            const float* p = verts + ((size_t)(vert_batch > 1 ? b : 0) * V + ids[n]) * 3;
             out[3 * n + 0] = p[0];
             out[3 * n + 1] = p[1];
             out[3 * n + 2] = p[2];

@@ -1,0 +1,266 @@
+// d3m_lit.h -- texture sampling and its backward with fill_back and lighting applied ON THE FLY.
+//
+// The reference materialises, per view, cat(textures, textures.permute(0,1,4,3,2,5)) (renderer.py:156,204)
+// and multiplies it in place by the per-face light (lighting.py:55-56) before sampling: 2 x B copies of the
+// texture array per step.  Here the sampler reads the ORIGINAL textures [Bx,F,ts,ts,ts,3] (Bx = 1: one mesh
+// shared by all views), maps a back face F+f to face f with the first and third cube axes swapped, and
+// multiplies each fetched texel by light[face] -- the same f32 product the reference stores, so the sampled
+// colours are bit-identical.  The backward gathers per visible face (no atomics for ts == 2).
+#pragma once
+#include "d3m_aux.h"
+#include "d3m_face_major.h"
+
+namespace d3m {
+
+struct LitTextures {
+    const float* textures;   // [Bx, F, ts^3, 3]
+    const float* light;      // [Bm, F', 3]
+    int F, Fp, ts, tex_batch, light_batch, fill_back;
+};
+
+// texel `isc` of virtual face f' of view b -> offset into `textures`, or -1 when outside the virtual array
+// (ts == 1 only: KCU:229-233 then runs into the following faces, see k_texture_sampling).
+__device__ __forceinline__ long lit_texel(const LitTextures& t, int B, int b, int fp, int isc, int* light_row) {
+    const int ts3 = t.ts * t.ts * t.ts;
+    long vf = (long)b * t.Fp + fp + isc / ts3;       // face reached in the virtual [B,F'] array
+    isc %= ts3;
+    if (vf >= (long)B * t.Fp) return -1;
+    const int bb = (int)(vf / t.Fp), ff = (int)(vf % t.Fp);
+    *light_row = (t.light_batch > 1 ? bb : 0) * t.Fp + ff;
+    int fo = ff, idx = isc;
+    if (ff >= t.F) {                                  // back copy: texel (a,b,c) of it = texel (c,b,a) of face ff - F
+        fo = ff - t.F;
+        const int a = isc / (t.ts * t.ts), bq = (isc / t.ts) % t.ts, c = isc % t.ts;
+        idx = c * t.ts * t.ts + bq * t.ts + a;
+    }
+    return (((long)(t.tex_batch > 1 ? bb : 0) * t.F + fo) * ts3 + idx) * 3;
+}
+
+// per-face light of the (virtual, fill_back) face array on WORLD-space vertices (renderer.py:159-167)
+__global__ void __launch_bounds__(256) k_face_light(IndexedFaces fs, LightParams lp, float* __restrict__ light, int Bm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Fp = fs.num_faces();
+    if (i >= (long)Bm * Fp) return;
+    float fc[9], l[3];
+    fs.load((int)(i / Fp), (int)(i % Fp), fc);
+    face_light(fc, lp, l, nullptr, nullptr, nullptr);
+    light[3 * i + 0] = l[0]; light[3 * i + 1] = l[1]; light[3 * i + 2] = l[2];
+}
+
+// grad_light [Bm,F',3] -> world-space vertex gradients through the face normal (atomics: a vertex is shared
+// by ~6 faces; only faces that received a gradient do anything)
+__global__ void __launch_bounds__(256) k_face_light_backward(IndexedFaces fs, LightParams lp, const float* __restrict__ g_light,
+                                                            float* __restrict__ grad_vertices, int vertices_batch, int Bm) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Fp = fs.num_faces();
+    if (i >= (long)Bm * Fp || lp.id == 0) return;
+    const float gl[3] = {g_light[3 * i], g_light[3 * i + 1], g_light[3 * i + 2]};
+    if (gl[0] == 0 && gl[1] == 0 && gl[2] == 0) return;
+    const int b = (int)(i / Fp), f = (int)(i % Fp);
+    float fc[9], l[3], nrm[3], len, cs;
+    fs.load(b, f, fc);
+    face_light(fc, lp, l, nrm, &len, &cs);
+    if (!(cs > 0)) return;
+    const float g_cos = lp.id * (lp.cd[0] * gl[0] + lp.cd[1] * gl[1] + lp.cd[2] * gl[2]);
+    const float gn[3] = {g_cos * lp.dir[0], g_cos * lp.dir[1], g_cos * lp.dir[2]};
+    float gc[3];
+    if (len > 1e-5f) {
+        const float dot = nrm[0] * gn[0] + nrm[1] * gn[1] + nrm[2] * gn[2];
+        for (int k = 0; k < 3; k++) gc[k] = (gn[k] - nrm[k] * dot) / len;
+    } else {
+        for (int k = 0; k < 3; k++) gc[k] = gn[k] / 1e-5f;
+    }
+    const float a[3] = {fc[0] - fc[3], fc[1] - fc[4], fc[2] - fc[5]};
+    const float bb[3] = {fc[6] - fc[3], fc[7] - fc[4], fc[8] - fc[5]};
+    float ga[3], gb[3];
+    cross3(bb, gc, ga);
+    cross3(gc, a, gb);
+    int ids[3];
+    fs.vertex_ids(b, f, ids);
+    float* base = grad_vertices + (size_t)(vertices_batch > 1 ? b : 0) * fs.V * 3;
+    for (int k = 0; k < 3; k++) {
+        atomicAdd(&base[(size_t)ids[0] * 3 + k], ga[k]);
+        atomicAdd(&base[(size_t)ids[2] * 3 + k], gb[k]);
+        atomicAdd(&base[(size_t)ids[1] * 3 + k], -(ga[k] + gb[k]));
+    }
+}
+
+// trilinear sample positions of one covered pixel: KCU:209-231 (shared by the sampler and its backward)
+__device__ __forceinline__ void sample_setup(const float* face, const float* weight, float depth, int ts, float eps,
+                                             int* fl, float* fr) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float t = weight[k] * (float)(ts - 1) * (depth / face[3 * k + 2]);
+        t = fmaxf(t, 0.0f);                              // max(NaN, 0.) = 0 as in CUDA
+        t = fminf(t, (float)(ts - 1) - eps);
+        fl[k] = f2i(t);
+        fr[k] = t - (float)fl[k];
+    }
+}
+__device__ __forceinline__ void sample_corner(int pn, int ts, const int* fl, const float* fr, float& w, int& isc) {
+    w = 1;
+    int tii[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (((pn >> k) & 1) == 0) { w *= 1 - fr[k]; tii[k] = fl[k]; }
+        else                      { w *= fr[k];     tii[k] = fl[k] + 1; }
+    }
+    isc = tii[0] * ts * ts + tii[1] * ts + tii[2];
+}
+
+// forward: rgb_map[b,y,x,:] = sum_corners w * (texel * light)   (KCU:217-240 on the virtual lit array)
+__global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __restrict__ faces, LitTextures lt,
+                                                             const int32_t* __restrict__ face_index_map,
+                                                             const float* __restrict__ weight_map,
+                                                             const float* __restrict__ depth_map, float* __restrict__ rgb_map,
+                                                             int B, int S, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * S * S) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int bn = (int)(i / ((long)S * S));
+    const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
+    const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+    int fl[3];
+    float fr[3];
+    sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);
+    float px[3] = {0, 0, 0};
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float w;
+        int isc, lrow = 0;
+        sample_corner(pn, lt.ts, fl, fr, w, isc);
+        const long off = lit_texel(lt, B, bn, fi, isc, &lrow);
+        if (off >= 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) px[k] += w * (lt.textures[off + k] * lt.light[3 * (size_t)lrow + k]);
+        }
+    }
+    rgb_map[3 * i + 0] = px[0];
+    rgb_map[3 * i + 1] = px[1];
+    rgb_map[3 * i + 2] = px[2];
+}
+
+// backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of
+// w * grad_rgb live in LDS, then   grad_textures[view, f, texel] = sum * light   (plain store: within a view
+// at most one of the two copies of a face is front-facing) and  grad_light[face] += sum * texel.
+__global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float* __restrict__ faces, LitTextures lt,
+                                                                    const int32_t* __restrict__ face_index_map,
+                                                                    const float* __restrict__ weight_map,
+                                                                    const float* __restrict__ depth_map,
+                                                                    const float* __restrict__ grad_rgb_map,
+                                                                    float* __restrict__ gtex_view /*[B,F,24] zeroed*/,
+                                                                    float* __restrict__ grad_light /*[Bm,F',3] zeroed or NULL*/,
+                                                                    int* __restrict__ flags, int B, int S, float eps) {
+    __shared__ float s_acc[24][256];
+    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Fp = lt.Fp;
+    if (gi >= (long)B * Fp || flags[gi] == FLAG_HIDDEN) return;
+    const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
+    const float* face = faces + (size_t)gi * 9;
+    float fc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) fc[k] = face[k];
+    int x0, x1, y0, y1;
+    if (!pixel_bbox(fc, S, x0, x1, y0, y1)) return;
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int l = threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
+    const size_t base = (size_t)bn * S * S;
+    for (int y = y0; y <= y1; y++) {
+        for (int x = x0; x <= x1; x++) {
+            const size_t p = base + (size_t)y * S + x;
+            if (face_index_map[p] != fn) continue;
+            const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+            const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
+            int fl[3];
+            float fr[3];
+            sample_setup(fc, weight, depth_map[p], 2, eps, fl, fr);
+#pragma unroll
+            for (int pn = 0; pn < 8; pn++) {
+                float w;
+                int isc;
+                sample_corner(pn, 2, fl, fr, w, isc);
+                isc &= 7;
+                s_acc[isc * 3 + 0][l] += w * g0;
+                s_acc[isc * 3 + 1][l] += w * g1;
+                s_acc[isc * 3 + 2][l] += w * g2;
+            }
+        }
+    }
+    const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
+    const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
+    float gl[3] = {0, 0, 0};
+    const int fo = fn >= lt.F ? fn - lt.F : fn;
+    const float* tex = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24;
+    float* gt = gtex_view + ((size_t)bn * lt.F + fo) * 24;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int to = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float g = s_acc[t * 3 + c][l];
+            gt[to * 3 + c] += g * li[c];
+            gl[c] += g * tex[to * 3 + c];
+        }
+    }
+    if (grad_light) {
+        atomicAdd(&grad_light[3 * (size_t)lrow + 0], gl[0]);
+        atomicAdd(&grad_light[3 * (size_t)lrow + 1], gl[1]);
+        atomicAdd(&grad_light[3 * (size_t)lrow + 2], gl[2]);
+    }
+}
+
+// backward, per pixel with float atomics: any ts, and the faces the gathered form marked LARGE
+__global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const float* __restrict__ faces, LitTextures lt,
+                                                                     const int32_t* __restrict__ face_index_map,
+                                                                     const float* __restrict__ weight_map,
+                                                                     const float* __restrict__ depth_map,
+                                                                     const float* __restrict__ grad_rgb_map,
+                                                                     float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
+                                                                     float* __restrict__ grad_light,
+                                                                     const int* __restrict__ only_large, int B, int S,
+                                                                     float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * S * S) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int bn = (int)(i / ((long)S * S));
+    if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) return;
+    const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
+    const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+    const float g[3] = {grad_rgb_map[3 * i], grad_rgb_map[3 * i + 1], grad_rgb_map[3 * i + 2]};
+    int fl[3];
+    float fr[3];
+    sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);
+    const int ts3 = lt.ts * lt.ts * lt.ts;
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        float w;
+        int isc, lrow = 0;
+        sample_corner(pn, lt.ts, fl, fr, w, isc);
+        const long off = lit_texel(lt, B, bn, fi, isc, &lrow);
+        if (off < 0) continue;
+        // off addresses `textures`; the per-view gradient buffer has the same [.., F, ts^3, 3] tail but batch B
+        const long in_batch = off % ((long)lt.F * ts3 * 3);
+        long vb = ((long)bn * lt.Fp + fi + isc / ts3) / lt.Fp;       // view of the face actually reached
+        float* gt = gtex_view + (size_t)vb * lt.F * ts3 * 3 + in_batch;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicAdd(&gt[k], w * g[k] * lt.light[3 * (size_t)lrow + k]);
+            if (grad_light) atomicAdd(&grad_light[3 * (size_t)lrow + k], w * g[k] * lt.textures[off + k]);
+        }
+    }
+}
+
+// out[j] = sum_b in[b, j]  (shared textures: per-view gradients -> one gradient)
+__global__ void __launch_bounds__(256) k_sum_over_views(const float* __restrict__ in, float* __restrict__ out, long n, int B) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0;
+    for (int b = 0; b < B; b++) acc += in[(size_t)b * n + j];
+    out[j] = acc;
+}
+
+}  // namespace d3m

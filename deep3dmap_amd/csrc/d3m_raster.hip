@@ -13,6 +13,7 @@
 #include "d3m_edge_grad.h"
 #include "d3m_face_major.h"
 #include "d3m_forward.h"
+#include "d3m_lit.h"
 
 using namespace d3m;
 
@@ -349,7 +350,7 @@ D3M_EXPORT int d3m_gather_faces(const float* vertices, const int32_t* tri, int t
                                 int batch_size, int num_vertices, int num_tri, int fill_back, d3m_stream_t stream) {
     if (!vertices || !tri || !faces_out || batch_size <= 0 || num_vertices <= 0 || num_tri <= 0) return D3M_ERR_INVALID;
     if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
-    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, batch_size};
     const long n = (long)batch_size * fs.num_faces() * 9;
     LAUNCH("k_gather_faces", k_gather_faces, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, faces_out,
                        batch_size);
@@ -362,7 +363,7 @@ D3M_EXPORT int d3m_scatter_face_grads(const float* grad_faces, const int32_t* tr
     if (!grad_faces || !tri || !grad_vertices || batch_size <= 0 || num_vertices <= 0 || num_tri <= 0)
         return D3M_ERR_INVALID;
     if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
-    IndexedFaces fs{nullptr, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0};
+    IndexedFaces fs{nullptr, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, batch_size};
     const long n = (long)batch_size * fs.num_faces() * 9;
     LAUNCH("k_scatter_face_grads", k_scatter_face_grads, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, grad_faces,
                        grad_vertices, batch_size);
@@ -401,6 +402,109 @@ D3M_EXPORT int d3m_lighting_backward(const float* faces, const float* textures_i
     LAUNCH("k_lighting_backward", k_lighting_backward, dim3(blocks_for(num_faces_total, 256)), dim3(256), (hipStream_t)stream, faces,
                        textures_in, grad_out, grad_textures, grad_faces, lp, num_faces_total,
                        texture_size * texture_size * texture_size * 3);
+    return check_launch();
+}
+
+// ---- lit sampling: fill_back and lighting on the fly, shared textures (d3m_lit.h) ----------------------
+D3M_EXPORT int d3m_face_light(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch, float* light,
+                              float intensity_ambient, float intensity_directional, const float* color_ambient,
+                              const float* color_directional, const float* direction, int light_batch, int num_vertices,
+                              int num_tri, int fill_back, d3m_stream_t stream) {
+    if (!vertices || !tri || !light || !color_ambient || !color_directional || !direction || light_batch <= 0 ||
+        num_vertices <= 0 || num_tri <= 0)
+        return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, vertices_batch};
+    const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    const long n = (long)light_batch * fs.num_faces();
+    LAUNCH("k_face_light", k_face_light, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, lp, light, light_batch);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch,
+                                       const float* grad_light, float* grad_vertices, float intensity_ambient,
+                                       float intensity_directional, const float* color_ambient,
+                                       const float* color_directional, const float* direction, int light_batch,
+                                       int num_vertices, int num_tri, int fill_back, d3m_stream_t stream) {
+    if (!vertices || !tri || !grad_light || !grad_vertices || !color_ambient || !color_directional || !direction ||
+        light_batch <= 0 || num_vertices <= 0 || num_tri <= 0)
+        return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, vertices_batch};
+    const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    const long n = (long)light_batch * fs.num_faces();
+    LAUNCH("k_face_light_backward", k_face_light_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, lp,
+           grad_light, grad_vertices, vertices_batch, light_batch);
+    return check_launch();
+}
+
+static int make_lit(LitTextures& lt, const float* textures, int textures_batch, const float* light, int light_batch,
+                    int num_tri, int texture_size, int fill_back, int B) {
+    if (!textures || !light || num_tri <= 0 || texture_size <= 0) return D3M_ERR_INVALID;
+    if ((textures_batch != 1 && textures_batch != B) || (light_batch != 1 && light_batch != B)) return D3M_ERR_INVALID;
+    lt.textures = textures; lt.light = light; lt.F = num_tri; lt.Fp = fill_back ? 2 * num_tri : num_tri;
+    lt.ts = texture_size; lt.tex_batch = textures_batch; lt.light_batch = light_batch; lt.fill_back = fill_back ? 1 : 0;
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, int textures_batch,
+                                                const float* light, int light_batch, const int32_t* face_index_map,
+                                                const float* weight_map, const float* depth_map, float* rgb_map,
+                                                int batch_size, int num_tri, int fill_back, int image_size,
+                                                int texture_size, float eps, d3m_stream_t stream) {
+    if (!faces || !face_index_map || !weight_map || !depth_map || !rgb_map || batch_size <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    LitTextures lt;
+    int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
+    if (rc) return rc;
+    const long n = (long)batch_size * image_size * image_size;
+    LAUNCH("k_texture_sampling_lit", k_texture_sampling_lit, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, faces, lt,
+           face_index_map, weight_map, depth_map, rgb_map, batch_size, image_size, eps);
+    return check_launch();
+}
+
+D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size) {
+    if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0) return 0;
+    const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
+    return align_up((size_t)batch_size * num_tri * ts3 * 12, 256) + (size_t)batch_size * num_tri * (fill_back ? 2 : 1) * 4;
+}
+
+D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
+                                         int light_batch, const int32_t* face_index_map, const float* weight_map,
+                                         const float* depth_map, const float* grad_rgb_map, float* grad_textures,
+                                         float* grad_light, int batch_size, int num_tri, int fill_back, int image_size,
+                                         int texture_size, float eps, void* workspace, size_t workspace_bytes,
+                                         d3m_stream_t stream) {
+    if (!faces || !face_index_map || !weight_map || !depth_map || !grad_rgb_map || !grad_textures || batch_size <= 0 ||
+        image_size <= 0)
+        return D3M_ERR_INVALID;
+    LitTextures lt;
+    int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < d3m_backward_textures_lit_workspace_bytes(batch_size, num_tri, fill_back, texture_size))
+        return D3M_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch_size, S = image_size;
+    const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
+    const size_t view_elems = (size_t)num_tri * ts3 * 3;
+    // per-view gradients: straight into grad_textures when every view has its own textures
+    float* gview = textures_batch > 1 ? grad_textures : (float*)workspace;
+    int* flags = (int*)((char*)workspace + align_up((size_t)B * view_elems * 4, 256));
+    const long n = (long)B * S * S, nf = (long)B * lt.Fp;
+    HIP_TRY(hipMemsetAsync(gview, 0, (size_t)B * view_elems * 4, st));
+    if (grad_light) HIP_TRY(hipMemsetAsync(grad_light, 0, (size_t)light_batch * lt.Fp * 12, st));
+    if (texture_size == 2) {
+        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+        LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
+        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, 256)), dim3(256), st, faces,
+               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, flags, B, S, eps);
+        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
+    } else {
+        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps);
+    }
+    if (textures_batch == 1)
+        LAUNCH("k_sum_over_views", k_sum_over_views, dim3(blocks_for((long)view_elems, 256)), dim3(256), st, (const float*)gview,
+               grad_textures, (long)view_elems, B);
     return check_launch();
 }
 

@@ -63,9 +63,8 @@ class MultiViewFit:
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices
         t = self.textures if textures is None else textures
-        B = self.n_local
-        return self.renderer(v[None].expand(B, -1, -1), self.triangles[None].expand(B, -1, -1),
-                             t[None].expand(B, *t.shape))
+        # one mesh, one texture set, n_local cameras (renderer.eye is [n_local, 3]): batch-1 inputs are shared
+        return self.renderer(v[None], self.triangles[None], t[None])
 
     @torch.no_grad()
     def set_targets_from(self, target_vertices):

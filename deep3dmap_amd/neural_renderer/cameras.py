@@ -92,9 +92,9 @@ def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
         raise ValueError('vertices Tensor should have 3 dimensions')
     _no_grad_param(eye, "eye")
     device = vertices.device
-    B = vertices.shape[0]
     eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
     nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
+    B = max(vertices.shape[0], nb)          # vertices of batch 1 = one mesh seen by every camera
     rot = _basis(eye_t, at_t, up_t, True, nb, device)
     params = dict(mode=_lib.CAMERA_LOOK_AT, batch=B, rot=rot, eye_or_t=eye_t,
                   perspective=_perspective_angle is not None,
@@ -108,10 +108,10 @@ def look(vertices, eye, direction=[0, 1, 0], up=None, _perspective_angle=None):
         raise ValueError('vertices Tensor should have 3 dimensions')
     _no_grad_param(eye, "eye")
     device = vertices.device
-    B = vertices.shape[0]
     eye_t, dir_t = _vec_param(eye, device), _vec_param(direction, device)
     up_t = _vec_param([0, 1, 0] if up is None else up, device)
     nb = max(eye_t.shape[0], dir_t.shape[0], up_t.shape[0])
+    B = max(vertices.shape[0], nb)
     rot = _basis(eye_t, dir_t, up_t, False, nb, device)
     params = dict(mode=_lib.CAMERA_LOOK, batch=B, rot=rot, eye_or_t=eye_t,
                   perspective=_perspective_angle is not None,
@@ -139,9 +139,11 @@ def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
         _no_grad_param(p, name)
     device = vertices.device
     tt = as_device_f32(t, device).reshape(-1, 3)
-    params = dict(mode=_lib.CAMERA_PROJECTION, batch=vertices.shape[0], rot=as_device_f32(R, device).reshape(-1, 3, 3),
-                  eye_or_t=tt, K=as_device_f32(K, device).reshape(-1, 3, 3),
-                  dist=as_device_f32(dist_coeffs, device).reshape(-1, 5), orig_size=float(orig_size))
+    rot, Kt, dist = (as_device_f32(R, device).reshape(-1, 3, 3), as_device_f32(K, device).reshape(-1, 3, 3),
+                     as_device_f32(dist_coeffs, device).reshape(-1, 5))
+    batch = max(vertices.shape[0], tt.shape[0], rot.shape[0], Kt.shape[0], dist.shape[0])
+    params = dict(mode=_lib.CAMERA_PROJECTION, batch=batch, rot=rot, eye_or_t=tt, K=Kt, dist=dist,
+                  orig_size=float(orig_size))
     return _CameraFunction.apply(vertices, params)
 
 

@@ -16,6 +16,8 @@ class _GatherFaces(torch.autograd.Function):
         Ft = tri.shape[1]
         Fp = 2 * Ft if fill_back else Ft
         out = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=v.device)
+        if tri.shape[0] not in (1, B):
+            raise ValueError("faces must have batch 1 (shared topology) or the batch size of vertices")
         rc = _lib.lib().d3m_gather_faces(_lib.ptr(v), _lib.ptr(tri), tri.shape[0], _lib.ptr(out), B, V, Ft,
                                          int(bool(fill_back)), _lib.stream_ptr())
         _lib.check(rc, "d3m_gather_faces")

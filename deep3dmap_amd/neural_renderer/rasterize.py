@@ -205,6 +205,112 @@ class _RasterizeImages(torch.autograd.Function):
         return (gf, gt) + (None,) * 9
 
 
+def _vec3_host(x):
+    if torch.is_tensor(x):
+        x = x.detach().cpu().numpy()
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+    if a.size != 3:
+        raise NotImplementedError("lighting: per-batch colours / directions are not supported by the HIP path")
+    return np.ctypeslib.as_ctypes(a)
+
+
+class _RasterizeLit(torch.autograd.Function):
+    """render / render_rgb in one autograd node with fill_back and lighting applied on the fly
+    (d3m_face_light + d3m_forward_texture_sampling_lit / d3m_backward_textures_lit): the per-view
+    cat(textures, permuted) * light array of NR/renderer.py:155-167 is never materialised and textures /
+    mesh may be shared by all views (batch 1)."""
+
+    @staticmethod
+    def forward(ctx, faces, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near, far, eps,
+                background_color, return_rgb, return_alpha, return_depth):
+        L = _lib.lib()
+        faces, vertices, textures = f32c(faces), f32c(vertices), f32c(textures)
+        tri = tri.to(torch.int32).contiguous()
+        dev = faces.device
+        B, Fp = faces.shape[:2]
+        Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
+        if textures.shape[0] not in (1, B) or textures.shape[1] != Ft or Fp != (2 * Ft if fill_back else Ft):
+            raise ValueError("textures must be [1 or B, num_faces, ts, ts, ts, 3] for the given faces")
+        S = int(image_size) * 2 if anti_aliasing else int(image_size)
+        ia, idr, ca, cd, direction = light_cfg
+        cca, ccd, cdir = _vec3_host(ca), _vec3_host(cd), _vec3_host(direction)
+        Bl = 1 if (vertices.shape[0] == 1 and tri.shape[0] == 1) else B
+        light = torch.empty(Bl, Fp, 3, dtype=torch.float32, device=dev)
+        _lib.check(L.d3m_face_light(_lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(light),
+                                    float(ia), float(idr), cca, ccd, cdir, Bl, V, Ft, int(bool(fill_back)),
+                                    _lib.stream_ptr()), "d3m_face_light")
+        background = _background_tensor(background_color, dev)
+        m, _ = _raster_forward(faces, None, S, float(near), float(far), float(eps), background, False, return_alpha,
+                               return_depth, False)
+        rgb_sampled = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
+        _lib.check(L.d3m_forward_texture_sampling_lit(
+            _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
+            _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(rgb_sampled), B, Ft, int(bool(fill_back)), S, ts,
+            float(eps), _lib.stream_ptr()), "d3m_forward_texture_sampling_lit")
+        rgb, alpha, depth = _epilogue(m, rgb_sampled, background, B, S, anti_aliasing, True, return_alpha, return_depth, True)
+        ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
+                   (float(ia), float(idr), ca, cd, direction), Bl)
+        ctx.maps = m
+        ctx.save_for_backward(faces, vertices, tri, textures, light)
+        empty = torch.tensor([])
+        return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth):
+        L = _lib.lib()
+        faces, vertices, tri, textures, light = ctx.saved_tensors
+        S, eps, aa, ra, rd, fill_back, (ia, idr, ca, cd, direction), Bl = ctx.cfg
+        m = ctx.maps
+        dev, B = faces.device, faces.shape[0]
+        Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
+        g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+        g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
+        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
+        _lib.check(L.d3m_output_epilogue_backward(
+            _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
+            _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
+            "d3m_output_epilogue_backward")
+        # K4 (overwrite) -> textures (separate buffers) -> K6 (add), as NR/rasterize.py:141-151
+        grad_faces, _ = _raster_backward(faces, None, m, S, eps, g_rgb_map, g_alpha_map, None, True, ra, False, False)
+        need_tex = ctx.needs_input_grad[3]
+        need_vert = ctx.needs_input_grad[1] and idr != 0
+        grad_textures = grad_vertices = None
+        if need_tex or need_vert:
+            grad_textures = torch.empty_like(textures)
+            grad_light = torch.empty_like(light) if need_vert else None
+            ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
+            _lib.check(L.d3m_backward_textures_lit(
+                _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
+                _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map), _lib.ptr(grad_textures),
+                _lib.ptr(grad_light), B, Ft, int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                "d3m_backward_textures_lit")
+            if need_vert:
+                grad_vertices = torch.zeros_like(vertices)
+                _lib.check(L.d3m_face_light_backward(
+                    _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
+                    _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V, Ft,
+                    int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
+            if not need_tex:
+                grad_textures = None
+        if rd:
+            ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
+                                   g_depth_map, grad_faces, S)
+        return (grad_faces, grad_vertices, None, grad_textures) + (None,) * 11
+
+
+def rasterize_lit(faces, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
+                  anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
+                  background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True):
+    """rgb (+alpha, depth) images of screen-space `faces` [B,F',3,3] textured with the ORIGINAL `textures`
+    [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face light (computed from world-space `vertices` / `tri`)
+    are applied on the fly.  Same outputs as lighting() + rasterize_rgbad() on the materialised arrays."""
+    rgb, alpha, depth = _RasterizeLit.apply(faces, vertices, tri, textures, light_cfg, fill_back, image_size,
+                                            anti_aliasing, near, far, eps, background_color, True, return_alpha,
+                                            return_depth)
+    return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
+
+
 def rasterize_rgbad(
         faces,
         textures=None,

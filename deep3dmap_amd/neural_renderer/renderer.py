@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import cameras, mesh_ops
-from .rasterize import rasterize, rasterize_depth, rasterize_rgbad, rasterize_silhouettes
+from .rasterize import rasterize, rasterize_depth, rasterize_lit, rasterize_rgbad, rasterize_silhouettes
 
 
 class Renderer(nn.Module):
@@ -57,6 +57,10 @@ class Renderer(nn.Module):
 
         # rasterization
         self.rasterizer_eps = 1e-3
+        # True: fill_back and lighting are applied on the fly inside the texture sampler (no per-view copy of
+        # the textures, textures / mesh of batch 1 are shared by all views).  False: the reference's sequence
+        # cat -> lighting -> rasterize on materialised arrays.  Same images either way.
+        self.lighting_on_the_fly = True
 
     def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
                 orig_size=None):
@@ -114,15 +118,27 @@ class Renderer(nn.Module):
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         return rasterize_depth(f, self.image_size, self.anti_aliasing)          # NR/renderer.py:149
 
+    def _light_cfg(self):
+        return (self.light_intensity_ambient, self.light_intensity_directional, self.light_color_ambient,
+                self.light_color_directional, self.light_direction)
+
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        textures = self._lit_textures(vertices, faces, textures)
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        if self.lighting_on_the_fly:
+            return rasterize_lit(f, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
+                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
+                                 False, False)['rgb']
+        textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
-                              self.rasterizer_eps, self.background_color)
+                         self.rasterizer_eps, self.background_color)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        textures = self._lit_textures(vertices, faces, textures)
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
-        out = rasterize_rgbad(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
-                                   self.rasterizer_eps, self.background_color)
+        if self.lighting_on_the_fly:
+            out = rasterize_lit(f, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
+                                self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color)
+        else:
+            textures = self._lit_textures(vertices, faces, textures)
+            out = rasterize_rgbad(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
+                                  self.rasterizer_eps, self.background_color)
         return out['rgb'], out['depth'], out['alpha']

@@ -183,6 +183,38 @@ int d3m_lighting_backward(const float* faces, const float* textures_in, const fl
                           float intensity_directional, const float* color_ambient, const float* color_directional,
                           const float* direction, long num_faces_total, int texture_size, d3m_stream_t stream);
 
+/* --- lighting and fill_back applied on the fly (instead of renderer.py:155-167,203-215 materialising
+ * cat(textures, textures.permute(0,1,4,3,2,5)) * light per view) ---------------------------------------
+ * light [Bl,F',3]: per-face light of the fill_back'd face array on WORLD vertices [Bv,V,3] / tri [Bt,F,3];
+ * Bl = 1 when one mesh is shared by every view, else the batch size. */
+int d3m_face_light(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch, float* light,
+                   float intensity_ambient, float intensity_directional, const float* color_ambient,
+                   const float* color_directional, const float* direction, int light_batch, int num_vertices,
+                   int num_tri, int fill_back, d3m_stream_t stream);
+/* grad_light [Bl,F',3] -> grad_vertices [Bv,V,3] += (through the face normals; float atomics). */
+int d3m_face_light_backward(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch,
+                            const float* grad_light, float* grad_vertices, float intensity_ambient,
+                            float intensity_directional, const float* color_ambient, const float* color_directional,
+                            const float* direction, int light_batch, int num_vertices, int num_tri, int fill_back,
+                            d3m_stream_t stream);
+/* forward_texture_sampling on the VIRTUAL lit array: faces [B,F',3,3] (F' = 2*num_tri if fill_back),
+ * textures [Bx,num_tri,ts,ts,ts,3] (Bx = 1: shared), light [Bl,F',3]; writes rgb_map [B,S,S,3] for covered
+ * pixels.  Colours are bit-identical to sampling the materialised array (same f32 products). */
+int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, int textures_batch, const float* light,
+                                     int light_batch, const int32_t* face_index_map, const float* weight_map,
+                                     const float* depth_map, float* rgb_map, int batch_size, int num_tri,
+                                     int fill_back, int image_size, int texture_size, float eps, d3m_stream_t stream);
+/* Its backward (replaces backward_textures + the adjoint of lighting and of the fill_back cat):
+ * grad_textures [Bx,num_tri,ts^3,3] is WRITTEN (summed over views when Bx = 1); grad_light [Bl,F',3] is
+ * written when not NULL.  Sampling weights are recomputed from weight_map / depth_map (no 64 B/pixel
+ * sampling maps).  Gathered per visible face for ts = 2, per-pixel float atomics otherwise. */
+size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size);
+int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
+                              int light_batch, const int32_t* face_index_map, const float* weight_map,
+                              const float* depth_map, const float* grad_rgb_map, float* grad_textures, float* grad_light,
+                              int batch_size, int num_tri, int fill_back, int image_size, int texture_size, float eps,
+                              void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.
  *   in : face_index_map [B,S,S], rgb_map [B,S,S,3] (sampled, NOT yet blended; NULL if !rgb),

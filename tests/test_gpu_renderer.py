@@ -246,3 +246,37 @@ def test_loss_kernels_match_reference_losses(golden):
     silhouette_loss(ag[:, 0], b[:, 0]).backward()
     assert np.allclose(silhouette_loss(a[:, 0], b[:, 0]).item(), ((a[:, 0] - b[:, 0]) ** 2).sum().item(), rtol=1e-5)
     assert torch.allclose(ag.grad, 2 * (a - b) * torch.tensor([1., 0, 0], device="cuda").view(1, 3, 1, 1), atol=1e-6)
+
+
+@pytest.mark.parametrize("ts", [1, 2, 4])
+@pytest.mark.parametrize("shared", [False, True])
+def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
+    """render() with fill_back + lighting applied inside the sampler (shared or per-view mesh/textures) against the
+    reference's sequence cat -> lighting -> rasterize on materialised arrays: same images, same gradients."""
+    nr = _nr()
+    from deep3dmap_amd import synthetic
+    v, tri = synthetic.grid_mesh(12)
+    tex = synthetic.random_textures(tri.shape[0], ts)
+    eyes = torch.from_numpy(synthetic.camera_ring(3)).cuda()
+    B = 3
+    res = []
+    for fly in (False, True):
+        r = nr.Renderer(image_size=40, anti_aliasing=False, camera_mode="look_at", light_direction=[0.3, 0.8, -0.5],
+                        background_color=[0.1, 0.2, 0.3])
+        r.eye = eyes
+        r.lighting_on_the_fly = fly
+        use_shared = shared and fly
+        vv = torch.from_numpy(v).cuda()[None].repeat(1 if use_shared else B, 1, 1).requires_grad_(True)
+        tt = torch.from_numpy(tex).cuda()[None].repeat(1 if use_shared else B, 1, 1, 1, 1, 1).requires_grad_(True)
+        ff = torch.from_numpy(tri).cuda()[None].repeat(1 if use_shared else B, 1, 1)
+        rgb, depth, alpha = r(vv, ff, tt)
+        w = torch.linspace(0.5, 1.5, rgb.numel(), device="cuda").view_as(rgb)
+        ((rgb * w).sum() + alpha.sum() + depth.clamp(max=5).sum()).backward()
+        gv = vv.grad if vv.shape[0] == 1 else vv.grad.sum(0, keepdim=True)
+        gt = tt.grad if tt.shape[0] == 1 else tt.grad.sum(0, keepdim=True)
+        res.append((rgb.detach(), depth.detach(), alpha.detach(), gv, gt))
+    a, b = res
+    assert torch.equal(a[2], b[2]) and torch.equal(a[1], b[1])
+    assert torch.allclose(a[0], b[0], rtol=0, atol=1e-6)
+    assert float((a[4] - b[4]).abs().max()) <= 1e-3 * max(1.0, float(a[4].abs().max()))
+    assert float((a[3] - b[3]).abs().max()) <= 1e-3 * max(1.0, float(a[3].abs().max()))
