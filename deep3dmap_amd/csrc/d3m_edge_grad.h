@@ -129,17 +129,20 @@ __device__ __forceinline__ void for_each_segment(float p00, float p01, float p10
 }
 
 // Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).  Branch-free: a pixel whose
-// diff_grad is <= 0 (KCU:401/:481) contributes 0 through the select, NaNs still propagate.
+// diff_grad is <= 0 (KCU:401/:481) is dropped by the final select (so a 0 * inf can never leak in);
+// NaN diff_grad still propagates, as in the reference.
 __device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, float q0, float q1, float m0, float m1,
                                             float two_over_is, float eps, float& g0, float& g1) {
-    const float d = (diff <= 0) ? 0.0f : diff;
     const float t = (float)d1 - d1_cross;
     float dist0 = q0 * t * two_over_is;
     dist0 = (0 < dist0) ? dist0 + eps : dist0 - eps;
-    g0 -= m0 * (d * __builtin_amdgcn_rcpf(dist0));
     float dist1 = q1 * t * two_over_is;
     dist1 = (0 < dist1) ? dist1 + eps : dist1 - eps;
-    g1 -= m1 * (d * __builtin_amdgcn_rcpf(dist1));
+    const float c0 = m0 * (diff * __builtin_amdgcn_rcpf(dist0));
+    const float c1 = m1 * (diff * __builtin_amdgcn_rcpf(dist1));
+    const bool skip = diff <= 0;
+    g0 -= skip ? 0.0f : c0;
+    g1 -= skip ? 0.0f : c1;
 }
 
 __device__ __forceinline__ SegRef load_ref(const AxisMaps& m, bool use_rgb, bool use_alpha, size_t idx) {
@@ -353,14 +356,30 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
+    const int* list = w.line_items + w.line_offset[line];
+    // Item fetch is two dependent global loads (list -> 48-byte record); software-pipeline it: the index two
+    // items ahead and the record one item ahead are in flight while the current item is walked.
+    constexpr int ST = EG_LINE_WAVES * EG_LINE_PARTS;
+    int it = part * EG_LINE_WAVES + wv;
+    int item = it < n_items ? list[it] : 0;
+    int item_n = it + ST < n_items ? list[it + ST] : 0;
+    uint4 q0v = make_uint4(0, 0, 0, 0), q1v = q0v, q2v = q0v;
+    if (it < n_items) {
+        const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
+        q0v = q[0]; q1v = q[1]; q2v = q[2];
+    }
     // LDS image of the line: per pixel one float4 of values (alpha, r, g, b) and one of their gradients,
     // then the owner indices: 2 x ds_read_b128 (+1 b32 for inward walks) per visited pixel.
     float4* s_val = (float4*)s_line;
     float4* s_grd = s_val + is;
     int* s_fi = (int*)(s_grd + is);
-    for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
-        s_fi[p] = m.fi[line_base + p];
+    int* s_live = s_fi + is;                                  // per 64-pixel strip: does any pixel carry a gradient?
+    const int n_strips = (is + 63) >> 6;
+    for (int p0 = wv * 64; p0 < n_strips * 64; p0 += EG_LINE_WAVES * 64) {
+        const int p = p0 + lane;
         float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
+        if (p < is) {
+        s_fi[p] = m.fi[line_base + p];
         if (USE_ALPHA) { v.x = m.alpha[line_base + p]; g.x = m.galpha[line_base + p]; }
         if (USE_RGB) {
             const size_t e = 3 * (line_base + p);
@@ -369,14 +388,21 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         }
         s_val[p] = v;
         s_grd[p] = g;
+        }
+        // a strip whose gradients are all zero contributes exactly 0 (diff_grad = (value - ref) * 0): walks skip
+        // it.  (NaN / inf gradients compare != 0 and keep their strip alive.)
+        const unsigned long long live = __ballot(p < is && (g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0));
+        if (lane == 0) s_live[p0 >> 6] = live != 0;
     }
     __syncthreads();
     const float two_over_is = 2.0f / (float)is;
-    const int* list = w.line_items + w.line_offset[line];
-    for (int it = part * EG_LINE_WAVES + wv; it < n_items; it += EG_LINE_WAVES * EG_LINE_PARTS) {
-        const int item = list[it];
-        const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-        const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
+    for (; it < n_items; it += ST) {
+        const int item_nn = it + 2 * ST < n_items ? list[it + 2 * ST] : 0;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
+        if (it + ST < n_items) {
+            const uint4* q = (const uint4*)(w.items + (size_t)item_n * EG_ITEM_DW);
+            n0 = q[0]; n1 = q[1]; n2 = q[2];
+        }
         const uint32_t bits = q0v.x;
         const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)q0v.w;
         const bool inward = bits & 1;
@@ -385,7 +411,10 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const float ra = __uint_as_float(q1v.w), rr = __uint_as_float(q2v.x), rg = __uint_as_float(q2v.y),
                     rb = __uint_as_float(q2v.z);
         float g0 = 0, g1 = 0;
-        for (int d1 = from + lane; d1 <= to; d1 += 64) {
+        for (int d1b = from; d1b <= to; d1b += 64) {          // d1b is wave-uniform
+            if (!(s_live[d1b >> 6] | s_live[min(d1b + 63, to) >> 6])) continue;
+            const int d1 = d1b + lane;
+            if (d1 > to) continue;
             const float4 v = s_val[d1], g = s_grd[d1];
             float diff = 0;
             if (USE_ALPHA) diff += (v.x - ra) * g.x;
@@ -400,6 +429,8 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         g0 = wave_sum(g0);
         g1 = wave_sum(g1);
         if (lane == 0) w.results[item] = make_float2(g0, g1);
+        item = item_n; item_n = item_nn;
+        q0v = n0; q1v = n1; q2v = n2;
     }
 }
 
@@ -561,7 +592,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    const size_t smem = (size_t)9 * S * 4;
+    const size_t smem = (size_t)9 * S * 4 + (size_t)((S + 63) / 64) * 4;
     const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
@@ -572,7 +603,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
         }                                                                                                            \
         LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_WAVES * 64), smem, st, a, w);                  \
     } while (0)
-    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > 4551)
+    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > ~4500)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);

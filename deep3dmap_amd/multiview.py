@@ -27,7 +27,14 @@ def allreduce_flat(tensors, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU-test / debug configuration only: gloo reduces on the host.  Under "nccl" (= RCCL) the buffer
+        # stays on the device and travels over xGMI.
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     out, o = [], 0
     for t in tensors:
         out.append(flat[o:o + t.numel()].view_as(t))
@@ -91,12 +98,12 @@ class MultiViewFit:
         ~50 short kernels, so eager launches are host-bound (~1 ms of Python per step).  Every kernel of
         libd3m_raster.so goes to torch's current stream and none allocates or synchronises, so the whole step
         is capturable.  Vertices / textures / targets are updated IN PLACE between replays."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._forward_backward()
-        torch.cuda.current_stream().wait_stream(side)
+        # Warm up on the CURRENT stream.  (Warming up on a side stream, as the generic PyTorch recipe does, made
+        # later replays fault on this ROCm build whenever the host synchronised between replays; on the current
+        # stream every pattern tested is clean -- tests/test_gpu_configs.py::test_graph_replay_with_host_syncs.)
+        for _ in range(warmup):
+            self._forward_backward()
+        torch.cuda.synchronize()
         self.vertices.grad = None
         self.textures.grad = None
         graph = torch.cuda.CUDAGraph()

@@ -208,3 +208,23 @@ def test_full_size_workload_properties():
     for i in range(2):
         r1.eye = eyes[i:i + 1]
         assert torch.equal(r1(vt[i:i + 1], ft[i:i + 1], mode="silhouettes")[0], sil[i])
+
+
+def test_graph_replay_with_host_syncs():
+    """Regression: replaying the captured step with host synchronisation, read-backs and fresh allocations between
+    replays (what a training loop with logging does) must keep reproducing the eager step."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(40)
+    fit = MultiViewFit(v, tri, synthetic.random_textures(tri.shape[0], 2), synthetic.camera_ring(4), image_size=96)
+    fit.set_targets_from(synthetic.perturb(v))
+    l0, gv0, gt0 = fit.step()
+    gv0, gt0, l0 = gv0.clone(), gt0.clone(), float(l0)
+    fit.capture_graph()
+    for i in range(6):
+        l, gv, gt = fit.step()
+        torch.cuda.synchronize()
+        assert abs(float(l) - l0) <= 1e-5 * abs(l0)
+        assert _rel_l2(gv, gv0) < 1e-4 and _rel_l2(gt, gt0) < 1e-5
+        junk = torch.zeros(1 << 20, device="cuda")   # allocator traffic between replays
+        del junk
