@@ -357,29 +357,14 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
     const int* list = w.line_items + w.line_offset[line];
-    // Item fetch is two dependent global loads (list -> 48-byte record); software-pipeline it: the index two
-    // items ahead and the record one item ahead are in flight while the current item is walked.
-    constexpr int ST = EG_LINE_WAVES * EG_LINE_PARTS;
-    int it = part * EG_LINE_WAVES + wv;
-    int item = it < n_items ? list[it] : 0;
-    int item_n = it + ST < n_items ? list[it + ST] : 0;
-    uint4 q0v = make_uint4(0, 0, 0, 0), q1v = q0v, q2v = q0v;
-    if (it < n_items) {
-        const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-        q0v = q[0]; q1v = q[1]; q2v = q[2];
-    }
     // LDS image of the line: per pixel one float4 of values (alpha, r, g, b) and one of their gradients,
     // then the owner indices: 2 x ds_read_b128 (+1 b32 for inward walks) per visited pixel.
     float4* s_val = (float4*)s_line;
     float4* s_grd = s_val + is;
     int* s_fi = (int*)(s_grd + is);
-    int* s_live = s_fi + is;                                  // per 64-pixel strip: does any pixel carry a gradient?
-    const int n_strips = (is + 63) >> 6;
-    for (int p0 = wv * 64; p0 < n_strips * 64; p0 += EG_LINE_WAVES * 64) {
-        const int p = p0 + lane;
-        float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
-        if (p < is) {
+    for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
         s_fi[p] = m.fi[line_base + p];
+        float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
         if (USE_ALPHA) { v.x = m.alpha[line_base + p]; g.x = m.galpha[line_base + p]; }
         if (USE_RGB) {
             const size_t e = 3 * (line_base + p);
@@ -388,21 +373,16 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         }
         s_val[p] = v;
         s_grd[p] = g;
-        }
-        // a strip whose gradients are all zero contributes exactly 0 (diff_grad = (value - ref) * 0): walks skip
-        // it.  (NaN / inf gradients compare != 0 and keep their strip alive.)
-        const unsigned long long live = __ballot(p < is && (g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0));
-        if (lane == 0) s_live[p0 >> 6] = live != 0;
     }
     __syncthreads();
     const float two_over_is = 2.0f / (float)is;
-    for (; it < n_items; it += ST) {
-        const int item_nn = it + 2 * ST < n_items ? list[it + 2 * ST] : 0;
-        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0, n2 = n0;
-        if (it + ST < n_items) {
-            const uint4* q = (const uint4*)(w.items + (size_t)item_n * EG_ITEM_DW);
-            n0 = q[0]; n1 = q[1]; n2 = q[2];
-        }
+    // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
+    //  zero, and software-pipelining the list -> record fetch.  The loop is VALU-bound: ~25 VALU instructions
+    //  per 64-pixel iteration, profiles/r01_*.)
+    for (int it = part * EG_LINE_WAVES + wv; it < n_items; it += EG_LINE_WAVES * EG_LINE_PARTS) {
+        const int item = list[it];
+        const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
+        const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
         const uint32_t bits = q0v.x;
         const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)q0v.w;
         const bool inward = bits & 1;
@@ -411,10 +391,7 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const float ra = __uint_as_float(q1v.w), rr = __uint_as_float(q2v.x), rg = __uint_as_float(q2v.y),
                     rb = __uint_as_float(q2v.z);
         float g0 = 0, g1 = 0;
-        for (int d1b = from; d1b <= to; d1b += 64) {          // d1b is wave-uniform
-            if (!(s_live[d1b >> 6] | s_live[min(d1b + 63, to) >> 6])) continue;
-            const int d1 = d1b + lane;
-            if (d1 > to) continue;
+        for (int d1 = from + lane; d1 <= to; d1 += 64) {
             const float4 v = s_val[d1], g = s_grd[d1];
             float diff = 0;
             if (USE_ALPHA) diff += (v.x - ra) * g.x;
@@ -429,8 +406,6 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         g0 = wave_sum(g0);
         g1 = wave_sum(g1);
         if (lane == 0) w.results[item] = make_float2(g0, g1);
-        item = item_n; item_n = item_nn;
-        q0v = n0; q1v = n1; q2v = n2;
     }
 }
 
@@ -592,7 +567,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    const size_t smem = (size_t)9 * S * 4 + (size_t)((S + 63) / 64) * 4;
+    const size_t smem = (size_t)9 * S * 4;
     const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \

@@ -107,7 +107,9 @@ class MultiViewFit:
         self.vertices.grad = None
         self.textures.grad = None
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime while this
+        # thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self._graph_loss = self._forward_backward()
         self._graph = graph
         return self
