@@ -34,13 +34,19 @@ __device__ __forceinline__ bool backside(const float* f) {
     return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
 }
 
-// NDC -> pixel coordinate, KCU:47 / :282 (the 0.5 literal makes the product double; it is exact)
-__device__ __forceinline__ float to_pixel(float v, int is) {
-    return (float)(0.5 * (double)(v * (float)is + (float)is - 1.0f));
-}
+// Where the reference promotes an f32 expression to double through a literal, the f32 form below is used only
+// when it is PROVABLY bit-identical:
+//   * x 0.5 is exact in either precision;
+//   * a quotient of two values that are exactly representable in f32, computed in f64 and rounded to f32,
+//     equals the correctly rounded f32 quotient (double rounding is innocuous for / when 53 >= 2*24 + 2);
+//   * fmin/fmax against the constants 0 and 1 select the same value in either precision.
+// The bit-exactness tests (tests/test_gpu_ops.py, array_equal against the brute-force oracle) guard this.
 
-// pixel centre in NDC, KCU:96-97 (double arithmetic, rounded once to f32)
-__device__ __forceinline__ float pixel_center(int i, int is) { return (float)((2. * i + 1 - is) / is); }
+// NDC -> pixel coordinate, KCU:47 / :282: 0.5 * (v * is + is - 1)
+__device__ __forceinline__ float to_pixel(float v, int is) { return 0.5f * (v * (float)is + (float)is - 1.0f); }
+
+// pixel centre in NDC, KCU:96-97: (2.*i + 1 - is) / is -- an integer numerator below 2^24 over an integer
+__device__ __forceinline__ float pixel_center(int i, int is) { return (float)(2 * i + 1 - is) / (float)is; }
 
 // inverse of [[x0,x1,x2],[y0,y1,y2],[1,1,1]] in pixel space, KCU:44-62
 __device__ __forceinline__ void face_inverse(const float* face, int is, float* out) {
@@ -80,12 +86,12 @@ __device__ __forceinline__ bool weights_depth(const float* face, const float* fi
     float w_sum = 0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        w[k] = (float)fmin(fmax((double)w[k], 0.), 1.);   // fmax/fmin drop a NaN operand, as in CUDA
+        w[k] = fminf(fmaxf(w[k], 0.0f), 1.0f);            // KCU:129; fmax/fmin drop a NaN operand, as in CUDA
         w_sum += w[k];
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) w[k] /= w_sum;
-    zp = (float)(1. / (double)(w[0] / face[2] + w[1] / face[5] + w[2] / face[8]));
+    zp = 1.0f / (w[0] / face[2] + w[1] / face[5] + w[2] / face[8]);                      // KCU:136
     return !(zp <= near || far <= zp) && (zp == zp);
 }
 

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_texture_sampling(const float* __restric
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float t = weight_map[3 * i + k] * (float)(ts - 1) * (depth / face[3 * k + 2]);
-        t = (float)fmax((double)t, 0.);
+        t = fmaxf(t, 0.0f);
         t = fminf(t, (float)(ts - 1) - eps);
         tif[k] = t;
     }
