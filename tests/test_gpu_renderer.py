@@ -280,3 +280,34 @@ def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
     assert torch.allclose(a[0], b[0], rtol=0, atol=1e-6)
     assert float((a[4] - b[4]).abs().max()) <= 1e-3 * max(1.0, float(a[4].abs().max()))
     assert float((a[3] - b[3]).abs().max()) <= 1e-3 * max(1.0, float(a[3].abs().max()))
+
+
+def test_obj_round_trip_tetrahedron(tmp_path):
+    """tests/test_load_obj.py:15-37 and tests/test_save_obj.py on a tetrahedron written by this test (the
+    reference's tests/data directory is not in its tree): load with and without normalisation, save, reload,
+    and render the loaded mesh."""
+    nr = _nr()
+    vertices_ref = np.array([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.], [0., 0., 0.]], 'float32')
+    faces_ref = np.array([[1, 3, 2], [3, 1, 0], [2, 0, 1], [0, 2, 3]], 'int32')
+    path = tmp_path / "tetrahedron.obj"
+    path.write_text("# tetrahedron\n" + "".join("v %g %g %g\n" % tuple(v) for v in vertices_ref) +
+                    "".join("f %d/1/1 %d/2/2 %d/3/3\n" % tuple(f + 1) for f in faces_ref))
+    vertices, faces = nr.load_obj(str(path), False)
+    assert torch.allclose(torch.from_numpy(vertices_ref).cuda(), vertices) and torch.equal(torch.from_numpy(faces_ref).cuda(), faces)
+    vertices, faces = nr.load_obj(str(path), True)
+    assert torch.allclose(torch.from_numpy(vertices_ref).cuda() * 2 - 1.0, vertices)
+    out = tmp_path / "out.obj"
+    nr.save_obj(str(out), vertices, faces)
+    v2, f2 = nr.load_obj(str(out), False)
+    assert torch.allclose(v2, vertices, atol=1e-6) and torch.equal(f2, faces)
+    quad = tmp_path / "quad.obj"                      # polygons are fanned into triangles
+    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    _, fq = nr.load_obj(str(quad), False)
+    assert fq.cpu().tolist() == [[0, 1, 2], [0, 2, 3]]
+    mesh = nr.Mesh.fromobj(str(path), texture_size=2)
+    assert mesh.num_faces == 4 and mesh.textures.shape == (4, 2, 2, 2, 3)
+    r = nr.Renderer(camera_mode="look_at", image_size=32)
+    sil = r(mesh.vertices[None], mesh.faces[None], mode="silhouettes")
+    assert sil.shape == (1, 32, 32) and 0.01 < float(sil.mean()) < 0.9
+    with pytest.raises(NotImplementedError):
+        nr.load_obj(str(path), load_texture=True)
