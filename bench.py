@@ -99,6 +99,69 @@ def cpu_baseline(n, image_size, ts, budget_s=25.0):
                       f"({best:.2f} s each), OpenMP over {O.num_threads()} threads, per-face bounding-box forward"}
 
 
+def gan2shape_workload(args):
+    """BASELINE config 3: the gan2shape training step's renderer block (models/frameworks/gan2shape.py:444-493):
+    canonical depth [16,64,64] -> NrRenderer.warp_canon_depth (grid mesh of 7,938 triangles, fill_back, projection
+    camera, 2x anti-aliasing) -> photometric loss on the warped depth + smooth loss, backward to the depth map and
+    the view parameters.  Single GPU; prints one JSON line."""
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.core import NrRenderer, photometric_loss, smooth_loss
+    torch.cuda.set_device(0)
+    b, hw = args.batch, 64
+    cfgs = dict(min_depth=0.9, max_depth=1.1, rot_center_depth=1.0, fov=10, tex_cube_size=2)
+    r = NrRenderer(cfgs, hw)
+    rng = np.random.default_rng(0)
+    noise = torch.from_numpy(rng.standard_normal((b, hw, hw)).astype(np.float32))
+    depth = (1.0 + 0.1 * torch.tanh(torch.nn.functional.avg_pool2d(noise[:, None], 5, 1, 2)[:, 0])).cuda().requires_grad_(True)
+    view = (torch.from_numpy(rng.uniform(-1, 1, (b, 6)).astype(np.float32)) *
+            torch.tensor([0.5, 1.0, 0.3, 0.1, 0.1, 0.02])).cuda().requires_grad_(True)
+    target = torch.full((b, 1, hw, hw), 1.0, device="cuda")
+
+    def step():
+        depth.grad = None
+        view.grad = None
+        r.set_transform_matrices(view)
+        warped = r.warp_canon_depth(depth)
+        loss = photometric_loss(warped[:, None], target) + 0.01 * smooth_loss(depth)
+        loss.backward()
+        return loss.detach()
+
+    from deep3dmap_amd.graph import CapturedStep
+    runner = CapturedStep(step)
+    loss_eager = runner()
+    g_eager = depth.grad.clone()
+    if not args.no_graph:
+        depth.grad = None
+        view.grad = None
+        runner.capture()
+    for _ in range(args.warmup):
+        runner()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rel = float(torch.linalg.norm(depth.grad - g_eager) / (torch.linalg.norm(g_eager) + 1e-20))
+    assert rel < 1e-3, rel
+    runner.release()
+    _lib.kernel_timing(True)
+    for _ in range(5):
+        runner()
+    ktimes = _lib.collect_kernel_times()
+    _lib.kernel_timing(False)
+    ms = elapsed / args.steps * 1e3
+    print(json.dumps({
+        "metric": "rendered Mpix/s fwd+bwd, gan2shape step (64x64 depth-to-mesh, batch 16)", "value": round(b * hw * hw / (elapsed / args.steps) / 1e6, 2),
+        "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"gan2shape renderer block: depth [{b},64,64] -> 7938-tri grid mesh x2 (fill_back) -> "
+                               "render_depth @64 with 2x AA (S=128) -> photometric + smooth loss -> backward",
+                   "hip_graph": not args.no_graph},
+        "d3m_kernel_ms_per_step": round(sum(m for _, m in ktimes.values()) / 5, 4),
+        "kernel_ms_per_step": {k: round(m / 5, 4) for k, (c, m) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])[:8]}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +173,12 @@ def main():
     ap.add_argument("--texture-size", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape"],
+                    help="multiview = the headline metric (default); gan2shape = BASELINE config 3 (secondary line)")
+    ap.add_argument("--batch", type=int, default=16, help="gan2shape workload: batch size")
     args = ap.parse_args()
+    if args.workload == "gan2shape":
+        return gan2shape_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,7 +224,7 @@ def main():
         except Exception as e:      # keep the benchmark alive: fall back to eager launches (still all-HIP kernels)
             print(f"[bench] HIP graph capture failed on rank {rank} ({type(e).__name__}: {e}); running eagerly",
                   file=sys.stderr)
-            fit._graph = None
+            fit.release_graph()
             graph_on = False
             torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -177,7 +245,7 @@ def main():
     assert rel < 1e-3 and abs(float(loss) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)) + 1e-7, (rel, loss, loss_eager)
 
     # instrumented pass (not part of `value`), eager: per-kernel HIP-event durations on the launch stream
-    fit._graph = None
+    fit.release_graph()
     _lib.kernel_timing(True)
     n_inst = max(3, min(args.steps, 10))
     for _ in range(n_inst):

@@ -5,8 +5,48 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from .. import neural_renderer as nr
+from ..neural_renderer._util import const_tensor, f32c
 from .renderer_utils import get_face_idx, get_grid, get_textures_from_im, get_transform_matrices
+
+
+class _DepthToVertices(torch.autograd.Function):
+    """depth_to_3d_grid -> rotate_pts -> translate_pts (renderer_nr.py:64-80,95-100) as one HIP pass with an
+    analytic adjoint for the depth map and for the view's rotation / translation."""
+
+    @staticmethod
+    def forward(ctx, depth, inv_K, rot_mat, trans_xyz, center_z):
+        d, iK, R, t = f32c(depth), f32c(inv_K), f32c(rot_mat), f32c(trans_xyz).reshape(-1, 3)
+        B, H, W = d.shape
+        if R.shape[0] != B or t.shape[0] != B:
+            R, t = R.expand(B, 3, 3).contiguous(), t.expand(B, 3).contiguous()
+        out = torch.empty(B, H * W, 3, dtype=torch.float32, device=d.device)
+        _lib.check(_lib.lib().d3m_depth_to_vertices(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(R), _lib.ptr(t),
+                                                    float(center_z), _lib.ptr(out), B, H, W, _lib.stream_ptr()),
+                   "d3m_depth_to_vertices")
+        ctx.save_for_backward(d, iK, R)
+        ctx.center_z = float(center_z)
+        ctx.shapes = (tuple(rot_mat.shape), tuple(trans_xyz.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, iK, R = ctx.saved_tensors
+        B, H, W = d.shape
+        g = f32c(g)
+        gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        gR = torch.empty(B, 3, 3, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[2] else None
+        gt = torch.empty(B, 3, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[3] else None
+        _lib.check(_lib.lib().d3m_depth_to_vertices_backward(
+            _lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(R), ctx.center_z, _lib.ptr(g), _lib.ptr(gd), _lib.ptr(gR),
+            _lib.ptr(gt), B, H, W, _lib.stream_ptr()), "d3m_depth_to_vertices_backward")
+        rot_shape, trans_shape = ctx.shapes
+        if gR is not None and rot_shape[0] != B:
+            gR = gR.sum(0, keepdim=True)
+        if gt is not None:
+            gt = (gt.sum(0, keepdim=True) if trans_shape[0] != B else gt).reshape(trans_shape)
+        return gd, None, gR, gt, None
 
 EPS = 1e-7
 
@@ -51,7 +91,7 @@ class NrRenderer():
         self.rot_mat, self.trans_xyz = get_transform_matrices(view)
 
     def rotate_pts(self, pts, rot_mat):
-        centroid = torch.tensor([0., 0., self.rot_center_depth], dtype=torch.float32, device=pts.device).view(1, 1, 3)
+        centroid = const_tensor([0., 0., self.rot_center_depth], pts.device, (1, 1, 3))
         return (pts - centroid).matmul(rot_mat.transpose(2, 1)) + centroid
 
     def translate_pts(self, pts, trans_xyz):
@@ -59,7 +99,7 @@ class NrRenderer():
 
     def depth_to_3d_grid(self, depth):
         b, h, w = depth.shape
-        grid_2d = get_grid(b, h, w, normalize=False).to(depth.device)  # Nxhxwx2
+        grid_2d = get_grid(b, h, w, normalize=False, device=depth.device)  # Nxhxwx2
         depth = depth.unsqueeze(-1)
         grid_3d = torch.cat((grid_2d, torch.ones_like(depth)), dim=3)
         return grid_3d.matmul(self.inv_K.to(depth.device).transpose(2, 1)) * depth
@@ -68,14 +108,14 @@ class NrRenderer():
         b, h, w, _ = grid_3d.shape
         grid_2d = grid_3d / grid_3d[..., 2:]
         grid_2d = grid_2d.matmul(self.K.to(grid_3d.device).transpose(2, 1))[:, :, :, :2]
-        WH = torch.tensor([w - 1, h - 1], dtype=torch.float32, device=grid_3d.device).view(1, 1, 1, 2)
+        WH = const_tensor([w - 1, h - 1], grid_3d.device, (1, 1, 1, 2))
         return grid_2d / WH * 2. - 1.  # normalize to -1~1
 
     def get_warped_3d_grid(self, depth):
         b, h, w = depth.shape
-        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
-        grid_3d = self.rotate_pts(grid_3d, self.rot_mat)
-        grid_3d = self.translate_pts(grid_3d, self.trans_xyz)
+        # depth_to_3d_grid -> rotate_pts -> translate_pts, fused (one kernel each way)
+        grid_3d = _DepthToVertices.apply(depth, self.inv_K.to(depth.device), self.rot_mat, self.trans_xyz,
+                                         self.rot_center_depth)
         return grid_3d.reshape(b, h, w, 3)
 
     def get_inv_warped_3d_grid(self, depth):
@@ -106,7 +146,7 @@ class NrRenderer():
         tu = grid_3d[:, 1:-1, 2:] - grid_3d[:, 1:-1, :-2]
         tv = grid_3d[:, 2:, 1:-1] - grid_3d[:, :-2, 1:-1]
         normal = tu.cross(tv, dim=3)
-        zero = torch.tensor([0., 0., 1.], dtype=torch.float32, device=depth.device)
+        zero = const_tensor([0., 0., 1.], depth.device)
         normal = torch.cat([zero.repeat(b, h - 2, 1, 1), normal, zero.repeat(b, h - 2, 1, 1)], 2)
         normal = torch.cat([zero.repeat(b, 1, w, 1), normal, zero.repeat(b, 1, w, 1)], 1)
         return normal / (((normal ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)

@@ -6,14 +6,26 @@ import torch
 _face_idx_cache = {}
 
 
-def get_grid(b, H, W, normalize=True):
-    """[b,H,W,2] grid in (x, y) order (utils.py:22-31)."""
-    if normalize:
-        h_range, w_range = torch.linspace(-1, 1, H), torch.linspace(-1, 1, W)
-    else:
-        h_range, w_range = torch.arange(0, H), torch.arange(0, W)
-    gy, gx = torch.meshgrid(h_range, w_range, indexing="ij")
-    return torch.stack((gx, gy), -1)[None].repeat(b, 1, 1, 1).float()
+_grid_cache = {}
+
+
+def get_grid(b, H, W, normalize=True, device=None):
+    """[b,H,W,2] grid in (x, y) order (utils.py:22-31).  With `device`, the single-batch grid is built once
+    per (H, W, normalize, device) and expanded -- the reference rebuilds it on the CPU and uploads it on every
+    call (renderer_nr.py:76)."""
+    key = (H, W, bool(normalize), str(device))
+    base = _grid_cache.get(key)
+    if base is None:
+        if normalize:
+            h_range, w_range = torch.linspace(-1, 1, H), torch.linspace(-1, 1, W)
+        else:
+            h_range, w_range = torch.arange(0, H), torch.arange(0, W)
+        gy, gx = torch.meshgrid(h_range, w_range, indexing="ij")
+        base = torch.stack((gx, gy), -1).float()
+        if device is not None:
+            base = base.to(device)
+        _grid_cache[key] = base
+    return base[None].repeat(b, 1, 1, 1)
 
 
 def get_rotation_matrix(tx, ty, tz):

@@ -539,7 +539,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     float* rgbT = (float*)(p + L.off_rgbT);
     float* grgbT = (float*)(p + L.off_grgbT);
     const dim3 grid1((S + 31) / 32, (S + 31) / 32, B), grid3((S + 31) / 32, (S + 31) / 32, B * 3);
-    hipError_t e = hipMemsetAsync(p + L.off_zero, 0, L.zero_bytes, st);
+    hipError_t e = zero_async(p + L.off_zero, L.zero_bytes, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     LAUNCH("k_transpose_map", k_transpose_map, grid1, dim3(256), st, (const uint32_t*)m.face_index_map, (uint32_t*)fiT, S, 1);
     if (m.use_alpha) {

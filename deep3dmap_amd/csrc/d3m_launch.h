@@ -1,6 +1,7 @@
 // d3m_launch.h -- kernel launch macro with optional HIP-event timing (see d3m_timing_* in d3m_raster.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 // ---------------------------------------------------------------------------------------------------
 // optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline figure).
 // Off by default: LAUNCH is then a plain hipLaunchKernelGGL.
@@ -38,3 +39,26 @@ struct LaunchTimer {
         LaunchTimer lt__(name, stream);                                         \
         hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
     } while (0)
+
+// Zero-fill as a KERNEL (not hipMemsetAsync): inside a captured HIP graph a memset becomes a memset node, and on
+// this ROCm build its ordering against the next kernel node was not reliable when the graph is replayed from an
+// idle non-default stream (tile counters were not cleared -> list overruns -> memory faults).  A fill kernel is an
+// ordinary kernel node.  `bytes` must be a multiple of 4 and `p` 4-byte aligned (16-byte fast path when possible).
+__global__ void __launch_bounds__(256) k_zero_fill(uint32_t* __restrict__ p, size_t n_words) {
+    const size_t n4 = n_words >> 2;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0;
+}
+
+inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) || ((uintptr_t)p & 15)) return hipMemsetAsync(p, 0, bytes, st);     // not used by this library
+    const size_t words = bytes >> 2;
+    size_t blocks = (words / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    LAUNCH("k_zero_fill", k_zero_fill, dim3((unsigned)blocks), dim3(256), st, (uint32_t*)p, words);
+    return hipGetLastError();
+}

@@ -151,7 +151,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ws, 0, fwd_layout(B, F, S).zero_bytes, st));
+    HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
     LAUNCH("k_bin_count", k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
@@ -229,7 +229,7 @@ static int run_backward_textures(FS fs, const float* faces_dummy, const int32_t*
     const long n = (long)B * S * S, nf = (long)B * F;
     if (flags && ts == 2) {
         if (!flags_ready) {
-            HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+            HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
         }
         LAUNCH("k_backward_textures_faces", k_backward_textures_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs,
@@ -251,7 +251,7 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
     const long n = (long)B * S * S, nf = (long)B * F;
     if (flags) {
         if (!flags_ready) {
-            HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+            HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
         }
         LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, depth_map,
@@ -405,6 +405,29 @@ D3M_EXPORT int d3m_lighting_backward(const float* faces, const float* textures_i
     return check_launch();
 }
 
+D3M_EXPORT int d3m_depth_to_vertices(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
+                                     const float* trans, float rot_center_depth, float* vertices, int batch_size,
+                                     int height, int width, d3m_stream_t stream) {
+    if (!depth || !inv_K || !rot || !trans || !vertices || batch_size <= 0 || height <= 0 || width <= 0)
+        return D3M_ERR_INVALID;
+    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
+    const long n = (long)batch_size * height * width;
+    LAUNCH("k_depth_to_vertices", k_depth_to_vertices, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, depth, inv_K,
+           inv_K_batch, rot, trans, rot_center_depth, vertices, batch_size, height, width);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_depth_to_vertices_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
+                                              float rot_center_depth, const float* grad_vertices, float* grad_depth,
+                                              float* grad_rot, float* grad_trans, int batch_size, int height,
+                                              int width, d3m_stream_t stream) {
+    if (!depth || !inv_K || !rot || !grad_vertices || batch_size <= 0 || height <= 0 || width <= 0) return D3M_ERR_INVALID;
+    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
+    LAUNCH("k_depth_to_vertices_backward", k_depth_to_vertices_backward, dim3(batch_size), dim3(256), (hipStream_t)stream,
+           depth, inv_K, inv_K_batch, rot, rot_center_depth, grad_vertices, grad_depth, grad_rot, grad_trans, height, width);
+    return check_launch();
+}
+
 // ---- lit sampling: fill_back and lighting on the fly, shared textures (d3m_lit.h) ----------------------
 D3M_EXPORT int d3m_face_light(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch, float* light,
                               float intensity_ambient, float intensity_directional, const float* color_ambient,
@@ -489,10 +512,10 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     float* gview = textures_batch > 1 ? grad_textures : (float*)workspace;
     int* flags = (int*)((char*)workspace + align_up((size_t)B * view_elems * 4, 256));
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
-    HIP_TRY(hipMemsetAsync(gview, 0, (size_t)B * view_elems * 4, st));
-    if (grad_light) HIP_TRY(hipMemsetAsync(grad_light, 0, (size_t)light_batch * lt.Fp * 12, st));
+    HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
+    if (grad_light) HIP_TRY(zero_async(grad_light, (size_t)light_batch * lt.Fp * 12, st));
     if (texture_size == 2) {
-        HIP_TRY(hipMemsetAsync(flags, 0, (size_t)nf * 4, st));
+        HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
         LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, 256)), dim3(256), st, faces,
                lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, flags, B, S, eps);

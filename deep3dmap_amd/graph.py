@@ -1,0 +1,68 @@
+"""HIP-graph capture of a whole training step (forward + loss + backward).
+
+A step on this path is ~45 short kernels, so eager launches are host-bound (~1 ms of Python per step).
+Every kernel of libd3m_raster.so goes to torch's current stream and none allocates or synchronises, so a
+step is capturable with torch.cuda.CUDAGraph.
+
+One rule makes that robust: the step must ALWAYS run on the same stream -- eager steps, warm-up, capture and
+replays.  Autograd binds a leaf's AccumulateGrad node to the stream that was current when the node was
+created; if a step is warmed up (or ever run eagerly) on one stream and captured on another, autograd
+inserts a cross-stream wait inside the capture, which either aborts the capture or leaves un-joined work
+in it -- observed here as GPU memory faults on later replays.  `CapturedStep` owns a dedicated stream and
+fences it against the caller's stream on entry and exit."""
+import torch
+
+
+class CapturedStep:
+    def __init__(self, fn):
+        """fn(): runs one step and returns a tensor / tuple of tensors that stay valid until the next call."""
+        self.fn = fn
+        self.stream = torch.cuda.Stream()
+        self.graph = None
+        self._static_out = None
+        self._last_eager_out = None
+
+    def _enter(self):
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)          # inputs written by the caller's stream are visible
+        return cur
+
+    def _exit(self, cur, out, eager):
+        cur.wait_stream(self.stream)          # results are visible to the caller's stream
+        # Eager outputs were allocated on the dedicated stream but are consumed on the caller's.  Instead of
+        # record_stream() (its deferred-free events are a hazard around graph capture) the last outputs are
+        # simply kept alive until the next call, whose entry fence makes their release stream-ordered.
+        self._last_eager_out = out if eager else None
+        return out
+
+    def __call__(self):
+        cur = self._enter()
+        eager = self.graph is None
+        with torch.cuda.stream(self.stream):
+            if eager:
+                out = self.fn()
+            else:
+                self.graph.replay()
+                out = self._static_out
+        return self._exit(cur, out, eager)
+
+    def capture(self, warmup=3):
+        """Warm up and capture on the dedicated stream.  Tensors the step reads (parameters, targets) must
+        from now on be updated IN PLACE; the returned tensors are static buffers rewritten by every replay."""
+        cur = self._enter()
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self.fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime meanwhile
+        with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+            self._static_out = self.fn()
+        self.graph = graph
+        cur.wait_stream(self.stream)
+        return self
+
+    def release(self):
+        """Back to eager execution (still on the dedicated stream)."""
+        self.graph = None
+        self._static_out = None

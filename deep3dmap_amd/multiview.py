@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import neural_renderer as nr
+from .graph import CapturedStep
 from .core.losses import photometric_loss, silhouette_loss
 
 
@@ -65,7 +66,7 @@ class MultiViewFit:
         self.renderer.eye = self.eyes
         self.image_size = image_size
         self.targets = None
-        self._graph = None
+        self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
 
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices
@@ -94,33 +95,23 @@ class MultiViewFit:
         return loss.detach()
 
     def capture_graph(self, warmup=3):
-        """Capture forward + loss + backward of one step into a HIP graph (torch.cuda.CUDAGraph): the step is
-        ~50 short kernels, so eager launches are host-bound (~1 ms of Python per step).  Every kernel of
-        libd3m_raster.so goes to torch's current stream and none allocates or synchronises, so the whole step
-        is capturable.  Vertices / textures / targets are updated IN PLACE between replays."""
-        # Warm up on the CURRENT stream.  (Warming up on a side stream, as the generic PyTorch recipe does, made
-        # later replays fault on this ROCm build whenever the host synchronised between replays; on the current
-        # stream every pattern tested is clean -- tests/test_gpu_configs.py::test_graph_replay_with_host_syncs.)
-        for _ in range(warmup):
-            self._forward_backward()
-        torch.cuda.synchronize()
+        """Capture forward + loss + backward of one step into a HIP graph (see deep3dmap_amd/graph.py).
+        Vertices / textures / targets are updated IN PLACE between replays."""
         self.vertices.grad = None
         self.textures.grad = None
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime while this
-        # thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self._graph_loss = self._forward_backward()
-        self._graph = graph
+        self._runner.capture(warmup)
         return self
+
+    def release_graph(self):
+        self._runner.release()
+
+    @property
+    def graph_captured(self):
+        return self._runner.graph is not None
 
     def step(self):
         """forward + loss + backward + gradient all-reduce.  Returns (loss, grad_vertices, grad_textures)."""
-        if self._graph is not None:
-            self._graph.replay()
-            loss = self._graph_loss
-        else:
-            loss = self._forward_backward()
+        loss = self._runner()
         grads = [self.vertices.grad] + ([self.textures.grad] if self.textures.requires_grad else [])
         grads = allreduce_flat(grads)
         return loss, grads[0], (grads[1] if len(grads) > 1 else None)

@@ -183,6 +183,19 @@ int d3m_lighting_backward(const float* faces, const float* textures_in, const fl
                           float intensity_directional, const float* color_ambient, const float* color_directional,
                           const float* direction, long num_faces_total, int texture_size, d3m_stream_t stream);
 
+/* NrRenderer's depth map -> mesh vertices in one pass (deep3dmap/core/renderer/renderer_nr.py:64-80,95-100:
+ * depth_to_3d_grid -> rotate_pts about (0,0,rot_center_depth) -> translate_pts):
+ *   vertices[b, y*W+x, :] = R_b (depth[b,y,x] * inv_K (x, y, 1)^T - c) + c + t_b
+ * depth [B,H,W], inv_K [1|B,3,3], rot [B,3,3], trans [B,3] -> vertices [B,H*W,3]. */
+int d3m_depth_to_vertices(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
+                          float rot_center_depth, float* vertices, int batch_size, int height, int width,
+                          d3m_stream_t stream);
+/* adjoint: grad_depth [B,H,W], grad_rot [B,3,3], grad_trans [B,3] are WRITTEN (each may be NULL). */
+int d3m_depth_to_vertices_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
+                                   float rot_center_depth, const float* grad_vertices, float* grad_depth,
+                                   float* grad_rot, float* grad_trans, int batch_size, int height, int width,
+                                   d3m_stream_t stream);
+
 /* --- lighting and fill_back applied on the fly (instead of renderer.py:155-167,203-215 materialising
  * cat(textures, textures.permute(0,1,4,3,2,5)) * light per view) ---------------------------------------
  * light [Bl,F',3]: per-face light of the fill_back'd face array on WORLD vertices [Bv,V,3] / tri [Bt,F,3];

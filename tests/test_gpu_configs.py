@@ -35,16 +35,18 @@ def test_gan2shape_step_warp_canon_depth_against_oracle():
     outs = []
     for r, dev, P, S in ((ro, "cpu", O.photometric_loss, O.smooth_loss), (rg, "cuda", photometric_loss, smooth_loss)):
         d = depth0.clone().to(dev).requires_grad_(True)
-        r.set_transform_matrices(view.to(dev))
+        vw = view.clone().to(dev).requires_grad_(True)          # gan2shape learns the view (gan2shape.py:440-444)
+        r.set_transform_matrices(vw)
         warped = r.warp_canon_depth(d)
         loss = P(warped[:, None], target.to(dev)[:, None]) + 0.01 * S(d)
         loss.backward()
-        outs.append((warped.detach().cpu(), float(loss), d.grad.cpu()))
-    (w0, l0, g0), (w1, l1, g1) = outs
+        outs.append((warped.detach().cpu(), float(loss.detach()), d.grad.cpu(), vw.grad.cpu()))
+    (w0, l0, g0, v0), (w1, l1, g1, v1) = outs
     assert w0.shape == w1.shape == (b, 64, 64)
     assert _rel_l2(w1, w0) < 2e-3
     assert abs(l1 - l0) < 2e-3 * abs(l0)
     assert _rel_l2(g1, g0) < 5e-2
+    assert _rel_l2(v1, v0) < 5e-2
 
 
 def test_pt3d_demo_plumbing_silhouette_fit_decreases_loss():
@@ -101,6 +103,7 @@ def test_multiview_fit_gradients_against_oracle_and_graph_replay():
     assert abs(float(loss) - float(lo)) < 5e-3 * abs(float(lo))
     assert _rel_l2(gv.cpu(), vt.grad) < 6e-2 and _rel_l2(gt.cpu(), tt.grad) < 2e-2
     fit.capture_graph()
+    assert fit.graph_captured
     for _ in range(2):
         loss2, gv2, gt2 = fit.step()
     assert abs(float(loss2) - float(loss)) < 1e-5 * abs(float(loss)) + 1e-8
@@ -228,3 +231,36 @@ def test_graph_replay_with_host_syncs():
         assert _rel_l2(gv, gv0) < 1e-4 and _rel_l2(gt, gt0) < 1e-5
         junk = torch.zeros(1 << 20, device="cuda")   # allocator traffic between replays
         del junk
+
+
+def test_graph_capture_with_retained_autograd_state():
+    """NrRenderer keeps rot_mat / trans_xyz (and so the previous step's autograd graph and the view's
+    AccumulateGrad node) alive between steps; capture must still work because every step runs on one stream
+    (deep3dmap_amd/graph.py)."""
+    from deep3dmap_amd.core import NrRenderer, photometric_loss
+    from deep3dmap_amd.graph import CapturedStep
+    b, hw = 4, 32
+    r = NrRenderer(dict(min_depth=0.9, max_depth=1.1, rot_center_depth=1.0, fov=10), hw)
+    depth = (1.0 + 0.05 * torch.rand(b, hw, hw)).cuda().requires_grad_(True)
+    view = (torch.rand(b, 6) * 0.1).cuda().requires_grad_(True)
+    target = torch.ones(b, 1, hw, hw, device="cuda")
+
+    def step():
+        depth.grad = None
+        view.grad = None
+        r.set_transform_matrices(view)
+        loss = photometric_loss(r.warp_canon_depth(depth)[:, None], target)
+        loss.backward()
+        return loss.detach()
+
+    run = CapturedStep(step)
+    l0 = float(run())
+    gd0, gv0 = depth.grad.clone(), view.grad.clone()
+    depth.grad = None
+    view.grad = None
+    run.capture()
+    for _ in range(4):
+        l = run()
+        torch.cuda.synchronize()
+        assert abs(float(l) - l0) <= 1e-5 * abs(l0)
+        assert _rel_l2(depth.grad, gd0) < 1e-4 and _rel_l2(view.grad, gv0) < 1e-4
