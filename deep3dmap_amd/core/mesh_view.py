@@ -33,5 +33,5 @@ class MeshViewRenderer:
             loss = silhouette_loss(self.silhouettes(vertices, faces, azimuths), target)
             loss.backward()
             opt.step()
-            history.append(float(loss))
+            history.append(float(loss.detach()))
         return history

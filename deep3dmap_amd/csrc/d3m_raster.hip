@@ -8,6 +8,7 @@
 #include "../../include/d3m_raster.h"
 #include "d3m_launch.h"
 #include "d3m_aux.h"
+#include "d3m_textures.h"
 #include "d3m_backward.h"
 #include "d3m_device.h"
 #include "d3m_edge_grad.h"
@@ -592,5 +593,37 @@ D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss
     const unsigned grid = (unsigned)((n + 2047) / 2048 < 1024 ? (n + 2047) / 2048 : 1024);
     LAUNCH("k_sum_squared_error", k_sum_squared_error, dim3(grid), dim3(256), st, a, b, scratch, grad_a, n);
     LAUNCH("k_sum_partials", k_sum_partials, dim3(1), dim3(256), st, (const float*)scratch, (int)grid, loss);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// D. texture assets
+// ---------------------------------------------------------------------------------------------------
+D3M_EXPORT int d3m_load_textures(const float* image, const int32_t* is_update, const float* faces_uv, float* textures,
+                                 int num_faces, int texture_size, int image_height, int image_width,
+                                 int texture_wrapping, int use_bilinear, d3m_stream_t stream) {
+    if (!image || !is_update || !faces_uv || !textures) return D3M_ERR_INVALID;
+    if (num_faces <= 0 || texture_size < 2 || image_height <= 0 || image_width <= 0) return D3M_ERR_INVALID;
+    if (texture_wrapping < 0 || texture_wrapping > 3) return D3M_ERR_INVALID;
+    if ((long)texture_size * texture_size * texture_size > 0x7FFFFFFF) return D3M_ERR_INVALID;
+    const long n = (long)num_faces * texture_size * texture_size * texture_size;
+    LAUNCH("k_load_textures", k_load_textures, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, image, is_update,
+           faces_uv, textures, n, texture_size, image_height, image_width, texture_wrapping, use_bilinear ? 1 : 0);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_create_texture_image(const float* vertices_all, const float* textures, float* image, int num_faces,
+                                        int texture_size_in, int image_height, int image_width, int tile_width,
+                                        float eps, d3m_stream_t stream) {
+    if (!vertices_all || !textures || !image) return D3M_ERR_INVALID;
+    if (num_faces <= 0 || texture_size_in <= 0 || image_height <= 0 || image_width <= 0 || tile_width <= 0)
+        return D3M_ERR_INVALID;
+    if (image_width % tile_width) return D3M_ERR_INVALID;
+    const int tso = image_width / tile_width;
+    if (image_height % tso) return D3M_ERR_INVALID;
+    if ((long)(image_height / tso) * tile_width < num_faces) return D3M_ERR_INVALID;
+    const long n = (long)image_height * image_width;
+    LAUNCH("k_create_texture_image", k_create_texture_image, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream,
+           vertices_all, textures, image, n, num_faces, texture_size_in, tso, tile_width, eps);
     return check_launch();
 }

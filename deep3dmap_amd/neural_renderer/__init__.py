@@ -1,6 +1,5 @@
 """MI355X-native mirror of the `neural_renderer` package surface deep3dmap imports
-(pnpmodules/neural_renderer/neural_renderer/__init__.py:1-12).  OBJ I/O is geometry-only (texture atlases are
-listed under "next" in DESIGN.md)."""
+(pnpmodules/neural_renderer/neural_renderer/__init__.py:1-12)."""
 from .cameras import get_points_from_angles, look, look_at, perspective, projection
 from .mesh_ops import lighting, vertices_to_faces
 from .obj_io import Mesh, load_obj, save_obj

@@ -262,6 +262,24 @@ int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, 
 int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, float* scratch, long n,
                           d3m_stream_t stream);
 
+/* ---- texture assets ----------------------------------------------------------------------------------------- */
+/* Replaces load_textures_cuda (NR/cuda/load_textures_cuda.cpp:6-37, kernel load_textures_cuda_kernel.cu:23-114):
+ * fills textures [F, ts, ts, ts, 3] of every face with is_update[f] != 0 by sampling image [H, W, 3] at
+ * barycentric combinations of the face's uv corners faces_uv [F, 3, 2].  texture_wrapping: 0 REPEAT,
+ * 1 MIRRORED_REPEAT, 2 CLAMP_TO_EDGE, 3 CLAMP_TO_BORDER (writes zeros, like the reference).  faces_uv is
+ * read-only here (the reference wraps it in place; see DESIGN.md for the one case where that matters). */
+int d3m_load_textures(const float* image, const int32_t* is_update, const float* faces_uv, float* textures,
+                      int num_faces, int texture_size, int image_height, int image_width, int texture_wrapping,
+                      int use_bilinear, d3m_stream_t stream);
+/* Replaces create_texture_image_cuda (NR/cuda/create_texture_image_cuda.cpp:6-30, kernels
+ * create_texture_image_cuda_kernel.cu:10-115, both launches in one pass): renders textures
+ * [F, tsi, tsi, tsi, 3] into the atlas image [image_height, image_width, 3] of tile_width tiles per row
+ * (tile edge = image_width / tile_width); vertices_all [F, 3, 2] are the tile-space corners.  Tiles beyond
+ * num_faces are zero-filled. */
+int d3m_create_texture_image(const float* vertices_all, const float* textures, float* image, int num_faces,
+                             int texture_size_in, int image_height, int image_width, int tile_width, float eps,
+                             d3m_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -494,3 +494,128 @@ ORC_API void orc_backward_depth_map(const float *faces, const float *depth_map, 
         }
     }
 }
+
+/* ===========================================================================
+ * Texture asset kernels.  LTK = NR/cuda/load_textures_cuda_kernel.cu,
+ * CTK = NR/cuda/create_texture_image_cuda_kernel.cu.
+ * ========================================================================= */
+
+/* LTK:6-14 */
+static inline float tex_mod(float x, float y) { return x > 0 ? fmodf(x, y) : y + fmodf(x, y); }
+
+/* load_textures_cuda_kernel, LTK:23-114: fills the ts^3 texture cube of every face whose is_update flag is set by
+ * sampling `image` [H,W,3] at barycentric combinations of the face's uv coordinates `faces` [F,3,2].
+ * The reference writes the wrapped uv back into the shared `faces` array from every texel thread: a race that is
+ * harmless except at integer coordinates under REPEAT (0 -> 1 -> 0 ...), where its result depends on scheduling.
+ * The port wraps a private copy ONCE, i.e. what a thread that sees the caller's input computes. */
+ORC_API void orc_load_textures(const float *image, const int32_t *is_update, const float *faces, float *textures,
+                               int num_faces, int texture_size, int image_height, int image_width,
+                               int texture_wrapping, int use_bilinear) {
+    const int ts = texture_size;
+    const long n = (long)num_faces * ts * ts * ts;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+        const int fn = (int)(i / ((long)ts * ts * ts));
+        float dim0 = (float)(((i / (ts * ts)) % ts) / (ts - 1.));
+        float dim1 = (float)(((i / ts) % ts) / (ts - 1.));
+        float dim2 = (float)((i % ts) / (ts - 1.));
+        if (0 < dim0 + dim1 + dim2) {
+            const float sum = dim0 + dim1 + dim2;
+            dim0 /= sum; dim1 /= sum; dim2 /= sum;
+        }
+        if (is_update[fn] == 0) continue;
+        float face[6];
+        for (int k = 0; k < 6; k++) face[k] = faces[fn * 6 + k];
+        if (texture_wrapping == 0) {                                           /* REPEAT */
+            for (int k = 0; k < 6; k++) face[k] = tex_mod(face[k], 1.0f);
+        } else if (texture_wrapping == 1) {                                    /* MIRRORED_REPEAT */
+            for (int k = 0; k < 6; k++)
+                face[k] = (tex_mod(face[k], 2.0f) < 1) ? tex_mod(face[k], 1.0f) : 1 - tex_mod(face[k], 1.0f);
+        } else if (texture_wrapping == 2) {                                    /* CLAMP_TO_EDGE */
+            for (int k = 0; k < 6; k++) face[k] = fmaxf(fminf(face[k], 1.0f), 0.0f);
+        }
+        const float pos_x = (face[0] * dim0 + face[2] * dim1 + face[4] * dim2) * (float)(image_width - 1);
+        const float pos_y = (face[1] * dim0 + face[3] * dim1 + face[5] * dim2) * (float)(image_height - 1);
+        float *tex = textures + i * 3;
+        if (texture_wrapping == 3) {                                           /* CLAMP_TO_BORDER: zeros (LTK:97,109) */
+            tex[0] = tex[1] = tex[2] = 0;
+            continue;
+        }
+        if (use_bilinear) {
+            const int xi = cuda_d2i((double)pos_x), yi = cuda_d2i((double)pos_y);
+            const float wx1 = pos_x - (float)xi, wx0 = 1 - wx1, wy1 = pos_y - (float)yi, wy0 = 1 - wy1;
+            const int y1 = imin(cuda_d2i((double)(pos_y + 1)), image_height - 1), x1 = imin(xi + 1, image_width - 1);
+            for (int k = 0; k < 3; k++) {
+                float c = 0;
+                c += image[((long)yi * image_width + xi) * 3 + k] * (wx0 * wy0);
+                c += image[((long)y1 * image_width + xi) * 3 + k] * (wx0 * wy1);
+                c += image[((long)yi * image_width + x1) * 3 + k] * (wx1 * wy0);
+                c += image[((long)y1 * image_width + x1) * 3 + k] * (wx1 * wy1);
+                tex[k] = c;
+            }
+        } else {
+            const int xi = cuda_d2i((double)roundf(pos_x)), yi = cuda_d2i((double)roundf(pos_y));
+            for (int k = 0; k < 3; k++) tex[k] = image[((long)yi * image_width + xi) * 3 + k];
+        }
+    }
+}
+
+/* create_texture_image_cuda_kernel + _boundary_, CTK:10-115: renders every face's texture cube into its tile of a
+ * texture atlas `image` [tile_h*tso, tile_w*tso, 3]; vertices_all [F,3,2] are the tile-space triangle corners. */
+ORC_API void orc_create_texture_image(const float *vertices_all, const float *textures, float *image, int num_faces,
+                                      int texture_size_in, int image_height, int image_width, int tile_width,
+                                      float eps) {
+    const int tsi = texture_size_in, tso = image_width / tile_width;
+    const long npx = (long)image_height * image_width;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < npx; i++) {
+        const int x = (int)(i % ((long)tile_width * tso)), y = (int)(i / ((long)tile_width * tso));
+        const int fn = x / tso + (y / tso) * tile_width;
+        /* The atlas has tile_width*tile_height >= num_faces tiles; for the padding tiles the reference reads
+         * past the end of `textures` and `vertices_all` (undefined values).  Defined here: padding tiles keep the
+         * zeros the image was created with (NR/save_obj.py:16). */
+        if (fn >= num_faces) { for (int k = 0; k < 3; k++) image[i * 3 + k] = 0.f; continue; }
+        const float *texture = textures + (long)fn * tsi * tsi * tsi * 3;
+        const float *p0 = vertices_all + (long)fn * 6, *p1 = p0 + 2, *p2 = p0 + 4;
+        float face_inv[9] = {
+            p1[1] - p2[1], p2[0] - p1[0], p1[0] * p2[1] - p2[0] * p1[1],
+            p2[1] - p0[1], p0[0] - p2[0], p2[0] * p0[1] - p0[0] * p2[1],
+            p0[1] - p1[1], p1[0] - p0[0], p0[0] * p1[1] - p1[0] * p0[1]};
+        const float den = p2[0] * (p0[1] - p1[1]) + p0[0] * (p1[1] - p2[1]) + p1[0] * (p2[1] - p0[1]);
+        for (int k = 0; k < 9; k++) face_inv[k] /= den;
+        float weight[3], weight_sum = 0;
+        for (int k = 0; k < 3; k++) {
+            weight[k] = face_inv[3 * k + 0] * (float)x + face_inv[3 * k + 1] * (float)y + face_inv[3 * k + 2];
+            weight_sum += weight[k];
+        }
+        for (int k = 0; k < 3; k++) weight[k] /= (weight_sum + eps);
+        float tif[3];
+        for (int k = 0; k < 3; k++) {
+            float t = weight[k] * (float)(tsi - 1);
+            t = (float)fmax((double)t, 0.);
+            t = fminf(t, (float)(tsi - 1) - eps);
+            tif[k] = t;
+        }
+        float px[3] = {0, 0, 0};
+        for (int pn = 0; pn < 8; pn++) {
+            float w = 1;
+            int tii[3];
+            for (int k = 0; k < 3; k++) {
+                const int fl = cuda_d2i((double)tif[k]);
+                if (((pn >> k) % 2) == 0) { w *= 1 - (tif[k] - (float)fl); tii[k] = fl; }
+                else                      { w *= tif[k] - (float)fl;       tii[k] = fl + 1; }
+            }
+            const int isc = tii[0] * tsi * tsi + tii[1] * tsi + tii[2];
+            /* texture_size_in == 1 indexes one cube past this face in the reference; stay inside the array */
+            const int in_range = (long)fn * tsi * tsi * tsi + isc < (long)num_faces * tsi * tsi * tsi;
+            for (int k = 0; k < 3; k++) px[k] += w * (in_range ? texture[isc * 3 + k] : 0.0f);
+        }
+        for (int k = 0; k < 3; k++) image[i * 3 + k] = px[k];
+    }
+    /* boundary fix-up, CTK:97-115 (a second launch in the reference: reads the finished image) */
+    for (long i = 0; i < npx; i++) {
+        const int x = (int)(i % ((long)tile_width * tso)), y = (int)(i / ((long)tile_width * tso));
+        if ((y % tso + 1) == (x % tso))
+            for (int k = 0; k < 3; k++) image[i * 3 + k] = image[((long)y * tile_width * tso + (x - 1)) * 3 + k];
+    }
+}

@@ -44,6 +44,8 @@ _SIGS = {
     "backward_pixel_map": [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _I, _I, _I, _FL, _I, _I],
     "backward_textures": [_i32p, _f32p, _i32p, _f32p, _f32p, _I, _I, _I, _I],
     "backward_depth_map": [_f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _I, _I, _I],
+    "load_textures": [_f32p, _i32p, _f32p, _f32p, _I, _I, _I, _I, _I, _I],
+    "create_texture_image": [_f32p, _f32p, _f32p, _I, _I, _I, _I, _I, _FL],
 }
 
 
@@ -188,6 +190,66 @@ def raster_backward(m, grad_rgb_map, grad_alpha_map, grad_depth_map, return_rgb,
         k.backward_depth_map(_fp(faces), _fp(m["depth_map"]), _ip(m["face_index_map"]), _fp(m["face_inv_map"]),
                              _fp(m["weight_map"]), _fp(g_depth), _fp(grad_faces), B, Fn, S)
     return grad_faces, grad_textures
+
+
+# --------------------------------------------------------------------------------------------
+# texture assets (NR/load_obj.py:33-98, NR/save_obj.py:10-38 and their kernels)
+# --------------------------------------------------------------------------------------------
+TEXTURE_WRAPPING = {'REPEAT': 0, 'MIRRORED_REPEAT': 1, 'CLAMP_TO_EDGE': 2, 'CLAMP_TO_BORDER': 3}
+
+
+def load_textures_np(image, faces_uv, textures, is_update, texture_wrapping=0, use_bilinear=True, backend="port"):
+    """Kernel of NR/load_obj.py:92-97: image [H,W,3] (already flipped), faces_uv [F,3,2], textures [F,ts,ts,ts,3]
+    (updated in place for faces with is_update != 0, returned)."""
+    k = kernels(backend)
+    image, faces_uv = _f32(image), _f32(faces_uv).copy()
+    textures = _f32(textures)
+    is_update = np.ascontiguousarray(is_update, dtype=np.int32)
+    k.load_textures(_fp(image), _ip(is_update), _fp(faces_uv), _fp(textures), textures.shape[0], textures.shape[1],
+                    image.shape[0], image.shape[1], int(texture_wrapping), int(bool(use_bilinear)))
+    return textures
+
+
+def create_texture_image_np(textures, texture_size_out=16, backend="port"):
+    """NR/save_obj.py:10-38: texture atlas [tile_h*tso, tile_w*tso, 3] (rows flipped on return) and the per-face
+    atlas uv coordinates [F,3,2] in [0,1]."""
+    k = kernels(backend)
+    textures = _f32(textures)
+    num_faces, tsi = textures.shape[:2]
+    tile_width = int((num_faces - 1.) ** 0.5) + 1
+    tile_height = int((num_faces - 1.) / tile_width) + 1
+    tso = texture_size_out
+    image = np.zeros((tile_height * tso, tile_width * tso, 3), np.float32)
+    vertices = np.zeros((num_faces, 3, 2), np.float32)
+    fn = np.arange(num_faces)
+    column, row = fn % tile_width, fn // tile_width
+    vertices[:, 0, 0] = column * tso
+    vertices[:, 0, 1] = row * tso
+    vertices[:, 1, 0] = column * tso
+    vertices[:, 1, 1] = (row + 1) * tso - 1
+    vertices[:, 2, 0] = (column + 1) * tso - 1
+    vertices[:, 2, 1] = (row + 1) * tso - 1
+    # the reference kernel reads tile_width*tile_height faces (padding tiles are out of bounds there): hand it
+    # padded copies so the read is defined; callers compare only the tiles of real faces.
+    n_tiles = tile_width * tile_height
+    vpad = np.zeros((n_tiles, 3, 2), np.float32)
+    vpad[:num_faces] = vertices
+    tpad = np.zeros((n_tiles,) + textures.shape[1:], np.float32)
+    tpad[:num_faces] = textures
+    k.create_texture_image(_fp(vpad), _fp(tpad), _fp(image), num_faces, tsi, image.shape[0], image.shape[1],
+                           tile_width, 1e-5)
+    vertices[:, :, 0] /= (image.shape[1] - 1)
+    vertices[:, :, 1] /= (image.shape[0] - 1)
+    return image[::-1].copy(), vertices
+
+
+def texture_atlas_valid_mask(num_faces, texture_size_out, image_shape):
+    """Boolean [H,W] mask (in the flipped, returned orientation) of atlas pixels that belong to a real face."""
+    tile_width = int((num_faces - 1.) ** 0.5) + 1
+    H, W = image_shape[:2]
+    y, x = np.mgrid[0:H, 0:W]
+    fn = x // texture_size_out + (y // texture_size_out) * tile_width
+    return (fn < num_faces)[::-1].copy()
 
 
 # --------------------------------------------------------------------------------------------

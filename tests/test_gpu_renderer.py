@@ -309,5 +309,5 @@ def test_obj_round_trip_tetrahedron(tmp_path):
     r = nr.Renderer(camera_mode="look_at", image_size=32)
     sil = r(mesh.vertices[None], mesh.faces[None], mode="silhouettes")
     assert sil.shape == (1, 32, 32) and 0.01 < float(sil.mean()) < 0.9
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception, match="Failed to load textures"):      # no mtllib line (load_obj.py:150-151)
         nr.load_obj(str(path), load_texture=True)
