@@ -13,6 +13,31 @@
 namespace d3m {
 
 constexpr int FM_MAX_BBOX_AREA = 1024;   // larger faces are left to the per-pixel atomic kernels
+// Lanes per face.  The bounding-box scan is a chain of dependent loads (owner index, then the pixel's maps): one
+// lane per face serialises ~10-25 of them.  FM_LANES adjacent lanes share a face, take every FM_LANES-th pixel of
+// its box and combine their partial sums with quad shuffles / LDS; the visible faces of a mesh come in long index
+// runs, so the waves stay dense.
+constexpr int FM_LANES = 8;
+constexpr int FM_FACES_PER_BLOCK = 256 / FM_LANES;
+
+// pixel `i` (row-major) of the box, advanced by FM_LANES per step
+struct BoxCursor {
+    int x, y, x0, x1, bw;
+    __device__ __forceinline__ BoxCursor(int x0_, int x1_, int y0_, int start) : x0(x0_), x1(x1_), bw(x1_ - x0_ + 1) {
+        y = y0_ + start / bw;
+        x = x0_ + start % bw;
+    }
+    __device__ __forceinline__ void advance() {
+        x += FM_LANES;
+        while (x > x1) { x -= bw; y++; }
+    }
+};
+
+__device__ __forceinline__ float quad_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < FM_LANES; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 constexpr int FLAG_HIDDEN = 0, FLAG_VISIBLE = 1, FLAG_LARGE = 2;
 
 // flags[b*F + f] = 1 for every face that owns at least one pixel (plain stores of the same value)
@@ -32,15 +57,17 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
                                                              const float* __restrict__ grad_depth_map,
                                                              float* __restrict__ grad_faces, int* __restrict__ flags, int B,
                                                              int S) {
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;
+    const int sub = threadIdx.x % FM_LANES;
     const int F = fs.num_faces();
-    if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;
+    if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;      // the FM_LANES lanes of a face leave together
     const int bn = (int)(gi / F), fn = (int)(gi % F);
     float face[9], finv[9];
     fs.load(bn, fn, face);
     int x0, x1, y0, y1;
     if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
-    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+    if (area > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
     face_inverse(face, S, finv);
     float tmp[3] = {0, 0, 0};
 #pragma unroll
@@ -50,24 +77,27 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
     }
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const size_t base = (size_t)bn * S * S;
-    for (int y = y0; y <= y1; y++) {
-        for (int x = x0; x <= x1; x++) {
-            const size_t p = base + (size_t)y * S + x;
-            if (face_index_map[p] != fn) continue;
-            const float depth = depth_map[p], g = grad_depth_map[p];
-            const float depth2 = depth * depth;
+    BoxCursor c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += FM_LANES, c.advance()) {
+        const size_t p = base + (size_t)c.y * S + c.x;
+        if (face_index_map[p] != fn) continue;
+        const float depth = depth_map[p], g = grad_depth_map[p];
+        const float depth2 = depth * depth;
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float wk = weight_map[3 * p + k], z_k = face[3 * k + 2];
-                acc[3 * k + 0] += -g * tmp[0] * wk * depth2 * (float)S / 2.0f;          // KCU:588
-                acc[3 * k + 1] += -g * tmp[1] * wk * depth2 * (float)S / 2.0f;
-                acc[3 * k + 2] += g * wk * depth2 / (z_k * z_k);                        // KCU:575
-            }
+        for (int k = 0; k < 3; k++) {
+            const float wk = weight_map[3 * p + k], z_k = face[3 * k + 2];
+            acc[3 * k + 0] += -g * tmp[0] * wk * depth2 * (float)S / 2.0f;          // KCU:588
+            acc[3 * k + 1] += -g * tmp[1] * wk * depth2 * (float)S / 2.0f;
+            acc[3 * k + 2] += g * wk * depth2 / (z_k * z_k);                        // KCU:575
         }
     }
-    float* gf = grad_faces + (size_t)gi * 9;
 #pragma unroll
-    for (int k = 0; k < 9; k++) gf[k] += acc[k];
+    for (int k = 0; k < 9; k++) acc[k] = quad_sum(acc[k]);
+    if (sub == 0) {
+        float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) gf[k] += acc[k];
+    }
 }
 
 // Texture backward for ts == 2, gathered: 8 texels x 3 channels per face kept in LDS.  grad_textures += .
@@ -79,7 +109,8 @@ __global__ void __launch_bounds__(256) k_backward_textures_faces(FS fs, const in
                                                                 float* __restrict__ grad_textures, int* __restrict__ flags,
                                                                 int B, int S) {
     __shared__ float s_acc[24][256];
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;
+    const int sub = threadIdx.x % FM_LANES;
     const int F = fs.num_faces();
     if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;
     const int bn = (int)(gi / F), fn = (int)(gi % F);
@@ -87,29 +118,40 @@ __global__ void __launch_bounds__(256) k_backward_textures_faces(FS fs, const in
     fs.load(bn, fn, face);
     int x0, x1, y0, y1;
     if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
-    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+    if (area > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
     const int l = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
     const size_t base = (size_t)bn * S * S;
-    for (int y = y0; y <= y1; y++) {
-        for (int x = x0; x <= x1; x++) {
-            const size_t p = base + (size_t)y * S + x;
-            if (face_index_map[p] != fn) continue;
-            const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
+    BoxCursor c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += FM_LANES, c.advance()) {
+        const size_t p = base + (size_t)c.y * S + c.x;
+        if (face_index_map[p] != fn) continue;
+        const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
 #pragma unroll
-            for (int pn = 0; pn < 8; pn++) {
-                const float w = sampling_weight_map[p * 8 + pn];
-                const int isc = sampling_index_map[p * 8 + pn] & 7;                     // ts == 2: 0..7
-                s_acc[isc * 3 + 0][l] += w * g0;                                        // KCU:537
-                s_acc[isc * 3 + 1][l] += w * g1;
-                s_acc[isc * 3 + 2][l] += w * g2;
-            }
+        for (int pn = 0; pn < 8; pn++) {
+            const float w = sampling_weight_map[p * 8 + pn];
+            const int isc = sampling_index_map[p * 8 + pn] & 7;                     // ts == 2: 0..7
+            s_acc[isc * 3 + 0][l] += w * g0;                                        // KCU:537
+            s_acc[isc * 3 + 1][l] += w * g1;
+            s_acc[isc * 3 + 2][l] += w * g2;
         }
     }
-    float* gt = grad_textures + (size_t)gi * 24;
+    // the face's lanes sit in one wave: their LDS columns are complete once the loop has reconverged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub == 0) {
+        float* gt = grad_textures + (size_t)gi * 24;
 #pragma unroll
-    for (int t = 0; t < 24; t++) gt[t] += s_acc[t][l];
+        for (int t = 0; t < 24; t++) {
+            float v = s_acc[t][l];
+#pragma unroll
+            for (int j = 1; j < FM_LANES; j++) v += s_acc[t][l + j];
+            gt[t] += v;
+        }
+    }
 }
 
 }  // namespace d3m

@@ -153,7 +153,8 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
                                                                     float* __restrict__ grad_light /*[Bm,F',3] zeroed or NULL*/,
                                                                     int* __restrict__ flags, int B, int S, float eps) {
     __shared__ float s_acc[24][256];
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+    const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;   // FM_LANES lanes per face
+    const int sub = threadIdx.x % FM_LANES;
     const int Fp = lt.Fp;
     if (gi >= (long)B * Fp || flags[gi] == FLAG_HIDDEN) return;
     const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
@@ -163,32 +164,37 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
     for (int k = 0; k < 9; k++) fc[k] = face[k];
     int x0, x1, y0, y1;
     if (!pixel_bbox(fc, S, x0, x1, y0, y1)) return;
-    if ((x1 - x0 + 1) * (y1 - y0 + 1) > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+    if (area > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
     const int l = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
     const size_t base = (size_t)bn * S * S;
-    for (int y = y0; y <= y1; y++) {
-        for (int x = x0; x <= x1; x++) {
-            const size_t p = base + (size_t)y * S + x;
-            if (face_index_map[p] != fn) continue;
-            const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-            const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
-            int fl[3];
-            float fr[3];
-            sample_setup(fc, weight, depth_map[p], 2, eps, fl, fr);
+    BoxCursor c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += FM_LANES, c.advance()) {
+        const size_t p = base + (size_t)c.y * S + c.x;
+        if (face_index_map[p] != fn) continue;
+        const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+        const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
+        int fl[3];
+        float fr[3];
+        sample_setup(fc, weight, depth_map[p], 2, eps, fl, fr);
 #pragma unroll
-            for (int pn = 0; pn < 8; pn++) {
-                float w;
-                int isc;
-                sample_corner(pn, 2, fl, fr, w, isc);
-                isc &= 7;
-                s_acc[isc * 3 + 0][l] += w * g0;
-                s_acc[isc * 3 + 1][l] += w * g1;
-                s_acc[isc * 3 + 2][l] += w * g2;
-            }
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc;
+            sample_corner(pn, 2, fl, fr, w, isc);
+            isc &= 7;
+            s_acc[isc * 3 + 0][l] += w * g0;
+            s_acc[isc * 3 + 1][l] += w * g1;
+            s_acc[isc * 3 + 2][l] += w * g2;
         }
     }
+    // the face's lanes sit in one wave: their LDS columns are complete once the loop has reconverged
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (sub != 0) return;
     const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
     const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
     float gl[3] = {0, 0, 0};
@@ -200,7 +206,9 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
         const int to = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float g = s_acc[t * 3 + c][l];
+            float g = s_acc[t * 3 + c][l];
+#pragma unroll
+            for (int j = 1; j < FM_LANES; j++) g += s_acc[t * 3 + c][l + j];
             gt[to * 3 + c] += g * li[c];
             gl[c] += g * tex[to * 3 + c];
         }

@@ -233,7 +233,7 @@ static int run_backward_textures(FS fs, const float* faces_dummy, const int32_t*
             HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
         }
-        LAUNCH("k_backward_textures_faces", k_backward_textures_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs,
+        LAUNCH("k_backward_textures_faces", k_backward_textures_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs,
                face_index_map, sw, si, grad_rgb_map, grad_textures, flags, B, S);
         LAUNCH("k_backward_textures", k_backward_textures, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, sw, si,
                grad_rgb_map, grad_textures, B, F, S, ts, (const int*)flags);
@@ -255,7 +255,7 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
             HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
         }
-        LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, depth_map,
+        LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S);
     }
     LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(blocks_for(n, 256)), dim3(256), st, fs, depth_map,
@@ -518,7 +518,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     if (texture_size == 2) {
         HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
         LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
-        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, 256)), dim3(256), st, faces,
+        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, faces,
                lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, flags, B, S, eps);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
