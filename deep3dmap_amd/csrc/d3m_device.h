@@ -147,10 +147,23 @@ __device__ __forceinline__ int wave_inclusive_scan(int v) {
     }
     return v;
 }
+// Sum over the 64 lanes, returned in every lane.  DPP within a 16-lane row (quad swaps, then the two mirrors: no
+// LDS-crossbar round trips as __shfl_xor would take), v_readlane across the four rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);    // row_half_mirror
+    v += dpp_f32<0x140>(v);    // row_mirror: every lane now holds its row's sum
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Wave-aggregated counter bump: lanes with `has` add 1 to counters[key]; lanes sharing a key are merged

@@ -33,8 +33,14 @@
 namespace d3m {
 
 constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are walked by the owning lane
-constexpr int EG_LINE_PARTS = 2;   // workgroups per line (items are dealt round-robin to the parts)
-constexpr int EG_LINE_WAVES = 8;   // waves per workgroup: parts x waves walk one line's items concurrently
+#ifndef D3M_EG_LINE_PARTS
+#define D3M_EG_LINE_PARTS 2
+#endif
+#ifndef D3M_EG_LINE_WAVES
+#define D3M_EG_LINE_WAVES 8
+#endif
+constexpr int EG_LINE_PARTS = D3M_EG_LINE_PARTS;   // workgroups per line (items are dealt round-robin to the parts)
+constexpr int EG_LINE_WAVES = D3M_EG_LINE_WAVES;   // waves per workgroup: parts x waves walk one line's items concurrently
 constexpr int EG_ITEM_DW = 12;     // dwords per item
 
 // Maps as one scan axis sees them: element (line d0, position d1) lives at b*S*S + d0*S + d1.
@@ -79,6 +85,7 @@ struct Segment {
     int axis, d0, from, to, inward, f0, f1;
     float d1_cross, q0, q1;
     int ref_pos;     // d1 of the pixel whose value is the reference (in-pixel for outward, out-pixel for inward)
+    int dir, d1_in;  // walk direction of KCU:297-308 and the in-pixel next to the crossing
 };
 
 // Enumerates the walk segments of ONE (edge, axis) pair of a face, in the reference's d0 order.
@@ -99,6 +106,8 @@ __device__ __forceinline__ void for_each_segment(float p00, float p01, float p10
         const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
         if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;             // KCU:325-328
         sg.d0 = d0;
+        sg.dir = direction;
+        sg.d1_in = d1_in;
         sg.d1_cross = d1_cross;
         sg.f0 = p10 != fd0;
         sg.f1 = p00 != fd0;
@@ -290,8 +299,18 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 }
 
 // ---- 3. walk short segments, emit long ones ------------------------------------------------------------
-// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2]; 1 unused; 2 from | to<<16; 3 fn; 4 d1_cross; 5 q0; 6 q1;
-// 7..10 reference alpha,r,g,b; 11 unused.  (line and slots are implied by where the item is indexed.)
+// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4]; 1 inv0; 2 from | to<<16; 3 fn;
+// 4 d1_cross; 5 u0; 6 u1; 7..10 reference alpha,r,g,b; 11 inv1.  (line and slots are implied by where the item is
+// indexed.)
+//
+// FACTORED DISTANCE.  Along one queued segment t = d1 - d1_cross keeps its sign s_t (outward: the walk direction;
+// inward: the opposite), so KCU:404-405's  dist = q*t*(2/is) +- eps  is  qc*(t + u)  with qc = q*2/is and the
+// per-item constant u = s_t*eps/|qc|, and the walk's sum  -sum diff/dist  becomes  (-1/qc) * sum diff/(t + u):
+// per pixel one packed add, two v_rcp and one packed fma for both vertices; inv = -1/qc is applied once per item.
+// |t + u| >= |u| > 0, so no quotient is infinite.  The one pixel where t == 0 (an inward walk starting exactly on
+// an integer crossing: the reference's `0 < dist` is false there, i.e. -eps whatever s_t says) is corrected after
+// the loop (fix_at_*).  Inward segments whose limit lies on the unexpected side of the in-pixel (possible only
+// within rounding of a vertex) are not queued.
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w) {
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
@@ -318,7 +337,8 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 const size_t line = ((size_t)bn * 2 + axis) * is + sg.d0;
                 // A long segment is queued only if both its item slot and its line's whole slice fit the
                 // capacity the workspace gives; otherwise this lane walks it (still correct, just serial).
-                const bool queued = is_long && item < w.cap &&
+                const bool oriented = !sg.inward || ((0 < sg.dir) ? sg.to == sg.d1_in : sg.from == sg.d1_in);
+                const bool queued = is_long && oriented && item < w.cap &&
                                     (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
                 if (!queued) {
                     if (is_long && item < w.cap) w.results[item] = make_float2(0.0f, 0.0f);   // keep the gather well-defined
@@ -326,12 +346,19 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                     return;
                 }
                 const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos);
+                const float qc0 = (sg.f0 ? sg.q0 : 1.0f) * two_over_is, qc1 = (sg.f1 ? sg.q1 : 1.0f) * two_over_is;
+                const float s_t = (float)(sg.inward ? -sg.dir : sg.dir);
+                const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
+                const bool fix = sg.inward && (float)sg.d1_in == sg.d1_cross;
+                const uint32_t bits = (uint32_t)sg.inward | ((uint32_t)sg.f0 << 1) | ((uint32_t)sg.f1 << 2) |
+                                      ((fix && sg.dir < 0) ? 8u : 0u) | ((fix && 0 < sg.dir) ? 16u : 0u);
                 uint4* q = (uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-                q[0] = make_uint4((uint32_t)sg.inward | ((uint32_t)sg.f0 << 1) | ((uint32_t)sg.f1 << 2), 0u,
-                                  (uint32_t)sg.from | ((uint32_t)sg.to << 16), (uint32_t)fn);
-                q[1] = make_uint4(__float_as_uint(sg.d1_cross), __float_as_uint(sg.f0 ? sg.q0 : 1.0f),
-                                  __float_as_uint(sg.f1 ? sg.q1 : 1.0f), __float_as_uint(ref.alpha));
-                q[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b), 0u);
+                q[0] = make_uint4(bits, __float_as_uint(-1.0f / qc0), (uint32_t)sg.from | ((uint32_t)sg.to << 16),
+                                  (uint32_t)fn);
+                q[1] = make_uint4(__float_as_uint(sg.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
+                                  __float_as_uint(ref.alpha));
+                q[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
+                                  __float_as_uint(-1.0f / qc1));
                 const int slot = wave_grouped_add(w.line_cursor, line, true, true);
                 w.line_items[(size_t)w.line_offset[line] + slot] = item;
             });
@@ -357,55 +384,86 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
     const int* list = w.line_items + w.line_offset[line];
-    // LDS image of the line: per pixel one float4 of values (alpha, r, g, b) and one of their gradients,
-    // then the owner indices: 2 x ds_read_b128 (+1 b32 for inward walks) per visited pixel.
-    float4* s_val = (float4*)s_line;
-    float4* s_grd = s_val + is;
-    int* s_fi = (int*)(s_grd + is);
+    // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b), their dot product with the
+    // pixel's own values T = sum value*grad (so diff = T - <reference, gradients>: 4 fma), and the owner index:
+    // ds_read_b128 + ds_read_b32 (+1 b32 for inward walks) per visited pixel.
+    float4* s_grd = (float4*)s_line;
+    float* s_dot = (float*)(s_grd + is);
+    int* s_fi = (int*)(s_dot + is);
     for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
         s_fi[p] = m.fi[line_base + p];
-        float4 v = make_float4(0, 0, 0, 0), g = make_float4(0, 0, 0, 0);
-        if (USE_ALPHA) { v.x = m.alpha[line_base + p]; g.x = m.galpha[line_base + p]; }
+        float4 g = make_float4(0, 0, 0, 0);
+        float dot = 0;
+        if (USE_ALPHA) { g.x = m.galpha[line_base + p]; dot += m.alpha[line_base + p] * g.x; }
         if (USE_RGB) {
             const size_t e = 3 * (line_base + p);
-            v.y = m.rgb[e]; v.z = m.rgb[e + 1]; v.w = m.rgb[e + 2];
             g.y = m.grgb[e]; g.z = m.grgb[e + 1]; g.w = m.grgb[e + 2];
+            dot += m.rgb[e] * g.y;
+            dot += m.rgb[e + 1] * g.z;
+            dot += m.rgb[e + 2] * g.w;
         }
-        s_val[p] = v;
         s_grd[p] = g;
+        s_dot[p] = dot;
     }
     __syncthreads();
-    const float two_over_is = 2.0f / (float)is;
     // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
-    //  zero, and software-pipelining the list -> record fetch.  The loop is VALU-bound: ~25 VALU instructions
-    //  per 64-pixel iteration, profiles/r01_*.)
-    for (int it = part * EG_LINE_WAVES + wv; it < n_items; it += EG_LINE_WAVES * EG_LINE_PARTS) {
-        const int item = list[it];
-        const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-        const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
+    //  zero, and software-pipelining the list -> record fetch.  The loop is VALU-bound, profiles/r01_*.)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // Everything about an item is wave-uniform: index and record go through the scalar cache (s_load), and the
+    // next record / next-but-one index are requested before the current item is walked, so their latency
+    // (two dependent loads) hides behind one walk.
+    constexpr int STRIDE = EG_LINE_WAVES * EG_LINE_PARTS;
+    int it = __builtin_amdgcn_readfirstlane(part * EG_LINE_WAVES + wv);
+    if (it >= n_items) return;                                 // this wave has no item (after the barrier above)
+    int item = list[it];
+    int item_next = it + STRIDE < n_items ? list[it + STRIDE] : 0;
+    const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
+    uint4 q0v = q[0], q1v = q[1], q2v = q[2];
+    for (; it < n_items; it += STRIDE) {
+        const bool has_next = it + STRIDE < n_items;
+        const uint4* qn = (const uint4*)(w.items + (size_t)(has_next ? item_next : item) * EG_ITEM_DW);
+        const uint4 n0v = qn[0], n1v = qn[1], n2v = qn[2];
+        const int item_next2 = it + 2 * STRIDE < n_items ? list[it + 2 * STRIDE] : 0;
         const uint32_t bits = q0v.x;
         const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)q0v.w;
         const bool inward = bits & 1;
-        const float m0 = (bits >> 1) & 1 ? 1.0f : 0.0f, m1 = (bits >> 2) & 1 ? 1.0f : 0.0f;
-        const float d1_cross = __uint_as_float(q1v.x), qq0 = __uint_as_float(q1v.y), qq1 = __uint_as_float(q1v.z);
-        const float ra = __uint_as_float(q1v.w), rr = __uint_as_float(q2v.x), rg = __uint_as_float(q2v.y),
-                    rb = __uint_as_float(q2v.z);
-        float g0 = 0, g1 = 0;
-        for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const float4 v = s_val[d1], g = s_grd[d1];
-            float diff = 0;
-            if (USE_ALPHA) diff += (v.x - ra) * g.x;
+        const float d1_cross = __uint_as_float(q1v.x);
+        const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
+        const float nra = -__uint_as_float(q1v.w), nrr = -__uint_as_float(q2v.x), nrg = -__uint_as_float(q2v.y),
+                    nrb = -__uint_as_float(q2v.z);
+        auto diff_at = [&](int d1) {
+            const float4 g = s_grd[d1];
+            float diff = s_dot[d1];
+            if (USE_ALPHA) diff = __builtin_fmaf(nra, g.x, diff);
             if (USE_RGB) {
-                diff += (v.y - rr) * g.y;
-                diff += (v.z - rg) * g.z;
-                diff += (v.w - rb) * g.w;
+                diff = __builtin_fmaf(nrr, g.y, diff);
+                diff = __builtin_fmaf(nrg, g.z, diff);
+                diff = __builtin_fmaf(nrb, g.w, diff);
             }
             if (inward && s_fi[d1] != fn) diff = 0;           // KCU:470: only this face's pixels
-            visit_pixel(diff, d1, d1_cross, qq0, qq1, m0, m1, two_over_is, a.eps, g0, g1);
+            return !(diff <= 0) ? diff : 0.0f;                // KCU:401/:481 (NaN passes, as in the reference)
+        };
+        v2f acc = {0.0f, 0.0f};
+        for (int d1 = from + lane; d1 <= to; d1 += 64) {
+            const float dpos = diff_at(d1);
+            const float t = (float)d1 - d1_cross;
+            const v2f den = u + t;
+            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            const v2f dp = {dpos, dpos};
+            acc = __builtin_elementwise_fma(dp, r, acc);
         }
-        g0 = wave_sum(g0);
-        g1 = wave_sum(g1);
-        if (lane == 0) w.results[item] = make_float2(g0, g1);
+        float s0 = wave_sum(acc.x), s1 = wave_sum(acc.y);
+        if (lane == 0) {
+            const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
+            if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
+                const float dpos = diff_at((bits & 8u) ? from : to);
+                if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
+                if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
+            }
+            w.results[item] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
+        }
+        item = item_next; item_next = item_next2;
+        q0v = n0v; q1v = n1v; q2v = n2v;
     }
 }
 
@@ -567,7 +625,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    const size_t smem = (size_t)9 * S * 4;
+    const size_t smem = (size_t)6 * S * 4;
     const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
