@@ -63,13 +63,14 @@ struct EdgeWork {
     int* visible;        // [B*F]   1 if the face owns a pixel (zeroed per call, set by k_mark_visible)
     int* visible_list;   // [B*F]   compacted indices of those faces
     int* n_visible;      // [1]     (zeroed per call)
-    int* lane_count;     // [6*B*F] long segments per (visible face, edge, axis) lane, indexed by list position
-    int* lane_offset;    // [6*B*F] first item slot of that lane
-    float2* lane_partial;// [6*B*F] short-walk sums of that lane
+    int2* lane_cross;    // [6*B*F] per (visible face, edge, axis) lane: first crossing within its workgroup, count
+    float2* lane_partial;// [6*B*F] overflow sums of that lane (segments whose slot did not fit the workspace)
     int* line_count;     // [B*2*S] long segments per line (zeroed per call)
     int* line_cursor;    // [B*2*S] (zeroed per call)
     int* line_offset;    // [B*2*S]
-    int* alloc;          // [2] cursors: item slots, line slices (zeroed per call)
+    int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
+    int* vis_block;      // [ceil(B*F/1024)+1] visible faces per 1024-face chunk, then (in place) their exclusive scan
+    int* lane_block;     // [ceil(B*F/42)+1]   crossings per k_edge_count workgroup iteration, then their scan
     uint32_t* items;     // [cap * EG_ITEM_DW]
     int* line_items;     // [cap] item indices grouped by line
     float2* results;     // [cap]
@@ -88,53 +89,64 @@ struct Segment {
     int dir, d1_in;  // walk direction of KCU:297-308 and the in-pixel next to the crossing
 };
 
-// Enumerates the walk segments of ONE (edge, axis) pair of a face, in the reference's d0 order.
-// p00..p21 = p[num][dim] of KCU:289-294 for that pair.  owner(d0, d1) must return face_index_map at that
-// line position; emit(const Segment&) is called for each non-empty segment.
-template <class Owner, class Emit>
-__device__ __forceinline__ void for_each_segment(float p00, float p01, float p10, float p11, float p20, float p21,
-                                                 int axis, int fn, int is, Owner&& owner, Emit&& emit) {
+// The d0 range of ONE (edge, axis) pair of a face (KCU:312-313): its crossings are d0_from .. d0_to.
+__device__ __forceinline__ void crossing_range(float p00, float p10, int is, int& d0_from, int& d0_to) {
+    d0_from = f2i(fmaxf(ceilf(fminf(p00, p10)), 0.0f));
+    d0_to = f2i(fminf(fmaxf(p00, p10), (float)(is - 1)));
+}
+
+// The (at most two) walk segments of ONE crossing d0 of an (edge, axis) pair: KCU:314-362 (outward) and :417-431
+// (inward).  p00..p21 = p[num][dim] of KCU:289-294 for that pair; owner(d0, d1) returns face_index_map at that
+// line position.  has_out / has_in tell which of `out` / `in` were filled.
+template <class Owner>
+__device__ __forceinline__ void crossing_segments(float p00, float p01, float p10, float p11, float p20, float p21,
+                                                  int axis, int fn, int is, int d0, Owner&& owner, Segment& out,
+                                                  bool& has_out, Segment& in, bool& has_in) {
+    has_out = has_in = false;
     const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
-    const int d0_from = f2i(fmaxf(ceilf(fminf(p00, p10)), 0.0f));                          // KCU:312
-    const int d0_to = f2i(fminf(fmaxf(p00, p10), (float)(is - 1)));                        // KCU:313
+    const float fd0 = (float)d0;
+    const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;                 // KCU:317
+    const int d1_in = (0 < direction) ? f2i(floorf(d1_cross)) : f2i(ceilf(d1_cross));
+    const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
+    if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) return;                   // KCU:325-328
     Segment sg;
     sg.axis = axis;
-    for (int d0 = d0_from; d0 <= d0_to; d0++) {
-        const float fd0 = (float)d0;
-        const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;             // KCU:317
-        const int d1_in = (0 < direction) ? f2i(floorf(d1_cross)) : f2i(ceilf(d1_cross));
-        const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
-        if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;             // KCU:325-328
-        sg.d0 = d0;
-        sg.dir = direction;
-        sg.d1_in = d1_in;
-        sg.d1_cross = d1_cross;
-        sg.f0 = p10 != fd0;
-        sg.f1 = p00 != fd0;
-        sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
-        sg.q1 = (p10 - p00) / (fd0 - p00);
-        // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
-        if (owner(d0, d1_in) == fn) {
-            const int d1_limit = (0 < direction) ? is - 1 : 0;
-            sg.from = max(min(d1_out, d1_limit), 0);
-            sg.to = min(max(d1_out, d1_limit), is - 1);
-            sg.inward = 0;
-            sg.ref_pos = d1_in;
-            emit(sg);
-        }
-        // inward: in-pixel .. opposite edge (KCU:417-431)
-        float d0_cross2;
-        if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
-        else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
-        const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
-        sg.from = max(min(d1_in, d1_limit), 0);
-        sg.to = min(max(d1_in, d1_limit), is - 1);
-        if (sg.from <= sg.to) {
-            sg.inward = 1;
-            sg.ref_pos = d1_out;
-            emit(sg);
-        }
+    sg.d0 = d0;
+    sg.dir = direction;
+    sg.d1_in = d1_in;
+    sg.d1_cross = d1_cross;
+    sg.f0 = p10 != fd0;
+    sg.f1 = p00 != fd0;
+    sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
+    sg.q1 = (p10 - p00) / (fd0 - p00);
+    // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
+    if (owner(d0, d1_in) == fn) {
+        const int d1_limit = (0 < direction) ? is - 1 : 0;
+        out = sg;
+        out.from = max(min(d1_out, d1_limit), 0);
+        out.to = min(max(d1_out, d1_limit), is - 1);
+        out.inward = 0;
+        out.ref_pos = d1_in;
+        has_out = true;
     }
+    // inward: in-pixel .. opposite edge (KCU:417-431)
+    float d0_cross2;
+    if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
+    else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
+    const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
+    in = sg;
+    in.from = max(min(d1_in, d1_limit), 0);
+    in.to = min(max(d1_in, d1_limit), is - 1);
+    in.inward = 1;
+    in.ref_pos = d1_out;
+    has_in = in.from <= in.to;
+}
+
+// A segment is handed to the line kernel when it is long and its pixels lie on the expected side of the crossing
+// (see "FACTORED DISTANCE" below); k_edge_count and k_edge_emit must agree on this.
+__device__ __forceinline__ bool segment_queueable(const Segment& sg) {
+    const bool oriented = !sg.inward || ((0 < sg.dir) ? sg.to == sg.d1_in : sg.from == sg.d1_in);
+    return sg.to - sg.from + 1 > EG_INLINE_MAX && oriented;
 }
 
 // Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).  Branch-free: a pixel whose
@@ -188,24 +200,67 @@ __device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, boo
 // ---- 0. compact the faces that own at least one pixel -------------------------------------------------
 // A face that owns no pixel cannot contribute: the outward walk needs its own in-pixel (KCU:354) and the
 // inward walk only counts its own pixels (KCU:470).
-__global__ void __launch_bounds__(256) k_compact_visible(const int* __restrict__ visible, int* __restrict__ list,
-                                                        int* __restrict__ n_visible, long n) {
+//
+// Slot allocation here and in k_edge_count goes through per-workgroup totals and ONE small scan kernel instead of
+// an atomic cursor: thousands of returning atomics on one address serialise at the L2 atomic unit (~15 ns each:
+// the 6272 of the old per-256-faces cursor cost 43 us, the 9200 per-wave ones of k_edge_count 130 us).
+constexpr int EG_COMPACT_CHUNK = 1024;      // faces per workgroup (4 per lane)
+
+__global__ void __launch_bounds__(256) k_count_visible(const int* __restrict__ visible, int* __restrict__ vis_block, long n) {
     __shared__ int s_wave[4];
-    __shared__ int s_base;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool v = i < n && visible[i] != 0;
-    const unsigned long long mask = __ballot(v);
+    const long i0 = (long)blockIdx.x * EG_COMPACT_CHUNK + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) c += (i0 + k < n && visible[i0 + k] != 0) ? 1 : 0;
+    const int incl = wave_inclusive_scan(c);
+    if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) vis_block[blockIdx.x] = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+}
+
+// In-place exclusive scan of counts[0 .. n) by ONE workgroup; counts[n] and *total receive the sum.
+// n comes from *n_ptr (divided by n_div, rounded up) when n_ptr is given: device-side sizes.
+__global__ void __launch_bounds__(1024) k_scan_small(int* __restrict__ counts, int n_host, const int* __restrict__ n_ptr,
+                                                    int n_div, int* __restrict__ total) {
+    __shared__ int s_wave[16];
+    __shared__ int s_run;
+    const int n = n_ptr ? (*n_ptr + n_div - 1) / n_div : n_host;
     const int lane = lane_id(), wv = threadIdx.x >> 6;
-    if (lane == 0) s_wave[wv] = __popcll(mask);
+    if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {                                   // one atomic per 256 faces
-        const int t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3];
-        const int tot = t0 + t1 + t2 + t3;
-        s_base = tot ? atomicAdd(n_visible, tot) : 0;
-        s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int c = i < n ? counts[i] : 0;
+        const int incl = wave_inclusive_scan(c);
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int before = s_run;
+        for (int k = 0; k < wv; k++) before += s_wave[k];
+        if (i < n) counts[i] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = before + incl;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) { counts[n] = s_run; *total = s_run; }
+}
+
+__global__ void __launch_bounds__(256) k_compact_visible(const int* __restrict__ visible, int* __restrict__ list,
+                                                        const int* __restrict__ vis_block, long n) {
+    __shared__ int s_wave[4];
+    const long i0 = (long)blockIdx.x * EG_COMPACT_CHUNK + threadIdx.x * 4;
+    bool v[4];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = i0 + k < n && visible[i0 + k] != 0; c += v[k] ? 1 : 0; }
+    const int incl = wave_inclusive_scan(c);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) s_wave[wv] = incl;
     __syncthreads();
-    if (v) list[s_base + s_wave[wv] + __popcll(mask & ((1ull << lane) - 1ull))] = (int)i;
+    int pos = vis_block[blockIdx.x] + incl - c;
+    for (int k = 0; k < wv; k++) pos += s_wave[k];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (v[k]) list[pos++] = (int)(i0 + k);             // ascending face order: neighbours stay neighbours
 }
 
 // Six lanes per visible face, one per (edge, axis) pair; 42 faces per 256-thread workgroup.
@@ -241,40 +296,97 @@ __device__ __forceinline__ bool load_face_lane(const FS& fs, const EdgeWork& w, 
     return true;
 }
 
-// ---- 1. count long segments per (face, edge, axis) lane and per line; reserve item slots ---------------
+// ---- 1./3. crossings, flattened -----------------------------------------------------------------------
+// A workgroup takes 42 visible faces = 252 (face, edge, axis) lanes.  The lanes publish their crossing ranges in
+// LDS, a workgroup prefix turns them into one flat list of crossings (~900 per workgroup on the headline mesh), and
+// the 256 threads then take ONE crossing each per round: no lane loops over its own d0 range, so a face with 30
+// crossings no longer holds 63 lanes with 2 crossings hostage (per-wave max trip count was 3.3x the mean).
+// Every crossing owns two result slots (2c: outward, 2c+1: inward) whether or not they end up queued; the slot is
+// the item index.
+struct LaneTable {
+    float p[6][256];
+    int fn[256], bn_axis[256], d0_from[256];
+    int pre[257];           // exclusive prefix of the lanes' crossing counts; pre[256] = total
+    int wave_tot[4];
+};
+
+template <class FS>
+__device__ __forceinline__ int publish_lanes(const FS& fs, const EdgeWork& w, int blk, int is, LaneTable& t, bool& on, int& pos,
+                                             int& ea, int& n_cross) {
+    int bn = 0, fn = 0;
+    long gi = 0;
+    float p00 = 0, p01 = 0, p10 = 0, p11 = 0, p20 = 0, p21 = 0;
+    on = load_face_lane(fs, w, blk, is, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21);
+    int d0_from = 0, d0_to = -1;
+    if (on) crossing_range(p00, p10, is, d0_from, d0_to);
+    n_cross = on ? max(d0_to - d0_from + 1, 0) : 0;
+    const int l = threadIdx.x;
+    t.p[0][l] = p00; t.p[1][l] = p01; t.p[2][l] = p10; t.p[3][l] = p11; t.p[4][l] = p20; t.p[5][l] = p21;
+    t.fn[l] = fn;
+    t.bn_axis[l] = (bn << 1) | (ea & 1);
+    t.d0_from[l] = d0_from;
+    const int incl = wave_inclusive_scan(n_cross);
+    const int wv = l >> 6;
+    if (lane_id() == 63) t.wave_tot[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < wv; k++) before += t.wave_tot[k];
+    t.pre[l] = before + incl - n_cross;
+    if (l == 255) t.pre[256] = before + incl;
+    __syncthreads();
+    return t.pre[256];
+}
+
+// crossing c of the workgroup -> owning lane (last l with pre[l] <= c) ...
+__device__ __forceinline__ int crossing_lane(const LaneTable& t, int c) {
+    int lo = 0, hi = 256;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int mid = (lo + hi) >> 1;
+        if (t.pre[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---- 1. per line: how many segments will be queued; per workgroup: how many crossings --------------------
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeWork w) {
+    __shared__ LaneTable t;
+    const int is = a.S;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {      // fixed grid, uniform trip count per workgroup
-        int pos = 0, ea = 0, bn = 0, fn = 0, n = 0;
-        long gi = 0;
-        float p00, p01, p10, p11, p20, p21;
-        const bool on = load_face_lane(fs, w, blk, a.S, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21);
-        if (on) {
-            const int is = a.S, axis = ea & 1;
-            const int32_t* fi = a.ax[axis].fi + (size_t)bn * is * is;
-            for_each_segment(
-                p00, p01, p10, p11, p20, p21, axis, fn, is, [&](int d0, int d1) { return fi[(size_t)d0 * is + d1]; },
-                [&](const Segment& sg) {
-                    if (sg.to - sg.from + 1 > EG_INLINE_MAX) {
-                        n++;
-                        // neighbouring faces cross the same lines: merge equal lines within the wave
-                        wave_grouped_add(w.line_count, ((size_t)bn * 2 + axis) * is + sg.d0, true, false);
-                    }
-                });
+        bool on;
+        int pos = 0, ea = 0, n_cross = 0;
+        const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
+        // every lane of a listed face gets its record (n_cross is 0 for a lane that is not `on`)
+        if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
+            const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
+            w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
+            w.lane_partial[lane6] = make_float2(0.0f, 0.0f);
         }
-        // item slots: wave prefix + ONE atomic per wave (slices need not be ordered)
-        const int incl = wave_inclusive_scan(n);
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (total > 0) {
-            if (lane_id() == 0) base = atomicAdd(w.alloc, total);
-            base = __shfl(base, 0, 64);
+        if (threadIdx.x == 0) w.lane_block[blk] = total;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            const int c = c0 + threadIdx.x;
+            bool q_out = false, q_in = false;
+            size_t line = 0;
+            if (c < total) {
+                const int l = crossing_lane(t, c);
+                const int d0 = t.d0_from[l] + (c - t.pre[l]);
+                const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
+                const int32_t* fi = a.ax[axis].fi + (size_t)bn * is * is;
+                Segment so, si;
+                bool has_out, has_in;
+                crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+                                  [&](int e0, int e1) { return fi[(size_t)e0 * is + e1]; }, so, has_out, si, has_in);
+                q_out = has_out && segment_queueable(so);
+                q_in = has_in && segment_queueable(si);
+                line = ((size_t)bn * 2 + axis) * is + d0;
+            }
+            // neighbouring crossings fall on the same lines: merge equal lines within the wave (uniform call sites)
+            wave_grouped_add(w.line_count, line, q_out, false);
+            wave_grouped_add(w.line_count, line, q_in, false);
         }
-        if (on) {
-            w.lane_count[(size_t)pos * 6 + ea] = n;
-            w.lane_offset[(size_t)pos * 6 + ea] = base + incl - n;
-        }
+        __syncthreads();                                    // the table is rewritten by the next iteration
     }
 }
 
@@ -313,56 +425,76 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 // within rounding of a vertex) are not queued.
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w) {
+    __shared__ LaneTable t;
+    const int is = a.S;
+    const float two_over_is = 2.0f / (float)is;
+    const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        int pos = 0, ea = 0, bn = 0, fn = 0;
-        long gi = 0;
-        float p00, p01, p10, p11, p20, p21;
-        if (!load_face_lane(fs, w, blk, a.S, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21)) continue;
-        const int is = a.S, axis = ea & 1;
-        const float two_over_is = 2.0f / (float)is;
-        const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
-        const AxisMaps m = a.ax[axis];
-        const size_t base = (size_t)bn * is * is;
-        const int my_offset = w.lane_offset[(size_t)pos * 6 + ea];
-        float g0 = 0, g1 = 0;
-        int k = 0;
-        for_each_segment(
-            p00, p01, p10, p11, p20, p21, axis, fn, is, [&](int d0, int d1) { return m.fi[base + (size_t)d0 * is + d1]; },
-            [&](const Segment& sg) {
-                const size_t line_base = base + (size_t)sg.d0 * is;
-                const bool is_long = sg.to - sg.from + 1 > EG_INLINE_MAX;
-                const int item = my_offset + k;
-                if (is_long) k++;
-                const size_t line = ((size_t)bn * 2 + axis) * is + sg.d0;
-                // A long segment is queued only if both its item slot and its line's whole slice fit the
-                // capacity the workspace gives; otherwise this lane walks it (still correct, just serial).
-                const bool oriented = !sg.inward || ((0 < sg.dir) ? sg.to == sg.d1_in : sg.from == sg.d1_in);
-                const bool queued = is_long && oriented && item < w.cap &&
+        bool on;
+        int pos = 0, ea = 0, n_cross = 0;
+        const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
+        const long cbase = w.lane_block[blk];               // scanned: first crossing of this workgroup
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            const int c = c0 + threadIdx.x;
+            const bool active = c < total;
+            Segment sg[2];
+            bool has[2] = {false, false};
+            int l = 0, fn = 0, axis = 0;
+            size_t base = 0, line = 0;
+            if (active) {
+                l = crossing_lane(t, c);
+                const int d0 = t.d0_from[l] + (c - t.pre[l]);
+                const int bn = t.bn_axis[l] >> 1;
+                axis = t.bn_axis[l] & 1;
+                fn = t.fn[l];
+                base = (size_t)bn * is * is;
+                const int32_t* fi = a.ax[axis].fi + base;
+                crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+                                  [&](int e0, int e1) { return fi[(size_t)e0 * is + e1]; }, sg[0], has[0], sg[1], has[1]);
+                line = ((size_t)bn * 2 + axis) * is + d0;
+            }
+            const AxisMaps& m = a.ax[axis];
+            const size_t line_base = base + (line % is) * is;
+#pragma unroll
+            for (int which = 0; which < 2; which++) {       // 0: outward, 1: inward
+                const long slot = 2 * (cbase + c) + which;
+                // queued only if the slot and its line's whole slice fit the capacity the workspace gives;
+                // otherwise this thread walks the segment itself (still correct, just serial)
+                const bool queued = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
                                     (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
-                if (!queued) {
-                    if (is_long && item < w.cap) w.results[item] = make_float2(0.0f, 0.0f);   // keep the gather well-defined
-                    walk_inline(m, use_rgb, use_alpha, line_base, sg, fn, two_over_is, a.eps, g0, g1);
-                    return;
+                if (queued) {
+                    const Segment& q = sg[which];
+                    const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + q.ref_pos);
+                    const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
+                    const float s_t = (float)(q.inward ? -q.dir : q.dir);
+                    const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
+                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross;
+                    const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
+                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
+                    uint4* rec = (uint4*)(w.items + (size_t)slot * EG_ITEM_DW);
+                    rec[0] = make_uint4(bits, __float_as_uint(-1.0f / qc0), (uint32_t)q.from | ((uint32_t)q.to << 16),
+                                        (uint32_t)fn);
+                    rec[1] = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
+                                        __float_as_uint(ref.alpha));
+                    rec[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
+                                        __float_as_uint(-1.0f / qc1));
+                } else if (active) {
+                    float g0 = 0, g1 = 0;
+                    if (has[which]) walk_inline(m, use_rgb, use_alpha, line_base, sg[which], fn, two_over_is, a.eps, g0, g1);
+                    if (slot < (long)w.cap) {
+                        w.results[slot] = make_float2(g0, g1);
+                    } else if (g0 != 0 || g1 != 0) {        // no slot left: fold into the lane's overflow sum
+                        const size_t lane_id6 = ((size_t)blk * EG_FACES_PER_BLOCK) * 6 + l;
+                        atomicAdd(&w.lane_partial[lane_id6].x, g0);
+                        atomicAdd(&w.lane_partial[lane_id6].y, g1);
+                    }
                 }
-                const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos);
-                const float qc0 = (sg.f0 ? sg.q0 : 1.0f) * two_over_is, qc1 = (sg.f1 ? sg.q1 : 1.0f) * two_over_is;
-                const float s_t = (float)(sg.inward ? -sg.dir : sg.dir);
-                const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
-                const bool fix = sg.inward && (float)sg.d1_in == sg.d1_cross;
-                const uint32_t bits = (uint32_t)sg.inward | ((uint32_t)sg.f0 << 1) | ((uint32_t)sg.f1 << 2) |
-                                      ((fix && sg.dir < 0) ? 8u : 0u) | ((fix && 0 < sg.dir) ? 16u : 0u);
-                uint4* q = (uint4*)(w.items + (size_t)item * EG_ITEM_DW);
-                q[0] = make_uint4(bits, __float_as_uint(-1.0f / qc0), (uint32_t)sg.from | ((uint32_t)sg.to << 16),
-                                  (uint32_t)fn);
-                q[1] = make_uint4(__float_as_uint(sg.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
-                                  __float_as_uint(ref.alpha));
-                q[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
-                                  __float_as_uint(-1.0f / qc1));
-                const int slot = wave_grouped_add(w.line_cursor, line, true, true);
-                w.line_items[(size_t)w.line_offset[line] + slot] = item;
-            });
-        w.lane_partial[(size_t)pos * 6 + ea] = make_float2(g0, g1);
+                const int in_line = wave_grouped_add(w.line_cursor, line, queued, true);     // uniform call site
+                if (queued) w.line_items[(size_t)w.line_offset[line] + in_line] = (int)slot;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -467,34 +599,47 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     }
 }
 
-// ---- 5. per visible face: the six lanes' short-walk sums + their items' results --------------------------
+// ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces) {
+    __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
-    for (int pos = blockIdx.x * 256 + threadIdx.x; pos < n_vis; pos += gridDim.x * 256) {
-    const long gi = w.visible_list[pos];
-    float acc[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int ea = 0; ea < 6; ea++) {
-        const int edge = ea >> 1, axis = ea & 1;
-        const int n = w.lane_count[(size_t)pos * 6 + ea], off = w.lane_offset[(size_t)pos * 6 + ea];
-        float2 g = w.lane_partial[(size_t)pos * 6 + ea];
-        for (int k = 0; k < n; k++) {
-            if (off + k >= w.cap) break;                      // those were walked inline by k_edge_emit
-            const float2 r = w.results[off + k];
-            g.x += r.x;
-            g.y += r.y;
+    const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int t = threadIdx.x;
+        const int pos = blk * EG_FACES_PER_BLOCK + t / 6, ea = t % 6;
+        const bool on = t < EG_FACES_PER_BLOCK * 6 && pos < n_vis;
+        float2 g = make_float2(0.0f, 0.0f);
+        if (on) {
+            const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
+            g = w.lane_partial[(size_t)pos * 6 + ea];
+            const long first = 2 * ((long)w.lane_block[blk] + lc.x), last = first + 2 * (long)lc.y;
+            for (long k = first; k < last && k < (long)w.cap; k++) {     // slots past cap were folded into lane_partial
+                const float2 r = w.results[k];
+                g.x += r.x;
+                g.y += r.y;
+            }
         }
-        acc[edge * 2 + (1 - axis)] += g.x;                    // vertex pi[0] = edge, component 1 - axis (KCU:406)
-        acc[((edge + 1) % 3) * 2 + (1 - axis)] += g.y;        // vertex pi[1] = edge + 1            (KCU:411)
-    }
-    float* gf = grad_faces + (size_t)gi * 9;
+        s_g[t] = g;
+        __syncthreads();
+        if (on && ea == 0) {
+            float acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int v = 0; v < 3; v++) {
-        gf[3 * v + 0] = acc[2 * v + 0];
-        gf[3 * v + 1] = acc[2 * v + 1];
-        gf[3 * v + 2] = 0.0f;
-    }
+            for (int e = 0; e < 6; e++) {
+                const int edge = e >> 1, axis = e & 1;
+                const float2 r = s_g[t + e];
+                acc[edge * 2 + (1 - axis)] += r.x;                    // vertex pi[0] = edge, component 1 - axis (KCU:406)
+                acc[((edge + 1) % 3) * 2 + (1 - axis)] += r.y;        // vertex pi[1] = edge + 1            (KCU:411)
+            }
+            float* gf = grad_faces + (size_t)w.visible_list[pos] * 9;
+#pragma unroll
+            for (int v = 0; v < 3; v++) {
+                gf[3 * v + 0] = acc[2 * v + 0];
+                gf[3 * v + 1] = acc[2 * v + 1];
+                gf[3 * v + 2] = 0.0f;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -521,8 +666,8 @@ __global__ void __launch_bounds__(256) k_transpose_map(const uint32_t* __restric
 struct EdgeLayout {
     size_t off_fiT, off_alphaT, off_galphaT, off_rgbT, off_grgbT;
     size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
-    size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_count, off_lane_offset,
-        off_lane_partial, off_line_offset;
+    size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_cross,
+        off_lane_partial, off_line_offset, off_vis_block, off_lane_block;
     size_t off_items;              // items | line_items | results follow, sized by capacity
     size_t fixed_bytes;
 };
@@ -546,10 +691,11 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.zero_bytes = o - L.off_zero;
     L.off_visible_list = o; o += eg_align(nf * 4);
     // at most half of the faces can be front-facing AND own a pixel only if ... no such bound: size for all
-    L.off_lane_count = o;   o += eg_align(nf * 6 * 4);
-    L.off_lane_offset = o;  o += eg_align(nf * 6 * 4);
+    L.off_lane_cross = o;   o += eg_align(nf * 6 * 8);
     L.off_lane_partial = o; o += eg_align(nf * 6 * 8);
     L.off_line_offset = o;  o += eg_align(nl * 4);
+    L.off_vis_block = o;    o += eg_align((nf / EG_COMPACT_CHUNK + 2) * 4);
+    L.off_lane_block = o;   o += eg_align((nf / EG_FACES_PER_BLOCK + 2) * 4);
     L.off_items = o;
     L.fixed_bytes = o;
     return L;
@@ -580,10 +726,11 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     w.alloc = (int*)(p + L.off_alloc);
     w.n_visible = w.alloc + 2;
     w.visible_list = (int*)(p + L.off_visible_list);
-    w.lane_count = (int*)(p + L.off_lane_count);
-    w.lane_offset = (int*)(p + L.off_lane_offset);
+    w.lane_cross = (int2*)(p + L.off_lane_cross);
     w.lane_partial = (float2*)(p + L.off_lane_partial);
     w.line_offset = (int*)(p + L.off_line_offset);
+    w.vis_block = (int*)(p + L.off_vis_block);
+    w.lane_block = (int*)(p + L.off_lane_block);
     w.items = (uint32_t*)(p + L.off_items);
     const size_t off_list = eg_align(L.off_items + cap * EG_ITEM_DW * 4);
     const size_t off_res = eg_align(off_list + cap * 4);
@@ -614,15 +761,20 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
     const long nf = (long)B * F, nl = (long)B * 2 * S;
     // worst-case grids (every face visible); workgroups past n_visible exit on their first load
-    const dim3 gf((unsigned)((nf + 255) / 256)), gl((unsigned)((nl + 255) / 256));
+    const dim3 gl((unsigned)((nl + 255) / 256));
     // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device)
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? g6_full : 8192));
-    const dim3 gg((unsigned)((nf + 255) / 256 < 2048 ? (nf + 255) / 256 : 2048));
     LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
            m.face_index_map, w.visible, B, F, S);
-    LAUNCH("k_compact_visible", k_compact_visible, gf, dim3(256), st, (const int*)w.visible, w.visible_list, w.n_visible, nf);
+    const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
+    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.vis_block, nf);
+    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.vis_block, n_chunks, (const int*)nullptr, 1, w.n_visible);
+    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.visible_list,
+           (const int*)w.vis_block, nf);
     LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
+    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
+           EG_FACES_PER_BLOCK, w.alloc);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
     const size_t smem = (size_t)6 * S * 4;
@@ -641,7 +793,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
 #undef D3M_LINES
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, gg, dim3(256), st, fs, w, grad_faces);
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, grad_faces);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

@@ -51,3 +51,36 @@ def main(n=225, S=512, views=8):
     h = np.histogram(ln, bins=[0,7,16,32,64,128,256,512,1024])
     print("len hist", dict(zip(h[1][1:], h[0])))
 main()
+
+def edge_extents(n=225, S=512, views=8):
+    dev = torch.device('cuda')
+    verts, tri = synthetic.grid_mesh(n)
+    verts = torch.from_numpy(verts).to(dev)[None]; tri = torch.from_numpy(tri).to(dev)[None]
+    eyes = torch.stack([torch.tensor(nr.get_points_from_angles(2.732, 20*np.sin(2*np.pi*i/views), 360*i/views)) for i in range(views)]).float().to(dev)
+    v = nr.look_at(verts.expand(views,-1,-1), eyes); v = nr.perspective(v, angle=30)
+    faces = nr.vertices_to_faces(v, tri.expand(views,-1,-1))
+    faces = torch.cat([faces, faces[:, :, [2,1,0]]], 1).contiguous()
+    B, F = faces.shape[:2]
+    m, _ = R._raster_forward(faces, None, S, 0.1, 100., 1e-3, None, False, True, False, False)
+    fi = m['face_index_map']
+    vis = torch.zeros(B, F, dtype=torch.bool, device=dev)
+    for b in range(B):
+        u = torch.unique(fi[b]); u = u[u >= 0]; vis[b, u.long()] = True
+    px = (faces[..., :2] * S + S - 1) / 2          # [B,F,3,2]
+    ext = []
+    for e in range(3):
+        a, c = px[:, :, e], px[:, :, (e + 1) % 3]
+        for ax in range(2):
+            lo = torch.ceil(torch.minimum(a[..., ax], c[..., ax])).clamp(min=0)
+            hi = torch.floor(torch.maximum(a[..., ax], c[..., ax])).clamp(max=S - 1)
+            ext.append((hi - lo + 1).clamp(min=0))
+    ext = torch.stack(ext, -1)[vis]            # [n_vis, 6]
+    print("visible", int(vis.sum()), "d0-range per lane: mean %.2f max %d" % (float(ext.mean()), int(ext.max())))
+    h = torch.histc(ext.flatten(), bins=20, min=0, max=20)
+    print("hist 0..19:", h.int().tolist(), " >=20:", int((ext >= 20).sum()))
+    # per-wave max (64 consecutive lanes in list order ~ index order)
+    flat = ext.flatten()
+    nw = flat.numel() // 64
+    wmax = flat[:nw * 64].view(nw, 64).max(1)[0]
+    print("per-wave max trip: mean %.1f, max %d; sum of maxes %d vs sum of means %.0f" % (float(wmax.mean()), int(wmax.max()), int(wmax.sum()), float(flat.sum()) / 64))
+edge_extents()
