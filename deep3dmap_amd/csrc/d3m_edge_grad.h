@@ -71,8 +71,7 @@ struct EdgeWork {
     int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
     int* vis_block;      // [ceil(B*F/1024)+1] visible faces per 1024-face chunk, then (in place) their exclusive scan
     int* lane_block;     // [ceil(B*F/42)+1]   crossings per k_edge_count workgroup iteration, then their scan
-    uint32_t* items;     // [cap * EG_ITEM_DW]
-    int* line_items;     // [cap] item indices grouped by line
+    uint32_t* items;     // [cap * EG_ITEM_DW] records of the queued segments, grouped by line
     float2* results;     // [cap]
     int cap;
 };
@@ -411,7 +410,7 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 }
 
 // ---- 3. walk short segments, emit long ones ------------------------------------------------------------
-// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4]; 1 inv0; 2 from | to<<16; 3 fn;
+// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] | fn << 6; 1 inv0; 2 from | to<<16; 3 slot;
 // 4 d1_cross; 5 u0; 6 u1; 7..10 reference alpha,r,g,b; 11 inv1.  (line and slots are implied by where the item is
 // indexed.)
 //
@@ -463,6 +462,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 // otherwise this thread walks the segment itself (still correct, just serial)
                 const bool queued = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
                                     (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
+                uint4 rec0, rec1, rec2;
                 if (queued) {
                     const Segment& q = sg[which];
                     const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + q.ref_pos);
@@ -472,13 +472,12 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                     const bool fix = q.inward && (float)q.d1_in == q.d1_cross;
                     const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
                                           ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
-                    uint4* rec = (uint4*)(w.items + (size_t)slot * EG_ITEM_DW);
-                    rec[0] = make_uint4(bits, __float_as_uint(-1.0f / qc0), (uint32_t)q.from | ((uint32_t)q.to << 16),
-                                        (uint32_t)fn);
-                    rec[1] = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
-                                        __float_as_uint(ref.alpha));
-                    rec[2] = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
-                                        __float_as_uint(-1.0f / qc1));
+                    rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-1.0f / qc0),
+                                      (uint32_t)q.from | ((uint32_t)q.to << 16), (uint32_t)slot);
+                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
+                                      __float_as_uint(ref.alpha));
+                    rec2 = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
+                                      __float_as_uint(-1.0f / qc1));
                 } else if (active) {
                     float g0 = 0, g1 = 0;
                     if (has[which]) walk_inline(m, use_rgb, use_alpha, line_base, sg[which], fn, two_over_is, a.eps, g0, g1);
@@ -490,8 +489,12 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                         atomicAdd(&w.lane_partial[lane_id6].y, g1);
                     }
                 }
+                // records are stored in LINE order (the line kernel streams its slice), slots in crossing order
                 const int in_line = wave_grouped_add(w.line_cursor, line, queued, true);     // uniform call site
-                if (queued) w.line_items[(size_t)w.line_offset[line] + in_line] = (int)slot;
+                if (queued) {
+                    uint4* rec = (uint4*)(w.items + ((size_t)w.line_offset[line] + in_line) * EG_ITEM_DW);
+                    rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
+                }
             }
         }
         __syncthreads();
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
-    const int* list = w.line_items + w.line_offset[line];
+    const uint32_t* recs = w.items + (size_t)w.line_offset[line] * EG_ITEM_DW;    // this line's records, contiguous
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b), their dot product with the
     // pixel's own values T = sum value*grad (so diff = T - <reference, gradients>: 4 fma), and the owner index:
     // ds_read_b128 + ds_read_b32 (+1 b32 for inward walks) per visited pixel.
@@ -541,23 +544,18 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
     //  zero, and software-pipelining the list -> record fetch.  The loop is VALU-bound, profiles/r01_*.)
     typedef float v2f __attribute__((ext_vector_type(2)));
-    // Everything about an item is wave-uniform: index and record go through the scalar cache (s_load), and the
-    // next record / next-but-one index are requested before the current item is walked, so their latency
-    // (two dependent loads) hides behind one walk.
+    // Everything about an item is wave-uniform: records go through the scalar cache (s_load), and the next record
+    // is requested before the current item is walked.
     constexpr int STRIDE = EG_LINE_WAVES * EG_LINE_PARTS;
     int it = __builtin_amdgcn_readfirstlane(part * EG_LINE_WAVES + wv);
     if (it >= n_items) return;                                 // this wave has no item (after the barrier above)
-    int item = list[it];
-    int item_next = it + STRIDE < n_items ? list[it + STRIDE] : 0;
-    const uint4* q = (const uint4*)(w.items + (size_t)item * EG_ITEM_DW);
+    const uint4* q = (const uint4*)(recs + (size_t)it * EG_ITEM_DW);
     uint4 q0v = q[0], q1v = q[1], q2v = q[2];
     for (; it < n_items; it += STRIDE) {
-        const bool has_next = it + STRIDE < n_items;
-        const uint4* qn = (const uint4*)(w.items + (size_t)(has_next ? item_next : item) * EG_ITEM_DW);
+        const uint4* qn = (const uint4*)(recs + (size_t)(it + STRIDE < n_items ? it + STRIDE : it) * EG_ITEM_DW);
         const uint4 n0v = qn[0], n1v = qn[1], n2v = qn[2];
-        const int item_next2 = it + 2 * STRIDE < n_items ? list[it + 2 * STRIDE] : 0;
-        const uint32_t bits = q0v.x;
-        const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)q0v.w;
+        const uint32_t bits = q0v.x & 63u;
+        const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)(q0v.x >> 6), item = (int)q0v.w;
         const bool inward = bits & 1;
         const float d1_cross = __uint_as_float(q1v.x);
         const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
@@ -594,7 +592,6 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
             }
             w.results[item] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
         }
-        item = item_next; item_next = item_next2;
         q0v = n0v; q1v = n1v; q2v = n2v;
     }
 }
@@ -668,7 +665,7 @@ struct EdgeLayout {
     size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
     size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_cross,
         off_lane_partial, off_line_offset, off_vis_block, off_lane_block;
-    size_t off_items;              // items | line_items | results follow, sized by capacity
+    size_t off_items;              // items | results follow, sized by capacity
     size_t fixed_bytes;
 };
 
@@ -701,7 +698,7 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     return L;
 }
 
-constexpr size_t EG_BYTES_PER_ITEM = EG_ITEM_DW * 4 + 4 + 8;
+constexpr size_t EG_BYTES_PER_ITEM = EG_ITEM_DW * 4 + 8;
 constexpr int EG_ITEMS_PER_FACE_DEFAULT = 4;
 
 inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
@@ -712,7 +709,7 @@ template <class FS>
 int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void* ws, size_t ws_bytes, hipStream_t st,
                   int* last_err) {
     const int S = m.S, F = fs.num_faces();
-    if (S > 65535) return 1;                                    // item packing limit (D3M_ERR_INVALID)
+    if (S > 65535 || F > (1 << 26)) return 1;                   // item packing limits (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + 1024) return 2;       // D3M_ERR_WORKSPACE
     char* p = (char*)ws;
@@ -732,9 +729,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     w.vis_block = (int*)(p + L.off_vis_block);
     w.lane_block = (int*)(p + L.off_lane_block);
     w.items = (uint32_t*)(p + L.off_items);
-    const size_t off_list = eg_align(L.off_items + cap * EG_ITEM_DW * 4);
-    const size_t off_res = eg_align(off_list + cap * 4);
-    w.line_items = (int*)(p + off_list);
+    const size_t off_res = eg_align(L.off_items + cap * EG_ITEM_DW * 4);
     w.results = (float2*)(p + off_res);
     w.cap = (int)cap;
 
