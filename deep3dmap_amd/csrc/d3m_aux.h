@@ -486,15 +486,30 @@ __global__ void __launch_bounds__(256) k_photometric_reduce(const float* __restr
     const float* pm = mask ? mask + (size_t)bn * hw : nullptr;
     const float* ps = sigma ? sigma + (size_t)bn * hw : nullptr;
     float num = 0, den = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        float l = fabsf(pa[i] - pb[i]);
+    auto term = [&](float va, float vb, float vm, float vs) {
+        float l = fabsf(va - vb);
         if (ps) {
-            const float sg = ps[i] + 1e-7f;
+            const float sg = vs + 1e-7f;
             l = l * 1.41421356237309515f / sg + logf(sg);
         }
-        const float m = pm ? pm[i] : 1.0f;
-        num += l * m;
-        den += m;
+        num += l * vm;
+        den += vm;
+    };
+    // planes whose size and base addresses allow it are streamed 16 bytes per lane
+    const bool vec = (hw & 3) == 0 && (((uintptr_t)pa | (uintptr_t)pb | (uintptr_t)pm | (uintptr_t)ps) & 15) == 0;
+    if (vec) {
+        const float4 one = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (hw >> 2); i += gridDim.x * 256) {
+            const float4 va = ((const float4*)pa)[i], vb = ((const float4*)pb)[i];
+            const float4 vm = pm ? ((const float4*)pm)[i] : one, vs = ps ? ((const float4*)ps)[i] : one;
+            term(va.x, vb.x, vm.x, vs.x);
+            term(va.y, vb.y, vm.y, vs.y);
+            term(va.z, vb.z, vm.z, vs.z);
+            term(va.w, vb.w, vm.w, vs.w);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
+            term(pa[i], pb[i], pm ? pm[i] : 1.0f, ps ? ps[i] : 1.0f);
     }
     num = block_sum_256(num, s_part);
     den = block_sum_256(den, s_part);
@@ -523,12 +538,25 @@ __global__ void __launch_bounds__(256) k_photometric_finish(const float* __restr
     const float* pm = mask ? mask + (size_t)bn * hw : nullptr;
     const float* ps = sigma ? sigma + (size_t)bn * hw : nullptr;
     float* pg = grad_a + (size_t)plane * hw;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
-        const float d = pa[i] - pb[i];
+    auto grad = [&](float va, float vb, float vm, float vs) {
+        const float d = va - vb;
         float g = d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f);
-        if (ps) g = g * 1.41421356237309515f / (ps[i] + 1e-7f);
-        const float m = pm ? pm[i] : 1.0f;
-        pg[i] = g * m / den;
+        if (ps) g = g * 1.41421356237309515f / (vs + 1e-7f);
+        return g * vm / den;
+    };
+    const bool vec = (hw & 3) == 0 &&
+                     (((uintptr_t)pa | (uintptr_t)pb | (uintptr_t)pm | (uintptr_t)ps | (uintptr_t)pg) & 15) == 0;
+    if (vec) {
+        const float4 one = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (hw >> 2); i += gridDim.x * 256) {
+            const float4 va = ((const float4*)pa)[i], vb = ((const float4*)pb)[i];
+            const float4 vm = pm ? ((const float4*)pm)[i] : one, vs = ps ? ((const float4*)ps)[i] : one;
+            ((float4*)pg)[i] = make_float4(grad(va.x, vb.x, vm.x, vs.x), grad(va.y, vb.y, vm.y, vs.y),
+                                           grad(va.z, vb.z, vm.z, vs.z), grad(va.w, vb.w, vm.w, vs.w));
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256)
+            pg[i] = grad(pa[i], pb[i], pm ? pm[i] : 1.0f, ps ? ps[i] : 1.0f);
     }
 }
 
@@ -537,7 +565,18 @@ __global__ void __launch_bounds__(256) k_sum_squared_error(const float* __restri
                                                           float* __restrict__ partials, float* __restrict__ grad_a, long n) {
     __shared__ float s_part[4];
     float acc = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const bool vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad_a) & 15) == 0;
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 va = ((const float4*)a)[i], vb = ((const float4*)b)[i];
+        const float4 d = make_float4(va.x - vb.x, va.y - vb.y, va.z - vb.z, va.w - vb.w);
+        acc += d.x * d.x;
+        acc += d.y * d.y;
+        acc += d.z * d.z;
+        acc += d.w * d.w;
+        if (grad_a) ((float4*)grad_a)[i] = make_float4(2.0f * d.x, 2.0f * d.y, 2.0f * d.z, 2.0f * d.w);
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float d = a[i] - b[i];
         acc += d * d;
         if (grad_a) grad_a[i] = 2.0f * d;

@@ -144,6 +144,9 @@ __global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __res
 // backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of
 // w * grad_rgb live in LDS, then   grad_textures[view, f, texel] = sum * light   (plain store: within a view
 // at most one of the two copies of a face is front-facing) and  grad_light[face] += sum * texel.
+// Entries of faces that own no pixel are NOT written: with shared textures the per-view buffer is scratch and
+// k_sum_over_views skips them by the visibility flags (no 77 MB zero fill per step on the headline workload);
+// a caller-visible per-view gradient is zero-filled by the host wrapper first.
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float* __restrict__ faces, LitTextures lt,
                                                                     const int32_t* __restrict__ face_index_map,
                                                                     const float* __restrict__ weight_map,
@@ -151,6 +154,8 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
                                                                     const float* __restrict__ grad_rgb_map,
                                                                     float* __restrict__ gtex_view /*[B,F,24] zeroed*/,
                                                                     float* __restrict__ grad_light /*[Bm,F',3] zeroed or NULL*/,
+                                                                    const float* __restrict__ grad_depth_map /*or NULL*/,
+                                                                    float* __restrict__ grad_faces /*[B,F',9], += */,
                                                                     int* __restrict__ flags, int B, int S, float eps) {
     __shared__ float s_acc[24][256];
     const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;   // FM_LANES lanes per face
@@ -165,20 +170,48 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
     int x0, x1, y0, y1;
     if (!pixel_bbox(fc, S, x0, x1, y0, y1)) return;
     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-    if (area > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    const int fo = fn >= lt.F ? fn - lt.F : fn;
+    float* gt = gtex_view + ((size_t)bn * lt.F + fo) * 24;
+    if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
+        flags[gi] = FLAG_LARGE;
+        for (int t = sub; t < 24; t += FM_LANES) gt[t] = 0.0f;
+        return;
+    }
     const int l = threadIdx.x;
 #pragma unroll
     for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
     const size_t base = (size_t)bn * S * S;
+    // the depth gradient (KCU:543-592) rides along when asked for: same pixels, same weights, same depth
+    float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
+    if (grad_depth_map) {
+        float finv[9];
+        face_inverse(fc, S, finv);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int l2 = 0; l2 < 3; l2++) dtmp[k] += -finv[3 * l2 + k] / fc[3 * l2 + 2];     // KCU:582
+        }
+    }
     BoxCursor c(x0, x1, y0, sub);
     for (int i = sub; i < area; i += FM_LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
         if (face_index_map[p] != fn) continue;
         const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
         const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
+        const float depth = depth_map[p];
+        if (grad_depth_map) {
+            const float g = grad_depth_map[p], depth2 = depth * depth;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float z_k = fc[3 * k + 2];
+                dacc[3 * k + 0] += -g * dtmp[0] * weight[k] * depth2 * (float)S / 2.0f;      // KCU:588
+                dacc[3 * k + 1] += -g * dtmp[1] * weight[k] * depth2 * (float)S / 2.0f;
+                dacc[3 * k + 2] += g * weight[k] * depth2 / (z_k * z_k);                    // KCU:575
+            }
+        }
         int fl[3];
         float fr[3];
-        sample_setup(fc, weight, depth_map[p], 2, eps, fl, fr);
+        sample_setup(fc, weight, depth, 2, eps, fl, fr);
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
             float w;
@@ -194,13 +227,20 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (grad_depth_map) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) dacc[k] = quad_sum(dacc[k]);
+        if (sub == 0) {
+            float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+        }
+    }
     if (sub != 0) return;
     const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
     const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
     float gl[3] = {0, 0, 0};
-    const int fo = fn >= lt.F ? fn - lt.F : fn;
     const float* tex = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24;
-    float* gt = gtex_view + ((size_t)bn * lt.F + fo) * 24;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
         const int to = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
@@ -209,7 +249,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
             float g = s_acc[t * 3 + c][l];
 #pragma unroll
             for (int j = 1; j < FM_LANES; j++) g += s_acc[t * 3 + c][l + j];
-            gt[to * 3 + c] += g * li[c];
+            gt[to * 3 + c] = g * li[c];          // plain store: see the kernel comment
             gl[c] += g * tex[to * 3 + c];
         }
     }
@@ -262,12 +302,39 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
     }
 }
 
-// out[j] = sum_b in[b, j]  (shared textures: per-view gradients -> one gradient)
-__global__ void __launch_bounds__(256) k_sum_over_views(const float* __restrict__ in, float* __restrict__ out, long n, int B) {
+// out[j] = sum_b in[b, j]  (shared textures: per-view gradients -> one gradient).  With `flags` ([B, F'] visibility
+// of the front and, at +F, back copies) only the views in which the face owns a pixel are read: the others were
+// never written.
+__global__ void __launch_bounds__(256) k_sum_over_views(const float* __restrict__ in, float* __restrict__ out, long n, int B,
+                                                       const int* __restrict__ flags, int F, int Fp, int per_face) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
+    const int f = (int)(j / per_face);
     float acc = 0;
-    for (int b = 0; b < B; b++) acc += in[(size_t)b * n + j];
+    for (int b = 0; b < B; b++) {
+        if (flags) {
+            const int* fl = flags + (size_t)b * Fp;
+            if (fl[f] == FLAG_HIDDEN && (Fp == F || fl[F + f] == FLAG_HIDDEN)) continue;
+        }
+        acc += in[(size_t)b * n + j];
+    }
+    out[j] = acc;
+}
+
+// The ts == 2 form of the above with flags: one lane per 4 consecutive floats of a face's 24 (six lanes per face),
+// 16-byte loads, the two flag loads shared by four elements.
+__global__ void __launch_bounds__(256) k_sum_over_views_ts2(const float4* __restrict__ in, float4* __restrict__ out, long n4,
+                                                           int B, const int* __restrict__ flags, int F, int Fp) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n4) return;
+    const int f = (int)(j / 6);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int b = 0; b < B; b++) {
+        const int* fl = flags + (size_t)b * Fp;
+        if (fl[f] == FLAG_HIDDEN && (Fp == F || fl[F + f] == FLAG_HIDDEN)) continue;
+        const float4 v = in[(size_t)b * n4 + j];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
     out[j] = acc;
 }
 

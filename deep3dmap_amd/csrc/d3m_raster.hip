@@ -494,9 +494,10 @@ D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int 
 D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
                                          int light_batch, const int32_t* face_index_map, const float* weight_map,
                                          const float* depth_map, const float* grad_rgb_map, float* grad_textures,
-                                         float* grad_light, int batch_size, int num_tri, int fill_back, int image_size,
-                                         int texture_size, float eps, void* workspace, size_t workspace_bytes,
-                                         d3m_stream_t stream) {
+                                         float* grad_light, const float* grad_depth_map, float* grad_faces, int batch_size,
+                                         int num_tri, int fill_back, int image_size, int texture_size, float eps,
+                                         void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
+    if ((grad_depth_map != nullptr) != (grad_faces != nullptr)) return D3M_ERR_INVALID;
     if (!faces || !face_index_map || !weight_map || !depth_map || !grad_rgb_map || !grad_textures || batch_size <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -513,22 +514,43 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     float* gview = textures_batch > 1 ? grad_textures : (float*)workspace;
     int* flags = (int*)((char*)workspace + align_up((size_t)B * view_elems * 4, 256));
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
-    HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
+    // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
+    const bool skip_zero = texture_size == 2 && textures_batch == 1;
+    if (!skip_zero) HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
     if (grad_light) HIP_TRY(zero_async(grad_light, (size_t)light_batch * lt.Fp * 12, st));
     if (texture_size == 2) {
         HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
         LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, faces,
-               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, flags, B, S, eps);
+               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map, grad_faces, flags,
+               B, S, eps);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
+        if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
+            DenseFaces fs{faces, lt.Fp};
+            LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
+                   depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
+                   (const int*)flags);
+        }
     } else {
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps);
+        if (grad_depth_map) {
+            DenseFaces fs{faces, lt.Fp};
+            const int rc2 = run_backward_depth(fs, depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map,
+                                               grad_faces, B, S, flags, false, st);
+            if (rc2) return rc2;
+        }
     }
-    if (textures_batch == 1)
-        LAUNCH("k_sum_over_views", k_sum_over_views, dim3(blocks_for((long)view_elems, 256)), dim3(256), st, (const float*)gview,
-               grad_textures, (long)view_elems, B);
+    if (textures_batch == 1) {
+        if (skip_zero && (((uintptr_t)gview | (uintptr_t)grad_textures) & 15) == 0)
+            LAUNCH("k_sum_over_views", k_sum_over_views_ts2, dim3(blocks_for((long)view_elems / 4, 256)), dim3(256), st,
+                   (const float4*)gview, (float4*)grad_textures, (long)view_elems / 4, B, (const int*)flags, num_tri, lt.Fp);
+        else
+            LAUNCH("k_sum_over_views", k_sum_over_views, dim3(blocks_for((long)view_elems, 256)), dim3(256), st,
+                   (const float*)gview, grad_textures, (long)view_elems, B,
+                   skip_zero ? (const int*)flags : (const int*)nullptr, num_tri, lt.Fp, (int)(ts3 * 3));
+    }
     return check_launch();
 }
 

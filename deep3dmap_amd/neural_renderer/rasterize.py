@@ -276,15 +276,18 @@ class _RasterizeLit(torch.autograd.Function):
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
         grad_textures = grad_vertices = None
+        depth_done = False
         if need_tex or need_vert:
             grad_textures = torch.empty_like(textures)
             grad_light = torch.empty_like(light) if need_vert else None
             ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
+            # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
             _lib.check(L.d3m_backward_textures_lit(
                 _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
                 _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map), _lib.ptr(grad_textures),
-                _lib.ptr(grad_light), B, Ft, int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                "d3m_backward_textures_lit")
+                _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, _lib.ptr(grad_faces) if rd else None, B, Ft,
+                int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "d3m_backward_textures_lit")
+            depth_done = rd
             if need_vert:
                 grad_vertices = torch.zeros_like(vertices)
                 _lib.check(L.d3m_face_light_backward(
@@ -293,7 +296,7 @@ class _RasterizeLit(torch.autograd.Function):
                     int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
             if not need_tex:
                 grad_textures = None
-        if rd:
+        if rd and not depth_done:
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)
         return (grad_faces, grad_vertices, None, grad_textures) + (None,) * 11

@@ -220,13 +220,17 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
 /* Its backward (replaces backward_textures + the adjoint of lighting and of the fill_back cat):
  * grad_textures [Bx,num_tri,ts^3,3] is WRITTEN (summed over views when Bx = 1); grad_light [Bl,F',3] is
  * written when not NULL.  Sampling weights are recomputed from weight_map / depth_map (no 64 B/pixel
- * sampling maps).  Gathered per visible face for ts = 2, per-pixel float atomics otherwise. */
+ * sampling maps).  Gathered per visible face for ts = 2, per-pixel float atomics otherwise.
+ * grad_depth_map [B,S,S] / grad_faces [B,F',3,3] (both or neither): when given, the depth gradient of
+ * backward_depth_map (KCU:543-592) is ADDED to grad_faces in the same pass over the faces' pixels, i.e. this one
+ * call then stands for backward_textures + backward_depth_map of rasterize.py:146-151. */
 size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size);
 int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
                               int light_batch, const int32_t* face_index_map, const float* weight_map,
                               const float* depth_map, const float* grad_rgb_map, float* grad_textures, float* grad_light,
-                              int batch_size, int num_tri, int fill_back, int image_size, int texture_size, float eps,
-                              void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+                              const float* grad_depth_map, float* grad_faces, int batch_size, int num_tri, int fill_back,
+                              int image_size, int texture_size, float eps, void* workspace, size_t workspace_bytes,
+                              d3m_stream_t stream);
 
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.
