@@ -43,17 +43,21 @@ constexpr int EG_LINE_PARTS = D3M_EG_LINE_PARTS;   // workgroups per line (items
 constexpr int EG_LINE_WAVES = D3M_EG_LINE_WAVES;   // waves per workgroup: parts x waves walk one line's items concurrently
 constexpr int EG_ITEM_DW = 12;     // dwords per item
 
-// Maps as one scan axis sees them: element (line d0, position d1) lives at b*S*S + d0*S + d1.
+// What a walk reads per pixel, as one scan axis sees it: element (line d0, position d1) lives at b*S*S + d0*S + d1.
+// k_pack_maps builds both orientations in one pass over the maps:
+//   grad[i] = (grad_alpha, grad_r, grad_g, grad_b)              (0 for a disabled output)
+//   dot[i]  = (sum value*grad of the pixel itself, owner face index bits)
+// so that  diff_grad = dot.x - <reference values, grad>  (KCU:385-396 / :473-479 regrouped: 4 fma).
 struct AxisMaps {
-    const int32_t* fi;
-    const float* alpha;
-    const float* galpha;
-    const float* rgb;
-    const float* grgb;
+    const float4* grad;
+    const float2* dot;
+    __device__ __forceinline__ int owner(size_t i) const { return __float_as_int(dot[i].y); }
 };
 
 struct EdgeGradArgs {
-    AxisMaps ax[2];   // [0]: axis 0 = column walks (transposed maps); [1]: axis 1 = row walks (original maps)
+    AxisMaps ax[2];   // [0]: axis 0 = column walks (transposed records); [1]: axis 1 = row walks
+    const float* alpha_map;   // original [B,S,S] / [B,S,S,3] maps: reference values of a segment (one pixel each)
+    const float* rgb_map;
     int S, use_rgb, use_alpha;
     float eps;
     unsigned n_lines;   // B*2*S
@@ -165,17 +169,18 @@ __device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, 
     g1 -= skip ? 0.0f : c1;
 }
 
-__device__ __forceinline__ SegRef load_ref(const AxisMaps& m, bool use_rgb, bool use_alpha, size_t idx) {
+// reference values of a segment: pixel (line d0, position d1) of `axis` in the ORIGINAL maps
+__device__ __forceinline__ SegRef load_ref(const EdgeGradArgs& a, int axis, size_t view_base, int d0, int d1) {
+    const size_t idx = view_base + (axis ? (size_t)d0 * a.S + d1 : (size_t)d1 * a.S + d0);
     SegRef r = {0, 0, 0, 0};
-    if (use_alpha) r.alpha = m.alpha[idx];
-    if (use_rgb) { r.r = m.rgb[3 * idx + 0]; r.g = m.rgb[3 * idx + 1]; r.b = m.rgb[3 * idx + 2]; }
+    if (a.use_alpha) r.alpha = a.alpha_map[idx];
+    if (a.use_rgb) { r.r = a.rgb_map[3 * idx + 0]; r.g = a.rgb_map[3 * idx + 1]; r.b = a.rgb_map[3 * idx + 2]; }
     return r;
 }
 
-// short segment, walked straight from global memory by the owning lane
-__device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, bool use_alpha, size_t line_base,
-                                            const Segment& sg, int fn, float two_over_is, float eps, float& g0,
-                                            float& g1) {
+// short segment, walked straight from global memory by the owning thread: 8 + 16 bytes per pixel
+__device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMaps& m, size_t view_base, size_t line_base,
+                                            const Segment& sg, int fn, float two_over_is, float& g0, float& g1) {
     bool have_ref = false;
     SegRef ref = {0, 0, 0, 0};
     // a multiplier of exactly 0 must not turn an inf/NaN quotient into a NaN: give disabled terms q = 1
@@ -183,16 +188,16 @@ __device__ __forceinline__ void walk_inline(const AxisMaps& m, bool use_rgb, boo
     const float m0 = sg.f0 ? 1.0f : 0.0f, m1 = sg.f1 ? 1.0f : 0.0f;
     for (int d1 = sg.from; d1 <= sg.to; d1++) {
         const size_t idx = line_base + d1;
-        if (sg.inward && m.fi[idx] != fn) continue;
-        if (!have_ref) { ref = load_ref(m, use_rgb, use_alpha, line_base + sg.ref_pos); have_ref = true; }
-        float diff = 0;
-        if (use_alpha) diff += (m.alpha[idx] - ref.alpha) * m.galpha[idx];
-        if (use_rgb) {
-            diff += (m.rgb[3 * idx + 0] - ref.r) * m.grgb[3 * idx + 0];
-            diff += (m.rgb[3 * idx + 1] - ref.g) * m.grgb[3 * idx + 1];
-            diff += (m.rgb[3 * idx + 2] - ref.b) * m.grgb[3 * idx + 2];
-        }
-        visit_pixel(diff, d1, sg.d1_cross, q0, q1, m0, m1, two_over_is, eps, g0, g1);
+        const float2 dt = m.dot[idx];
+        if (sg.inward && __float_as_int(dt.y) != fn) continue;
+        if (!have_ref) { ref = load_ref(a, sg.axis, view_base, sg.d0, sg.ref_pos); have_ref = true; }
+        const float4 g = m.grad[idx];
+        float diff = dt.x;
+        diff = __builtin_fmaf(-ref.alpha, g.x, diff);
+        diff = __builtin_fmaf(-ref.r, g.y, diff);
+        diff = __builtin_fmaf(-ref.g, g.z, diff);
+        diff = __builtin_fmaf(-ref.b, g.w, diff);
+        visit_pixel(diff, d1, sg.d1_cross, q0, q1, m0, m1, two_over_is, a.eps, g0, g1);
     }
 }
 
@@ -372,11 +377,13 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
                 const int l = crossing_lane(t, c);
                 const int d0 = t.d0_from[l] + (c - t.pre[l]);
                 const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
-                const int32_t* fi = a.ax[axis].fi + (size_t)bn * is * is;
+                const AxisMaps& m = a.ax[axis];
+                const size_t vb = (size_t)bn * is * is;
                 Segment so, si;
                 bool has_out, has_in;
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  [&](int e0, int e1) { return fi[(size_t)e0 * is + e1]; }, so, has_out, si, has_in);
+                                  [&](int e0, int e1) { return m.owner(vb + (size_t)e0 * is + e1); }, so, has_out, si,
+                                  has_in);
                 q_out = has_out && segment_queueable(so);
                 q_in = has_in && segment_queueable(si);
                 line = ((size_t)bn * 2 + axis) * is + d0;
@@ -427,7 +434,6 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     __shared__ LaneTable t;
     const int is = a.S;
     const float two_over_is = 2.0f / (float)is;
-    const bool use_rgb = a.use_rgb != 0, use_alpha = a.use_alpha != 0;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         bool on;
@@ -448,9 +454,10 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 axis = t.bn_axis[l] & 1;
                 fn = t.fn[l];
                 base = (size_t)bn * is * is;
-                const int32_t* fi = a.ax[axis].fi + base;
+                const AxisMaps& mo = a.ax[axis];
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  [&](int e0, int e1) { return fi[(size_t)e0 * is + e1]; }, sg[0], has[0], sg[1], has[1]);
+                                  [&](int e0, int e1) { return mo.owner(base + (size_t)e0 * is + e1); }, sg[0], has[0],
+                                  sg[1], has[1]);
                 line = ((size_t)bn * 2 + axis) * is + d0;
             }
             const AxisMaps& m = a.ax[axis];
@@ -465,7 +472,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 uint4 rec0, rec1, rec2;
                 if (queued) {
                     const Segment& q = sg[which];
-                    const SegRef ref = load_ref(m, use_rgb, use_alpha, line_base + q.ref_pos);
+                    const SegRef ref = load_ref(a, axis, base, q.d0, q.ref_pos);
                     const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
                     const float s_t = (float)(q.inward ? -q.dir : q.dir);
                     const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
@@ -480,7 +487,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                                       __float_as_uint(-1.0f / qc1));
                 } else if (active) {
                     float g0 = 0, g1 = 0;
-                    if (has[which]) walk_inline(m, use_rgb, use_alpha, line_base, sg[which], fn, two_over_is, a.eps, g0, g1);
+                    if (has[which]) walk_inline(a, m, base, line_base, sg[which], fn, two_over_is, g0, g1);
                     if (slot < (long)w.cap) {
                         w.results[slot] = make_float2(g0, g1);
                     } else if (g0 != 0 || g1 != 0) {        // no slot left: fold into the lane's overflow sum
@@ -526,19 +533,10 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     float* s_dot = (float*)(s_grd + is);
     int* s_fi = (int*)(s_dot + is);
     for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
-        s_fi[p] = m.fi[line_base + p];
-        float4 g = make_float4(0, 0, 0, 0);
-        float dot = 0;
-        if (USE_ALPHA) { g.x = m.galpha[line_base + p]; dot += m.alpha[line_base + p] * g.x; }
-        if (USE_RGB) {
-            const size_t e = 3 * (line_base + p);
-            g.y = m.grgb[e]; g.z = m.grgb[e + 1]; g.w = m.grgb[e + 2];
-            dot += m.rgb[e] * g.y;
-            dot += m.rgb[e + 1] * g.z;
-            dot += m.rgb[e + 2] * g.w;
-        }
-        s_grd[p] = g;
-        s_dot[p] = dot;
+        const float2 dt = m.dot[line_base + p];
+        s_grd[p] = m.grad[line_base + p];
+        s_dot[p] = dt.x;
+        s_fi[p] = __float_as_int(dt.y);
     }
     __syncthreads();
     // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
@@ -640,28 +638,53 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* _
     }
 }
 
-// [B,S,S,C] -> [B,S(x),S(y),C] through a 32x33 LDS tile; 4-byte elements (f32 or i32 bit patterns).
-__global__ void __launch_bounds__(256) k_transpose_map(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int S,
-                                                      int C) {
-    __shared__ uint32_t tile[32][33];
-    const int bc = blockIdx.z, b = bc / C, c = bc % C;
+// Per-pixel walk records in both orientations, one pass over the maps (replaces five transposes): a 32x32 tile per
+// workgroup; the row-major records are written straight away, the column-major ones through an LDS tile.
+__global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ fi, const float* __restrict__ alpha,
+                                                  const float* __restrict__ galpha, const float* __restrict__ rgb,
+                                                  const float* __restrict__ grgb, float4* __restrict__ grad_row,
+                                                  float2* __restrict__ dot_row, float4* __restrict__ grad_col,
+                                                  float2* __restrict__ dot_col, int S) {
+    __shared__ float4 t_grad[32][33];
+    __shared__ float2 t_dot[32][33];
+    const int b = blockIdx.z;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const size_t plane = (size_t)b * S * S;
     for (int r = ty; r < 32; r += 8) {
         const int y = y0 + r, x = x0 + tx;
-        if (y < S && x < S) tile[r][tx] = src[(plane + (size_t)y * S + x) * C + c];
+        if (y < S && x < S) {
+            const size_t i = plane + (size_t)y * S + x;
+            float4 g = make_float4(0, 0, 0, 0);
+            float dot = 0;
+            if (alpha) { g.x = galpha[i]; dot += alpha[i] * g.x; }
+            if (rgb) {
+                g.y = grgb[3 * i]; g.z = grgb[3 * i + 1]; g.w = grgb[3 * i + 2];
+                dot += rgb[3 * i] * g.y;
+                dot += rgb[3 * i + 1] * g.z;
+                dot += rgb[3 * i + 2] * g.w;
+            }
+            const float2 d = make_float2(dot, __int_as_float(fi[i]));
+            grad_row[i] = g;
+            dot_row[i] = d;
+            t_grad[r][tx] = g;
+            t_dot[r][tx] = d;
+        }
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int x = x0 + r, y = y0 + tx;
-        if (x < S && y < S) dst[(plane + (size_t)x * S + y) * C + c] = tile[tx][r];
+        if (x < S && y < S) {
+            const size_t i = plane + (size_t)x * S + y;
+            grad_col[i] = t_grad[tx][r];
+            dot_col[i] = t_dot[tx][r];
+        }
     }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
 struct EdgeLayout {
-    size_t off_fiT, off_alphaT, off_galphaT, off_rgbT, off_grgbT;
+    size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
     size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
     size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_cross,
         off_lane_partial, off_line_offset, off_vis_block, off_lane_block;
@@ -675,11 +698,10 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     const size_t px = (size_t)B * S * S, nf = (size_t)B * F, nl = (size_t)B * 2 * S;
     EdgeLayout L;
     size_t o = 0;
-    L.off_fiT = o;      o += eg_align(px * 4);
-    L.off_alphaT = o;   o += eg_align(px * 4);
-    L.off_galphaT = o;  o += eg_align(px * 4);
-    L.off_rgbT = o;     o += eg_align(px * 12);
-    L.off_grgbT = o;    o += eg_align(px * 12);
+    L.off_grad_row = o; o += eg_align(px * 16);
+    L.off_dot_row = o;  o += eg_align(px * 8);
+    L.off_grad_col = o; o += eg_align(px * 16);
+    L.off_dot_col = o;  o += eg_align(px * 8);
     L.off_zero = o;
     L.off_visible = o;      o += eg_align(nf * 4);
     L.off_line_count = o;   o += eg_align(nl * 4);
@@ -733,26 +755,19 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     w.results = (float2*)(p + off_res);
     w.cap = (int)cap;
 
-    int32_t* fiT = (int32_t*)(p + L.off_fiT);
-    float* alphaT = (float*)(p + L.off_alphaT);
-    float* galphaT = (float*)(p + L.off_galphaT);
-    float* rgbT = (float*)(p + L.off_rgbT);
-    float* grgbT = (float*)(p + L.off_grgbT);
-    const dim3 grid1((S + 31) / 32, (S + 31) / 32, B), grid3((S + 31) / 32, (S + 31) / 32, B * 3);
+    float4* grad_row = (float4*)(p + L.off_grad_row);
+    float2* dot_row = (float2*)(p + L.off_dot_row);
+    float4* grad_col = (float4*)(p + L.off_grad_col);
+    float2* dot_col = (float2*)(p + L.off_dot_col);
     hipError_t e = zero_async(p + L.off_zero, L.zero_bytes, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
-    LAUNCH("k_transpose_map", k_transpose_map, grid1, dim3(256), st, (const uint32_t*)m.face_index_map, (uint32_t*)fiT, S, 1);
-    if (m.use_alpha) {
-        LAUNCH("k_transpose_map", k_transpose_map, grid1, dim3(256), st, (const uint32_t*)m.alpha_map, (uint32_t*)alphaT, S, 1);
-        LAUNCH("k_transpose_map", k_transpose_map, grid1, dim3(256), st, (const uint32_t*)m.grad_alpha_map, (uint32_t*)galphaT, S, 1);
-    }
-    if (m.use_rgb) {
-        LAUNCH("k_transpose_map", k_transpose_map, grid3, dim3(256), st, (const uint32_t*)m.rgb_map, (uint32_t*)rgbT, S, 3);
-        LAUNCH("k_transpose_map", k_transpose_map, grid3, dim3(256), st, (const uint32_t*)m.grad_rgb_map, (uint32_t*)grgbT, S, 3);
-    }
+    LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
+           m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
+           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, S);
     EdgeGradArgs a;
-    a.ax[0] = AxisMaps{fiT, alphaT, galphaT, rgbT, grgbT};
-    a.ax[1] = AxisMaps{m.face_index_map, m.alpha_map, m.grad_alpha_map, m.rgb_map, m.grad_rgb_map};
+    a.ax[0] = AxisMaps{grad_col, dot_col};
+    a.ax[1] = AxisMaps{grad_row, dot_row};
+    a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
     const long nf = (long)B * F, nl = (long)B * 2 * S;
     // worst-case grids (every face visible); workgroups past n_visible exit on their first load
