@@ -48,6 +48,8 @@ _SIGNATURES = {
     "d3m_face_light_backward": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_forward_texture_sampling_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_textures_lit_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
+                                     _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
                                        _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

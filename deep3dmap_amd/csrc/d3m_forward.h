@@ -240,24 +240,38 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
         }
     }
 
-    // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store
+    // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store.  Pixels
+    // nobody covers get the reference's initial values (rasterize.py:50-58: index -1, weights 0, depth far, inverse
+    // 0), so the caller's pre-fill is not relied upon: every pixel of every map is written here.
     const unsigned long long key = s_z[lane];
     const int xi = px0 + (lane & 7), yi = py0 + (lane >> 3);
-    if (key != ~0ull && xi < S && yi < S) {
-        const int fid = (int)(uint32_t)(key & 0xFFFFFFFFull);
-        float face[9], finv[9], w[3], zp;
-        fs.load(b, fid, face);
-        face_inverse(face, S, finv);
-        weights_depth(face, finv, xi, yi, near, far, w, zp);
+    if (xi < S && yi < S) {
         const size_t i = ((size_t)b * S + yi) * S + xi;
-        out.depth_map[i] = zp;
-        out.face_index_map[i] = fid;
-        out.weight_map[3 * i + 0] = w[0];
-        out.weight_map[3 * i + 1] = w[1];
-        out.weight_map[3 * i + 2] = w[2];
-        if (out.face_inv_map) {
+        if (key != ~0ull) {
+            const int fid = (int)(uint32_t)(key & 0xFFFFFFFFull);
+            float face[9], finv[9], w[3], zp;
+            fs.load(b, fid, face);
+            face_inverse(face, S, finv);
+            weights_depth(face, finv, xi, yi, near, far, w, zp);
+            out.depth_map[i] = zp;
+            out.face_index_map[i] = fid;
+            out.weight_map[3 * i + 0] = w[0];
+            out.weight_map[3 * i + 1] = w[1];
+            out.weight_map[3 * i + 2] = w[2];
+            if (out.face_inv_map) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
+                for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
+            }
+        } else {
+            out.depth_map[i] = far;
+            out.face_index_map[i] = -1;
+            out.weight_map[3 * i + 0] = 0.0f;
+            out.weight_map[3 * i + 1] = 0.0f;
+            out.weight_map[3 * i + 2] = 0.0f;
+            if (out.face_inv_map) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = 0.0f;
+            }
         }
     }
 }

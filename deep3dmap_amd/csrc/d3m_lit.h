@@ -108,23 +108,14 @@ __device__ __forceinline__ void sample_corner(int pn, int ts, const int* fl, con
     isc = tii[0] * ts * ts + tii[1] * ts + tii[2];
 }
 
-// forward: rgb_map[b,y,x,:] = sum_corners w * (texel * light)   (KCU:217-240 on the virtual lit array)
-__global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __restrict__ faces, LitTextures lt,
-                                                             const int32_t* __restrict__ face_index_map,
-                                                             const float* __restrict__ weight_map,
-                                                             const float* __restrict__ depth_map, float* __restrict__ rgb_map,
-                                                             int B, int S, float eps) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * S * S) return;
-    const int fi = face_index_map[i];
-    if (fi < 0) return;
-    const int bn = (int)(i / ((long)S * S));
+// colour of one covered pixel: sum_corners w * (texel * light)   (KCU:217-240 on the virtual lit array)
+__device__ __forceinline__ void sample_pixel_lit(const float* __restrict__ faces, const LitTextures& lt, int B, int bn, int fi,
+                                                 const float* weight, float depth, float eps, float* px) {
     const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
-    const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
     int fl[3];
     float fr[3];
-    sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);
-    float px[3] = {0, 0, 0};
+    sample_setup(face, weight, depth, lt.ts, eps, fl, fr);
+    px[0] = px[1] = px[2] = 0;
 #pragma unroll
     for (int pn = 0; pn < 8; pn++) {
         float w;
@@ -136,9 +127,75 @@ __global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __res
             for (int k = 0; k < 3; k++) px[k] += w * (lt.textures[off + k] * lt.light[3 * (size_t)lrow + k]);
         }
     }
+}
+
+// forward: rgb_map[b,y,x,:] of every covered pixel
+__global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __restrict__ faces, LitTextures lt,
+                                                             const int32_t* __restrict__ face_index_map,
+                                                             const float* __restrict__ weight_map,
+                                                             const float* __restrict__ depth_map, float* __restrict__ rgb_map,
+                                                             int B, int S, float eps) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * S * S) return;
+    const int fi = face_index_map[i];
+    if (fi < 0) return;
+    const int bn = (int)(i / ((long)S * S));
+    const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+    float px[3];
+    sample_pixel_lit(faces, lt, B, bn, fi, weight, depth_map[i], eps, px);
     rgb_map[3 * i + 0] = px[0];
     rgb_map[3 * i + 1] = px[1];
     rgb_map[3 * i + 2] = px[2];
+}
+
+// forward, sampling and the output epilogue of rasterize_rgbad in ONE pass (no rgb_sampled round trip): one lane
+// per OUTPUT pixel; per internal pixel  rgb = covered ? sampled : background  (what rasterize.py:187-195 computes
+// from a zero-initialised rgb_map), alpha = covered; then vertical flip, HWC->CHW and the 2x2 mean when
+// anti-aliasing (rasterize.py:305-326).  rgb_blended / alpha_map are the internal-resolution maps the backward
+// pass reads.
+__global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __restrict__ faces, LitTextures lt,
+                                                            const int32_t* __restrict__ face_index_map,
+                                                            const float* __restrict__ weight_map,
+                                                            const float* __restrict__ depth_map,
+                                                            const float* __restrict__ background, int bg_b,
+                                                            float* __restrict__ rgb_blended, float* __restrict__ alpha_map,
+                                                            float* __restrict__ rgb_out, float* __restrict__ alpha_out,
+                                                            float* __restrict__ depth_out, int B, int S, int aa, float eps) {
+    const int s = aa ? S / 2 : S;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * s * s) return;
+    const int b = (int)(i / ((long)s * s));
+    const int yo = (int)((i / s) % s), xo = (int)(i % s);
+    const int n = aa ? 2 : 1;
+    const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
+    float acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
+    for (int dy = 0; dy < n; dy++) {
+        for (int dx = 0; dx < n; dx++) {
+            const int yi = S - 1 - (yo * n + dy), xi = xo * n + dx;
+            const size_t p = ((size_t)b * S + yi) * S + xi;
+            const int fi = face_index_map[p];
+            const float depth = depth_map[p];
+            float v[3] = {bg[0], bg[1], bg[2]};
+            if (fi >= 0) {
+                const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                sample_pixel_lit(faces, lt, B, b, fi, weight, depth, eps, v);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                rgb_blended[3 * p + k] = v[k];
+                acc_rgb[k] += v[k];
+            }
+            const float mask = fi >= 0 ? 1.0f : 0.0f;
+            if (alpha_map) alpha_map[p] = mask;
+            acc_a += mask;
+            acc_d += depth;
+        }
+    }
+    const float inv = aa ? 0.25f : 1.0f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] = acc_rgb[k] * inv;
+    if (alpha_out) alpha_out[i] = acc_a * inv;
+    if (depth_out) depth_out[i] = acc_d * inv;
 }
 
 // backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of

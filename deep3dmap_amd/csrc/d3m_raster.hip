@@ -485,6 +485,28 @@ D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float*
     return check_launch();
 }
 
+D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
+                                       int light_batch, const int32_t* face_index_map, const float* weight_map,
+                                       const float* depth_map, const float* background, int background_batch,
+                                       float* rgb_blended, float* alpha_map, float* rgb_out, float* alpha_out,
+                                       float* depth_out, int batch_size, int num_tri, int fill_back, int image_size,
+                                       int texture_size, float eps, int anti_aliasing, d3m_stream_t stream) {
+    if (!faces || !face_index_map || !weight_map || !depth_map || !background || !rgb_blended || !rgb_out ||
+        batch_size <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
+    if (background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
+    LitTextures lt;
+    int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
+    if (rc) return rc;
+    const int s = anti_aliasing ? image_size / 2 : image_size;
+    const long n = (long)batch_size * s * s;
+    LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, faces, lt,
+           face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
+           depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps);
+    return check_launch();
+}
+
 D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size) {
     if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0) return 0;
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;

@@ -35,12 +35,14 @@ def _raster_forward(faces, textures, image_size, near, far, eps, background, ret
     B, F = faces.shape[:2]
     S = int(image_size)
     m = {}
-    m["face_index_map"] = torch.full((B, S, S), -1, dtype=torch.int32, device=dev)
-    m["weight_map"] = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
-    m["depth_map"] = torch.full((B, S, S), float(far), dtype=torch.float32, device=dev)
+    # the reference pre-fills these (-1 / 0 / far / 0, rasterize.py:50-58); d3m_forward_face_index_map writes every
+    # pixel, covered or not, so they are only allocated here
+    m["face_index_map"] = torch.empty((B, S, S), dtype=torch.int32, device=dev)
+    m["weight_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+    m["depth_map"] = torch.empty((B, S, S), dtype=torch.float32, device=dev)
     dummy = torch.zeros(1, dtype=torch.float32, device=dev)
     want_finv = return_depth and keep_reference_maps
-    face_inv_map = torch.zeros(B, S, S, 3, 3, dtype=torch.float32, device=dev) if want_finv else dummy
+    face_inv_map = torch.empty(B, S, S, 3, 3, dtype=torch.float32, device=dev) if want_finv else dummy
     faces_inv = torch.zeros_like(faces) if keep_reference_maps else dummy
     ops.forward_face_index_map(faces, m["face_index_map"], m["weight_map"], m["depth_map"], face_inv_map, faces_inv,
                                S, near, far, return_rgb, return_alpha, want_finv)
@@ -243,12 +245,18 @@ class _RasterizeLit(torch.autograd.Function):
         background = _background_tensor(background_color, dev)
         m, _ = _raster_forward(faces, None, S, float(near), float(far), float(eps), background, False, return_alpha,
                                return_depth, False)
-        rgb_sampled = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)
-        _lib.check(L.d3m_forward_texture_sampling_lit(
+        # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
+        s_out = S // 2 if anti_aliasing else S
+        m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+        m["alpha_map"] = torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None
+        rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
+        alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
+        depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
+        _lib.check(L.d3m_render_lit_epilogue(
             _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
-            _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(rgb_sampled), B, Ft, int(bool(fill_back)), S, ts,
-            float(eps), _lib.stream_ptr()), "d3m_forward_texture_sampling_lit")
-        rgb, alpha, depth = _epilogue(m, rgb_sampled, background, B, S, anti_aliasing, True, return_alpha, return_depth, True)
+            _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
+            _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), B, Ft,
+            int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_render_lit_epilogue")
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl)
         ctx.maps = m

@@ -63,10 +63,12 @@ size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_
 
 /* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
  *   faces          [B,F,3,3] f32 in   NDC x,y in [-1,1] (+y up), z = depth
- *   face_index_map [B,S,S]   i32 i/o  index of the nearest covering face, untouched where uncovered
- *   weight_map     [B,S,S,3] f32 i/o  clamped+renormalised barycentrics of that face
- *   depth_map      [B,S,S]   f32 i/o  perspective-correct depth
- *   face_inv_map   [B,S,S,3,3] f32 i/o, written only if return_depth != 0 (may be NULL otherwise)
+ *   face_index_map [B,S,S]   i32 out  index of the nearest covering face, -1 where uncovered
+ *   weight_map     [B,S,S,3] f32 out  clamped+renormalised barycentrics of that face, 0 where uncovered
+ *   depth_map      [B,S,S]   f32 out  perspective-correct depth, `far` where uncovered
+ *   face_inv_map   [B,S,S,3,3] f32 out, written only if return_depth != 0 (may be NULL otherwise), 0 where uncovered
+ *   (the uncovered values are the reference's pre-fill, rasterize.py:50-58: every pixel is written, so a caller
+ *   that pre-fills as the reference does and one that passes uninitialised memory get the same maps)
  *   faces_inv      [B,F,3,3] f32 i/o  scratch the reference fills for front-facing faces (may be NULL)
  * Row 0 of the maps is the BOTTOM of the image (the flip happens in Python, rasterize.py:305-317). */
 int d3m_forward_face_index_map(const float* faces, int32_t* face_index_map, float* weight_map,
@@ -217,6 +219,16 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
                                      int light_batch, const int32_t* face_index_map, const float* weight_map,
                                      const float* depth_map, float* rgb_map, int batch_size, int num_tri,
                                      int fill_back, int image_size, int texture_size, float eps, d3m_stream_t stream);
+/* d3m_forward_texture_sampling_lit followed by d3m_output_epilogue in one pass, without the intermediate
+ * rgb_map: writes the blended internal-resolution rgb_blended [B,S,S,3] (covered ? sampled : background) and
+ * alpha_map [B,S,S] (NULL to skip) that the backward pass reads, and the output images rgb_out [B,3,s,s],
+ * alpha_out / depth_out [B,s,s] (NULL to skip; s = S/2 when anti_aliasing), flipped as rasterize.py:305-326. */
+int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
+                            int light_batch, const int32_t* face_index_map, const float* weight_map,
+                            const float* depth_map, const float* background, int background_batch,
+                            float* rgb_blended, float* alpha_map, float* rgb_out, float* alpha_out, float* depth_out,
+                            int batch_size, int num_tri, int fill_back, int image_size, int texture_size, float eps,
+                            int anti_aliasing, d3m_stream_t stream);
 /* Its backward (replaces backward_textures + the adjoint of lighting and of the fill_back cat):
  * grad_textures [Bx,num_tri,ts^3,3] is WRITTEN (summed over views when Bx = 1); grad_light [Bl,F',3] is
  * written when not NULL.  Sampling weights are recomputed from weight_map / depth_map (no 64 B/pixel
