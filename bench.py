@@ -239,7 +239,8 @@ def main():
         tmax = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
+    if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):
+        assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
     # the replayed graph must reproduce the eager step (same inputs every step: no optimiser in the loop)
     rel = float(torch.linalg.norm(gv - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
     if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):      # (kernel-timing experiments with deliberately wrong results)

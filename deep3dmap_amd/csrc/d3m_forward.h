@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
     __shared__ float s_finv[9][WAVE];
     __shared__ int s_fid[WAVE];
     __shared__ uint32_t s_box[WAVE];
+    __shared__ uint32_t s_zkey[WAVE];
     __shared__ int s_pre[WAVE + 1];
     __shared__ unsigned long long s_z[WAVE];
     __shared__ float s_cx[TILE], s_cy[TILE];
@@ -201,6 +202,13 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
 #pragma unroll
                         for (int k = 0; k < 9; k++) { s_face[k][lane] = face[k]; s_finv[k][lane] = finv[k]; }
                         s_fid[lane] = fid;
+                        // EARLY Z.  The interpolated depth of KCU:136 is a weighted harmonic mean of the three vertex
+                        // depths (weights clamped to [0,1] and renormalised), so for positive depths it cannot fall
+                        // below their minimum by more than a few ulp.  A candidate whose (minimum - margin) already
+                        // lies behind the pixel's current winner can neither win nor tie: skip its arithmetic.  With
+                        // fill_back half of the listed faces are the far side of the mesh.
+                        const float zmin = fminf(face[2], fminf(face[5], face[8]));
+                        s_zkey[lane] = (zmin > 0.0f) ? ordered_bits(zmin * 0.99999f) : 0u;
                         // x | y<<4 | width<<8 | ceil(65536/width)<<12  (exact floor(c/width) for c < 64)
                         s_box[lane] = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 4) | ((uint32_t)bw << 8) |
                                       ((uint32_t)((65536 + bw - 1) / bw) << 12);
@@ -223,6 +231,7 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
                 const int bw = (box >> 8) & 15;
                 const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
                 const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
+                if (s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32)) continue;      // early z (see above)
                 float face[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) face[k] = s_face[k][lo];
