@@ -67,6 +67,42 @@ def silhouette_loss(image, image_ref):
     return _SumSquaredError.apply(image, image_ref.expand_as(image))
 
 
+class _MultiViewFitLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask):
+        t = [f32c(x) for x in (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)]
+        B, C, H, W = t[0].shape
+        if C != 3 or any(tuple(x.shape) != (B, H, W) for x in t[2:]) or tuple(t[1].shape) != (B, 3, H, W):
+            raise ValueError("multiview_fit_loss: rgb [B,3,H,W]; depth, alpha, mask and their targets [B,H,W]")
+        loss = torch.empty((), dtype=torch.float32, device=t[0].device)
+        scratch = torch.empty(4104, dtype=torch.float32, device=t[0].device)
+        _lib.check(_lib.lib().d3m_fit_loss_forward(*[_lib.ptr(x) for x in t], _lib.ptr(loss), _lib.ptr(scratch), B, H, W,
+                                                   _lib.stream_ptr()), "d3m_fit_loss_forward")
+        ctx.save_for_backward(*t, scratch)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        *t, scratch = ctx.saved_tensors
+        B, _, H, W = t[0].shape
+        need = ctx.needs_input_grad
+        g_rgb = torch.empty_like(t[0]) if need[0] else None
+        g_depth = torch.empty_like(t[2]) if need[1] else None
+        g_alpha = torch.empty_like(t[4]) if need[2] else None
+        _lib.check(_lib.lib().d3m_fit_loss_backward(*[_lib.ptr(x) for x in t], _lib.ptr(scratch), _lib.ptr(f32c(g)),
+                                                    _lib.ptr(g_rgb), _lib.ptr(g_depth), _lib.ptr(g_alpha), B, H, W,
+                                                    _lib.stream_ptr()), "d3m_fit_loss_backward")
+        return g_rgb, g_depth, g_alpha, None, None, None, None
+
+
+def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask):
+    """photometric_loss(rgb, rgb_target, mask) + silhouette_loss(alpha, alpha_target) / (H*W) +
+    photometric_loss(depth, depth_target, mask): the multi-view fit objective as ONE autograd node (a reduction and a
+    finish launch forward, one gradient launch backward) instead of three loss nodes and their eager glue.
+    rgb [B,3,H,W]; depth, alpha, mask and the targets [B,H,W]."""
+    return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask)
+
+
 def smooth_loss(pred_map):
     """Second-order smoothness over a (pyramid of) map(s) (utils.py:82-102): sum of mean |dxx|, |dxy|, |dyx|,
     |dyy|, weights 1, 1/2.3, ... per level.  Acts on the network's depth maps, not on rasterizer output; kept

@@ -560,6 +560,90 @@ __global__ void __launch_bounds__(256) k_photometric_finish(const float* __restr
     }
 }
 
+// ---- the multi-view fit objective in three launches ------------------------------------------------------------
+//   loss = photometric(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / pixels + photometric(depth, depth_t, mask)
+// (photometric_loss = utils.py:105-114 without sigma; the silhouette term = examples/example2.py:46), i.e. what
+// core/losses.py composes from d3m_photometric_loss x2 + d3m_sum_squared_error + eager adds: 11 launches and two
+// extra passes over the gradients.  Here: one reduction over all inputs, a one-workgroup finish, and (in the
+// backward pass) one kernel that writes the three gradients already scaled by the incoming gradient.
+// partials: 4 floats per workgroup = sum|rgb-rgb_t|*m, sum|d-d_t|*m, sum m, sum (a-a_t)^2.
+struct FitLossArgs {
+    const float *rgb, *rgb_t, *depth, *depth_t, *alpha, *alpha_t, *mask;
+    int B, hw;
+    float pixels;
+};
+
+__global__ void __launch_bounds__(256) k_fit_loss_reduce(FitLossArgs a, float* __restrict__ partials) {
+    __shared__ float s_part[4];
+    const int b = blockIdx.y, hw = a.hw;
+    const float* pm = a.mask + (size_t)b * hw;
+    float n_rgb = 0, n_d = 0, den = 0, sse = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const float m = pm[i];
+        const size_t p = (size_t)b * hw + i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const size_t q = ((size_t)b * 3 + c) * hw + i;
+            n_rgb += fabsf(a.rgb[q] - a.rgb_t[q]) * m;
+        }
+        n_d += fabsf(a.depth[p] - a.depth_t[p]) * m;
+        den += m;
+        const float d = a.alpha[p] - a.alpha_t[p];
+        sse += d * d;
+    }
+    n_rgb = block_sum_256(n_rgb, s_part);
+    n_d = block_sum_256(n_d, s_part);
+    den = block_sum_256(den, s_part);
+    sse = block_sum_256(sse, s_part);
+    if (threadIdx.x == 0) {
+        float* o = partials + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = n_rgb; o[1] = n_d; o[2] = den; o[3] = sse;
+    }
+}
+
+// totals[0..3] = the four sums; totals[4] = loss
+__global__ void __launch_bounds__(256) k_fit_loss_finish(const float* __restrict__ partials, int n, float pixels,
+                                                        float* __restrict__ totals, float* __restrict__ loss) {
+    __shared__ float s_part[4];
+    float acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += partials[4 * i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = block_sum_256(acc[k], s_part);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) totals[k] = acc[k];
+        const float l = (acc[0] / (3.0f * acc[2]) + acc[3] / pixels) + acc[1] / acc[2];
+        totals[4] = l;
+        *loss = l;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fit_loss_grad(FitLossArgs a, const float* __restrict__ totals,
+                                                      const float* __restrict__ grad_out, float* __restrict__ g_rgb,
+                                                      float* __restrict__ g_depth, float* __restrict__ g_alpha) {
+    const int b = blockIdx.y, hw = a.hw;
+    const float go = grad_out ? *grad_out : 1.0f;
+    const float den = totals[2];
+    const float* pm = a.mask + (size_t)b * hw;
+    auto sgn = [](float d) { return d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f); };
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hw; i += gridDim.x * 256) {
+        const float m = pm[i];
+        const size_t p = (size_t)b * hw + i;
+        if (g_rgb) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const size_t q = ((size_t)b * 3 + c) * hw + i;
+                g_rgb[q] = sgn(a.rgb[q] - a.rgb_t[q]) * m / (3.0f * den) * go;
+            }
+        }
+        if (g_depth) g_depth[p] = sgn(a.depth[p] - a.depth_t[p]) * m / den * go;
+        if (g_alpha) g_alpha[p] = 2.0f * (a.alpha[p] - a.alpha_t[p]) / a.pixels * go;
+    }
+}
+
 // sum((a-b)^2): per-workgroup partials, then one small workgroup adds them (no same-address atomics)
 __global__ void __launch_bounds__(256) k_sum_squared_error(const float* __restrict__ a, const float* __restrict__ b,
                                                           float* __restrict__ partials, float* __restrict__ grad_a, long n) {

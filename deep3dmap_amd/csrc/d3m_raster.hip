@@ -640,6 +640,50 @@ D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss
     return check_launch();
 }
 
+static int fit_loss_grid(int batch_size, long hw, dim3& grid) {
+    if (batch_size <= 0 || hw <= 0 || hw > 0x7FFFFFFF || batch_size > 1024) return D3M_ERR_INVALID;
+    unsigned gx = (unsigned)((hw + 1023) / 1024);
+    const unsigned cap = 1024u / (unsigned)batch_size;            // at most 1024 partial records (4096 floats)
+    if (gx > cap) gx = cap;
+    if (gx == 0) gx = 1;
+    grid = dim3(gx, (unsigned)batch_size);
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_fit_loss_forward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
+                                    const float* alpha, const float* alpha_target, const float* mask, float* loss,
+                                    float* scratch, int batch_size, int height, int width, d3m_stream_t stream) {
+    if (!rgb || !rgb_target || !depth || !depth_target || !alpha || !alpha_target || !mask || !loss || !scratch)
+        return D3M_ERR_INVALID;
+    dim3 grid;
+    const long hw = (long)height * width;
+    int rc = fit_loss_grid(batch_size, hw, grid);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    FitLossArgs a{rgb, rgb_target, depth, depth_target, alpha, alpha_target, mask, batch_size, (int)hw, (float)hw};
+    LAUNCH("k_fit_loss_reduce", k_fit_loss_reduce, grid, dim3(256), st, a, scratch + 8);
+    LAUNCH("k_fit_loss_finish", k_fit_loss_finish, dim3(1), dim3(256), st, (const float*)(scratch + 8),
+           (int)(grid.x * grid.y), (float)hw, scratch, loss);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float* depth,
+                                     const float* depth_target, const float* alpha, const float* alpha_target,
+                                     const float* mask, const float* scratch, const float* grad_loss, float* grad_rgb,
+                                     float* grad_depth, float* grad_alpha, int batch_size, int height, int width,
+                                     d3m_stream_t stream) {
+    if (!rgb || !rgb_target || !depth || !depth_target || !alpha || !alpha_target || !mask || !scratch)
+        return D3M_ERR_INVALID;
+    dim3 grid;
+    const long hw = (long)height * width;
+    int rc = fit_loss_grid(batch_size, hw, grid);
+    if (rc) return rc;
+    FitLossArgs a{rgb, rgb_target, depth, depth_target, alpha, alpha_target, mask, batch_size, (int)hw, (float)hw};
+    LAUNCH("k_fit_loss_grad", k_fit_loss_grad, grid, dim3(256), (hipStream_t)stream, a, scratch, grad_loss, grad_rgb, grad_depth,
+           grad_alpha);
+    return check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // D. texture assets
 // ---------------------------------------------------------------------------------------------------

@@ -278,6 +278,20 @@ int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, 
 int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, float* scratch, long n,
                           d3m_stream_t stream);
 
+/* The multi-view fit objective in one reduction + one finish launch, and its gradients in one
+ * more:  loss = photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (H*W)
+ *             + photometric_loss(depth, depth_target, mask)
+ * with rgb [B,3,H,W], depth / alpha / mask [B,H,W].  Same value and gradients as composing the three operators
+ * above.  scratch: 4104 floats, written by forward and read by backward (it keeps the reduction totals).
+ * grad_loss: device scalar (NULL = 1).  Any of the grad_* outputs may be NULL. */
+int d3m_fit_loss_forward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
+                         const float* alpha, const float* alpha_target, const float* mask, float* loss, float* scratch,
+                         int batch_size, int height, int width, d3m_stream_t stream);
+int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
+                          const float* alpha, const float* alpha_target, const float* mask, const float* scratch,
+                          const float* grad_loss, float* grad_rgb, float* grad_depth, float* grad_alpha, int batch_size,
+                          int height, int width, d3m_stream_t stream);
+
 /* ---- texture assets ----------------------------------------------------------------------------------------- */
 /* Replaces load_textures_cuda (NR/cuda/load_textures_cuda.cpp:6-37, kernel load_textures_cuda_kernel.cu:23-114):
  * fills textures [F, ts, ts, ts, 3] of every face with is_update[f] != 0 by sampling image [H, W, 3] at

@@ -248,6 +248,42 @@ def test_loss_kernels_match_reference_losses(golden):
     assert torch.allclose(ag.grad, 2 * (a - b) * torch.tensor([1., 0, 0], device="cuda").view(1, 3, 1, 1), atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 20, 12), (1, 64, 64)])
+def test_fused_fit_loss_matches_composed_losses_and_oracle(shape):
+    """multiview_fit_loss (3 launches) against photometric + silhouette/P + photometric composed from the loss
+    operators, and against torch autograd of the oracle's restatement of utils.py:105-114; a non-unit upstream
+    gradient exercises the in-kernel scaling."""
+    from deep3dmap_amd.core import multiview_fit_loss, photometric_loss, silhouette_loss
+    from oracle import nr_oracle as O
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(B * 1000 + H)
+    rgb, rgb_t = torch.rand(B, 3, H, W, generator=gen), torch.rand(B, 3, H, W, generator=gen)
+    depth, depth_t = torch.rand(B, H, W, generator=gen) + 1, torch.rand(B, H, W, generator=gen) + 1
+    alpha = (torch.rand(B, H, W, generator=gen) > 0.4).float()
+    alpha_t = (torch.rand(B, H, W, generator=gen) > 0.5).float()
+    rgb[0, 1, 0, 0] = rgb_t[0, 1, 0, 0]                       # a zero difference: sign() must give 0 there
+
+    def run(fn, dev):
+        xs = [x.to(dev).clone().requires_grad_(True) for x in (rgb, depth, alpha)]
+        ts_ = [x.to(dev) for x in (rgb_t, depth_t, alpha_t)]
+        loss = fn(*xs, *ts_)
+        (loss * 2.5).backward()
+        return loss.detach().cpu(), [x.grad.cpu() for x in xs]
+
+    fused = run(lambda r, d, a, rt, dt, at: multiview_fit_loss(r, d, a, rt, dt, at, at), "cuda")
+    composed = run(lambda r, d, a, rt, dt, at: photometric_loss(r, rt, mask=at[:, None]) + silhouette_loss(a, at) / (H * W) +
+                   photometric_loss(d[:, None], dt[:, None], mask=at[:, None]), "cuda")
+    oracle = run(lambda r, d, a, rt, dt, at: O.photometric_loss(r, rt, mask=at[:, None]) + ((a - at) ** 2).sum() / (H * W) +
+                 O.photometric_loss(d[:, None], dt[:, None], mask=at[:, None]), "cpu")
+    for other in (composed, oracle):
+        assert torch.allclose(fused[0], other[0], rtol=1e-5)
+        for g, go in zip(fused[1], other[1]):
+            assert torch.allclose(g, go, rtol=1e-5, atol=1e-8)
+    with pytest.raises(ValueError):
+        multiview_fit_loss(rgb.cuda()[:, :2], depth.cuda(), alpha.cuda(), rgb_t.cuda()[:, :2], depth_t.cuda(),
+                           alpha_t.cuda(), alpha_t.cuda())
+
+
 @pytest.mark.parametrize("ts", [1, 2, 4])
 @pytest.mark.parametrize("shared", [False, True])
 def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
