@@ -18,6 +18,11 @@ class D3MCamera(ctypes.Structure):
                 ("rot_batch", _I), ("eye_batch", _I), ("K_batch", _I), ("dist_batch", _I)]
 
 
+class D3MVertexTarget(ctypes.Structure):
+    _fields_ = [("grad_vertices", _P), ("tri", _P), ("num_vertices", _I), ("num_tri", _I), ("tri_batch", _I),
+                ("fill_back", _I)]
+
+
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
 
 _SIGNATURES = {
@@ -31,7 +36,7 @@ _SIGNATURES = {
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P]),
+    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P]),
     "d3m_backward_faces_workspace_bytes": (_SZ, [_I, _I]),
     "d3m_backward_textures": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "d3m_backward_depth_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
@@ -51,7 +56,7 @@ _SIGNATURES = {
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
                                      _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
-                                       _P]),
+                                       _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            const float* __restrict__ weight_map,
                                                            const float* __restrict__ grad_depth_map,
                                                            float* __restrict__ grad_faces, int B, int S,
-                                                           const int* __restrict__ only_large) {
+                                                           const int* __restrict__ only_large, VertexTarget vt) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fn = face_index_map[i];
@@ -74,7 +74,6 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
     const float depth = depth_map[i];
     const float depth2 = depth * depth;
     const float g = grad_depth_map[i];
-    float* grad_face = grad_faces + ((size_t)bn * F + fn) * 9;
     float tmp[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -85,9 +84,10 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
     for (int k = 0; k < 3; k++) {
         const float wk = weight_map[3 * i + k];
         const float z_k = face[3 * k + 2];
-        atomicAdd(&grad_face[3 * k + 0], -g * tmp[0] * wk * depth2 * (float)S / 2.0f);
-        atomicAdd(&grad_face[3 * k + 1], -g * tmp[1] * wk * depth2 * (float)S / 2.0f);
-        atomicAdd(&grad_face[3 * k + 2], g * wk * depth2 / (z_k * z_k));
+        float* gk = vt.gv ? vt.vertex(bn, fn, k) : grad_faces + ((size_t)bn * F + fn) * 9 + 3 * k;
+        atomicAdd(&gk[0], -g * tmp[0] * wk * depth2 * (float)S / 2.0f);
+        atomicAdd(&gk[1], -g * tmp[1] * wk * depth2 * (float)S / 2.0f);
+        atomicAdd(&gk[2], g * wk * depth2 / (z_k * z_k));
     }
 }
 

@@ -137,6 +137,20 @@ struct IndexedFaces {
     }
 };
 
+// Where face gradients go.  gv == NULL: the dense [B,F',3,3] array of the reference operators.  Otherwise they are
+// accumulated (float atomics) straight into the gradient of the vertices the faces were gathered from
+// (vertices_to_faces + fill_back, renderer.py:86): no 36 B/face array to zero, fill and scatter afterwards.
+struct VertexTarget {
+    float* gv;             // [B, V, 3]
+    const int32_t* tri;    // [tri_batch, Ft, 3]
+    int V, Ft, tri_batch;
+    __device__ __forceinline__ float* vertex(int b, int f, int n) const {      // vertex n of (virtual) face f
+        const bool back = f >= Ft;
+        const int32_t* t = tri + ((size_t)(tri_batch > 1 ? b : 0) * Ft + (back ? f - Ft : f)) * 3;
+        return gv + ((size_t)b * V + t[back ? 2 - n : n]) * 3;
+    }
+};
+
 // ---- wave-level primitives -----------------------------------------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = lane_id();

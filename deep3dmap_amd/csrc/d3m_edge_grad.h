@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
 
 // ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces) {
+__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces, VertexTarget vt) {
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
@@ -626,12 +626,24 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* _
                 acc[edge * 2 + (1 - axis)] += r.x;                    // vertex pi[0] = edge, component 1 - axis (KCU:406)
                 acc[((edge + 1) % 3) * 2 + (1 - axis)] += r.y;        // vertex pi[1] = edge + 1            (KCU:411)
             }
-            float* gf = grad_faces + (size_t)w.visible_list[pos] * 9;
+            const long gi = w.visible_list[pos];
+            if (vt.gv) {
+                const int Fp = fs.num_faces();
+                const int b = (int)(gi / Fp), f = (int)(gi % Fp);
 #pragma unroll
-            for (int v = 0; v < 3; v++) {
-                gf[3 * v + 0] = acc[2 * v + 0];
-                gf[3 * v + 1] = acc[2 * v + 1];
-                gf[3 * v + 2] = 0.0f;
+                for (int v = 0; v < 3; v++) {
+                    float* g = vt.vertex(b, f, v);
+                    atomicAdd(&g[0], acc[2 * v + 0]);
+                    atomicAdd(&g[1], acc[2 * v + 1]);
+                }
+            } else {
+                float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+                for (int v = 0; v < 3; v++) {
+                    gf[3 * v + 0] = acc[2 * v + 0];
+                    gf[3 * v + 1] = acc[2 * v + 1];
+                    gf[3 * v + 2] = 0.0f;
+                }
             }
         }
         __syncthreads();
@@ -728,8 +740,8 @@ inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
 }
 
 template <class FS>
-int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void* ws, size_t ws_bytes, hipStream_t st,
-                  int* last_err) {
+int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, int B, float eps, void* ws, size_t ws_bytes,
+                  hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26)) return 1;                   // item packing limits (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
@@ -803,7 +815,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, int B, float eps, void*
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
 #undef D3M_LINES
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, grad_faces);
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, grad_faces, vt);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

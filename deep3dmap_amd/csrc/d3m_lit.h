@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
                                                                     float* __restrict__ grad_light /*[Bm,F',3] zeroed or NULL*/,
                                                                     const float* __restrict__ grad_depth_map /*or NULL*/,
                                                                     float* __restrict__ grad_faces /*[B,F',9], += */,
+                                                                    VertexTarget vt /* instead of grad_faces */,
                                                                     int* __restrict__ flags, int B, int S, float eps) {
     __shared__ float s_acc[24][256];
     const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;   // FM_LANES lanes per face
@@ -288,9 +289,18 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
 #pragma unroll
         for (int k = 0; k < 9; k++) dacc[k] = quad_sum(dacc[k]);
         if (sub == 0) {
-            float* gf = grad_faces + (size_t)gi * 9;
+            if (vt.gv) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+                for (int n = 0; n < 3; n++) {
+                    float* g = vt.vertex(bn, fn, n);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) atomicAdd(&g[k], dacc[3 * n + k]);
+                }
+            } else {
+                float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+            }
         }
     }
     if (sub != 0) return;

@@ -163,6 +163,15 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     return check_launch();
 }
 
+static int to_vertex_target(const d3m_vertex_target* h, int num_faces, VertexTarget& vt) {
+    vt = VertexTarget{nullptr, nullptr, 0, 0, 1};
+    if (!h) return D3M_OK;
+    if (!h->grad_vertices || !h->tri || h->num_vertices <= 0 || h->num_tri <= 0) return D3M_ERR_INVALID;
+    if ((h->fill_back ? 2 : 1) * h->num_tri != num_faces) return D3M_ERR_INVALID;
+    vt = VertexTarget{h->grad_vertices, h->tri, h->num_vertices, h->num_tri, h->tri_batch};
+    return D3M_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // A. the five operators
 // ---------------------------------------------------------------------------------------------------
@@ -203,16 +212,19 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                                       float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                                       int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                                      d3m_stream_t stream) {
-    if (!faces || !face_index_map || !grad_faces || batch_size <= 0 || num_faces <= 0 || image_size <= 0)
+                                      const d3m_vertex_target* vertex_target, d3m_stream_t stream) {
+    if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
+        image_size <= 0)
         return D3M_ERR_INVALID;
+    VertexTarget vt;
+    if (int rc = to_vertex_target(vertex_target, num_faces, vt)) return rc;
     if (return_rgb && (!rgb_map || !grad_rgb_map)) return D3M_ERR_INVALID;
     if (return_alpha && (!alpha_map || !grad_alpha_map)) return D3M_ERR_INVALID;
     if (!return_rgb && !return_alpha) return D3M_OK;    // rasterize.py:200-201
     DenseFaces fs{faces, num_faces};
     PixelMaps m{face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb != 0,
                 return_alpha != 0};
-    return run_edge_grad(fs, m, grad_faces, batch_size, eps, workspace, workspace_bytes, (hipStream_t)stream,
+    return run_edge_grad(fs, m, grad_faces, vt, batch_size, eps, workspace, workspace_bytes, (hipStream_t)stream,
                          &g_last_hip_error);
 }
 
@@ -259,7 +271,8 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
                face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S);
     }
     LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(blocks_for(n, 256)), dim3(256), st, fs, depth_map,
-           face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags);
+           face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags,
+           VertexTarget{nullptr, nullptr, 0, 0, 1});
     return check_launch();
 }
 
@@ -518,8 +531,11 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
                                          const float* depth_map, const float* grad_rgb_map, float* grad_textures,
                                          float* grad_light, const float* grad_depth_map, float* grad_faces, int batch_size,
                                          int num_tri, int fill_back, int image_size, int texture_size, float eps,
-                                         void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
-    if ((grad_depth_map != nullptr) != (grad_faces != nullptr)) return D3M_ERR_INVALID;
+                                         void* workspace, size_t workspace_bytes, const d3m_vertex_target* vertex_target,
+                                         d3m_stream_t stream) {
+    if ((grad_depth_map != nullptr) != (grad_faces != nullptr || vertex_target != nullptr)) return D3M_ERR_INVALID;
+    VertexTarget vt;
+    if (int rcv = to_vertex_target(vertex_target, (fill_back ? 2 : 1) * num_tri, vt)) return rcv;
     if (!faces || !face_index_map || !weight_map || !depth_map || !grad_rgb_map || !grad_textures || batch_size <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -544,24 +560,30 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
         LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, faces,
-               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map, grad_faces, flags,
-               B, S, eps);
+               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map, grad_faces, vt,
+               flags, B, S, eps);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
             DenseFaces fs{faces, lt.Fp};
             LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
                    depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
-                   (const int*)flags);
+                   (const int*)flags, vt);
         }
     } else {
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps);
         if (grad_depth_map) {
             DenseFaces fs{faces, lt.Fp};
-            const int rc2 = run_backward_depth(fs, depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map,
-                                               grad_faces, B, S, flags, false, st);
-            if (rc2) return rc2;
+            if (vt.gv) {
+                LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
+                       depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S,
+                       (const int*)nullptr, vt);
+            } else {
+                const int rc2 = run_backward_depth(fs, depth_map, face_index_map, (const float*)nullptr, weight_map,
+                                                   grad_depth_map, grad_faces, B, S, flags, false, st);
+                if (rc2) return rc2;
+            }
         }
     }
     if (textures_batch == 1) {

@@ -1,6 +1,8 @@
 """Differentiable rasterization: RasterizeFunction / Rasterize / rasterize_rgbad and friends, same
 signatures and semantics as pnpmodules/neural_renderer/neural_renderer/rasterize.py (NR/rasterize.py),
 running on the HIP operators of libd3m_raster.so.  CUDA(=HIP)-device tensors only, like the reference."""
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -219,21 +221,29 @@ def _vec3_host(x):
 
 class _RasterizeLit(torch.autograd.Function):
     """render / render_rgb in one autograd node with fill_back and lighting applied on the fly
-    (d3m_face_light + d3m_forward_texture_sampling_lit / d3m_backward_textures_lit): the per-view
+    (d3m_face_light + d3m_render_lit_epilogue / d3m_backward_textures_lit): the per-view
     cat(textures, permuted) * light array of NR/renderer.py:155-167 is never materialised and textures /
-    mesh may be shared by all views (batch 1)."""
+    mesh may be shared by all views (batch 1).  The node starts from the SCREEN-space vertices: the face gather
+    (vertices_to_faces + fill_back) happens inside, and backward accumulates the face gradients straight into the
+    gradient of those vertices (d3m_vertex_target) instead of filling a [B,F',3,3] array for a scatter pass."""
 
     @staticmethod
-    def forward(ctx, faces, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near, far, eps,
-                background_color, return_rgb, return_alpha, return_depth):
+    def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
+                far, eps, background_color, return_rgb, return_alpha, return_depth):
         L = _lib.lib()
-        faces, vertices, textures = f32c(faces), f32c(vertices), f32c(textures)
+        sv, vertices, textures = f32c(screen_vertices), f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
-        dev = faces.device
-        B, Fp = faces.shape[:2]
+        dev = sv.device
+        B = sv.shape[0]
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
-        if textures.shape[0] not in (1, B) or textures.shape[1] != Ft or Fp != (2 * Ft if fill_back else Ft):
+        Fp = 2 * Ft if fill_back else Ft
+        if sv.shape[1] != V or tri.shape[0] not in (1, B):
+            raise ValueError("screen_vertices must be [B, V, 3] and faces [1 or B, F, 3]")
+        if textures.shape[0] not in (1, B) or textures.shape[1] != Ft:
             raise ValueError("textures must be [1 or B, num_faces, ts, ts, ts, 3] for the given faces")
+        faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
+        _lib.check(L.d3m_gather_faces(_lib.ptr(sv), _lib.ptr(tri), tri.shape[0], _lib.ptr(faces), B, V, Ft,
+                                      int(bool(fill_back)), _lib.stream_ptr()), "d3m_gather_faces")
         S = int(image_size) * 2 if anti_aliasing else int(image_size)
         ia, idr, ca, cd, direction = light_cfg
         cca, ccd, cdir = _vec3_host(ca), _vec3_host(cd), _vec3_host(direction)
@@ -272,6 +282,8 @@ class _RasterizeLit(torch.autograd.Function):
         m = ctx.maps
         dev, B = faces.device, faces.shape[0]
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
+        grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
+        target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
         g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
         g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
         g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
@@ -279,8 +291,9 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
             _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
             "d3m_output_epilogue_backward")
-        # K4 (overwrite) -> textures (separate buffers) -> K6 (add), as NR/rasterize.py:141-151
-        grad_faces, _ = _raster_backward(faces, None, m, S, eps, g_rgb_map, g_alpha_map, None, True, ra, False, False)
+        # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv
+        ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
+                               g_alpha_map, None, S, eps, True, ra, vertex_target=target)
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
         grad_textures = grad_vertices = None
@@ -293,8 +306,9 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.check(L.d3m_backward_textures_lit(
                 _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
                 _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map), _lib.ptr(grad_textures),
-                _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, _lib.ptr(grad_faces) if rd else None, B, Ft,
-                int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "d3m_backward_textures_lit")
+                _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft, int(fill_back), S, ts, eps,
+                _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.stream_ptr()),
+                "d3m_backward_textures_lit")
             depth_done = rd
             if need_vert:
                 grad_vertices = torch.zeros_like(vertices)
@@ -304,19 +318,23 @@ class _RasterizeLit(torch.autograd.Function):
                     int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
             if not need_tex:
                 grad_textures = None
-        if rd and not depth_done:
+        if rd and not depth_done:           # textures and lighting need no gradient: the depth term on its own
+            grad_faces = torch.zeros_like(faces)
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)
-        return (grad_faces, grad_vertices, None, grad_textures) + (None,) * 11
+            _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
+                                                Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 11
 
 
-def rasterize_lit(faces, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
+def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
                   anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
                   background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True):
-    """rgb (+alpha, depth) images of screen-space `faces` [B,F',3,3] textured with the ORIGINAL `textures`
-    [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face light (computed from world-space `vertices` / `tri`)
-    are applied on the fly.  Same outputs as lighting() + rasterize_rgbad() on the materialised arrays."""
-    rgb, alpha, depth = _RasterizeLit.apply(faces, vertices, tri, textures, light_cfg, fill_back, image_size,
+    """rgb (+alpha, depth) images of the mesh (`screen_vertices` [B,V,3] after the camera transform, triangles
+    `tri` [1|B,F,3]) textured with the ORIGINAL `textures` [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face
+    light (computed from world-space `vertices`) are applied on the fly.  Same outputs as vertices_to_faces() +
+    lighting() + rasterize_rgbad() on the materialised arrays."""
+    rgb, alpha, depth = _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size,
                                             anti_aliasing, near, far, eps, background_color, True, return_alpha,
                                             return_depth)
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}

@@ -3,6 +3,8 @@
 same argument order, same ownership rule (caller allocates and pre-fills, callee mutates in place and
 returns the same tensors), same errors (non-CUDA / non-contiguous -> RuntimeError).  Each call is one
 entry point of libd3m_raster.so; kernels run on torch's current stream."""
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -56,7 +58,9 @@ def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_
 
 
 def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
-                       image_size, eps, return_rgb, return_alpha):
+                       image_size, eps, return_rgb, return_alpha, vertex_target=None):
+    """`vertex_target` (a _lib.D3MVertexTarget, not part of the reference signature) sends the face gradients
+    straight into the gradient of the vertices the faces were gathered from; grad_faces may then be None."""
     _lib.require_device(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
                         names=["faces", "face_index_map", "rgb_map", "alpha_map", "grad_rgb_map", "grad_alpha_map",
                                "grad_faces"])
@@ -67,7 +71,8 @@ def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, 
         _lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(rgb_map if return_rgb else None),
         _lib.ptr(alpha_map if return_alpha else None), _lib.ptr(grad_rgb_map if return_rgb else None),
         _lib.ptr(grad_alpha_map if return_alpha else None), _lib.ptr(grad_faces), B, F, int(image_size), float(eps),
-        int(bool(return_rgb)), int(bool(return_alpha)), _lib.ptr(ws), ws.numel(), _lib.stream_ptr())
+        int(bool(return_rgb)), int(bool(return_alpha)), _lib.ptr(ws), ws.numel(),
+        ctypes.byref(vertex_target) if vertex_target is not None else None, _lib.stream_ptr())
     _lib.check(rc, "backward_pixel_map")
     return grad_faces
 

@@ -123,21 +123,23 @@ class Renderer(nn.Module):
                 self.light_color_directional, self.light_direction)
 
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         if self.lighting_on_the_fly:
-            return rasterize_lit(f, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
+            sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+            return rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                  self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
                                  False, False)['rgb']
+        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
                          self.rasterizer_eps, self.background_color)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         if self.lighting_on_the_fly:
-            out = rasterize_lit(f, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
+            sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+            out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color)
         else:
+            f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
             textures = self._lit_textures(vertices, faces, textures)
             out = rasterize_rgbad(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
                                   self.rasterizer_eps, self.background_color)

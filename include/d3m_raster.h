@@ -93,11 +93,20 @@ int d3m_forward_texture_sampling(const float* faces, const float* textures, cons
  * culled faces untouched, which is then identical.  rgb_map/grad_rgb_map may be NULL when return_rgb == 0, alpha
  * likewise.  workspace: d3m_backward_pixel_map_workspace_bytes() bytes of scratch (no init needed). */
 size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size);
+/* Optional destination of face gradients (an ADDITION to the reference's interface; NULL = the dense grad_faces):
+ * when `faces` was gathered from vertices (vertices_to_faces + fill_back, renderer.py:86 / vertices_to_faces.py),
+ * the gradient of each face corner is accumulated straight into grad_vertices [B,num_vertices,3] (+=, float
+ * atomics) - the composition with the adjoint of that gather - and grad_faces may be NULL. */
+typedef struct {
+    float* grad_vertices;
+    const int32_t* tri;     /* [tri_batch, num_tri, 3]; num_faces = (fill_back ? 2 : 1) * num_tri */
+    int num_vertices, num_tri, tri_batch, fill_back;
+} d3m_vertex_target;
 int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                            float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                            int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                           d3m_stream_t stream);
+                           const d3m_vertex_target* vertex_target, d3m_stream_t stream);
 
 /* Scratch for the two entry points below: one int per face.  With it the sums are GATHERED per visible
  * face (no atomics; faces with a very large bounding box still use the per-pixel atomic kernel);
@@ -235,14 +244,15 @@ int d3m_render_lit_epilogue(const float* faces, const float* textures, int textu
  * sampling maps).  Gathered per visible face for ts = 2, per-pixel float atomics otherwise.
  * grad_depth_map [B,S,S] / grad_faces [B,F',3,3] (both or neither): when given, the depth gradient of
  * backward_depth_map (KCU:543-592) is ADDED to grad_faces in the same pass over the faces' pixels, i.e. this one
- * call then stands for backward_textures + backward_depth_map of rasterize.py:146-151. */
+ * call then stands for backward_textures + backward_depth_map of rasterize.py:146-151.  With vertex_target the
+ * depth gradient goes to grad_vertices instead and grad_faces may be NULL. */
 size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size);
 int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
                               int light_batch, const int32_t* face_index_map, const float* weight_map,
                               const float* depth_map, const float* grad_rgb_map, float* grad_textures, float* grad_light,
                               const float* grad_depth_map, float* grad_faces, int batch_size, int num_tri, int fill_back,
                               int image_size, int texture_size, float eps, void* workspace, size_t workspace_bytes,
-                              d3m_stream_t stream);
+                              const d3m_vertex_target* vertex_target, d3m_stream_t stream);
 
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.
