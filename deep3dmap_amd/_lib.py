@@ -36,7 +36,9 @@ _SIGNATURES = {
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P]),
+    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P]),
+    "d3m_visibility_bytes": (_SZ, [_I, _I]),
+    "d3m_visibility": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),
     "d3m_backward_faces_workspace_bytes": (_SZ, [_I, _I]),
     "d3m_backward_textures": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "d3m_backward_depth_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
@@ -56,7 +58,7 @@ _SIGNATURES = {
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
                                      _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
-                                       _P, _P]),
+                                       _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

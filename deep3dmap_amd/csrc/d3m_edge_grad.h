@@ -694,6 +694,46 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
     }
 }
 
+inline size_t eg_align(size_t v) { return (v + 255) / 256 * 256; }
+
+// ---- shared visibility ------------------------------------------------------------------------------------
+// Which faces own a pixel depends only on face_index_map.  One blob (flags | compacted list | chunk scan | count)
+// can be built once per forward result and handed to every backward operator (d3m_visibility in the C ABI).
+struct VisibilityView {
+    int* flags;        // [B*F]  FLAG_HIDDEN / FLAG_VISIBLE (FLAG_LARGE is written later by the gathered passes)
+    int* list;         // [B*F]  ascending indices of the faces with flags != 0
+    int* vis_block;    // [B*F/1024 + 2]
+    int* count;        // [1]
+};
+
+inline size_t visibility_bytes(long nf) {
+    return eg_align((size_t)nf * 4) * 2 + eg_align(((size_t)nf / EG_COMPACT_CHUNK + 2) * 4) + 256;
+}
+
+inline VisibilityView visibility_view(void* blob, long nf) {
+    char* p = (char*)blob;
+    VisibilityView v;
+    v.flags = (int*)p;                        p += eg_align((size_t)nf * 4);
+    v.list = (int*)p;                         p += eg_align((size_t)nf * 4);
+    v.vis_block = (int*)p;                    p += eg_align(((size_t)nf / EG_COMPACT_CHUNK + 2) * 4);
+    v.count = (int*)p;
+    return v;
+}
+
+inline hipError_t run_visibility(const int32_t* face_index_map, const VisibilityView& v, int B, int F, int S, hipStream_t st) {
+    const long nf = (long)B * F;
+    hipError_t e = zero_async(v.flags, eg_align((size_t)nf * 4), st);
+    if (e != hipSuccess) return e;
+    LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st, face_index_map,
+           v.flags, B, F, S);
+    const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
+    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)v.flags, v.vis_block, nf);
+    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, v.vis_block, n_chunks, (const int*)nullptr, 1, v.count);
+    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)v.flags, v.list,
+           (const int*)v.vis_block, nf);
+    return hipGetLastError();
+}
+
 // ---- host side ----------------------------------------------------------------------------------------
 struct EdgeLayout {
     size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
@@ -704,7 +744,6 @@ struct EdgeLayout {
     size_t fixed_bytes;
 };
 
-inline size_t eg_align(size_t v) { return (v + 255) / 256 * 256; }
 
 inline EdgeLayout edge_layout(int B, int F, int S) {
     const size_t px = (size_t)B * S * S, nf = (size_t)B * F, nl = (size_t)B * 2 * S;
@@ -740,8 +779,8 @@ inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
 }
 
 template <class FS>
-int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, int B, float eps, void* ws, size_t ws_bytes,
-                  hipStream_t st, int* last_err) {
+int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis, int B,
+                  float eps, void* ws, size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26)) return 1;                   // item packing limits (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
@@ -771,8 +810,15 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, int B,
     float2* dot_row = (float2*)(p + L.off_dot_row);
     float4* grad_col = (float4*)(p + L.off_grad_col);
     float2* dot_col = (float2*)(p + L.off_dot_col);
-    hipError_t e = zero_async(p + L.off_zero, L.zero_bytes, st);
+    // per-call counters; the visibility flags too unless the caller brought a d3m_visibility
+    hipError_t e = shared_vis ? zero_async(p + L.off_line_count, L.zero_bytes - (L.off_line_count - L.off_zero), st)
+                              : zero_async(p + L.off_zero, L.zero_bytes, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
+    if (shared_vis) {
+        w.visible = shared_vis->flags;
+        w.visible_list = shared_vis->list;
+        w.n_visible = shared_vis->count;
+    }
     LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
            m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
            m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, S);
@@ -787,13 +833,16 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, int B,
     // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device)
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? g6_full : 8192));
-    LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
-           m.face_index_map, w.visible, B, F, S);
-    const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
-    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.vis_block, nf);
-    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.vis_block, n_chunks, (const int*)nullptr, 1, w.n_visible);
-    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.visible_list,
-           (const int*)w.vis_block, nf);
+    if (!shared_vis) {
+        LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
+               m.face_index_map, w.visible, B, F, S);
+        const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
+        LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.vis_block, nf);
+        LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.vis_block, n_chunks, (const int*)nullptr, 1,
+               w.n_visible);
+        LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.visible_list,
+               (const int*)w.vis_block, nf);
+    }
     LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
     LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
            EG_FACES_PER_BLOCK, w.alloc);

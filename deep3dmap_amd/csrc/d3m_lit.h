@@ -204,22 +204,40 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
 // Entries of faces that own no pixel are NOT written: with shared textures the per-view buffer is scratch and
 // k_sum_over_views skips them by the visibility flags (no 77 MB zero fill per step on the headline workload);
 // a caller-visible per-view gradient is zero-filled by the host wrapper first.
-__global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float* __restrict__ faces, LitTextures lt,
-                                                                    const int32_t* __restrict__ face_index_map,
-                                                                    const float* __restrict__ weight_map,
-                                                                    const float* __restrict__ depth_map,
-                                                                    const float* __restrict__ grad_rgb_map,
-                                                                    float* __restrict__ gtex_view /*[B,F,24] zeroed*/,
-                                                                    float* __restrict__ grad_light /*[Bm,F',3] zeroed or NULL*/,
-                                                                    const float* __restrict__ grad_depth_map /*or NULL*/,
-                                                                    float* __restrict__ grad_faces /*[B,F',9], += */,
-                                                                    VertexTarget vt /* instead of grad_faces */,
-                                                                    int* __restrict__ flags, int B, int S, float eps) {
-    __shared__ float s_acc[24][256];
-    const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;   // FM_LANES lanes per face
-    const int sub = threadIdx.x % FM_LANES;
+struct LitFaceArgs {
+    const float* faces;
+    LitTextures lt;
+    const int32_t* face_index_map;
+    const float *weight_map, *depth_map, *grad_rgb_map;
+    float* gtex_view;              // [B,F,24]
+    float* grad_light;             // [Bm,F',3] zeroed, or NULL
+    const float* grad_depth_map;   // or NULL
+    float* grad_faces;             // [B,F',9], += (depth gradient), unless vt.gv
+    VertexTarget vt;
+    int* flags;
+    const int* list;               // compacted visible faces + their count, or NULL: every face is tried
+    const int* n_list;
+    int B, S;
+    float eps;
+};
+
+__device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&s_acc)[24][256], long gi, int sub) {
+    const float* __restrict__ faces = a.faces;
+    const LitTextures& lt = a.lt;
+    const int32_t* __restrict__ face_index_map = a.face_index_map;
+    const float* __restrict__ weight_map = a.weight_map;
+    const float* __restrict__ depth_map = a.depth_map;
+    const float* __restrict__ grad_rgb_map = a.grad_rgb_map;
+    float* __restrict__ gtex_view = a.gtex_view;
+    float* __restrict__ grad_light = a.grad_light;
+    const float* __restrict__ grad_depth_map = a.grad_depth_map;
+    float* __restrict__ grad_faces = a.grad_faces;
+    const VertexTarget& vt = a.vt;
+    int* __restrict__ flags = a.flags;
+    const int S = a.S;
+    const float eps = a.eps;
     const int Fp = lt.Fp;
-    if (gi >= (long)B * Fp || flags[gi] == FLAG_HIDDEN) return;
+    if (flags[gi] == FLAG_HIDDEN) return;
     const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
     const float* face = faces + (size_t)gi * 9;
     float fc[9];
@@ -324,6 +342,23 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(const float
         atomicAdd(&grad_light[3 * (size_t)lrow + 0], gl[0]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 1], gl[1]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 2], gl[2]);
+    }
+}
+
+// FM_LANES lanes per face.  Without a list every face of [B,F'] gets its lanes (hidden ones leave at once: ~95 % of
+// a fill_back mesh, i.e. mostly idle waves); with the compacted list of a d3m_visibility only faces that own a pixel
+// do, on a fixed grid that strides over the list.
+__global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs a) {
+    __shared__ float s_acc[24][256];
+    const int sub = threadIdx.x % FM_LANES, slot = threadIdx.x / FM_LANES;
+    if (a.list) {
+        const int n = *a.n_list;
+        for (long base = (long)blockIdx.x * FM_FACES_PER_BLOCK; base < n; base += (long)gridDim.x * FM_FACES_PER_BLOCK) {
+            if (base + slot < n) lit_face_backward(a, s_acc, a.list[base + slot], sub);
+        }
+    } else {
+        const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + slot;
+        if (gi < (long)a.B * a.lt.Fp) lit_face_backward(a, s_acc, gi, sub);
     }
 }
 

@@ -163,6 +163,20 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     return check_launch();
 }
 
+D3M_EXPORT size_t d3m_visibility_bytes(int batch_size, int num_faces) {
+    if (batch_size <= 0 || num_faces <= 0) return 0;
+    return visibility_bytes((long)batch_size * num_faces);
+}
+
+D3M_EXPORT int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
+                              int num_faces, int image_size, d3m_stream_t stream) {
+    if (!face_index_map || !visibility || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if (visibility_size < d3m_visibility_bytes(batch_size, num_faces)) return D3M_ERR_WORKSPACE;
+    const VisibilityView v = visibility_view(visibility, (long)batch_size * num_faces);
+    HIP_TRY(run_visibility(face_index_map, v, batch_size, num_faces, image_size, (hipStream_t)stream));
+    return check_launch();
+}
+
 static int to_vertex_target(const d3m_vertex_target* h, int num_faces, VertexTarget& vt) {
     vt = VertexTarget{nullptr, nullptr, 0, 0, 1};
     if (!h) return D3M_OK;
@@ -212,7 +226,7 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                                       float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                                       int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                                      const d3m_vertex_target* vertex_target, d3m_stream_t stream) {
+                                      const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream) {
     if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -224,7 +238,10 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
     DenseFaces fs{faces, num_faces};
     PixelMaps m{face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb != 0,
                 return_alpha != 0};
-    return run_edge_grad(fs, m, grad_faces, vt, batch_size, eps, workspace, workspace_bytes, (hipStream_t)stream,
+    VisibilityView vis;
+    if (visibility) vis = visibility_view(visibility, (long)batch_size * num_faces);
+    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, batch_size, eps, workspace, workspace_bytes,
+                         (hipStream_t)stream,
                          &g_last_hip_error);
 }
 
@@ -532,7 +549,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
                                          float* grad_light, const float* grad_depth_map, float* grad_faces, int batch_size,
                                          int num_tri, int fill_back, int image_size, int texture_size, float eps,
                                          void* workspace, size_t workspace_bytes, const d3m_vertex_target* vertex_target,
-                                         d3m_stream_t stream) {
+                                         void* visibility, d3m_stream_t stream) {
     if ((grad_depth_map != nullptr) != (grad_faces != nullptr || vertex_target != nullptr)) return D3M_ERR_INVALID;
     VertexTarget vt;
     if (int rcv = to_vertex_target(vertex_target, (fill_back ? 2 : 1) * num_tri, vt)) return rcv;
@@ -556,12 +573,22 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     const bool skip_zero = texture_size == 2 && textures_batch == 1;
     if (!skip_zero) HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
     if (grad_light) HIP_TRY(zero_async(grad_light, (size_t)light_batch * lt.Fp * 12, st));
+    const int* list = nullptr;
+    const int* n_list = nullptr;
+    if (visibility) {                                  // flags and the compacted list come from d3m_visibility
+        const VisibilityView v = visibility_view(visibility, nf);
+        flags = v.flags; list = v.list; n_list = v.count;
+    }
     if (texture_size == 2) {
-        HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
-        LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
-        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, faces,
-               lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map, grad_faces, vt,
-               flags, B, S, eps);
+        if (!visibility) {
+            HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
+            LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
+        }
+        LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
+                       grad_faces, vt, flags, list, n_list, B, S, eps};
+        const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
+        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list && all_blocks > 4096 ? 4096 : all_blocks),
+               dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE

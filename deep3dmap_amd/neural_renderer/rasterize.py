@@ -291,9 +291,11 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
             _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
             "d3m_output_epilogue_backward")
-        # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv
+        # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
+        # and both passes run over one compacted list of the faces that own a pixel
+        vis = ops.visibility(m["face_index_map"], faces.shape[1])
         ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
-                               g_alpha_map, None, S, eps, True, ra, vertex_target=target)
+                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis)
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
         grad_textures = grad_vertices = None
@@ -307,7 +309,7 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
                 _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map), _lib.ptr(grad_textures),
                 _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft, int(fill_back), S, ts, eps,
-                _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.stream_ptr()),
+                _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis), _lib.stream_ptr()),
                 "d3m_backward_textures_lit")
             depth_done = rd
             if need_vert:

@@ -21,6 +21,17 @@ def _workspace(key, nbytes, device):
     return buf
 
 
+def visibility(face_index_map, num_faces):
+    """The flags + compacted list of the faces that own a pixel (d3m_visibility), shared by the backward operators
+    of one forward result.  Returns the (cached, reused) blob."""
+    L = _lib.lib()
+    B, S = face_index_map.shape[0], face_index_map.shape[1]
+    blob = _workspace("visibility", L.d3m_visibility_bytes(B, num_faces), face_index_map.device)
+    _lib.check(L.d3m_visibility(_lib.ptr(face_index_map), _lib.ptr(blob), blob.numel(), B, num_faces, S,
+                                _lib.stream_ptr()), "d3m_visibility")
+    return blob
+
+
 def _opt(t):
     """The reference passes 1-element dummies for disabled outputs (rasterize.py:46,59-69)."""
     return None if (t is None or t.numel() <= 1) else t
@@ -58,7 +69,7 @@ def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_
 
 
 def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
-                       image_size, eps, return_rgb, return_alpha, vertex_target=None):
+                       image_size, eps, return_rgb, return_alpha, vertex_target=None, visibility=None):
     """`vertex_target` (a _lib.D3MVertexTarget, not part of the reference signature) sends the face gradients
     straight into the gradient of the vertices the faces were gathered from; grad_faces may then be None."""
     _lib.require_device(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
@@ -72,7 +83,7 @@ def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, 
         _lib.ptr(alpha_map if return_alpha else None), _lib.ptr(grad_rgb_map if return_rgb else None),
         _lib.ptr(grad_alpha_map if return_alpha else None), _lib.ptr(grad_faces), B, F, int(image_size), float(eps),
         int(bool(return_rgb)), int(bool(return_alpha)), _lib.ptr(ws), ws.numel(),
-        ctypes.byref(vertex_target) if vertex_target is not None else None, _lib.stream_ptr())
+        ctypes.byref(vertex_target) if vertex_target is not None else None, _lib.ptr(visibility), _lib.stream_ptr())
     _lib.check(rc, "backward_pixel_map")
     return grad_faces
 

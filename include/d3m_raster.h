@@ -106,7 +106,14 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                            float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                            int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                           const d3m_vertex_target* vertex_target, d3m_stream_t stream);
+                           const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream);
+
+/* Which faces own a pixel depends on face_index_map only.  d3m_visibility builds, once per forward result, the
+ * flags and the compacted list of those faces in a caller-owned blob of d3m_visibility_bytes(); backward operators
+ * that are handed the blob (`visibility`, NULL = each builds its own) skip that work and run over the list. */
+size_t d3m_visibility_bytes(int batch_size, int num_faces);
+int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
+                   int num_faces, int image_size, d3m_stream_t stream);
 
 /* Scratch for the two entry points below: one int per face.  With it the sums are GATHERED per visible
  * face (no atomics; faces with a very large bounding box still use the per-pixel atomic kernel);
@@ -252,7 +259,7 @@ int d3m_backward_textures_lit(const float* faces, const float* textures, int tex
                               const float* depth_map, const float* grad_rgb_map, float* grad_textures, float* grad_light,
                               const float* grad_depth_map, float* grad_faces, int batch_size, int num_tri, int fill_back,
                               int image_size, int texture_size, float eps, void* workspace, size_t workspace_bytes,
-                              const d3m_vertex_target* vertex_target, d3m_stream_t stream);
+                              const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream);
 
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.

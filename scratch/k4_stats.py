@@ -26,7 +26,7 @@ def main(n=225, S=512, views=8):
     nbytes = L.d3m_backward_pixel_map_workspace_bytes(B, F, S)
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     gf = torch.zeros_like(faces)
-    _lib.check(L.d3m_backward_pixel_map(_lib.ptr(faces), _lib.ptr(m['face_index_map']), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(grgb), _lib.ptr(galpha), _lib.ptr(gf), B, F, S, 1e-3, 1, 1, _lib.ptr(ws), nbytes, None, _lib.stream_ptr()), 'k4')
+    _lib.check(L.d3m_backward_pixel_map(_lib.ptr(faces), _lib.ptr(m['face_index_map']), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(grgb), _lib.ptr(galpha), _lib.ptr(gf), B, F, S, 1e-3, 1, 1, _lib.ptr(ws), nbytes, None, None, _lib.stream_ptr()), 'k4')
     torch.cuda.synchronize()
     px, nf, nl = B*S*S, B*F, B*2*S
     o = 0
