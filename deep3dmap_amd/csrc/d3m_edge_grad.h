@@ -26,6 +26,7 @@
 // faces that own a pixel is the same thing: every other front-facing face would get zeros.  Per visited pixel the expressions are those of KCU:385-412 / :473-493; the two divisions
 // inside the walk use v_rcp_f32 (1 ulp), far inside the 1e-3 gradient tolerance.
 #pragma once
+#include <type_traits>
 #include "d3m_backward.h"
 #include "d3m_face_major.h"
 #include "d3m_launch.h"
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     //  onto one XCD.  Parts of a line are consecutive workgroups, i.e. spread over the XCDs.)
     const int part = blockIdx.x % EG_LINE_PARTS;
     const size_t line = blockIdx.x / EG_LINE_PARTS;          // (b*2 + axis)*S + d0
-    const int n_items = w.line_cursor[line];                  // items actually queued under this line
+    const int n_items = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);     // items queued under this line
     if (part * EG_LINE_WAVES >= n_items) return;              // nothing for this workgroup (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int d0 = (int)(line % is);
@@ -525,22 +526,20 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
-    const uint32_t* recs = w.items + (size_t)w.line_offset[line] * EG_ITEM_DW;    // this line's records, contiguous
-    // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b), their dot product with the
-    // pixel's own values T = sum value*grad (so diff = T - <reference, gradients>: 4 fma), and the owner index:
-    // ds_read_b128 + ds_read_b32 (+1 b32 for inward walks) per visited pixel.
+    // this line's records, contiguous; a wave-uniform address, so that they are fetched with scalar loads
+    const uint32_t* recs = w.items + (size_t)__builtin_amdgcn_readfirstlane(w.line_offset[line]) * EG_ITEM_DW;
+    // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T, owner) with
+    // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
+    // visited pixel, both conflict-free (16- and 8-byte lane strides).
     float4* s_grd = (float4*)s_line;
-    float* s_dot = (float*)(s_grd + is);
-    int* s_fi = (int*)(s_dot + is);
+    float2* s_df = (float2*)(s_grd + is);
     for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
-        const float2 dt = m.dot[line_base + p];
         s_grd[p] = m.grad[line_base + p];
-        s_dot[p] = dt.x;
-        s_fi[p] = __float_as_int(dt.y);
+        s_df[p] = m.dot[line_base + p];
     }
     __syncthreads();
     // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
-    //  zero, and software-pipelining the list -> record fetch.  The loop is VALU-bound, profiles/r01_*.)
+    //  zero.  The loop is VALU-issue-bound, profiles/r01_*.)
     typedef float v2f __attribute__((ext_vector_type(2)));
     // Everything about an item is wave-uniform: records go through the scalar cache (s_load), and the next record
     // is requested before the current item is walked.
@@ -557,34 +556,46 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const bool inward = bits & 1;
         const float d1_cross = __uint_as_float(q1v.x);
         const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
-        const float nra = -__uint_as_float(q1v.w), nrr = -__uint_as_float(q2v.x), nrg = -__uint_as_float(q2v.y),
-                    nrb = -__uint_as_float(q2v.z);
-        auto diff_at = [&](int d1) {
-            const float4 g = s_grd[d1];
-            float diff = s_dot[d1];
-            if (USE_ALPHA) diff = __builtin_fmaf(nra, g.x, diff);
-            if (USE_RGB) {
-                diff = __builtin_fmaf(nrr, g.y, diff);
-                diff = __builtin_fmaf(nrg, g.z, diff);
-                diff = __builtin_fmaf(nrb, g.w, diff);
-            }
-            if (inward && s_fi[d1] != fn) diff = 0;           // KCU:470: only this face's pixels
-            return !(diff <= 0) ? diff : 0.0f;                // KCU:401/:481 (NaN passes, as in the reference)
+        const v2f nref_ar = {USE_ALPHA ? -__uint_as_float(q1v.w) : 0.0f, USE_RGB ? -__uint_as_float(q2v.x) : 0.0f};
+        const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
+        // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped), clamped at 0 (KCU:401/:481; NaN passes, as in
+        // the reference); inward walks only count the face's own pixels (KCU:470).  Two packed fma + one add.
+        auto dpos_of = [&](const float4 g, const float2 d, bool inw) {
+            v2f p = {d.x, 0.0f};
+            p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
+            p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
+            const float diff = p.x + p.y;
+            const bool keep = !(diff <= 0) && (!inw || __float_as_int(d.y) == fn);
+            return keep ? diff : 0.0f;
         };
+        // 64 pixels per iteration: uniform trip count, one masked tail; t = d1 - d1_cross advances by exact steps
+        const int first = from + lane;
+        const int n_full = (to - from + 1) >> 6;
         v2f acc = {0.0f, 0.0f};
-        for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const float dpos = diff_at(d1);
-            const float t = (float)d1 - d1_cross;
-            const v2f den = u + t;
-            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            const v2f dp = {dpos, dpos};
-            acc = __builtin_elementwise_fma(dp, r, acc);
-        }
+        auto walk = [&](auto inw_tag) {
+            constexpr bool INW = decltype(inw_tag)::value;
+            float t = (float)first - d1_cross;
+            const float4* pg = s_grd + first;
+            const float2* pd = s_df + first;
+            auto visit = [&]() {
+                const float dpos = dpos_of(*pg, *pd, INW);
+                const v2f den = u + t;
+                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
+            };
+            for (int k = 0; k < n_full; k++) {
+                visit();
+                pg += 64; pd += 64; t += 64.0f;
+            }
+            if (first + (n_full << 6) <= to) visit();
+        };
+        if (inward) walk(std::true_type{}); else walk(std::false_type{});
         float s0 = wave_sum(acc.x), s1 = wave_sum(acc.y);
         if (lane == 0) {
             const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
             if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
-                const float dpos = diff_at((bits & 8u) ? from : to);
+                const int d1 = (bits & 8u) ? from : to;
+                const float dpos = dpos_of(s_grd[d1], s_df[d1], inward);
                 if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
                 if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
             }
