@@ -47,9 +47,13 @@ def kernel_bytes(name, V, F, S, ts):
         "k_bin_count": 12 * V + 12 * F,
         "k_bin_fill": 12 * F,
         "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
+        "k_render_lit_epilogue": F * ts ** 3 * 12 + 20 * P + 12 * P + P * (4 + 4 + 12),
+        "k_pack_maps": maps + grads,
         "k_edge_lines": maps + grads,
-        "k_edge_emit": 12 * V + 12 * F + maps + 12 * V,
+        "k_edge_emit": 12 * V + 12 * F + maps + grads,
         "k_edge_count": 12 * V + 12 * F + 4 * P,
+        "k_edge_gather": 12 * F + 12 * V,
+        "k_backward_textures_lit_faces": 12 * V + 12 * F + P * (20 + 12 + 4) + F * ts ** 3 * 12 + 12 * V,
         "k_backward_textures_faces": 12 * V + 12 * F + P * (4 + 12 + 12) + F * ts ** 3 * 12,
         "k_backward_textures": P * (4 + 12) + F * ts ** 3 * 12,
         "k_backward_depth_faces": 12 * V + 12 * F + P * (20 + 4) + 12 * V,
