@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--views-per-gpu", type=int, default=8)
+    ap.add_argument("--views-per-gpu", type=int, default=32,
+                    help="cameras per GPU (weak scaling); 32 = the camera count of BASELINE.json's 100k-triangle config")
     ap.add_argument("--mesh-n", type=int, default=225, help="grid_mesh(n): 225 -> 100,352 triangles")
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)

@@ -34,7 +34,7 @@ def main():
         write_kib = w[k][1] / w[k][0] if k in w and w[k][0] else 0.0
         out[k] = {"launches": f[k][0], "fetch_size_KiB_raw": round(fetch_kib, 1), "write_size_KiB": round(write_kib, 1),
                   "hbm_bytes_per_launch": int((2 * fetch_kib + write_kib) * 1024)}
-    json.dump({"note": "bench.py --steps 3 --warmup 1 --no-graph, 8 views, 100352 tris, 512^2; hbm = 2*FETCH_SIZE + WRITE_SIZE",
+    json.dump({"note": "bench.py --steps 3 --warmup 1 --no-graph, 32 views, 100352 tris, 512^2; hbm = 2*FETCH_SIZE + WRITE_SIZE",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k in sorted(out, key=lambda k: -out[k]["hbm_bytes_per_launch"]):
         print(f"{k:32s} {out[k]['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch")
