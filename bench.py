@@ -166,6 +166,59 @@ def gan2shape_workload(args):
         "kernel_ms_per_step": {k: round(m / 5, 4) for k, (c, m) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])[:8]}}))
 
 
+def mesh_family_workload(args):
+    """the face3d utility rasterizer (mesh_cython) at the size its caller uses (tools/data_gen/prnet.py:
+    a BFM-sized mesh, 52,900 vertices / 104,882 triangles, 256x256): render_colors + get_triangle_buffer +
+    vis_of_vertices per step, data resident on the device.  The CPU figure beside it is the reference's own C++
+    (oracle/_ref/libmesh_ref.so, compiled from its sources in the build container; one thread, as the reference runs
+    it) where that file travelled, the C port otherwise."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import mesh_scenes
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.mesh_cython import render
+    from oracle import mesh_oracle as M
+    torch.cuda.set_device(0)
+    h = w = 256
+    s = mesh_scenes.grid_scene(230, h, w, 21, jitter=0.25)
+    v, t, col = (torch.from_numpy(s[k]).cuda() for k in ("vertices", "triangles", "colors"))
+
+    def step():
+        return render.render_colors(v, t, col, h, w), render.get_triangle_buffer(v, t, h, w), render.vis_of_vertices(v, t, h, w)
+
+    img, tb, vis = step()
+    be = M.default_backend()
+    t0 = time.perf_counter()
+    ref = (M.render_colors(s["vertices"], s["triangles"], s["colors"], h, w, backend=be),
+           M.get_triangle_buffer(s["vertices"], s["triangles"], h, w, backend=be),
+           M.vis_of_vertices(s["vertices"], s["triangles"], h, w, backend=be))
+    cpu_s = time.perf_counter() - t0
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip((img, tb, vis), ref)), "GPU result differs from the oracle"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / args.steps
+    _lib.kernel_timing(True)
+    for _ in range(3):
+        step()
+    ktimes = _lib.collect_kernel_times()
+    _lib.kernel_timing(False)
+    print(json.dumps({
+        "metric": "rendered Mpix/s, face3d mesh_cython family (render_colors + triangle buffer + vertex visibility)",
+        "value": round(3 * h * w / elapsed / 1e6, 2), "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"mesh_cython family on a {s['vertices'].shape[1]}-vertex / {s['triangles'].shape[1]}-triangle "
+                               f"mesh @ {h}x{w}: render_colors + get_triangle_buffer + vis_of_vertices, bit-identical to the oracle"},
+        "kernel_ms_per_step": {k: round(m / 3, 4) for k, (c, m) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])[:8]},
+        "cpu_baseline": {"value": round(3 * h * w / cpu_s / 1e6, 3), "unit": "Mpix/s", "cores": 1,
+                         "kind": "reference" if be == "ref" else "port",
+                         "sample": f"the same three calls once ({cpu_s:.2f} s), single thread"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,12 +231,14 @@ def main():
     ap.add_argument("--texture-size", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
-    ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape"],
+    ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape", "mesh_family"],
                     help="multiview = the headline metric (default); gan2shape = BASELINE config 3 (secondary line)")
     ap.add_argument("--batch", type=int, default=16, help="gan2shape workload: batch size")
     args = ap.parse_args()
     if args.workload == "gan2shape":
         return gan2shape_workload(args)
+    if args.workload == "mesh_family":
+        return mesh_family_workload(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -65,6 +65,17 @@ _SIGNATURES = {
     "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_mesh_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "d3m_mesh_render_colors": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
+    "d3m_mesh_render_texture": (_I, [_P] * 8 + [_I] * 10 + [_P, _SZ, _P]),
+    "d3m_mesh_map_texture": (_I, [_P] * 6 + [_I] * 8 + [_P]),
+    "d3m_mesh_vis_of_vertices": (_I, [_P] * 6 + [_I] * 4 + [_P, _SZ, _P]),
+    "d3m_mesh_get_triangle_buffer": (_I, [_P] * 5 + [_I] * 4 + [_P, _SZ, _P]),
+    "d3m_mesh_get_norm_direction": (_I, [_P, _P, _P, _I, _I, _P, _SZ, _P]),
+    "d3m_mesh_triangle_mean": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "d3m_mesh_triangle_normals": (_I, [_P, _P, _P, _I, _I, _P]),
+    "d3m_mesh_normalize": (_I, [_P, _I, _P]),
+    "d3m_mesh_get_correspondence": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _SZ, _P]),
     "d3m_load_textures": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "d3m_create_texture_image": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
 }

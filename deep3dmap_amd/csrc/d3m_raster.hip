@@ -9,6 +9,7 @@
 #include "d3m_launch.h"
 #include "d3m_aux.h"
 #include "d3m_textures.h"
+#include "d3m_mesh.h"
 #include "d3m_backward.h"
 #include "d3m_device.h"
 #include "d3m_edge_grad.h"
@@ -762,5 +763,206 @@ D3M_EXPORT int d3m_create_texture_image(const float* vertices_all, const float* 
     const long n = (long)image_height * image_width;
     LAUNCH("k_create_texture_image", k_create_texture_image, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream,
            vertices_all, textures, image, n, num_faces, texture_size_in, tso, tile_width, eps);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// E. the face3d utility rasterizer family (f64)
+// ---------------------------------------------------------------------------------------------------
+struct MeshWs {
+    unsigned long long* zkey;     // [h*w]
+    unsigned long long* tmp_key;  // [h*w]
+    int *owner, *head;            // [h*w]
+    int *big_list;                // [ntri]
+    int *entries;                 // [3*ntri]
+    int *next, *count, *cursor, *last_pixel;   // [nver(+1)]
+    int *big_count;
+    size_t bytes;
+};
+
+static MeshWs mesh_ws(void* base, int nver, int ntri, int h, int w) {
+    const size_t px = (size_t)(h > 0 ? h : 0) * (w > 0 ? w : 0), nv = nver > 0 ? nver : 0, nt = ntri > 0 ? ntri : 0;
+    char* p = (char*)base;
+    size_t o = 0;
+    auto take = [&](size_t n) { char* r = p + o; o += align_up(n, 256); return r; };
+    MeshWs m;
+    m.zkey = (unsigned long long*)take(px * 8);
+    m.tmp_key = (unsigned long long*)take(px * 8);
+    m.owner = (int*)take(px * 4);
+    m.head = (int*)take(px * 4);
+    m.big_list = (int*)take(nt * 4);
+    m.entries = (int*)take(nt * 12);
+    m.next = (int*)take(nv * 4);
+    m.count = (int*)take((nv + 2) * 4);
+    m.cursor = (int*)take(nv * 4);
+    m.last_pixel = (int*)take(nv * 4);
+    m.big_count = (int*)take(256);
+    m.bytes = o;
+    return m;
+}
+
+D3M_EXPORT size_t d3m_mesh_workspace_bytes(int nver, int ntri, int h, int w) { return mesh_ws(nullptr, nver, ntri, h, w).bytes; }
+
+// the shared two-pass resolve: zkey / owner of every pixel
+static int mesh_resolve(const MeshTris& m, const double* depth_buffer, const MeshWs& ws, hipStream_t st) {
+    const long px = (long)m.h * m.w;
+    LAUNCH("k_mesh_init", k_mesh_init, dim3(blocks_for(px, 256)), dim3(256), st, depth_buffer, ws.zkey, ws.owner, ws.big_count, px);
+    const dim3 gt(blocks_for(m.ntri, 256)), gb(1024);
+    LAUNCH("k_mesh_depth", k_mesh_tris<0>, gt, dim3(256), st, m, depth_buffer, ws.zkey, ws.owner, ws.big_list, ws.big_count);
+    LAUNCH("k_mesh_depth_big", k_mesh_big_tris<0>, gb, dim3(256), st, m, depth_buffer, ws.zkey, ws.owner,
+           (const int*)ws.big_list, (const int*)ws.big_count);
+    LAUNCH("k_mesh_owner", k_mesh_tris<1>, gt, dim3(256), st, m, depth_buffer, ws.zkey, ws.owner, ws.big_list, ws.big_count);
+    LAUNCH("k_mesh_owner_big", k_mesh_big_tris<1>, gb, dim3(256), st, m, depth_buffer, ws.zkey, ws.owner,
+           (const int*)ws.big_list, (const int*)ws.big_count);
+    return check_launch();
+}
+
+static int mesh_args_ok(const void* a, const void* b, const void* c, const void* d, int nver, int ntri, int h, int w,
+                        const void* ws, size_t ws_bytes) {
+    if (!a || !b || !c || !d || nver <= 0 || ntri <= 0 || h <= 0 || w <= 0) return D3M_ERR_INVALID;
+    if ((long)h * w > 0x7FFFFFF0L) return D3M_ERR_INVALID;
+    if (!ws || ws_bytes < d3m_mesh_workspace_bytes(nver, ntri, h, w)) return D3M_ERR_WORKSPACE;
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_mesh_render_colors(double* image, const double* vertices, const int32_t* triangles,
+                                      const double* tri_depth, const double* tri_tex, double* depth_buffer, int nver,
+                                      int ntri, int h, int w, int c, void* workspace, size_t workspace_bytes,
+                                      d3m_stream_t stream) {
+    if (int rc = mesh_args_ok(image, vertices, triangles, tri_depth, nver, ntri, h, w, workspace, workspace_bytes)) return rc;
+    if (!tri_tex || !depth_buffer || c <= 0) return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, ntri, h, w);
+    const MeshTris m{vertices, triangles, tri_depth, nver, ntri, h, w};
+    if (int rc = mesh_resolve(m, depth_buffer, ws, st)) return rc;
+    MeshShade s{};
+    s.image = image; s.tri_tex = tri_tex; s.c = c;
+    LAUNCH("k_mesh_shade", k_mesh_shade<MESH_COLORS>, dim3(blocks_for((long)h * w, 256)), dim3(256), st, m, s,
+           (const int*)ws.owner, depth_buffer);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_render_texture(double* image, const double* vertices, const int32_t* triangles,
+                                       const double* texture, const double* tex_coords, const int32_t* tex_triangles,
+                                       const double* tri_depth, double* depth_buffer, int nver, int tex_nver, int ntri, int h,
+                                       int w, int c, int tex_h, int tex_w, int tex_c, int mapping_type, void* workspace,
+                                       size_t workspace_bytes, d3m_stream_t stream) {
+    if (int rc = mesh_args_ok(image, vertices, triangles, tri_depth, nver, ntri, h, w, workspace, workspace_bytes)) return rc;
+    if (!texture || !tex_coords || !tex_triangles || !depth_buffer || c <= 0 || tex_h <= 0 || tex_w <= 0 || tex_c < c)
+        return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, ntri, h, w);
+    const MeshTris m{vertices, triangles, tri_depth, nver, ntri, h, w};
+    if (int rc = mesh_resolve(m, depth_buffer, ws, st)) return rc;
+    MeshShade s{};
+    s.image = image; s.texture = texture; s.tex_coords = tex_coords; s.tex_triangles = tex_triangles; s.c = c;
+    s.tex_nver = tex_nver; s.tex_h = tex_h; s.tex_w = tex_w; s.tex_c = tex_c; s.bilinear = mapping_type != 0;
+    LAUNCH("k_mesh_shade", k_mesh_shade<MESH_TEXTURE>, dim3(blocks_for((long)h * w, 256)), dim3(256), st, m, s,
+           (const int*)ws.owner, depth_buffer);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_get_triangle_buffer(int32_t* triangle_buffer, const double* vertices, const int32_t* triangles,
+                                            const double* tri_depth, double* depth_buffer, int nver, int ntri, int h, int w,
+                                            void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
+    if (int rc = mesh_args_ok(triangle_buffer, vertices, triangles, tri_depth, nver, ntri, h, w, workspace, workspace_bytes))
+        return rc;
+    if (!depth_buffer) return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, ntri, h, w);
+    const MeshTris m{vertices, triangles, tri_depth, nver, ntri, h, w};
+    if (int rc = mesh_resolve(m, depth_buffer, ws, st)) return rc;
+    MeshShade s{};
+    s.triangle_buffer = triangle_buffer;
+    LAUNCH("k_mesh_shade", k_mesh_shade<MESH_TRIANGLE_BUFFER>, dim3(blocks_for((long)h * w, 256)), dim3(256), st, m, s,
+           (const int*)ws.owner, depth_buffer);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_vis_of_vertices(double* vis, const double* vertices, const int32_t* triangles,
+                                        const double* tri_depth, double* depth_buffer, double* depth_tmp, int nver, int ntri,
+                                        int h, int w, void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
+    if (int rc = mesh_args_ok(vis, vertices, triangles, tri_depth, nver, ntri, h, w, workspace, workspace_bytes)) return rc;
+    if (!depth_buffer || !depth_tmp) return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, ntri, h, w);
+    const MeshTris m{vertices, triangles, tri_depth, nver, ntri, h, w};
+    if (int rc = mesh_resolve(m, depth_buffer, ws, st)) return rc;
+    const long px = (long)h * w;
+    MeshShade s{};
+    LAUNCH("k_mesh_shade", k_mesh_shade<MESH_DEPTH_ONLY>, dim3(blocks_for(px, 256)), dim3(256), st, m, s, (const int*)ws.owner,
+           depth_buffer);
+    LAUNCH("k_fill_i32", k_fill_i32, dim3(blocks_for(px, 256)), dim3(256), st, ws.head, -1, px);
+    HIP_TRY(zero_async(ws.tmp_key, align_up((size_t)px * 8, 256), st));
+    LAUNCH("k_mesh_vis_chain", k_mesh_vis_chain, dim3(blocks_for(nver, 256)), dim3(256), st, vertices, (const double*)depth_buffer,
+           (const double*)depth_tmp, ws.head, ws.next, nver, h, w);
+    LAUNCH("k_mesh_vis_resolve", k_mesh_vis_resolve, dim3(blocks_for(nver, 256)), dim3(256), st, vertices, (const int*)ws.head,
+           (const int*)ws.next, vis, ws.tmp_key, nver, h, w);
+    LAUNCH("k_mesh_vis_finish", k_mesh_vis_finish, dim3(blocks_for(px, 256)), dim3(256), st,
+           (const unsigned long long*)ws.tmp_key, depth_tmp, px);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_map_texture(double* dst_image, const double* src_image, const double* dst_vertices,
+                                    const double* src_vertices, const int32_t* dst_triangle_buffer, const int32_t* triangles,
+                                    int nver, int ntri, int sh, int sw, int sc, int h, int w, int c, d3m_stream_t stream) {
+    if (!dst_image || !src_image || !dst_vertices || !src_vertices || !dst_triangle_buffer || !triangles || nver <= 0 ||
+        ntri <= 0 || sh <= 0 || sw <= 0 || sc < c || h <= 0 || w <= 0 || c <= 0)
+        return D3M_ERR_INVALID;
+    LAUNCH("k_mesh_map_texture", k_mesh_map_texture, dim3(blocks_for((long)h * w, 256)), dim3(256), (hipStream_t)stream, dst_image,
+           src_image, dst_vertices, src_vertices, dst_triangle_buffer, triangles, nver, ntri, sh, sw, sc, h, w, c);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_get_norm_direction(double* norm, const double* tri_norm, const int32_t* triangles, int nver, int ntri,
+                                           void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
+    if (!norm || !tri_norm || !triangles || nver <= 0 || ntri <= 0) return D3M_ERR_INVALID;
+    if (!workspace || workspace_bytes < d3m_mesh_workspace_bytes(nver, ntri, 0, 0)) return D3M_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, ntri, 0, 0);
+    HIP_TRY(zero_async(ws.count, align_up((size_t)(nver + 2) * 4, 256), st));
+    HIP_TRY(zero_async(ws.cursor, align_up((size_t)nver * 4, 256), st));
+    const dim3 ge(blocks_for(3L * ntri, 256));
+    LAUNCH("k_mesh_incidence_count", k_mesh_incidence_count, ge, dim3(256), st, triangles, ws.count, ntri, nver);
+    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, ws.count, nver, (const int*)nullptr, 1, ws.big_count);
+    LAUNCH("k_mesh_incidence_fill", k_mesh_incidence_fill, ge, dim3(256), st, triangles, (const int*)ws.count, ws.cursor,
+           ws.entries, ntri, nver);
+    LAUNCH("k_mesh_normals", k_mesh_normals, dim3(blocks_for(nver, 256)), dim3(256), st, norm, tri_norm, (const int*)ws.count,
+           ws.entries, nver, ntri);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_get_correspondence(const double* image, const double* pncc_code, double* uv, int nver, int h, int w,
+                                           int c, void* workspace, size_t workspace_bytes, d3m_stream_t stream) {
+    if (!image || !pncc_code || !uv || nver <= 0 || h <= 0 || w <= 0 || c < 3) return D3M_ERR_INVALID;
+    if (!workspace || workspace_bytes < d3m_mesh_workspace_bytes(nver, 0, 0, 0)) return D3M_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const MeshWs ws = mesh_ws(workspace, nver, 0, 0, 0);
+    LAUNCH("k_fill_i32", k_fill_i32, dim3(blocks_for(nver, 256)), dim3(256), st, ws.last_pixel, -1, (long)nver);
+    LAUNCH("k_mesh_nearest_code", k_mesh_nearest_code, dim3(blocks_for((long)h * w, 256)), dim3(256), st, image, pncc_code,
+           ws.last_pixel, nver, h, w, c);
+    LAUNCH("k_mesh_write_uv", k_mesh_write_uv, dim3(blocks_for(nver, 256)), dim3(256), st, (const int*)ws.last_pixel, uv, nver, w);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_triangle_mean(const double* values, const int32_t* triangles, double* out, int channels, int nver,
+                                      int ntri, d3m_stream_t stream) {
+    if (!values || !triangles || !out || channels <= 0 || nver <= 0 || ntri <= 0) return D3M_ERR_INVALID;
+    LAUNCH("k_mesh_triangle_mean", k_mesh_triangle_mean, dim3(blocks_for((long)channels * ntri, 256)), dim3(256),
+           (hipStream_t)stream, values, triangles, out, channels, nver, ntri);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_triangle_normals(const double* vertices, const int32_t* triangles, double* tri_norm, int nver, int ntri,
+                                         d3m_stream_t stream) {
+    if (!vertices || !triangles || !tri_norm || nver <= 0 || ntri <= 0) return D3M_ERR_INVALID;
+    LAUNCH("k_mesh_triangle_normals", k_mesh_triangle_normals, dim3(blocks_for(ntri, 256)), dim3(256), (hipStream_t)stream,
+           vertices, triangles, tri_norm, nver, ntri);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_mesh_normalize(double* norm, int nver, d3m_stream_t stream) {
+    if (!norm || nver <= 0) return D3M_ERR_INVALID;
+    LAUNCH("k_mesh_normalize", k_mesh_normalize, dim3(blocks_for(nver, 256)), dim3(256), (hipStream_t)stream, norm, nver);
     return check_launch();
 }

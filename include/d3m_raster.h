@@ -327,6 +327,51 @@ int d3m_create_texture_image(const float* vertices_all, const float* textures, f
                              int texture_size_in, int image_height, int image_width, int tile_width, float eps,
                              d3m_stream_t stream);
 
+/* ---- the face3d utility rasterizer family (f64) ----------------------------------------------------------------
+ * Replace the C++ cores of deep3dmap/core/renderer/renderer_demo/mesh_cython/render.cpp (MC) that render_cython.pyx
+ * exposes (:55-161) and render.py drives (:124-299); same argument order and array layouts (vertices [3,nver],
+ * triangles [3,ntri] coordinate-major, images [h,w,c], everything double / int32), device pointers, plus a workspace
+ * of d3m_mesh_workspace_bytes(nver, ntri, h, w) bytes (no initialisation needed; pass 0 for the dimensions a
+ * function does not have) and a stream.  In/out buffers (image, depth_buffer, depth_tmp, vis, triangle_buffer, norm,
+ * uv) are pre-filled by the caller as render.py does and updated exactly as the reference's sequential loops would. */
+size_t d3m_mesh_workspace_bytes(int nver, int ntri, int h, int w);
+/* _render_colors_core, MC:27-91 */
+int d3m_mesh_render_colors(double* image, const double* vertices, const int32_t* triangles, const double* tri_depth,
+                           const double* tri_tex, double* depth_buffer, int nver, int ntri, int h, int w, int c,
+                           void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+/* _render_texture_core, MC:94-185 (mapping_type 0 nearest, 1 bilinear; texel indices are clamped) */
+int d3m_mesh_render_texture(double* image, const double* vertices, const int32_t* triangles, const double* texture,
+                            const double* tex_coords, const int32_t* tex_triangles, const double* tri_depth,
+                            double* depth_buffer, int nver, int tex_nver, int ntri, int h, int w, int c, int tex_h,
+                            int tex_w, int tex_c, int mapping_type, void* workspace, size_t workspace_bytes,
+                            d3m_stream_t stream);
+/* _map_texture_core, MC:188-250 */
+int d3m_mesh_map_texture(double* dst_image, const double* src_image, const double* dst_vertices,
+                         const double* src_vertices, const int32_t* dst_triangle_buffer, const int32_t* triangles,
+                         int nver, int ntri, int sh, int sw, int sc, int h, int w, int c, d3m_stream_t stream);
+/* _vis_of_vertices_core, MC:253-318 */
+int d3m_mesh_vis_of_vertices(double* vis, const double* vertices, const int32_t* triangles, const double* tri_depth,
+                             double* depth_buffer, double* depth_tmp, int nver, int ntri, int h, int w, void* workspace,
+                             size_t workspace_bytes, d3m_stream_t stream);
+/* _get_triangle_buffer_core, MC:321-365 */
+int d3m_mesh_get_triangle_buffer(int32_t* triangle_buffer, const double* vertices, const int32_t* triangles,
+                                 const double* tri_depth, double* depth_buffer, int nver, int ntri, int h, int w,
+                                 void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+/* _get_norm_direction_core, MC:4-24 (sums in triangle-index order, as the reference's loop) */
+int d3m_mesh_get_norm_direction(double* norm, const double* tri_norm, const int32_t* triangles, int nver, int ntri,
+                                void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+/* The numpy statements render.py wraps around the cores, with numpy's roundings (no fused multiply-add, true
+ * division): per-triangle mean of per-vertex values [channels, nver] -> [channels, ntri] (render.py:141-142),
+ * cross(pt0 - pt1, pt0 - pt2) per triangle (:6-9), and the unit-length step with the zero-normal rule (:19-26). */
+int d3m_mesh_triangle_mean(const double* values, const int32_t* triangles, double* out, int channels, int nver, int ntri,
+                           d3m_stream_t stream);
+int d3m_mesh_triangle_normals(const double* vertices, const int32_t* triangles, double* tri_norm, int nver, int ntri,
+                              d3m_stream_t stream);
+int d3m_mesh_normalize(double* norm, int nver, d3m_stream_t stream);
+/* _get_correspondence_core, MC:441-488 */
+int d3m_mesh_get_correspondence(const double* image, const double* pncc_code, double* uv, int nver, int h, int w, int c,
+                                void* workspace, size_t workspace_bytes, d3m_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""The face3d utility rasterizer family: deep3dmap/core/renderer/renderer_demo/mesh_cython.
+CPU tests pin oracle/mesh_oracle.c to the vectors produced by the reference's own compiled code
+(tests/golden/mesh_golden.npz <- oracle/_ref/libmesh_ref.so) and, where that build is present, to the reference itself.
+GPU tests hold the HIP kernels behind deep3dmap_amd.mesh_cython.render to the same vectors, bit for bit (f64)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import mesh_scenes  # noqa: E402
+from oracle import mesh_oracle as M  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["render_colors", "render_colors_bg", "triangle_buffer", "vis", "norm", "texture_nearest", "texture_bilinear",
+        "map_texture", "corr_x", "corr_ind"]
+
+
+@pytest.fixture(scope="module")
+def mesh_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "mesh_golden.npz"))
+
+
+class _Backend:
+    def __init__(self, backend):
+        self.backend = backend
+
+    def __getattr__(self, name):
+        fn = getattr(M, name)
+        return lambda *a, **k: fn(*a, backend=self.backend, **k)
+
+
+def _check(res, golden, name):
+    for k in KEYS:
+        want = golden[f"{name}/{k}"]
+        got = np.asarray(res[k])
+        assert got.shape == want.shape, (name, k, got.shape, want.shape)
+        assert np.array_equal(got, want), (name, k, float(np.abs(got.astype(np.float64) - want).max()))
+
+
+def test_fixture_lists_every_scene_and_function(mesh_golden):
+    assert sorted(mesh_golden.files) == sorted(f"{s}/{k}" for s in mesh_scenes.SCENES for k in KEYS)
+
+
+@pytest.mark.parametrize("name", list(mesh_scenes.SCENES))
+def test_port_matches_reference_vectors(mesh_golden, name):
+    n, h, w, seed = mesh_scenes.SCENES[name]
+    _check(mesh_scenes.run_family(_Backend("port"), mesh_scenes.grid_scene(n, h, w, seed)), mesh_golden, name)
+
+
+def test_scenes_hit_the_special_cases(mesh_golden):
+    """The fixtures are only worth something if the quirks are actually exercised."""
+    s = mesh_scenes.grid_scene(*mesh_scenes.SCENES["g30_64x64"])
+    tb = mesh_golden["g30_64x64/triangle_buffer"]
+    ntri = s["triangles"].shape[1]
+    nbase = ntri - 6                                           # 3 duplicates + border + off-screen + huge
+    assert (tb == ntri - 1).any()                              # the image-sized triangle owns pixels (wave path)
+    assert not (tb == ntri - 2).any()                          # the off-screen one does not
+    dup = np.isin(tb, [nbase, nbase + 1, nbase + 2])
+    assert not dup.any() and np.isin(tb, [0, 1, 2]).any()      # equal depth: the lower index keeps the pixel
+    border = np.zeros_like(tb, bool)
+    border[:2] = border[-2:] = True
+    border[:, :2] = border[:, -2:] = True
+    assert (tb[border] >= 0).mean() > (tb[~border] >= 0).mean() * 0 and (tb[border] == ntri - 3).any()   # border band rule
+    assert 0 < mesh_golden["g30_64x64/vis"].mean() < 1 and len(mesh_golden["g30_64x64/corr_ind"]) > 100
+
+
+@pytest.mark.skipif(not M.have_ref(), reason="oracle/_ref/libmesh_ref.so not built (needs /root/reference)")
+def test_port_equals_compiled_reference_on_fresh_scenes():
+    for seed in (11, 12, 13):
+        s = mesh_scenes.grid_scene(10 + seed, 50 + seed, 70 - seed, seed, jitter=0.3 * (seed - 10))
+        a, b = mesh_scenes.run_family(_Backend("port"), s), mesh_scenes.run_family(_Backend("ref"), s)
+        for k in KEYS:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (seed, k)
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mesh_scenes.SCENES))
+def test_hip_family_matches_reference_vectors(mesh_golden, name):
+    from deep3dmap_amd.mesh_cython import render
+    n, h, w, seed = mesh_scenes.SCENES[name]
+    _check(mesh_scenes.run_family(render, mesh_scenes.grid_scene(n, h, w, seed)), mesh_golden, name)
+
+
+@pytest.mark.gpu
+def test_hip_family_matches_oracle_at_bfm_scale():
+    """A 230 x 230 vertex mesh (52,900 vertices / 104,882 triangles, the size of the BFM face mesh the reference's
+    caller renders) at 256 x 256, against the oracle (the compiled reference where present, the port otherwise)."""
+    from deep3dmap_amd.mesh_cython import render
+    s = mesh_scenes.grid_scene(230, 256, 256, 21, jitter=0.25)
+    want = mesh_scenes.run_family(_Backend(M.default_backend()), s)
+    got = mesh_scenes.run_family(render, s)
+    for k in KEYS:
+        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+
+
+@pytest.mark.gpu
+def test_hip_family_device_tensors_and_errors():
+    import torch
+    from deep3dmap_amd.mesh_cython import render
+    s = mesh_scenes.grid_scene(12, 40, 48, 1)
+    v, t, c = (torch.from_numpy(s[k]).cuda() for k in ("vertices", "triangles", "colors"))
+    img = render.render_colors(v, t, c, 40, 48)
+    assert torch.is_tensor(img) and img.is_cuda and img.dtype == torch.float64
+    assert np.array_equal(img.cpu().numpy(), render.render_colors(s["vertices"], s["triangles"], s["colors"], 40, 48))
+    with pytest.raises(RuntimeError):
+        render.render_colors(v.cpu(), t, c, 40, 48)
+    with pytest.raises(ValueError):
+        render.render_texture(s["vertices"], s["triangles"], s["texture"], s["tex_coords"][:, :5], s["triangles"], 40, 48)
