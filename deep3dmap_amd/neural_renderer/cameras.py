@@ -59,10 +59,48 @@ def _camera_struct(p, device):
     return cam, keep
 
 
-def _no_grad_param(t, name):
-    if torch.is_tensor(t) and t.requires_grad:
-        raise NotImplementedError(f"gradient with respect to the camera parameter `{name}` is not implemented in "
-                                  "the HIP path (DESIGN.md, 'Out of scope this round')")
+def _learnable(*params):
+    """A camera parameter that requires grad (camera optimisation, e.g. neural_renderer's example4): the fused camera
+    kernels only differentiate with respect to the vertices, so these few [batch, 3]-sized quantities then go through
+    the device-side torch composition below and autograd."""
+    return any(torch.is_tensor(p) and p.requires_grad for p in params)
+
+
+def _unit(v):
+    return v / v.norm(dim=-1, keepdim=True).clamp_min(1e-5)            # F.normalize(eps=1e-5), look_at.py:47-50
+
+
+def _frame_torch(eye, target, up, is_look_at):
+    """Rows (x, y, z) of the camera frame [b,3,3] from differentiable inputs (look_at.py:47-53, look.py:40-46)."""
+    z = _unit(target - eye) if is_look_at else _unit(target)
+    x = _unit(torch.linalg.cross(up.expand_as(z), z, dim=-1))
+    y = _unit(torch.linalg.cross(z, x, dim=-1))
+    return torch.stack((x, y, z), dim=1)
+
+
+def _view_torch(vertices, eye, frame, perspective_angle):
+    """(v - eye) expressed in the camera frame, then the optional perspective division (perspective.py:15-20)."""
+    out = torch.einsum('bvk,bjk->bvj', vertices - eye[:, None, :], frame)
+    if perspective_angle is not None:
+        width = _tan_width(perspective_angle)
+        zc = out[..., 2]
+        out = torch.stack((out[..., 0] / zc / width, out[..., 1] / zc / width, zc), dim=-1)
+    return out
+
+
+def _projection_torch(vertices, K, R, t, dist, orig_size, eps):
+    """projection.py:19-43 as one differentiable device-side composition (all five inputs may require grad)."""
+    cam = torch.einsum('bvk,bjk->bvj', vertices, R) + t.reshape(-1, 1, 3)
+    z = cam[..., 2]
+    xn, yn = cam[..., 0] / (z + eps), cam[..., 1] / (z + eps)
+    k1, k2, p1, p2, k3 = (dist[:, None, i] for i in range(5))
+    r2 = torch.sqrt(xn ** 2 + yn ** 2) ** 2
+    radial = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = xn * radial + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn ** 2)
+    yd = yn * radial + p1 * (r2 + 2 * yn ** 2) + 2 * p2 * xn * yn
+    pix = torch.einsum('bvk,bjk->bvj', torch.stack((xd, yd, torch.ones_like(z)), dim=-1), K)
+    u, v = pix[..., 0], orig_size - pix[..., 1]
+    return torch.stack((2 * (u - orig_size / 2.) / orig_size, 2 * (v - orig_size / 2.) / orig_size, z), dim=-1)
 
 
 def _tan_width(angle):
@@ -90,11 +128,14 @@ def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
     `eye`, `at`, `up`: list / tuple / ndarray / tensor of shape [3] or [batch, 3]."""
     if vertices.ndimension() != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
-    _no_grad_param(eye, "eye")
     device = vertices.device
     eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
     nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
     B = max(vertices.shape[0], nb)          # vertices of batch 1 = one mesh seen by every camera
+    if _learnable(eye, at, up):
+        return _view_torch(vertices.float().expand(B, -1, -1), eye_t.expand(B, 3),
+                           _frame_torch(eye_t.expand(B, 3), at_t.expand(B, 3), up_t.expand(B, 3), True),
+                           _perspective_angle)
     rot = _basis(eye_t, at_t, up_t, True, nb, device)
     params = dict(mode=_lib.CAMERA_LOOK_AT, batch=B, rot=rot, eye_or_t=eye_t,
                   perspective=_perspective_angle is not None,
@@ -106,12 +147,15 @@ def look(vertices, eye, direction=[0, 1, 0], up=None, _perspective_angle=None):
     """"Look" transformation of vertices (NR/look.py:6-53); `up` defaults to [0, 1, 0]."""
     if vertices.ndimension() != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
-    _no_grad_param(eye, "eye")
     device = vertices.device
     eye_t, dir_t = _vec_param(eye, device), _vec_param(direction, device)
     up_t = _vec_param([0, 1, 0] if up is None else up, device)
     nb = max(eye_t.shape[0], dir_t.shape[0], up_t.shape[0])
     B = max(vertices.shape[0], nb)
+    if _learnable(eye, direction, up):
+        return _view_torch(vertices.float().expand(B, -1, -1), eye_t.expand(B, 3),
+                           _frame_torch(eye_t.expand(B, 3), dir_t.expand(B, 3), up_t.expand(B, 3), False),
+                           _perspective_angle)
     rot = _basis(eye_t, dir_t, up_t, False, nb, device)
     params = dict(mode=_lib.CAMERA_LOOK, batch=B, rot=rot, eye_or_t=eye_t,
                   perspective=_perspective_angle is not None,
@@ -133,15 +177,14 @@ def perspective(vertices, angle=30.):
 def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
     """Projective transformation with lens distortion (NR/projection.py:6-43).
     K [b,3,3], R [b,3,3], t [b,1,3] (or [b,3]), dist_coeffs [b,5]; b is 1 or the batch size."""
-    if eps != 1e-9:
-        raise NotImplementedError("projection: only the reference's default eps=1e-9 is supported")
-    for name, p in (("K", K), ("R", R), ("t", t), ("dist_coeffs", dist_coeffs)):
-        _no_grad_param(p, name)
     device = vertices.device
     tt = as_device_f32(t, device).reshape(-1, 3)
     rot, Kt, dist = (as_device_f32(R, device).reshape(-1, 3, 3), as_device_f32(K, device).reshape(-1, 3, 3),
                      as_device_f32(dist_coeffs, device).reshape(-1, 5))
     batch = max(vertices.shape[0], tt.shape[0], rot.shape[0], Kt.shape[0], dist.shape[0])
+    if _learnable(K, R, t, dist_coeffs) or eps != 1e-9:      # the fused kernel has the reference's default eps built in
+        return _projection_torch(vertices.float().expand(batch, -1, -1), Kt.expand(batch, 3, 3), rot.expand(batch, 3, 3),
+                                 tt.expand(batch, 3), dist.expand(batch, 5), float(orig_size), eps)
     params = dict(mode=_lib.CAMERA_PROJECTION, batch=batch, rot=rot, eye_or_t=tt, K=Kt, dist=dist,
                   orig_size=float(orig_size))
     return _CameraFunction.apply(vertices, params)

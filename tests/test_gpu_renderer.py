@@ -248,6 +248,48 @@ def test_loss_kernels_match_reference_losses(golden):
     assert torch.allclose(ag.grad, 2 * (a - b) * torch.tensor([1., 0, 0], device="cuda").view(1, 3, 1, 1), atol=1e-6)
 
 
+def test_camera_parameter_gradients_match_oracle_autograd():
+    """eye (look_at, look) and K / R / t / dist_coeffs (projection) as learnable parameters: values and gradients of a
+    scalar of the transformed vertices against torch autograd of the oracle's restatement of NR/look_at.py, look.py,
+    projection.py (camera optimisation as in neural_renderer's example4); then a silhouette render whose loss moves
+    the eye."""
+    nr = _nr()
+    from oracle import nr_oracle as O
+    gen = torch.Generator().manual_seed(4)
+    v = torch.randn(2, 30, 3, generator=gen) * 0.4
+    wgt = torch.randn(2, 30, 3, generator=gen)
+
+    def both(fn_gpu, fn_cpu, params):
+        res = []
+        for fn, dev in ((fn_gpu, "cuda"), (fn_cpu, "cpu")):
+            ps = [p.clone().to(dev).requires_grad_(True) for p in params]
+            vv = v.clone().to(dev).requires_grad_(True)
+            out = fn(vv, *ps)
+            (out * wgt.to(dev)).sum().backward()
+            res.append([out.detach().cpu(), vv.grad.cpu()] + [p.grad.cpu() for p in ps])
+        for a, b in zip(*res):
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-5), float((a - b).abs().max())
+
+    eye = torch.tensor([[0.3, 0.6, -2.5], [-1.0, 0.2, -2.0]])
+    both(lambda vv, e: nr.perspective(nr.look_at(vv, e), angle=30), lambda vv, e: O.perspective(O.look_at(vv, e), angle=30), [eye])
+    both(lambda vv, e: nr.look(vv, e, direction=[0.1, 0.2, 1.0]), lambda vv, e: O.look(vv, e, direction=[0.1, 0.2, 1.0]), [eye])
+    K = torch.tensor([[[300., 0, 128], [0, 310., 120], [0, 0, 1]]]).repeat(2, 1, 1)
+    R = torch.linalg.qr(torch.randn(2, 3, 3, generator=gen))[0]
+    t = torch.tensor([[[0.1, -0.2, 3.0]], [[0.0, 0.1, 2.5]]])
+    dist = torch.tensor([[0.05, -0.02, 0.001, 0.002, 0.01]]).repeat(2, 1)
+    both(lambda vv, K_, R_, t_, d_: nr.projection(vv, K_, R_, t_, d_, 256),
+         lambda vv, K_, R_, t_, d_: O.projection(vv, K_, R_, t_, d_, 256), [K, R, t, dist])
+    # end to end: the silhouette loss reaches the eye through the rasterizer
+    from deep3dmap_amd import synthetic
+    mv, mt = synthetic.grid_mesh(10)
+    mv, mt = torch.from_numpy(mv).cuda()[None], torch.from_numpy(mt).cuda()[None]
+    r = nr.Renderer(camera_mode="look_at", image_size=48, anti_aliasing=False)
+    r.eye = torch.tensor([0.5, 0.8, -2.6], device="cuda", requires_grad=True)
+    sil = r(mv, mt, mode="silhouettes")
+    (sil[:, :, :24].sum() - sil[:, :, 24:].sum()).backward()
+    assert r.eye.grad is not None and torch.isfinite(r.eye.grad).all() and float(r.eye.grad.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8), (3, 20, 12), (1, 64, 64)])
 def test_fused_fit_loss_matches_composed_losses_and_oracle(shape):
     """multiview_fit_loss (3 launches) against photometric + silhouette/P + photometric composed from the loss
