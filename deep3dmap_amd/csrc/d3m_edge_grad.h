@@ -59,6 +59,10 @@ struct EdgeGradArgs {
     AxisMaps ax[2];   // [0]: axis 0 = column walks (transposed records); [1]: axis 1 = row walks
     const float* alpha_map;   // original [B,S,S] / [B,S,S,3] maps: reference values of a segment (one pixel each)
     const float* rgb_map;
+    // per line (b*2 + axis)*S + d0: extent of the pixels whose gradients are not all zero, built by k_pack_maps with
+    // atomicMax on zeroed arrays: nz_lo_inv = S - (first such d1), nz_hi1 = (last such d1) + 1; 0 = none.
+    const int* nz_lo_inv;
+    const int* nz_hi1;
     int S, use_rgb, use_alpha;
     float eps;
     unsigned n_lines;   // B*2*S
@@ -91,6 +95,7 @@ struct Segment {
     float d1_cross, q0, q1;
     int ref_pos;     // d1 of the pixel whose value is the reference (in-pixel for outward, out-pixel for inward)
     int dir, d1_in;  // walk direction of KCU:297-308 and the in-pixel next to the crossing
+    int oriented;    // every pixel lies on the expected side of the crossing (always true for outward walks)
 };
 
 // The d0 range of ONE (edge, axis) pair of a face (KCU:312-313): its crossings are d0_from .. d0_to.
@@ -104,9 +109,13 @@ __device__ __forceinline__ void crossing_range(float p00, float p10, int is, int
 // line position.  has_out / has_in tell which of `out` / `in` were filled.
 template <class Owner>
 __device__ __forceinline__ void crossing_segments(float p00, float p01, float p10, float p11, float p20, float p21,
-                                                  int axis, int fn, int is, int d0, Owner&& owner, Segment& out,
-                                                  bool& has_out, Segment& in, bool& has_in) {
+                                                  int axis, int fn, int is, int d0, int nz_lo, int nz_hi, Owner&& owner,
+                                                  Segment& out, bool& has_out, Segment& in, bool& has_in) {
+    // [nz_lo, nz_hi]: the line's pixels with a non-zero gradient.  Outside it diff_grad is exactly 0 and KCU:401/:481
+    // skip the pixel, so every segment is clipped to it (with a masked loss the gradients vanish outside the object,
+    // and the outward walks, which run to the image BORDER, lose most of their length or disappear).
     has_out = has_in = false;
+    if (nz_hi < nz_lo) return;
     const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
     const float fd0 = (float)d0;
     const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;                 // KCU:317
@@ -127,11 +136,12 @@ __device__ __forceinline__ void crossing_segments(float p00, float p01, float p1
     if (owner(d0, d1_in) == fn) {
         const int d1_limit = (0 < direction) ? is - 1 : 0;
         out = sg;
-        out.from = max(min(d1_out, d1_limit), 0);
-        out.to = min(max(d1_out, d1_limit), is - 1);
+        out.from = max(max(min(d1_out, d1_limit), 0), nz_lo);
+        out.to = min(min(max(d1_out, d1_limit), is - 1), nz_hi);
         out.inward = 0;
+        out.oriented = 1;
         out.ref_pos = d1_in;
-        has_out = true;
+        has_out = out.from <= out.to;
     }
     // inward: in-pixel .. opposite edge (KCU:417-431)
     float d0_cross2;
@@ -141,6 +151,10 @@ __device__ __forceinline__ void crossing_segments(float p00, float p01, float p1
     in = sg;
     in.from = max(min(d1_in, d1_limit), 0);
     in.to = min(max(d1_in, d1_limit), is - 1);
+    // all pixels on the expected side of the crossing (see "FACTORED DISTANCE"): decided before clipping
+    in.oriented = (0 < direction) ? in.to == d1_in : in.from == d1_in;
+    in.from = max(in.from, nz_lo);
+    in.to = min(in.to, nz_hi);
     in.inward = 1;
     in.ref_pos = d1_out;
     has_in = in.from <= in.to;
@@ -149,8 +163,7 @@ __device__ __forceinline__ void crossing_segments(float p00, float p01, float p1
 // A segment is handed to the line kernel when it is long and its pixels lie on the expected side of the crossing
 // (see "FACTORED DISTANCE" below); k_edge_count and k_edge_emit must agree on this.
 __device__ __forceinline__ bool segment_queueable(const Segment& sg) {
-    const bool oriented = !sg.inward || ((0 < sg.dir) ? sg.to == sg.d1_in : sg.from == sg.d1_in);
-    return sg.to - sg.from + 1 > EG_INLINE_MAX && oriented;
+    return sg.to - sg.from + 1 > EG_INLINE_MAX && sg.oriented;
 }
 
 // Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).  Branch-free: a pixel whose
@@ -382,12 +395,13 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
                 const size_t vb = (size_t)bn * is * is;
                 Segment so, si;
                 bool has_out, has_in;
+                line = ((size_t)bn * 2 + axis) * is + d0;
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+                                  is - a.nz_lo_inv[line], a.nz_hi1[line] - 1,
                                   [&](int e0, int e1) { return m.owner(vb + (size_t)e0 * is + e1); }, so, has_out, si,
                                   has_in);
                 q_out = has_out && segment_queueable(so);
                 q_in = has_in && segment_queueable(si);
-                line = ((size_t)bn * 2 + axis) * is + d0;
             }
             // neighbouring crossings fall on the same lines: merge equal lines within the wave (uniform call sites)
             wave_grouped_add(w.line_count, line, q_out, false);
@@ -428,8 +442,8 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 // per pixel one packed add, two v_rcp and one packed fma for both vertices; inv = -1/qc is applied once per item.
 // |t + u| >= |u| > 0, so no quotient is infinite.  The one pixel where t == 0 (an inward walk starting exactly on
 // an integer crossing: the reference's `0 < dist` is false there, i.e. -eps whatever s_t says) is corrected after
-// the loop (fix_at_*).  Inward segments whose limit lies on the unexpected side of the in-pixel (possible only
-// within rounding of a vertex) are not queued.
+// the loop (fix_at_*; only if that pixel survived the clip to the line's non-zero extent).  Inward segments whose
+// limit lies on the unexpected side of the in-pixel (possible only within rounding of a vertex) are not queued.
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w) {
     __shared__ LaneTable t;
@@ -456,10 +470,11 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 fn = t.fn[l];
                 base = (size_t)bn * is * is;
                 const AxisMaps& mo = a.ax[axis];
+                line = ((size_t)bn * 2 + axis) * is + d0;
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+                                  is - a.nz_lo_inv[line], a.nz_hi1[line] - 1,
                                   [&](int e0, int e1) { return mo.owner(base + (size_t)e0 * is + e1); }, sg[0], has[0],
                                   sg[1], has[1]);
-                line = ((size_t)bn * 2 + axis) * is + d0;
             }
             const AxisMaps& m = a.ax[axis];
             const size_t line_base = base + (line % is) * is;
@@ -477,7 +492,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                     const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
                     const float s_t = (float)(q.inward ? -q.dir : q.dir);
                     const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
-                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross;
+                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
                     const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
                                           ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
                     rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-1.0f / qc0),
@@ -667,15 +682,20 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
                                                   const float* __restrict__ galpha, const float* __restrict__ rgb,
                                                   const float* __restrict__ grgb, float4* __restrict__ grad_row,
                                                   float2* __restrict__ dot_row, float4* __restrict__ grad_col,
-                                                  float2* __restrict__ dot_col, int S) {
+                                                  float2* __restrict__ dot_col, int* __restrict__ nz_lo_inv,
+                                                  int* __restrict__ nz_hi1, int S) {
     __shared__ float4 t_grad[32][33];
     __shared__ float2 t_dot[32][33];
+    __shared__ int s_col_lo_inv[32], s_col_hi1[32];
+    if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
+    __syncthreads();
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const size_t plane = (size_t)b * S * S;
     for (int r = ty; r < 32; r += 8) {
         const int y = y0 + r, x = x0 + tx;
+        bool nz = false;
         if (y < S && x < S) {
             const size_t i = plane + (size_t)y * S + x;
             float4 g = make_float4(0, 0, 0, 0);
@@ -692,9 +712,27 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
             dot_row[i] = d;
             t_grad[r][tx] = g;
             t_dot[r][tx] = d;
+            nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
+        }
+        // non-zero extents: this tile's share of row y (one half-wave = one tile row) and of its 32 columns
+        const unsigned long long ball = __ballot(nz);
+        const unsigned half = (threadIdx.x & 32) ? (unsigned)(ball >> 32) : (unsigned)ball;
+        if (half != 0 && tx == 0) {
+            const size_t line = ((size_t)b * 2 + 1) * S + (y0 + r);
+            atomicMax(&nz_lo_inv[line], S - (x0 + (__ffs((int)half) - 1)));
+            atomicMax(&nz_hi1[line], x0 + (32 - __clz((int)half)));
+        }
+        if (nz) {
+            atomicMax(&s_col_lo_inv[tx], S - (y0 + r));
+            atomicMax(&s_col_hi1[tx], y0 + r + 1);
         }
     }
     __syncthreads();
+    if (threadIdx.x < 32 && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
+        const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
+        atomicMax(&nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
+        atomicMax(&nz_hi1[line], s_col_hi1[threadIdx.x]);
+    }
     for (int r = ty; r < 32; r += 8) {
         const int x = x0 + r, y = y0 + tx;
         if (x < S && y < S) {
@@ -749,7 +787,7 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
 struct EdgeLayout {
     size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
     size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
-    size_t off_visible, off_line_count, off_line_cursor, off_alloc, off_visible_list, off_lane_cross,
+    size_t off_visible, off_line_count, off_line_cursor, off_nz_lo, off_nz_hi, off_alloc, off_visible_list, off_lane_cross,
         off_lane_partial, off_line_offset, off_vis_block, off_lane_block;
     size_t off_items;              // items | results follow, sized by capacity
     size_t fixed_bytes;
@@ -768,6 +806,8 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.off_visible = o;      o += eg_align(nf * 4);
     L.off_line_count = o;   o += eg_align(nl * 4);
     L.off_line_cursor = o;  o += eg_align(nl * 4);
+    L.off_nz_lo = o;        o += eg_align(nl * 4);
+    L.off_nz_hi = o;        o += eg_align(nl * 4);
     L.off_alloc = o;        o += 256;                 // alloc[0], alloc[1], n_visible (alloc[2])
     L.zero_bytes = o - L.off_zero;
     L.off_visible_list = o; o += eg_align(nf * 4);
@@ -832,11 +872,13 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     }
     LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
            m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
-           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, S);
+           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
+           (int*)(p + L.off_nz_hi), S);
     EdgeGradArgs a;
     a.ax[0] = AxisMaps{grad_col, dot_col};
     a.ax[1] = AxisMaps{grad_row, dot_row};
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
+    a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
     const long nf = (long)B * F, nl = (long)B * 2 * S;
     // worst-case grids (every face visible); workgroups past n_visible exit on their first load
