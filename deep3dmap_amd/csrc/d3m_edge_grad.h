@@ -35,7 +35,7 @@ namespace d3m {
 
 constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are walked by the owning lane
 #ifndef D3M_EG_LINE_PARTS
-#define D3M_EG_LINE_PARTS 2
+#define D3M_EG_LINE_PARTS 1
 #endif
 #ifndef D3M_EG_LINE_WAVES
 #define D3M_EG_LINE_WAVES 8
@@ -524,6 +524,10 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     }
 }
 
+constexpr int EG_SEG_PER_WAVE = 4;   // segments walked concurrently by one wave (one per 16-lane row)
+constexpr int EG_SORT_CHUNK = 1024;  // segments ordered by length at a time (a multiple of the workgroup size)
+__device__ __forceinline__ int from0_clamp(int from, int is) { return min(max(from, 0), is - 1); }
+
 // ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
 template <bool USE_RGB, bool USE_ALPHA>
 __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
@@ -533,19 +537,21 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     //  onto one XCD.  Parts of a line are consecutive workgroups, i.e. spread over the XCDs.)
     const int part = blockIdx.x % EG_LINE_PARTS;
     const size_t line = blockIdx.x / EG_LINE_PARTS;          // (b*2 + axis)*S + d0
-    const int n_items = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);     // items queued under this line
-    if (part * EG_LINE_WAVES >= n_items) return;              // nothing for this workgroup (uniform exit)
+    const int n_line = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // items queued under this line
+    // this workgroup's share of them: a contiguous range (EG_LINE_PARTS = 1: all)
+    const int item_lo = (int)((long)n_line * part / EG_LINE_PARTS), item_hi = (int)((long)n_line * (part + 1) / EG_LINE_PARTS);
+    const int n_items = item_hi - item_lo;
+    if (n_items <= 0) return;                                 // nothing for this workgroup (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int d0 = (int)(line % is);
     const int axis = (int)((line / is) & 1);
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
-    // this line's records, contiguous; a wave-uniform address, so that they are fetched with scalar loads
-    const uint32_t* recs = w.items + (size_t)__builtin_amdgcn_readfirstlane(w.line_offset[line]) * EG_ITEM_DW;
+    const uint32_t* recs = w.items + ((size_t)w.line_offset[line] + item_lo) * EG_ITEM_DW;    // contiguous records
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
-    // visited pixel, both conflict-free (16- and 8-byte lane strides).
+    // visited pixel, both conflict-free (16- and 8-byte lane strides within a 16-lane row).
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + is);
     for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
@@ -553,21 +559,51 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         s_df[p] = m.dot[line_base + p];
     }
     __syncthreads();
-    // (Tried and measured slower on the headline workload: skipping 64-pixel strips whose gradients are all
-    //  zero.  The loop is VALU-issue-bound, profiles/r01_*.)
+    // FOUR segments per wave, one per 16-lane row: the segments are short once clipped (tens of pixels), so a whole
+    // wave per segment spent most of its time on the per-segment prologue / reduction / epilogue.  Here those are
+    // per-lane vector work shared by four segments, the reduction is four DPP steps inside the row, and a walk
+    // iteration covers 16 pixels of each of the four segments.
     typedef float v2f __attribute__((ext_vector_type(2)));
-    // Everything about an item is wave-uniform: records go through the scalar cache (s_load), and the next record
-    // is requested before the current item is walked.
-    constexpr int STRIDE = EG_LINE_WAVES * EG_LINE_PARTS;
-    int it = __builtin_amdgcn_readfirstlane(part * EG_LINE_WAVES + wv);
-    if (it >= n_items) return;                                 // this wave has no item (after the barrier above)
-    const uint4* q = (const uint4*)(recs + (size_t)it * EG_ITEM_DW);
-    uint4 q0v = q[0], q1v = q[1], q2v = q[2];
-    for (; it < n_items; it += STRIDE) {
-        const uint4* qn = (const uint4*)(recs + (size_t)(it + STRIDE < n_items ? it + STRIDE : it) * EG_ITEM_DW);
-        const uint4 n0v = qn[0], n1v = qn[1], n2v = qn[2];
+    const int row = lane >> 4, rl = lane & 15;
+    // The four segments of a wave advance in lock step, so they should be about equally long: the workgroup first
+    // orders its segments by length (counting sort on length / 16, longest first, in chunks of EG_SORT_CHUNK) and the
+    // waves then take consecutive quadruples of that order.  Unsorted, a quadruple ran at 64 % lane efficiency.
+    __shared__ int s_hist[33];
+    __shared__ unsigned short s_order[EG_SORT_CHUNK];
+    for (int chunk0 = 0; chunk0 < n_items; chunk0 += EG_SORT_CHUNK) {
+    const int nc = min(EG_SORT_CHUNK, n_items - chunk0);
+    if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    int my_key[EG_SORT_CHUNK / (EG_LINE_WAVES * 64)], my_rank[EG_SORT_CHUNK / (EG_LINE_WAVES * 64)];
+#pragma unroll
+    for (int j = 0; j < EG_SORT_CHUNK / (EG_LINE_WAVES * 64); j++) {
+        const int i = threadIdx.x + j * EG_LINE_WAVES * 64;
+        my_key[j] = -1;
+        if (i < nc) {
+            const uint32_t ft = recs[(size_t)(chunk0 + i) * EG_ITEM_DW + 2];
+            const int len = (int)(ft >> 16) - (int)(ft & 0xFFFF) + 1;
+            my_key[j] = 31 - min(len >> 4, 31);
+            my_rank[j] = atomicAdd(&s_hist[my_key[j]], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = 0; k < 32; k++) { const int c = s_hist[k]; s_hist[k] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EG_SORT_CHUNK / (EG_LINE_WAVES * 64); j++)
+        if (my_key[j] >= 0) s_order[s_hist[my_key[j]] + my_rank[j]] = (unsigned short)(threadIdx.x + j * EG_LINE_WAVES * 64);
+    __syncthreads();
+    constexpr int STRIDE = EG_LINE_WAVES * EG_SEG_PER_WAVE;
+    for (int base = wv * EG_SEG_PER_WAVE; base < nc; base += STRIDE) {
+        const bool have = base + row < nc;
+        const int it = chunk0 + (have ? s_order[base + row] : s_order[base]);
+        const uint4* q = (const uint4*)(recs + (size_t)it * EG_ITEM_DW);
+        const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
         const uint32_t bits = q0v.x & 63u;
-        const int from = (int)(q0v.z & 0xFFFF), to = (int)(q0v.z >> 16), fn = (int)(q0v.x >> 6), item = (int)q0v.w;
+        const int from = (int)(q0v.z & 0xFFFF), to = have ? (int)(q0v.z >> 16) : -1, fn = (int)(q0v.x >> 6);
         const bool inward = bits & 1;
         const float d1_cross = __uint_as_float(q1v.x);
         const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
@@ -575,48 +611,46 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
         // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped), clamped at 0 (KCU:401/:481; NaN passes, as in
         // the reference); inward walks only count the face's own pixels (KCU:470).  Two packed fma + one add.
-        auto dpos_of = [&](const float4 g, const float2 d, bool inw) {
+        auto dpos_of = [&](const float4 g, const float2 d, bool on) {
             v2f p = {d.x, 0.0f};
             p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
             p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
             const float diff = p.x + p.y;
-            const bool keep = !(diff <= 0) && (!inw || __float_as_int(d.y) == fn);
+            const bool keep = on && !(diff <= 0) && (!inward || __float_as_int(d.y) == fn);
             return keep ? diff : 0.0f;
         };
-        // 64 pixels per iteration: uniform trip count, one masked tail; t = d1 - d1_cross advances by exact steps
-        const int first = from + lane;
-        const int n_full = (to - from + 1) >> 6;
+        // 16 pixels of each row's segment per iteration; t = d1 - d1_cross advances by exact steps
+        int d1 = from + rl;
+        float t = (float)d1 - d1_cross;
         v2f acc = {0.0f, 0.0f};
-        auto walk = [&](auto inw_tag) {
-            constexpr bool INW = decltype(inw_tag)::value;
-            float t = (float)first - d1_cross;
-            const float4* pg = s_grd + first;
-            const float2* pd = s_df + first;
-            auto visit = [&]() {
-                const float dpos = dpos_of(*pg, *pd, INW);
-                const v2f den = u + t;
-                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
-            };
-            for (int k = 0; k < n_full; k++) {
-                visit();
-                pg += 64; pd += 64; t += 64.0f;
-            }
-            if (first + (n_full << 6) <= to) visit();
-        };
-        if (inward) walk(std::true_type{}); else walk(std::false_type{});
-        float s0 = wave_sum(acc.x), s1 = wave_sum(acc.y);
-        if (lane == 0) {
+        while (__any(d1 <= to)) {
+            const bool on = d1 <= to;
+            const int dc = on ? d1 : from0_clamp(from, is);          // keep the LDS address inside the line
+            const float dpos = dpos_of(s_grd[dc], s_df[dc], on);
+            const v2f den = u + t;
+            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+            acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
+            d1 += 16;
+            t += 16.0f;
+        }
+        // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
+        float s0 = acc.x, s1 = acc.y;
+        s0 += dpp_f32<0xB1>(s0);  s1 += dpp_f32<0xB1>(s1);
+        s0 += dpp_f32<0x4E>(s0);  s1 += dpp_f32<0x4E>(s1);
+        s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1);
+        s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1);
+        if (have && rl == 0) {
             const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
             if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
-                const int d1 = (bits & 8u) ? from : to;
-                const float dpos = dpos_of(s_grd[d1], s_df[d1], inward);
+                const int df = (bits & 8u) ? from : to;
+                const float dpos = dpos_of(s_grd[df], s_df[df], true);
                 if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
                 if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
             }
-            w.results[item] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
+            w.results[(int)q0v.w] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
         }
-        q0v = n0v; q1v = n1v; q2v = n2v;
+    }
+    __syncthreads();                                          // s_order / s_hist are rewritten by the next chunk
     }
 }
 

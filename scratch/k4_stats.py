@@ -20,8 +20,8 @@ def main(n=225, S=512, views=8):
     B, F = faces.shape[:2]
     m, _ = R._raster_forward(faces, None, S, 0.1, 100., 1e-3, None, False, True, False, False)
     alpha = (m['face_index_map'] >= 0).float()
-    galpha = torch.randn(B, S, S, device=dev)
-    rgb = torch.rand(B, S, S, 3, device=dev); grgb = torch.randn(B, S, S, 3, device=dev)
+    galpha = torch.randn(B, S, S, device=dev) * alpha          # masked, as with the bench's loss
+    rgb = torch.rand(B, S, S, 3, device=dev); grgb = torch.randn(B, S, S, 3, device=dev) * alpha[..., None]
     L = _lib.lib()
     nbytes = L.d3m_backward_pixel_map_workspace_bytes(B, F, S)
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
@@ -30,26 +30,41 @@ def main(n=225, S=512, views=8):
     torch.cuda.synchronize()
     px, nf, nl = B*S*S, B*F, B*2*S
     o = 0
-    o += al(px*4)*3 + al(px*12)*2
+    o += al(px*16) + al(px*8) + al(px*16) + al(px*8)
     off_visible = o; o += al(nf*4)
     off_line_count = o; o += al(nl*4)
     off_line_cursor = o; o += al(nl*4)
+    o += al(nl*4) * 2
     off_alloc = o; o += 256
-    o += al(nf*4) + al(nf*24)*2 + al(nf*48) + al(nl*4)
+    o += al(nf*4) + al(nf*48)*2
+    off_line_offset = o; o += al(nl*4)
+    o += al((nf//1024 + 2)*4) + al((nf//42 + 2)*4)
     off_items = o
     w = ws.cpu().numpy()
     alloc = w[off_alloc:off_alloc+12].view(np.int32)
-    n_items, n_vis = int(alloc[0]), int(alloc[2])
     lc = w[off_line_cursor:off_line_cursor+nl*4].view(np.int32)
-    items = w[off_items:off_items+n_items*48].view(np.uint32).reshape(-1, 12)
+    lo = w[off_line_offset:off_line_offset+nl*4].view(np.int32)
+    n_rec = int(lc.sum())
+    recs = []
+    for l in np.nonzero(lc)[0]:
+        recs.append(w[off_items + int(lo[l])*48: off_items + (int(lo[l])+int(lc[l]))*48].view(np.uint32).reshape(-1, 12))
+    items = np.concatenate(recs)
     frm, to = items[:,2] & 0xFFFF, items[:,2] >> 16
     ln = (to.astype(np.int64) - frm + 1)
     inward = items[:,0] & 1
-    print(f"visible faces {n_vis} of {nf}; items {n_items} ({n_items/n_vis:.2f}/visible face), queued {lc.sum()}")
-    print(f"pixel visits {ln.sum():,}  mean len {ln.mean():.1f}  wave-iterations {np.ceil(ln/64).sum():,.0f}  inward frac {inward.mean():.3f}")
-    print(f"items per line: mean {lc.mean():.0f} max {lc.max()} ; lines {nl}; nonempty {np.count_nonzero(lc)}")
-    h = np.histogram(ln, bins=[0,7,16,32,64,128,256,512,1024])
-    print("len hist", dict(zip(h[1][1:], h[0])))
+    print(f"crossings {int(alloc[0])}; queued segments {n_rec}; nonempty lines {np.count_nonzero(lc)}; per line mean {lc[lc>0].mean():.0f} max {lc.max()}")
+    print(f"pixel visits {ln.sum():,}  mean len {ln.mean():.1f} median {np.median(ln)}  inward frac {inward.mean():.3f}")
+    print("len hist", dict(zip([8,16,32,48,64,96,128,192,256,512], np.histogram(ln, bins=[0,8,16,32,48,64,96,128,192,256,512])[0].tolist())))
+    # quarter-wave efficiency: groups of 4 consecutive records of a line, 16 px per iteration
+    it_ideal = np.ceil(ln/16).sum()/4
+    it_real = 0
+    k = 0
+    for r in recs:
+        l = (r[:,2] >> 16).astype(np.int64) - (r[:,2] & 0xFFFF) + 1
+        pad = (-len(l)) % 4
+        l = np.concatenate([l, np.zeros(pad, np.int64)]).reshape(-1, 4)
+        it_real += np.ceil(l.max(1)/16).sum()
+    print(f"quarter-wave iterations: real {it_real:,.0f} vs balanced {it_ideal:,.0f} (efficiency {it_ideal/it_real:.2f})")
 main()
 
 def edge_extents(n=225, S=512, views=8):
@@ -83,4 +98,3 @@ def edge_extents(n=225, S=512, views=8):
     nw = flat.numel() // 64
     wmax = flat[:nw * 64].view(nw, 64).max(1)[0]
     print("per-wave max trip: mean %.1f, max %d; sum of maxes %d vs sum of means %.0f" % (float(wmax.mean()), int(wmax.max()), int(wmax.sum()), float(flat.sum()) / 64))
-edge_extents()
