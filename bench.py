@@ -68,7 +68,8 @@ def measured_traffic(name):
     """HBM bytes per launch of `name` from the newest committed PMC summary (profiles/*pmc_traffic*.json, made by
     profiles/pmc_traffic.py from two rocprofv3 --pmc passes of this same command), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")),
+                   key=lambda f: ("final" in os.path.basename(f), os.path.basename(f)))
     if not files:
         return None
     k = json.load(open(files[-1])).get("kernels", {}).get(name)
