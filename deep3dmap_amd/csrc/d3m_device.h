@@ -185,29 +185,46 @@ __device__ __forceinline__ float wave_sum(float v) {
 // all leaders' atomics go out in a single wave instruction instead of a chain of dependent round trips.
 // Returns this lane's slot (base + rank among equal keys) when `want_slot`: usable both for counting and
 // for cursor-style list fills.
-__device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot) {
+struct GroupedAdd {
+    int leader, rank, base;     // base: the counter's old value, valid in the leader lane once the atomic has returned
+};
+
+// Phase 1: group discovery (ballot / readlane only) and ONE atomic per distinct key, issued by the group's leader.
+// Nothing waits for the atomics here: do independent work before wave_grouped_add_end().
+__device__ __forceinline__ GroupedAdd wave_grouped_add_begin(int* counters, size_t key, bool has, bool want_slot) {
     unsigned long long pending = __ballot(has);
     const int lane = lane_id();
-    int my_leader = lane, my_rank = 0, my_count = 0;
+    const uint32_t k32_lo = (uint32_t)key, k32_hi = (uint32_t)((unsigned long long)key >> 32);
+    GroupedAdd g{lane, 0, 0};
+    int my_count = 0;
     while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;
-        const unsigned long long k_lo = __shfl((unsigned long long)key, leader, 64);
-        const unsigned long long same = __ballot(has && (unsigned long long)key == k_lo);
-        if (has && (unsigned long long)key == k_lo) {
-            my_leader = leader;
-            my_rank = __popcll(same & ((1ull << lane) - 1ull));
+        const int leader = __ffsll((long long)pending) - 1;                       // wave-uniform
+        const uint32_t l_lo = (uint32_t)__builtin_amdgcn_readlane((int)k32_lo, leader);
+        const uint32_t l_hi = (uint32_t)__builtin_amdgcn_readlane((int)k32_hi, leader);
+        const bool mine = has && k32_lo == l_lo && k32_hi == l_hi;
+        const unsigned long long same = __ballot(mine);
+        if (mine) {
+            g.leader = leader;
+            g.rank = __popcll(same & ((1ull << lane) - 1ull));
             my_count = __popcll(same);
         }
         pending &= ~same;
     }
-    int base = 0;
-    if (has && lane == my_leader) {
-        if (want_slot) base = atomicAdd(&counters[key], my_count);
+    if (has && lane == g.leader) {
+        if (want_slot) g.base = atomicAdd(&counters[key], my_count);
         else atomicAdd(&counters[key], my_count);
     }
-    if (!want_slot) return 0;
-    base = __shfl(base, my_leader, 64);
-    return base + my_rank;
+    return g;
+}
+
+// Phase 2: this lane's slot = the leader's old counter value + rank among the lanes with the same key.
+__device__ __forceinline__ int wave_grouped_add_end(const GroupedAdd& g) {
+    return __shfl(g.base, g.leader, 64) + g.rank;
+}
+
+__device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot) {
+    const GroupedAdd g = wave_grouped_add_begin(counters, key, has, want_slot);
+    return want_slot ? wave_grouped_add_end(g) : 0;
 }
 
 }  // namespace d3m

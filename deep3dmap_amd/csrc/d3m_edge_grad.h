@@ -478,15 +478,23 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             }
             const AxisMaps& m = a.ax[axis];
             const size_t line_base = base + (line % is) * is;
+            // queued only if the slot and its line's whole slice fit the capacity the workspace gives; otherwise
+            // this thread walks the segment itself (still correct, just serial)
+            bool queued[2];
+            GroupedAdd ga[2];
 #pragma unroll
             for (int which = 0; which < 2; which++) {       // 0: outward, 1: inward
                 const long slot = 2 * (cbase + c) + which;
-                // queued only if the slot and its line's whole slice fit the capacity the workspace gives;
-                // otherwise this thread walks the segment itself (still correct, just serial)
-                const bool queued = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
-                                    (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
+                queued[which] = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
+                                (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
+                // the line-cursor atomics of both segments go out now and are only waited for after the work below
+                ga[which] = wave_grouped_add_begin(w.line_cursor, line, queued[which], true);     // uniform call site
+            }
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                const long slot = 2 * (cbase + c) + which;
                 uint4 rec0, rec1, rec2;
-                if (queued) {
+                if (queued[which]) {
                     const Segment& q = sg[which];
                     const SegRef ref = load_ref(a, axis, base, q.d0, q.ref_pos);
                     const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
@@ -513,8 +521,8 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                     }
                 }
                 // records are stored in LINE order (the line kernel streams its slice), slots in crossing order
-                const int in_line = wave_grouped_add(w.line_cursor, line, queued, true);     // uniform call site
-                if (queued) {
+                const int in_line = wave_grouped_add_end(ga[which]);
+                if (queued[which]) {
                     uint4* rec = (uint4*)(w.items + ((size_t)w.line_offset[line] + in_line) * EG_ITEM_DW);
                     rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
                 }
