@@ -52,9 +52,12 @@ __device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& 
 }
 
 // ---- pass 1: one lane per (view, face): cull, tile rectangle, per-tile counts ---------------------
-// Also fills the reference's faces_inv scratch (KCU:24-67) when the caller passes it.
+// Also fills the reference's faces_inv scratch (KCU:24-67) when the caller passes it, and -- when the faces come
+// from an indexed mesh -- the dense [B,F,3,3] copy of every front-facing face that the later passes read
+// (vertices_to_faces + fill_back without a pass of its own; culled faces are never read again).
 template <class FS>
-__global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv) {
+__global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
+                                                  float* __restrict__ faces_dense_out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int F = bb.F;
     const bool in_range = i < (long)bb.B * F;
@@ -66,6 +69,10 @@ __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* 
         float face[9];
         fs.load(b, f, face);
         if (!backside(face)) {
+            if (faces_dense_out) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
+            }
             if (faces_inv) {
                 float fi[9];
                 face_inverse(face, bb.S, fi);

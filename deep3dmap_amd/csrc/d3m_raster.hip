@@ -155,12 +155,34 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv);
+    LAUNCH("k_bin_count", k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv, (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
     LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     LAUNCH("k_raster_tiles", k_raster_tiles<FS>, dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
+    return check_launch();
+}
+
+// The same with the faces of an indexed mesh: the first pass reads them through the indices and leaves the dense
+// copy (front-facing faces only) that the tile pass and every later operator use.
+static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, float near, float far, RasterOut out, void* ws,
+                            size_t ws_bytes, hipStream_t st) {
+    if (S > 8 * 65535) return D3M_ERR_INVALID;
+    const int F = ifs.num_faces();
+    BinBuffers bb;
+    int rc = make_bins(bb, B, F, S, ws, ws_bytes);
+    if (rc) return rc;
+    HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
+    const long nf = (long)B * F;
+    LAUNCH("k_bin_count", k_bin_count<IndexedFaces>, dim3(blocks_for(nf, 256)), dim3(256), st, ifs, bb, (float*)nullptr,
+           faces_out);
+    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
+    const int n_tiles = B * bb.T;
+    const int per = (n_tiles + 7) / 8;
+    DenseFaces fs{faces_out, F};
+    LAUNCH("k_raster_tiles", k_raster_tiles<DenseFaces>, dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
@@ -202,6 +224,21 @@ D3M_EXPORT int d3m_forward_face_index_map(const float* faces, int32_t* face_inde
     RasterOut out{face_index_map, weight_map, depth_map, return_depth ? face_inv_map : nullptr};
     return run_forward(fs, batch_size, num_faces, image_size, near, far, out, faces_inv, workspace, workspace_bytes,
                        (hipStream_t)stream);
+}
+
+D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, int tri_batch, int num_vertices,
+                                               int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
+                                               float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
+                                               int image_size, float near, float far, void* workspace,
+                                               size_t workspace_bytes, d3m_stream_t stream) {
+    if (!vertices || !tri || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
+        num_vertices <= 0 || num_tri <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
+    IndexedFaces ifs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, batch_size};
+    RasterOut out{face_index_map, weight_map, depth_map, face_inv_map};
+    return run_forward_mesh(ifs, faces_out, batch_size, image_size, near, far, out, workspace, workspace_bytes,
+                            (hipStream_t)stream);
 }
 
 D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* textures, const int32_t* face_index_map,

@@ -241,9 +241,6 @@ class _RasterizeLit(torch.autograd.Function):
             raise ValueError("screen_vertices must be [B, V, 3] and faces [1 or B, F, 3]")
         if textures.shape[0] not in (1, B) or textures.shape[1] != Ft:
             raise ValueError("textures must be [1 or B, num_faces, ts, ts, ts, 3] for the given faces")
-        faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
-        _lib.check(L.d3m_gather_faces(_lib.ptr(sv), _lib.ptr(tri), tri.shape[0], _lib.ptr(faces), B, V, Ft,
-                                      int(bool(fill_back)), _lib.stream_ptr()), "d3m_gather_faces")
         S = int(image_size) * 2 if anti_aliasing else int(image_size)
         ia, idr, ca, cd, direction = light_cfg
         cca, ccd, cdir = _vec3_host(ca), _vec3_host(cd), _vec3_host(direction)
@@ -253,8 +250,18 @@ class _RasterizeLit(torch.autograd.Function):
                                     float(ia), float(idr), cca, ccd, cdir, Bl, V, Ft, int(bool(fill_back)),
                                     _lib.stream_ptr()), "d3m_face_light")
         background = _background_tensor(background_color, dev)
-        m, _ = _raster_forward(faces, None, S, float(near), float(far), float(eps), background, False, return_alpha,
-                               return_depth, False)
+        # coverage straight from the indexed mesh: the binning pass reads the faces through `tri` and leaves the dense
+        # copy of the front-facing ones in `faces` (no vertices_to_faces pass); culled entries are never read
+        faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
+        m = {"face_index_map": torch.empty((B, S, S), dtype=torch.int32, device=dev),
+             "weight_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
+             "depth_map": torch.empty((B, S, S), dtype=torch.float32, device=dev),
+             "face_inv_map": torch.zeros(1, dtype=torch.float32, device=dev)}
+        ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
+        _lib.check(L.d3m_forward_face_index_map_mesh(
+            _lib.ptr(sv), _lib.ptr(tri), tri.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces),
+            _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), None, B, S, float(near),
+            float(far), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
         # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
         s_out = S // 2 if anti_aliasing else S
         m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)

@@ -77,6 +77,18 @@ int d3m_forward_face_index_map(const float* faces, int32_t* face_index_map, floa
                                int return_alpha, int return_depth, void* workspace, size_t workspace_bytes,
                                d3m_stream_t stream);
 
+/* d3m_forward_face_index_map on an INDEXED mesh (an addition): vertices [B,V,3] (screen space), tri [Bt,Ft,3]
+ * (Bt = 1: shared), fill_back appends the reversed-winding copies (renderer.py:86), i.e. num_faces =
+ * (fill_back ? 2 : 1) * num_tri.  The faces are read through the indices and faces_out [B,num_faces,3,3] receives
+ * the dense copy of every FRONT-FACING face -- what vertices_to_faces would have produced for the faces any later
+ * operator can touch -- so the gather needs no pass of its own.  Workspace as d3m_forward_workspace_bytes(B,
+ * num_faces, S). */
+int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, int tri_batch, int num_vertices,
+                                    int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
+                                    float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
+                                    int image_size, float near, float far, void* workspace, size_t workspace_bytes,
+                                    d3m_stream_t stream);
+
 /* Replaces forward_texture_sampling (KCPP:97-124 -> KCU:172-242).
  *   textures [B,F,ts,ts,ts,3] f32 in; rgb_map [B,S,S,3] f32 i/o; sampling_index_map [B,S,S,8] i32 i/o;
  *   sampling_weight_map [B,S,S,8] f32 i/o (the last two may be NULL: they are recomputable). */
