@@ -33,9 +33,13 @@ struct BoxCursor {
     }
 };
 
+// sum over the FM_LANES (= 8) adjacent lanes of a face, in every one of them: two quad swaps and the half-row
+// mirror, all DPP (no LDS crossbar)
 __device__ __forceinline__ float quad_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < FM_LANES; o <<= 1) v += __shfl_xor(v, o, 64);
+    static_assert(FM_LANES == 8, "quad_sum is written for 8 lanes per face");
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror: the other quad of the 8
     return v;
 }
 constexpr int FLAG_HIDDEN = 0, FLAG_VISIBLE = 1, FLAG_LARGE = 2;

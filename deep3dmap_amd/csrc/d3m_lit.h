@@ -221,7 +221,7 @@ struct LitFaceArgs {
     float eps;
 };
 
-__device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&s_acc)[24][256], long gi, int sub) {
+__device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi, int sub) {
     const float* __restrict__ faces = a.faces;
     const LitTextures& lt = a.lt;
     const int32_t* __restrict__ face_index_map = a.face_index_map;
@@ -253,9 +253,11 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&
         for (int t = sub; t < 24; t += FM_LANES) gt[t] = 0.0f;
         return;
     }
-    const int l = threadIdx.x;
+    // ts == 2: the sample position is clamped below 1 (KCU:222-223), so its integer part is 0 and corner pn of the
+    // trilinear stencil is ALWAYS texel (pn&1, pn>>1&1, pn>>2&1): the 24 sums have static indices and live in registers
+    float acc[24];
 #pragma unroll
-    for (int t = 0; t < 24; t++) s_acc[t][l] = 0;
+    for (int t = 0; t < 24; t++) acc[t] = 0.0f;
     const size_t base = (size_t)bn * S * S;
     // the depth gradient (KCU:543-592) rides along when asked for: same pixels, same weights, same depth
     float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
@@ -291,18 +293,16 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
             float w;
-            int isc;
-            sample_corner(pn, 2, fl, fr, w, isc);
-            isc &= 7;
-            s_acc[isc * 3 + 0][l] += w * g0;
-            s_acc[isc * 3 + 1][l] += w * g1;
-            s_acc[isc * 3 + 2][l] += w * g2;
+            int isc_dyn;
+            sample_corner(pn, 2, fl, fr, w, isc_dyn);
+            const int isc = ((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1);        // = isc_dyn, since fl == 0
+            acc[isc * 3 + 0] += w * g0;
+            acc[isc * 3 + 1] += w * g1;
+            acc[isc * 3 + 2] += w * g2;
         }
     }
-    // the face's lanes sit in one wave: their LDS columns are complete once the loop has reconverged
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 24; t++) acc[t] = quad_sum(acc[t]);
     if (grad_depth_map) {
 #pragma unroll
         for (int k = 0; k < 9; k++) dacc[k] = quad_sum(dacc[k]);
@@ -331,9 +331,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&
         const int to = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            float g = s_acc[t * 3 + c][l];
-#pragma unroll
-            for (int j = 1; j < FM_LANES; j++) g += s_acc[t * 3 + c][l + j];
+            const float g = acc[t * 3 + c];
             gt[to * 3 + c] = g * li[c];          // plain store: see the kernel comment
             gl[c] += g * tex[to * 3 + c];
         }
@@ -349,16 +347,15 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, float (&
 // a fill_back mesh, i.e. mostly idle waves); with the compacted list of a d3m_visibility only faces that own a pixel
 // do, on a fixed grid that strides over the list.
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs a) {
-    __shared__ float s_acc[24][256];
     const int sub = threadIdx.x % FM_LANES, slot = threadIdx.x / FM_LANES;
     if (a.list) {
         const int n = *a.n_list;
         for (long base = (long)blockIdx.x * FM_FACES_PER_BLOCK; base < n; base += (long)gridDim.x * FM_FACES_PER_BLOCK) {
-            if (base + slot < n) lit_face_backward(a, s_acc, a.list[base + slot], sub);
+            if (base + slot < n) lit_face_backward(a, a.list[base + slot], sub);
         }
     } else {
         const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + slot;
-        if (gi < (long)a.B * a.lt.Fp) lit_face_backward(a, s_acc, gi, sub);
+        if (gi < (long)a.B * a.lt.Fp) lit_face_backward(a, gi, sub);
     }
 }
 
