@@ -64,6 +64,8 @@ _SIGNATURES = {
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "d3m_smooth_loss_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "d3m_smooth_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_mesh_workspace_bytes": (_SZ, [_I, _I, _I, _I]),

@@ -103,21 +103,36 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
     return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask)
 
 
+class _SmoothLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred):
+        p = f32c(pred)
+        B, H, W = p.shape
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        scratch = torch.empty(4096, dtype=torch.float32, device=p.device)
+        _lib.check(_lib.lib().d3m_smooth_loss_forward(_lib.ptr(p), _lib.ptr(loss), _lib.ptr(scratch), B, H, W,
+                                                      _lib.stream_ptr()), "d3m_smooth_loss_forward")
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        B, H, W = p.shape
+        grad = torch.empty_like(p)
+        _lib.check(_lib.lib().d3m_smooth_loss_backward(_lib.ptr(p), _lib.ptr(f32c(g)), _lib.ptr(grad), B, H, W,
+                                                       _lib.stream_ptr()), "d3m_smooth_loss_backward")
+        return grad
+
+
 def smooth_loss(pred_map):
     """Second-order smoothness over a (pyramid of) map(s) (utils.py:82-102): sum of mean |dxx|, |dxy|, |dyx|,
-    |dyy|, weights 1, 1/2.3, ... per level.  Acts on the network's depth maps, not on rasterizer output; kept
-    as a short eager composition (listed under "next" for a fused kernel)."""
-    def gradient(pred):
-        if pred.dim() == 4:
-            pred = pred.reshape(-1, pred.size(2), pred.size(3))
-        return pred[:, :, 1:] - pred[:, :, :-1], pred[:, 1:] - pred[:, :-1]
-
+    |dyy| per level, weights 1, 1/2.3, ....  Each level is one autograd node (a reduction, a finish and, backward, one
+    gather kernel) instead of the reference's ~25 eager slice / abs / mean kernels forward and ~60 backward."""
     maps = pred_map if type(pred_map) in (tuple, list) else [pred_map]
     loss, weight = 0, 1.
     for scaled_map in maps:
-        dx, dy = gradient(scaled_map)
-        dx2, dxdy = gradient(dx)
-        dydx, dy2 = gradient(dy)
-        loss = loss + (dx2.abs().mean() + dxdy.abs().mean() + dydx.abs().mean() + dy2.abs().mean()) * weight
+        m = scaled_map.reshape(-1, scaled_map.size(-2), scaled_map.size(-1)) if scaled_map.dim() == 4 else scaled_map
+        loss = loss + _SmoothLevel.apply(m) * weight
         weight /= 2.3
     return loss

@@ -560,6 +560,87 @@ __global__ void __launch_bounds__(256) k_photometric_finish(const float* __restr
     }
 }
 
+// ---- smooth_loss of one map (deep3dmap/core/utils/utils.py:82-102, one pyramid level) --------------------------
+//   mean|dxx| + mean|dxy| + mean|dyx| + mean|dyy|   with the reference's nested first differences
+// (dx = p[..,1:] - p[..,:-1], dy = p[:,1:] - p[:,:-1], then the same again), i.e. the same f32 subtractions in the
+// same order.  The eager form is ~25 slice/abs/mean kernels forward and ~60 backward (every slice's backward is a
+// zero fill plus a copy); here: one reduction, one finish, one gradient kernel.
+__device__ __forceinline__ float sm_dxx(const float* p, int x) { return (p[x + 2] - p[x + 1]) - (p[x + 1] - p[x]); }
+__device__ __forceinline__ float sm_dxy(const float* r0, const float* r1, int x) {      // gradient(dx)[1]
+    return (r1[x + 1] - r1[x]) - (r0[x + 1] - r0[x]);
+}
+__device__ __forceinline__ float sm_dyx(const float* r0, const float* r1, int x) {      // gradient(dy)[0]
+    return (r1[x + 1] - r0[x + 1]) - (r1[x] - r0[x]);
+}
+__device__ __forceinline__ float sm_dyy(const float* r0, const float* r1, const float* r2, int x) {
+    return (r2[x] - r1[x]) - (r1[x] - r0[x]);
+}
+__device__ __forceinline__ float sm_sign(float v) { return v > 0 ? 1.0f : (v < 0 ? -1.0f : 0.0f); }
+
+// partials: 4 floats per workgroup = sum|dxx|, sum|dxy|, sum|dyx|, sum|dyy|
+__global__ void __launch_bounds__(256) k_smooth_reduce(const float* __restrict__ pred, float* __restrict__ partials, int B,
+                                                      int H, int W) {
+    __shared__ float s_part[4];
+    float acc[4] = {0, 0, 0, 0};
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float* r0 = pred + (i - x);
+        if (x + 2 < W) acc[0] += fabsf(sm_dxx(r0, x));
+        if (y + 1 < H && x + 1 < W) {
+            acc[1] += fabsf(sm_dxy(r0, r0 + W, x));
+            acc[2] += fabsf(sm_dyx(r0, r0 + W, x));
+        }
+        if (y + 2 < H) acc[3] += fabsf(sm_dyy(r0, r0 + W, r0 + 2 * W, x));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = block_sum_256(acc[k], s_part);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) partials[4 * blockIdx.x + k] = acc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_smooth_finish(const float* __restrict__ partials, int n, float n_xx, float n_xy,
+                                                      float n_yy, float* __restrict__ loss) {
+    __shared__ float s_part[4];
+    float acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += partials[4 * i + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) acc[k] = block_sum_256(acc[k], s_part);
+    if (threadIdx.x == 0) *loss = ((acc[0] / n_xx + acc[1] / n_xy) + acc[2] / n_xy) + acc[3] / n_yy;
+}
+
+// grad_pred[b,y,x] = grad_loss * sum over the (up to 14) second differences that contain the pixel of
+// sign(difference) * coefficient / count -- gathered, one lane per pixel
+__global__ void __launch_bounds__(256) k_smooth_grad(const float* __restrict__ pred, const float* __restrict__ grad_loss,
+                                                    float* __restrict__ grad_pred, int B, int H, int W, float n_xx,
+                                                    float n_xy, float n_yy) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const float* r0 = pred + (i - x);                        // row y
+    float gxx = 0, gxy = 0, gyy = 0;
+    // dxx terms starting at x, x-1, x-2 (coefficients +1, -2, +1)
+    if (x + 2 < W) gxx += sm_sign(sm_dxx(r0, x));
+    if (x >= 1 && x + 1 < W) gxx -= 2.0f * sm_sign(sm_dxx(r0, x - 1));
+    if (x >= 2) gxx += sm_sign(sm_dxx(r0, x - 2));
+    // dyy terms starting at y, y-1, y-2
+    if (y + 2 < H) gyy += sm_sign(sm_dyy(r0, r0 + W, r0 + 2 * W, x));
+    if (y >= 1 && y + 1 < H) gyy -= 2.0f * sm_sign(sm_dyy(r0 - W, r0, r0 + W, x));
+    if (y >= 2) gyy += sm_sign(sm_dyy(r0 - 2 * W, r0 - W, r0, x));
+    // the mixed terms with corner (y0, x0): +p11 - p10 - p01 + p00
+    auto mixed = [&](const float* a0, const float* a1, int x0) { return sm_sign(sm_dxy(a0, a1, x0)) + sm_sign(sm_dyx(a0, a1, x0)); };
+    if (y + 1 < H && x + 1 < W) gxy += mixed(r0, r0 + W, x);                 // pixel is p00
+    if (y + 1 < H && x >= 1) gxy -= mixed(r0, r0 + W, x - 1);                  // p01
+    if (y >= 1 && x + 1 < W) gxy -= mixed(r0 - W, r0, x);                      // p10
+    if (y >= 1 && x >= 1) gxy += mixed(r0 - W, r0, x - 1);                     // p11
+    grad_pred[i] = (*grad_loss) * (gxx / n_xx + gxy / n_xy + gyy / n_yy);
+}
+
 // ---- the multi-view fit objective in three launches ------------------------------------------------------------
 //   loss = photometric(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / pixels + photometric(depth, depth_t, mask)
 // (photometric_loss = utils.py:105-114 without sigma; the silhouette term = examples/example2.py:46), i.e. what

@@ -727,6 +727,38 @@ D3M_EXPORT int d3m_sum_squared_error(const float* a, const float* b, float* loss
     return check_launch();
 }
 
+static int smooth_dims(int B, int H, int W, float& n_xx, float& n_xy, float& n_yy) {
+    if (B <= 0 || H < 3 || W < 3 || (long)B * H * W > 0x7FFFFFFFL) return D3M_ERR_INVALID;
+    n_xx = (float)((long)B * H * (W - 2));
+    n_xy = (float)((long)B * (H - 1) * (W - 1));
+    n_yy = (float)((long)B * (H - 2) * W);
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_smooth_loss_forward(const float* pred, float* loss, float* scratch, int batch_size, int height, int width,
+                                       d3m_stream_t stream) {
+    if (!pred || !loss || !scratch) return D3M_ERR_INVALID;
+    float n_xx, n_xy, n_yy;
+    if (int rc = smooth_dims(batch_size, height, width, n_xx, n_xy, n_yy)) return rc;
+    const long n = (long)batch_size * height * width;
+    const unsigned grid = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+    hipStream_t st = (hipStream_t)stream;
+    LAUNCH("k_smooth_reduce", k_smooth_reduce, dim3(grid), dim3(256), st, pred, scratch, batch_size, height, width);
+    LAUNCH("k_smooth_finish", k_smooth_finish, dim3(1), dim3(256), st, (const float*)scratch, (int)grid, n_xx, n_xy, n_yy, loss);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_smooth_loss_backward(const float* pred, const float* grad_loss, float* grad_pred, int batch_size,
+                                        int height, int width, d3m_stream_t stream) {
+    if (!pred || !grad_loss || !grad_pred) return D3M_ERR_INVALID;
+    float n_xx, n_xy, n_yy;
+    if (int rc = smooth_dims(batch_size, height, width, n_xx, n_xy, n_yy)) return rc;
+    const long n = (long)batch_size * height * width;
+    LAUNCH("k_smooth_grad", k_smooth_grad, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, pred, grad_loss, grad_pred,
+           batch_size, height, width, n_xx, n_xy, n_yy);
+    return check_launch();
+}
+
 static int fit_loss_grid(int batch_size, long hw, dim3& grid) {
     if (batch_size <= 0 || hw <= 0 || hw > 0x7FFFFFFF || batch_size > 1024) return D3M_ERR_INVALID;
     unsigned gx = (unsigned)((hw + 1023) / 1024);

@@ -307,6 +307,14 @@ int d3m_photometric_loss(const float* im1, const float* im2, const float* mask, 
 int d3m_sum_squared_error(const float* a, const float* b, float* loss, float* grad_a, float* scratch, long n,
                           d3m_stream_t stream);
 
+/* smooth_loss of ONE map pred [B,H,W] (deep3dmap/core/utils/utils.py:82-102, one pyramid level, weight 1):
+ * mean|dxx| + mean|dxy| + mean|dyx| + mean|dyy| of the nested first differences; H, W >= 3.  scratch: 4096 floats.
+ * backward: grad_pred = *grad_loss * d loss / d pred (grad_loss is a device scalar). */
+int d3m_smooth_loss_forward(const float* pred, float* loss, float* scratch, int batch_size, int height, int width,
+                            d3m_stream_t stream);
+int d3m_smooth_loss_backward(const float* pred, const float* grad_loss, float* grad_pred, int batch_size, int height,
+                             int width, d3m_stream_t stream);
+
 /* The multi-view fit objective in one reduction + one finish launch, and its gradients in one
  * more:  loss = photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (H*W)
  *             + photometric_loss(depth, depth_target, mask)

@@ -248,6 +248,33 @@ def test_loss_kernels_match_reference_losses(golden):
     assert torch.allclose(ag.grad, 2 * (a - b) * torch.tensor([1., 0, 0], device="cuda").view(1, 3, 1, 1), atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8), (3, 17, 5), (16, 64, 64), (1, 3, 3)])
+def test_fused_smooth_loss_matches_reference_vectors_and_oracle_autograd(golden, shape):
+    """smooth_loss as three kernels per pyramid level: the reference's own values (tests/golden: loss/smooth*), and
+    value + gradient against torch autograd of the oracle's restatement of utils.py:82-102, incl. a pyramid, a 4-D
+    input, an upstream gradient != 1 and plateaus (sign(0) = 0)."""
+    from deep3dmap_amd.core import smooth_loss
+    from oracle import nr_oracle as O
+    a, b = _t(golden, "loss/a"), _t(golden, "loss/b")
+    assert np.allclose(smooth_loss(a[:, 0]).item(), golden["loss/smooth"], rtol=1e-5)
+    assert np.allclose(smooth_loss([a[:, 0], b[:, 0, ::2, ::2]]).item(), golden["loss/smooth_pyramid"], rtol=1e-5)
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, H, W, generator=gen)
+    x[:, : H // 2, : W // 2] = 0.25                      # a plateau: exact zeros among the second differences
+    res = []
+    for fn, dev in ((smooth_loss, "cuda"), (O.smooth_loss, "cpu")):
+        xx = x.clone().to(dev).requires_grad_(True)
+        pyr = [xx, xx[:, ::2, ::2].contiguous()] if min(H, W) >= 6 else xx
+        loss = fn(pyr)
+        (loss * 1.7).backward()
+        res.append((loss.detach().cpu(), xx.grad.cpu()))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-8)
+    x4 = x[:, None].cuda()
+    assert torch.allclose(smooth_loss(x4), smooth_loss(x.cuda()))
+
+
 def test_camera_parameter_gradients_match_oracle_autograd():
     """eye (look_at, look) and K / R / t / dist_coeffs (projection) as learnable parameters: values and gradients of a
     scalar of the transformed vertices against torch autograd of the oracle's restatement of NR/look_at.py, look.py,
