@@ -1,6 +1,6 @@
 #!/bin/bash
-# on the GPU box: bench each scratch/lib_v*.so
-for f in scratch/lib_v*.so; do
+# on the GPU box: bench each tools_dev/lib_v*.so
+for f in tools_dev/lib_v*.so; do
   cp $f deep3dmap_amd/lib/libd3m_raster.so
   echo "== $f"
   D3M_BENCH_TIMING_EXPERIMENT=1 timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
