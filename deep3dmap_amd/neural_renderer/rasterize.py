@@ -219,6 +219,17 @@ def _vec3_host(x):
     return np.ctypeslib.as_ctypes(a)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One extra stream per device for the branch of the lit backward that runs beside the edge gradient."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 class _RasterizeLit(torch.autograd.Function):
     """render / render_rgb in one autograd node with fill_back and lighting applied on the fly
     (d3m_face_light + d3m_render_lit_epilogue / d3m_backward_textures_lit): the per-view
@@ -301,24 +312,34 @@ class _RasterizeLit(torch.autograd.Function):
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over one compacted list of the faces that own a pixel
         vis = ops.visibility(m["face_index_map"], faces.shape[1])
-        ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
-                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis)
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
-        grad_textures = grad_vertices = None
+        grad_textures = grad_vertices = grad_light = None
         depth_done = False
-        if need_tex or need_vert:
+        # The edge gradient (K4: ~8 latency-bound launches) and the gathered texture / depth pass (K5+K6) are
+        # independent -- they only meet in the float atomics on grad_sv -- so the second one runs on a side stream,
+        # forked from and joined to the current one (inside a captured step: a parallel branch of the graph).
+        # Everything it writes is allocated here, on the current stream, so no tensor changes its owning stream.
+        cur = torch.cuda.current_stream()
+        side = _side_stream(dev) if (need_tex or need_vert) else None
+        if side is not None:
             grad_textures = torch.empty_like(textures)
             grad_light = torch.empty_like(light) if need_vert else None
             ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
-            # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
-            _lib.check(L.d3m_backward_textures_lit(
-                _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
-                _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map), _lib.ptr(grad_textures),
-                _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft, int(fill_back), S, ts, eps,
-                _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis), _lib.stream_ptr()),
-                "d3m_backward_textures_lit")
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
+                _lib.check(L.d3m_backward_textures_lit(
+                    _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl,
+                    _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map),
+                    _lib.ptr(grad_textures), _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft,
+                    int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None,
+                    _lib.ptr(vis), _lib.stream_ptr()), "d3m_backward_textures_lit")
             depth_done = rd
+        ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
+                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis)
+        if side is not None:
+            cur.wait_stream(side)
             if need_vert:
                 grad_vertices = torch.zeros_like(vertices)
                 _lib.check(L.d3m_face_light_backward(
