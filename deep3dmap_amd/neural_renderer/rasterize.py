@@ -273,6 +273,16 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.ptr(sv), _lib.ptr(tri), tri.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces),
             _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), None, B, S, float(near),
             float(far), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+        # which faces own a pixel is known now and only the backward pass needs it: build that list on the side
+        # stream while the sampling / epilogue pass below runs (its own buffer: this node's backward may run late)
+        vis = None
+        if any(ctx.needs_input_grad[:4]):
+            vis = torch.empty(int(L.d3m_visibility_bytes(B, Fp)), dtype=torch.uint8, device=dev)
+            cur, side = torch.cuda.current_stream(), _side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                _lib.check(L.d3m_visibility(_lib.ptr(m["face_index_map"]), _lib.ptr(vis), vis.numel(), B, Fp, S,
+                                            _lib.stream_ptr()), "d3m_visibility")
         # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
         s_out = S // 2 if anti_aliasing else S
         m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
@@ -285,6 +295,9 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
             _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), B, Ft,
             int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_render_lit_epilogue")
+        if vis is not None:
+            cur.wait_stream(side)
+        m["visibility"] = vis
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl)
         ctx.maps = m
@@ -311,7 +324,7 @@ class _RasterizeLit(torch.autograd.Function):
             "d3m_output_epilogue_backward")
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over one compacted list of the faces that own a pixel
-        vis = ops.visibility(m["face_index_map"], faces.shape[1])
+        vis = m["visibility"]
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
         grad_textures = grad_vertices = grad_light = None
