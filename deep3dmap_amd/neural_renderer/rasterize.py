@@ -224,7 +224,8 @@ _side_streams = {}
 
 def _side_stream(device):
     """One extra stream per device for the branch of the lit backward that runs beside the edge gradient."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(device).cuda_stream)       # one per stream that forks
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]

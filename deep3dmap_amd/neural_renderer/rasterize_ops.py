@@ -13,11 +13,13 @@ _workspaces = {}
 
 
 def _workspace(key, nbytes, device):
-    """Scratch buffers are cached per (kind, device) and only ever grow."""
-    buf = _workspaces.get((key, device))
+    """Scratch buffers are cached per (kind, device, stream) and only ever grow: operators that run concurrently on
+    different streams (view groups, the side branch of the lit backward) must not share scratch."""
+    k = (key, device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[(key, device)] = buf
+        _workspaces[k] = buf
     return buf
 
 
