@@ -3,6 +3,6 @@
 for f in tools_dev/lib_v*.so; do
   cp $f deep3dmap_amd/lib/libd3m_raster.so
   echo "== $f"
-  D3M_BENCH_TIMING_EXPERIMENT=1 timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
+  timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d['kernel_ms_per_step']; print(d['value'], d['ms_per_step'], {a:k[a] for a in list(k)[:7]})"
 done
