@@ -133,3 +133,40 @@ def test_forward_equals_oracle_bruteforce_on_random_scenes(S, F, size):
     assert np.array_equal(wm.cpu().numpy(), ref["weight_map"])
     assert np.array_equal(dm.cpu().numpy(), ref["depth_map"])
     assert np.array_equal(fim.cpu().numpy(), ref["face_inv_map"])
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_edge_gradient_crowded_lines_and_clipped_walks(masked):
+    """K4 on a scene built to stress the line kernel: 700 flat 40 x 1.4-pixel faces stacked down a 1024-pixel image,
+    so every column line under them carries > 1024 walk segments (two length-sort chunks), short and long ones mixed;
+    with `masked` the gradient maps vanish outside a band, so walks are clipped to the non-zero extent (and many
+    disappear).  Against the oracle's per-face walk (KCU:245-503)."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    S, n = 1024, 700
+    rng = np.random.default_rng(7 + int(masked))
+    y0 = np.linspace(-0.95, 0.93, n)
+    x0 = rng.uniform(-0.05, -0.03, n)             # every face crosses the columns around x = 0
+    h, w = 1.4 * 2 / S, 40 * 2 / S
+    # counter-clockwise in NDC so that they are front-facing; slightly tilted so edges cross rows too
+    tri = np.stack([np.stack([x0, y0], -1), np.stack([x0 + w, y0 + 0.3 * h], -1), np.stack([x0 + 0.4 * w, y0 + h], -1)], 1)
+    z = rng.uniform(1.0, 2.0, (n, 3, 1))
+    faces = np.concatenate([tri, z], -1)[None].astype(np.float32)
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
+    m = O.raster_forward(faces, rng.uniform(0, 1, (1, 2 * n, 2, 2, 2, 3)).astype(np.float32), S, 0.1, 100.0, 1e-3,
+                         (0.1, 0.2, 0.3), True, True, False)
+    assert (m["face_index_map"] >= 0).sum() > 10000
+    assert ((m["face_index_map"][0, :, S // 2] >= 0).sum()) > 300     # the central column is owned by hundreds of faces
+    g_rgb = rng.normal(size=(1, S, S, 3)).astype(np.float32)
+    g_alpha = rng.normal(size=(1, S, S)).astype(np.float32)
+    if masked:
+        band = np.zeros((1, S, S), np.float32)
+        band[:, 100:900, 380:520] = 1.0
+        g_rgb *= band[..., None]
+        g_alpha *= band
+    gf_ref, _ = O.raster_backward(m, g_rgb, g_alpha, None, True, True, False)
+    fd = _dev(faces)
+    gf = torch.zeros_like(fd)
+    ops.backward_pixel_map(fd, _dev(m["face_index_map"]), _dev(m["rgb_map"]), _dev(m["alpha_map"]), _dev(g_rgb), _dev(g_alpha),
+                           gf, S, 1e-3, True, True)
+    assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
