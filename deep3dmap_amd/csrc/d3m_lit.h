@@ -116,6 +116,34 @@ __device__ __forceinline__ void sample_pixel_lit(const float* __restrict__ faces
     float fr[3];
     sample_setup(face, weight, depth, lt.ts, eps, fl, fr);
     px[0] = px[1] = px[2] = 0;
+    if (lt.ts == 2) {
+        // ts = 2: the sample position is clamped below 1, its integer part is 0, so corner pn is always texel
+        // (pn&1, pn>>1&1, pn>>2&1) of THIS face: the whole 2x2x2 cube is 24 contiguous floats (six 16-byte loads) and
+        // the face's light is loaded once; same products and the same corner order as the general loop below
+        const bool back = fi >= lt.F;
+        const int fo = back ? fi - lt.F : fi;
+        const float4* cube = (const float4*)(lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24);
+        float tex[24];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float4 v = cube[q];
+            tex[4 * q] = v.x; tex[4 * q + 1] = v.y; tex[4 * q + 2] = v.z; tex[4 * q + 3] = v.w;
+        }
+        const float* li = lt.light + 3 * ((size_t)(lt.light_batch > 1 ? bn : 0) * lt.Fp + fi);
+        const float l0 = li[0], l1 = li[1], l2 = li[2];
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc;
+            sample_corner(pn, 2, fl, fr, w, isc);
+            const int rev = ((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1);      // = isc
+            const int idx = back ? pn : rev;                                    // back copy: texel (c,b,a)
+            px[0] += w * (tex[idx * 3 + 0] * l0);
+            px[1] += w * (tex[idx * 3 + 1] * l1);
+            px[2] += w * (tex[idx * 3 + 2] * l2);
+        }
+        return;
+    }
 #pragma unroll
     for (int pn = 0; pn < 8; pn++) {
         float w;
