@@ -51,6 +51,38 @@ __device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& 
     return true;
 }
 
+// ---- per-workgroup aggregation of tile counters ---------------------------------------------------------------
+// The 256 consecutive faces of a workgroup land in a few dozen tiles.  Instead of one (wave-merged) global atomic per
+// (face, tile) pair, the pairs are first counted in a small LDS hash table keyed by the tile (LDS atomics), and each
+// distinct tile then costs ONE global atomic per workgroup.  The wave-merged form spent ~110 us per binning pass on
+// its serial group-discovery loops.
+constexpr int TA_SLOTS = 512;            // power of two; a workgroup touches far fewer distinct tiles
+constexpr int TA_PROBES = 12;
+struct TileAgg {
+    int key[TA_SLOTS];                   // tile id + 1, 0 = empty
+    int cnt[TA_SLOTS];
+    int base[TA_SLOTS];
+};
+
+__device__ __forceinline__ void ta_clear(TileAgg& t) {
+    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x) { t.key[k] = 0; t.cnt[k] = 0; }
+    __syncthreads();
+}
+
+// slot of `tile` (inserted if new) and this pair's rank among the workgroup's pairs of that tile; -1: table too full
+__device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
+    unsigned h = ((unsigned)tile * 2654435761u) >> 23;                 // top 9 bits
+    for (int p = 0; p < TA_PROBES; p++, h = (h + 1) & (TA_SLOTS - 1)) {
+        int k = t.key[h];
+        if (k == 0) k = atomicCAS(&t.key[h], 0, tile + 1);
+        if (k == 0 || k == tile + 1) {
+            rank = atomicAdd(&t.cnt[h], 1);
+            return (int)h;
+        }
+    }
+    return -1;
+}
+
 // ---- pass 1: one lane per (view, face): cull, tile rectangle, per-tile counts ---------------------
 // Also fills the reference's faces_inv scratch (KCU:24-67) when the caller passes it, and -- when the faces come
 // from an indexed mesh -- the dense [B,F,3,3] copy of every front-facing face that the later passes read
@@ -58,6 +90,8 @@ __device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& 
 template <class FS>
 __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
                                                   float* __restrict__ faces_dense_out) {
+    __shared__ TileAgg agg;
+    ta_clear(agg);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int F = bb.F;
     const bool in_range = i < (long)bb.B * F;
@@ -92,14 +126,16 @@ __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* 
         }
         bb.rect[i] = r;
     }
-    // Neighbouring faces land in the same tiles: walk the (at most kcap) tiles of every small face in
-    // lock step and merge equal tile ids within the wave into one atomic.
+    // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
     const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
-    for (int s = 0; __any(s < nt); s++) {
-        const bool has = s < nt;
-        const int tx = has ? tx0 + s % w : 0, ty = has ? ty0 + s / w : 0;
-        wave_grouped_add(bb.tile_count, (size_t)b * bb.T + ty * bb.tiles_x + tx, has, false);
+    for (int s = 0; s < nt; s++) {
+        const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
+        int rank;
+        if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
+        if (agg.key[k]) atomicAdd(&bb.tile_count[agg.key[k] - 1], agg.cnt[k]);
 }
 
 // ---- pass 2: give every tile a slice of `pairs` (one atomic per 256 tiles; order is irrelevant) ---
@@ -124,6 +160,8 @@ __global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
 
 // ---- pass 3: scatter face ids into the per-tile lists ------------------------------------------
 __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
+    __shared__ TileAgg agg;
+    ta_clear(agg);
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
     if (i < (long)bb.B * bb.F) {
@@ -137,13 +175,34 @@ __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
             b = (int)(i / bb.F); f = (int)(i % bb.F);
         }
     }
-    for (int s = 0; __any(s < nt); s++) {
-        const bool has = s < nt;
-        const int tx = has ? tx0 + s % w : 0, ty = has ? ty0 + s / w : 0;
-        const size_t t = (size_t)b * bb.T + ty * bb.tiles_x + tx;
-        const int pos = wave_grouped_add(bb.tile_cursor, t, has, true);
-        if (has) bb.pairs[(size_t)bb.tile_offset[t] + pos] = f;
+    // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a
+    // full table go straight to the global cursor), one cursor atomic per distinct tile, then the scatter
+    constexpr int TA_LOCAL = 4;
+    int packed[TA_LOCAL];
+#pragma unroll
+    for (int s = 0; s < TA_LOCAL; s++) packed[s] = -1;
+    for (int s = 0; s < nt; s++) {
+        const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
+        int rank = 0, slot = -1;
+        if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
+        if (slot >= 0) {
+#pragma unroll
+            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[q] = (slot << 16) | rank;
+        } else {
+            const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
+            bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
+        }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
+        if (agg.key[k]) {
+            const int tile = agg.key[k] - 1;
+            agg.base[k] = bb.tile_offset[tile] + atomicAdd(&bb.tile_cursor[tile], agg.cnt[k]);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < TA_LOCAL; s++)
+        if (packed[s] >= 0) bb.pairs[(size_t)agg.base[packed[s] >> 16] + (packed[s] & 0xFFFF)] = f;
 }
 
 // ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------
