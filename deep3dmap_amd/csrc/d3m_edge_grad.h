@@ -3,28 +3,29 @@
 //
 // The reference runs one thread per face; for every integer crossing d0 of every edge, on both axes,
 // that thread walks the image from the edge out to the image BORDER (KCU:354-414) and inward to the
-// opposite edge (KCU:417-495).  The outward walks are hundreds of pixels long whatever the triangle
-// size: ~6e8 pixel visits x 32 B for 8 views of the 100k-triangle mesh at 512^2, i.e. tens of GB of
-// cache traffic if every walk reads the maps itself.
+// opposite edge (KCU:417-495): 1.35 M walks of ~250 pixels for 8 views of the 100k-triangle mesh at 512^2.
 //
 // LINE-MAJOR formulation.  A walk only ever moves along ONE image line (a row for axis 1, a column for
 // axis 0), and a line is shared by hundreds of walks.  So:
-//   0. k_mark_visible / k_compact_visible   faces that own no pixel cannot contribute: drop them;
-//   1. k_edge_count   SIX lanes per visible face, one per (edge, axis): enumerate crossings exactly as
-//                     the reference does, count the LONG walk segments per lane and per line, reserve
-//                     item slots (wave prefix + one atomic per wave);
-//   2. k_alloc_ranges hand every line a slice of the item index (order-free);
-//   3. k_edge_emit    same lanes: enumerate again; walk SHORT segments in-lane (a handful of pixels)
-//                     and write each long segment as a 48-byte item, indexed under its line;
-//   4. k_edge_lines   one workgroup per (view, axis, line, part): stage the line's maps in LDS ONCE
-//                     (unit stride: column lines read transposed copies of the maps), then one wave
-//                     per item walks 64 pixels per iteration out of LDS and wave-reduces;
-//   5. k_edge_gather  one lane per visible face: its six lanes' sums + their items' results, stored once.
-// No global atomics on the gradient and the result is deterministic.  The reference OVERWRITES the 9
-// entries of every front-facing face (KCU:501-502) and leaves culled ones alone (KCU:270); with the
-// caller's zero-initialised grad_faces (rasterize.py:111, a precondition of the C ABI) writing only the
-// faces that own a pixel is the same thing: every other front-facing face would get zeros.  Per visited pixel the expressions are those of KCU:385-412 / :473-493; the two divisions
-// inside the walk use v_rcp_f32 (1 ulp), far inside the 1e-3 gradient tolerance.
+//   0. visibility     faces that own no pixel cannot contribute: flags + compacted list (shared with the gathered
+//                     texture / depth pass through d3m_visibility);
+//   1. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- packed in both
+//                     orientations (rows, columns), plus each line's non-zero-gradient extent;
+//   2. k_edge_count   a workgroup publishes the crossing ranges of its 42 faces x 6 (edge, axis) lanes in LDS and
+//                     its threads take ONE crossing each per round; counts the segments each line will receive;
+//   3. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
+//   4. k_edge_emit    same flattening: every crossing owns two result slots; segments are clipped to the line's
+//                     extent, short ones walked in-thread, long ones written as 48-byte records in LINE order;
+//   5. k_edge_lines   one workgroup per (view, axis, line): the line's records staged in LDS once, the line's
+//                     segments ordered by length, four segments per wave (one per 16-lane row), factored distance;
+//   6. k_edge_gather  six lanes per visible face add their crossings' slots in order; stored to grad_faces or
+//                     accumulated into the vertex gradient (VertexTarget).
+// Deterministic up to the final vertex atomics.  The reference OVERWRITES the 9 entries of every front-facing face
+// (KCU:501-502) and leaves culled ones alone (KCU:270); with the caller's zero-initialised grad_faces
+// (rasterize.py:111, a precondition of the C ABI) writing only the faces that own a pixel is the same thing: every
+// other front-facing face would get zeros.  Per visited pixel the expressions are those of KCU:385-412 / :473-493
+// regrouped (see "FACTORED DISTANCE" and k_pack_maps); the divisions inside the walk use v_rcp_f32 (1 ulp), far
+// inside the 1e-3 gradient tolerance.
 #pragma once
 #include <type_traits>
 #include "d3m_backward.h"
@@ -75,7 +76,7 @@ struct EdgeWork {
     int2* lane_cross;    // [6*B*F] per (visible face, edge, axis) lane: first crossing within its workgroup, count
     float2* lane_partial;// [6*B*F] overflow sums of that lane (segments whose slot did not fit the workspace)
     int* line_count;     // [B*2*S] long segments per line (zeroed per call)
-    int* line_cursor;    // [B*2*S] (zeroed per call)
+    int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
     int* line_offset;    // [B*2*S]
     int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
     int* vis_block;      // [ceil(B*F/1024)+1] visible faces per 1024-face chunk, then (in place) their exclusive scan

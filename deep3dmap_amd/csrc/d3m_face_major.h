@@ -2,8 +2,8 @@
 //
 // The reference scatters from pixels with float atomics: 24 per covered pixel for the texture cube
 // (KCU:531-538), 9 for the depth gradient (KCU:573-590).  A face owns only the pixels inside its
-// bounding box, so the sums can instead be GATHERED: one lane per visible face walks its (small)
-// bounding box, keeps the sums in registers / LDS and stores them once.  Faces that own no pixel
+// bounding box, so the sums can instead be GATHERED: FM_LANES lanes per visible face share the walk over its
+// (small) bounding box, keep the sums in registers / LDS, combine them and store once.  Faces that own no pixel
 // (culled, hidden or off screen: ~95% of the 2F' faces of a closed mesh) are skipped via a visibility
 // flag; faces with a large bounding box fall back to the per-pixel atomic kernels.
 #pragma once
