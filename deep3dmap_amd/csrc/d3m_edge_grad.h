@@ -168,20 +168,22 @@ __device__ __forceinline__ bool segment_queueable(const Segment& sg) {
 }
 
 // Accumulate one visited pixel: KCU:385-412 (outward) / :470-493 (inward).  Branch-free: a pixel whose
-// diff_grad is <= 0 (KCU:401/:481) is dropped by the final select (so a 0 * inf can never leak in);
-// NaN diff_grad still propagates, as in the reference.
-__device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, float q0, float q1, float m0, float m1,
+// diff_grad is <= 0 (KCU:401/:481) and a term the reference does not evaluate (f0 / f1 false: KCU:403/:408, the edge
+// end lies on this very line) are dropped by SELECTS, never by a multiplication with 0: their quotient can be inf or
+// NaN (an edge parallel to the walk on an integer coordinate makes d1_cross itself NaN).  NaN diff_grad still
+// propagates, as in the reference.
+__device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, float q0, float q1, bool f0, bool f1,
                                             float two_over_is, float eps, float& g0, float& g1) {
     const float t = (float)d1 - d1_cross;
     float dist0 = q0 * t * two_over_is;
     dist0 = (0 < dist0) ? dist0 + eps : dist0 - eps;
     float dist1 = q1 * t * two_over_is;
     dist1 = (0 < dist1) ? dist1 + eps : dist1 - eps;
-    const float c0 = m0 * (diff * __builtin_amdgcn_rcpf(dist0));
-    const float c1 = m1 * (diff * __builtin_amdgcn_rcpf(dist1));
+    const float c0 = diff * __builtin_amdgcn_rcpf(dist0);
+    const float c1 = diff * __builtin_amdgcn_rcpf(dist1);
     const bool skip = diff <= 0;
-    g0 -= skip ? 0.0f : c0;
-    g1 -= skip ? 0.0f : c1;
+    g0 -= (skip || !f0) ? 0.0f : c0;
+    g1 -= (skip || !f1) ? 0.0f : c1;
 }
 
 // reference values of a segment: pixel (line d0, position d1) of `axis` in the ORIGINAL maps
@@ -198,9 +200,7 @@ __device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMap
                                             const Segment& sg, int fn, float two_over_is, float& g0, float& g1) {
     bool have_ref = false;
     SegRef ref = {0, 0, 0, 0};
-    // a multiplier of exactly 0 must not turn an inf/NaN quotient into a NaN: give disabled terms q = 1
     const float q0 = sg.f0 ? sg.q0 : 1.0f, q1 = sg.f1 ? sg.q1 : 1.0f;
-    const float m0 = sg.f0 ? 1.0f : 0.0f, m1 = sg.f1 ? 1.0f : 0.0f;
     for (int d1 = sg.from; d1 <= sg.to; d1++) {
         const size_t idx = line_base + d1;
         const float2 dt = m.dot[idx];
@@ -212,7 +212,7 @@ __device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMap
         diff = __builtin_fmaf(-ref.r, g.y, diff);
         diff = __builtin_fmaf(-ref.g, g.z, diff);
         diff = __builtin_fmaf(-ref.b, g.w, diff);
-        visit_pixel(diff, d1, sg.d1_cross, q0, q1, m0, m1, two_over_is, a.eps, g0, g1);
+        visit_pixel(diff, d1, sg.d1_cross, q0, q1, sg.f0 != 0, sg.f1 != 0, two_over_is, a.eps, g0, g1);
     }
 }
 

@@ -170,3 +170,63 @@ def test_edge_gradient_crowded_lines_and_clipped_walks(masked):
     ops.backward_pixel_map(fd, _dev(m["face_index_map"]), _dev(m["rgb_map"]), _dev(m["alpha_map"]), _dev(g_rgb), _dev(g_alpha),
                            gf, S, 1e-3, True, True)
     assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_backward_operators_differential_fuzz(seed):
+    """Random small scenes through K4 / K5 / K6 against the oracle: triangle sizes from sub-pixel to screen-filling,
+    vertices snapped to pixel centres or pixel edges in some scenes (integer crossings -> the t == 0 pixel of inward
+    walks, shared-edge ties), duplicated and degenerate faces, faces partly or wholly off screen, and gradient maps
+    that are dense, masked to a box (clipped walks) or a single pixel."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 3))
+    S = int(rng.choice([16, 24, 33, 48, 64]))
+    Fn = int(rng.integers(1, 40))
+    size = float(rng.choice([0.03, 0.15, 0.6, 2.0]))
+    xy = rng.uniform(-1.2, 1.2, (B, Fn, 1, 2)) + rng.uniform(-size, size, (B, Fn, 3, 2))
+    mode = seed % 4
+    if mode == 1:                                  # pixel centres: (2i + 1 - S) / S
+        xy = (2 * np.round((xy * S + S - 1) / 2) + 1 - S) / S
+    elif mode == 2:                                # pixel edges
+        xy = np.round(xy * S / 2) * 2 / S
+    faces = np.concatenate([xy, rng.uniform(0.3, 4.0, (B, Fn, 3, 1))], -1).astype(np.float32)
+    if Fn > 3:
+        faces[:, -1] = faces[:, 0]                 # exact duplicate: equal depth, lowest index wins
+        faces[:, -2, 1] = faces[:, -2, 0]          # two coincident vertices: zero area
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
+    F2, ts = faces.shape[1], 2
+    tex = rng.uniform(0, 1, (B, F2, ts, ts, ts, 3)).astype(np.float32)
+    m = O.raster_forward(faces, tex, S, 0.5, 3.5, 1e-3, (0.1, 0.2, 0.3), True, True, True)
+    g_rgb = rng.normal(size=(B, S, S, 3)).astype(np.float32)
+    g_alpha = rng.normal(size=(B, S, S)).astype(np.float32)
+    g_depth = rng.normal(size=(B, S, S)).astype(np.float32)
+    gmode = (seed // 4) % 3
+    if gmode == 1:
+        box = np.zeros((B, S, S), np.float32)
+        box[:, S // 4: 3 * S // 4, S // 3: S - 2] = 1
+        g_rgb, g_alpha = g_rgb * box[..., None], g_alpha * box
+    elif gmode == 2:
+        one = np.zeros((B, S, S), np.float32)
+        one[:, S // 2, S // 2] = 1
+        g_rgb, g_alpha = g_rgb * 0, g_alpha * one
+    gf_ref, gt_ref = O.raster_backward(m, g_rgb, g_alpha, g_depth, True, True, True)
+    fd, td = _dev(faces), _dev(tex)
+    fi, wm, dm = _dev(m["face_index_map"]), _dev(m["weight_map"]), _dev(m["depth_map"])
+    gf = torch.zeros_like(fd)
+    ops.backward_pixel_map(fd, fi, _dev(m["rgb_map"]), _dev(m["alpha_map"]), _dev(g_rgb), _dev(g_alpha), gf, S, 1e-3, True, True)
+    gt = torch.zeros_like(td)
+    ops.backward_textures(fi, _dev(m["sampling_weight_map"]), _dev(m["sampling_index_map"]), _dev(g_rgb), gt, F2, faces=fd)
+    ops.backward_depth_map(fd, dm, fi, _dev(m["face_inv_map"]), wm, _dev(g_depth), gf, S)
+    assert np.isfinite(gf_ref).all() == np.isfinite(gf.cpu().numpy()).all()
+    ok = np.isfinite(gf_ref)
+    scale = max(1.0, float(np.abs(gf_ref[ok]).max())) if ok.any() else 1.0
+    assert np.abs(gf.cpu().numpy()[ok] - gf_ref[ok]).max() <= GRAD_RTOL * scale, (B, S, Fn, size, mode, gmode)
+    assert _grad_close(gt.cpu().numpy(), gt_ref)
+    # and the forward maps of the same scene, bit for bit
+    fi2 = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
+    wm2, dm2 = torch.zeros(B, S, S, 3, device="cuda"), torch.full((B, S, S), 3.5, device="cuda")
+    ops.forward_face_index_map(fd, fi2, wm2, dm2, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), S, 0.5, 3.5, 1, 1, 0)
+    assert np.array_equal(fi2.cpu().numpy(), m["face_index_map"]) and np.array_equal(dm2.cpu().numpy(), m["depth_map"])
+    assert np.array_equal(wm2.cpu().numpy(), m["weight_map"])
