@@ -243,6 +243,7 @@ struct LitFaceArgs {
     float* grad_faces;             // [B,F',9], += (depth gradient), unless vt.gv
     VertexTarget vt;
     int* flags;
+    unsigned* view_mask;           // [F, ceil(B/32)] zeroed, or NULL: bit b of word b/32 = "view b wrote gtex_view[b, f]"
     const int* list;               // compacted visible faces + their count, or NULL: every face is tried
     const int* n_list;
     int B, S;
@@ -276,6 +277,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
     const int fo = fn >= lt.F ? fn - lt.F : fn;
     float* gt = gtex_view + ((size_t)bn * lt.F + fo) * 24;
+    if (sub == 0 && a.view_mask) atomicOr(&a.view_mask[(size_t)fo * ((a.B + 31) >> 5) + (bn >> 5)], 1u << (bn & 31));
     if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
         flags[gi] = FLAG_LARGE;
         for (int t = sub; t < 24; t += FM_LANES) gt[t] = 0.0f;
@@ -448,19 +450,23 @@ __global__ void __launch_bounds__(256) k_sum_over_views(const float* __restrict_
     out[j] = acc;
 }
 
-// The ts == 2 form of the above with flags: one lane per 4 consecutive floats of a face's 24 (six lanes per face),
-// 16-byte loads, the two flag loads shared by four elements.
+// The ts == 2 form of the above: one lane per 4 consecutive floats of a face's 24 (six lanes per face), 16-byte loads.
+// view_mask (written by k_backward_textures_lit_faces) names the views that wrote this face's entry, in view order:
+// typically 4 of 32, found with ffs instead of 2 x B flag loads.
 __global__ void __launch_bounds__(256) k_sum_over_views_ts2(const float4* __restrict__ in, float4* __restrict__ out, long n4,
-                                                           int B, const int* __restrict__ flags, int F, int Fp) {
+                                                           int B, const unsigned* __restrict__ view_mask) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n4) return;
-    const int f = (int)(j / 6);
+    const int f = (int)(j / 6), words = (B + 31) >> 5;
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int b = 0; b < B; b++) {
-        const int* fl = flags + (size_t)b * Fp;
-        if (fl[f] == FLAG_HIDDEN && (Fp == F || fl[F + f] == FLAG_HIDDEN)) continue;
-        const float4 v = in[(size_t)b * n4 + j];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int wd = 0; wd < words; wd++) {
+        unsigned m = view_mask[(size_t)f * words + wd];
+        while (m) {
+            const int b = (wd << 5) + __ffs((int)m) - 1;
+            m &= m - 1;
+            const float4 v = in[(size_t)b * n4 + j];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
     }
     out[j] = acc;
 }

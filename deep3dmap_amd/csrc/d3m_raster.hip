@@ -578,7 +578,9 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
 D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size) {
     if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0) return 0;
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
-    return align_up((size_t)batch_size * num_tri * ts3 * 12, 256) + (size_t)batch_size * num_tri * (fill_back ? 2 : 1) * 4;
+    return align_up((size_t)batch_size * num_tri * ts3 * 12, 256) +
+           align_up((size_t)batch_size * num_tri * (fill_back ? 2 : 1) * 4, 256) +
+           align_up((size_t)num_tri * ((batch_size + 31) / 32) * 4, 256);      // per-view gradients | flags | view masks
 }
 
 D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
@@ -607,6 +609,8 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     float* gview = textures_batch > 1 ? grad_textures : (float*)workspace;
     int* flags = (int*)((char*)workspace + align_up((size_t)B * view_elems * 4, 256));
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
+    unsigned* view_mask = (unsigned*)((char*)flags + align_up((size_t)nf * 4, 256));
+    const size_t mask_bytes = align_up((size_t)num_tri * ((B + 31) / 32) * 4, 256);
     // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
     const bool skip_zero = texture_size == 2 && textures_batch == 1;
     if (!skip_zero) HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
@@ -622,8 +626,10 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
             HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         }
+        const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
+        if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes, st));
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, list, n_list, B, S, eps};
+                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps};
         const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list && all_blocks > 4096 ? 4096 : all_blocks),
                dim3(256), st, fa);
@@ -654,7 +660,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     if (textures_batch == 1) {
         if (skip_zero && (((uintptr_t)gview | (uintptr_t)grad_textures) & 15) == 0)
             LAUNCH("k_sum_over_views", k_sum_over_views_ts2, dim3(blocks_for((long)view_elems / 4, 256)), dim3(256), st,
-                   (const float4*)gview, (float4*)grad_textures, (long)view_elems / 4, B, (const int*)flags, num_tri, lt.Fp);
+                   (const float4*)gview, (float4*)grad_textures, (long)view_elems / 4, B, (const unsigned*)view_mask);
         else
             LAUNCH("k_sum_over_views", k_sum_over_views, dim3(blocks_for((long)view_elems, 256)), dim3(256), st,
                    (const float*)gview, grad_textures, (long)view_elems, B,
