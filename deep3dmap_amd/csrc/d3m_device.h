@@ -191,7 +191,8 @@ struct GroupedAdd {
 
 // Phase 1: group discovery (ballot / readlane only) and ONE atomic per distinct key, issued by the group's leader.
 // Nothing waits for the atomics here: do independent work before wave_grouped_add_end().
-__device__ __forceinline__ GroupedAdd wave_grouped_add_begin(int* counters, size_t key, bool has, bool want_slot) {
+__device__ __forceinline__ GroupedAdd wave_grouped_add_begin(int* counters, size_t key, bool has, bool want_slot,
+                                                             int weight = 1) {
     unsigned long long pending = __ballot(has);
     const int lane = lane_id();
     const uint32_t k32_lo = (uint32_t)key, k32_hi = (uint32_t)((unsigned long long)key >> 32);
@@ -211,8 +212,8 @@ __device__ __forceinline__ GroupedAdd wave_grouped_add_begin(int* counters, size
         pending &= ~same;
     }
     if (has && lane == g.leader) {
-        if (want_slot) g.base = atomicAdd(&counters[key], my_count);
-        else atomicAdd(&counters[key], my_count);
+        if (want_slot) g.base = atomicAdd(&counters[key], my_count * weight);
+        else atomicAdd(&counters[key], my_count * weight);
     }
     return g;
 }
@@ -222,8 +223,8 @@ __device__ __forceinline__ int wave_grouped_add_end(const GroupedAdd& g) {
     return __shfl(g.base, g.leader, 64) + g.rank;
 }
 
-__device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot) {
-    const GroupedAdd g = wave_grouped_add_begin(counters, key, has, want_slot);
+__device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot, int weight = 1) {
+    const GroupedAdd g = wave_grouped_add_begin(counters, key, has, want_slot, weight);
     return want_slot ? wave_grouped_add_end(g) : 0;
 }
 

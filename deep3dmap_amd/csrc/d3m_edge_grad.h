@@ -12,7 +12,8 @@
 //   1. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- packed in both
 //                     orientations (rows, columns), plus each line's non-zero-gradient extent;
 //   2. k_edge_count   a workgroup publishes the crossing ranges of its 42 faces x 6 (edge, axis) lanes in LDS and
-//                     its threads take ONE crossing each per round; counts the segments each line will receive;
+//                     its threads take ONE crossing each per round; bounds the records each line will receive
+//                     (two per crossing) without touching the maps;
 //   3. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
 //   4. k_edge_emit    same flattening: every crossing owns two result slots; segments are clipped to the line's
 //                     extent, short ones walked in-thread, long ones written as 48-byte records in LINE order;
@@ -75,7 +76,7 @@ struct EdgeWork {
     int* n_visible;      // [1]     (zeroed per call)
     int2* lane_cross;    // [6*B*F] per (visible face, edge, axis) lane: first crossing within its workgroup, count
     float2* lane_partial;// [6*B*F] overflow sums of that lane (segments whose slot did not fit the workspace)
-    int* line_count;     // [B*2*S] long segments per line (zeroed per call)
+    int* line_count;     // [B*2*S] upper bound (2 per crossing) of the records each line receives = its slice (zeroed per call)
     int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
     int* line_offset;    // [B*2*S]
     int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
@@ -367,7 +368,9 @@ __device__ __forceinline__ int crossing_lane(const LaneTable& t, int c) {
     return lo;
 }
 
-// ---- 1. per line: how many segments will be queued; per workgroup: how many crossings --------------------
+// ---- 1. per workgroup: how many crossings; per line: an upper bound of the segments it will receive ------------
+// Every crossing yields at most two segments, so 2 x (crossings on the line) bounds the line's record slice without
+// looking at the maps at all (no owner loads, no divisions: those happen once, in k_edge_emit).
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeWork w) {
     __shared__ LaneTable t;
@@ -386,27 +389,14 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
         if (threadIdx.x == 0) w.lane_block[blk] = total;
         for (int c0 = 0; c0 < total; c0 += 256) {
             const int c = c0 + threadIdx.x;
-            bool q_out = false, q_in = false;
             size_t line = 0;
             if (c < total) {
                 const int l = crossing_lane(t, c);
-                const int d0 = t.d0_from[l] + (c - t.pre[l]);
-                const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
-                const AxisMaps& m = a.ax[axis];
-                const size_t vb = (size_t)bn * is * is;
-                Segment so, si;
-                bool has_out, has_in;
-                line = ((size_t)bn * 2 + axis) * is + d0;
-                crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  is - a.nz_lo_inv[line], a.nz_hi1[line] - 1,
-                                  [&](int e0, int e1) { return m.owner(vb + (size_t)e0 * is + e1); }, so, has_out, si,
-                                  has_in);
-                q_out = has_out && segment_queueable(so);
-                q_in = has_in && segment_queueable(si);
+                line = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l] + (c - t.pre[l]);
             }
-            // neighbouring crossings fall on the same lines: merge equal lines within the wave (uniform call sites)
-            wave_grouped_add(w.line_count, line, q_out, false);
-            wave_grouped_add(w.line_count, line, q_in, false);
+            // neighbouring crossings fall on the same lines: merge equal lines within the wave (uniform call site);
+            // every lane stands for the TWO segments its crossing can yield
+            wave_grouped_add(w.line_count, line, c < total, false, 2);
         }
         __syncthreads();                                    // the table is rewritten by the next iteration
     }
