@@ -211,6 +211,13 @@ __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
 // over the 64 lanes, so a chunk of sub-pixel triangles costs a few iterations and a tile-filling
 // triangle costs one iteration per face.  Winners are kept in a 64-entry LDS z-buffer of
 // (ordered depth bits << 32 | face index).
+// order this wave's LDS writes before its later LDS reads (one wave: program order + a compiler/memory fence)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct RasterOut {
     int32_t* face_index_map;
     float* weight_map;
@@ -218,16 +225,27 @@ struct RasterOut {
     float* face_inv_map;   // NULL unless the caller wants the reference's [B,S,S,3,3] map
 };
 
-template <class FS>
-__global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
-    __shared__ float s_face[9][WAVE];
-    __shared__ float s_finv[9][WAVE];
-    __shared__ int s_fid[WAVE];
-    __shared__ uint32_t s_box[WAVE];
-    __shared__ uint32_t s_zkey[WAVE];
-    __shared__ int s_pre[WAVE + 1];
+// W waves per tile: W = 1 when there are enough tiles to fill the chip; W = 4 for small rasters (a few thousand
+// tiles), where the hottest tiles' chunk chains would otherwise run on one wave each with nothing to overlap their
+// latency: the chunks of a tile are dealt to its waves, which share the tile's LDS z-buffer and never wait for one
+// another between chunks (each stages into its own arrays; only the z-buffer is common, through LDS atomics).
+template <class FS, int W>
+__global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
+    __shared__ float s_face_all[W][9][WAVE];
+    __shared__ float s_finv_all[W][9][WAVE];
+    __shared__ int s_fid_all[W][WAVE];
+    __shared__ uint32_t s_box_all[W][WAVE];
+    __shared__ uint32_t s_zkey_all[W][WAVE];
+    __shared__ int s_pre_all[W][WAVE + 1];
     __shared__ unsigned long long s_z[WAVE];
     __shared__ float s_cx[TILE], s_cy[TILE];
+    const int wv = W == 1 ? 0 : (int)(threadIdx.x >> 6);
+    float (&s_face)[9][WAVE] = s_face_all[wv];
+    float (&s_finv)[9][WAVE] = s_finv_all[wv];
+    int (&s_fid)[WAVE] = s_fid_all[wv];
+    uint32_t (&s_box)[WAVE] = s_box_all[wv];
+    uint32_t (&s_zkey)[WAVE] = s_zkey_all[wv];
+    int (&s_pre)[WAVE + 1] = s_pre_all[wv];
 
     // XCD-aware order: consecutive blocks are dealt round-robin to the 8 XCDs, so give XCD x the
     // contiguous tile range [x*per, (x+1)*per): neighbouring tiles (shared faces, shared vertex
@@ -241,16 +259,18 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
     const int S = bb.S;
     const int lane = lane_id();
 
-    if (lane < TILE) s_cx[lane] = pixel_center(px0 + lane, S);
-    else if (lane < 2 * TILE) s_cy[lane - TILE] = pixel_center(py0 + lane - TILE, S);
-    s_z[lane] = ~0ull;
+    if (wv == 0) {
+        if (lane < TILE) s_cx[lane] = pixel_center(px0 + lane, S);
+        else if (lane < 2 * TILE) s_cy[lane - TILE] = pixel_center(py0 + lane - TILE, S);
+        s_z[lane] = ~0ull;
+    }
     if (lane == 0) s_pre[0] = 0;
     __syncthreads();
 
     for (int which = 0; which < 2; which++) {
         const int* list = which == 0 ? bb.pairs + bb.tile_offset[tile] : bb.big_list + (size_t)b * bb.F;
         const int n = which == 0 ? bb.tile_count[tile] : bb.big_count[b];
-        for (int base = 0; base < n; base += WAVE) {
+        for (int base = wv * WAVE; base < n; base += W * WAVE) {
             int cnt = 0;
             if (base + lane < n) {
                 const int fid = list[base + lane];
@@ -284,7 +304,7 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
             const int incl = wave_inclusive_scan(cnt);
             s_pre[lane + 1] = incl;
             const int total = __shfl(incl, 63, 64);
-            __syncthreads();
+            wave_lds_sync();                        // this wave's staging is complete (its own arrays: no block barrier)
             for (int c = lane; c < total; c += WAVE) {
                 int lo = 0, hi = WAVE;                 // s_pre[lo] <= c < s_pre[hi]
 #pragma unroll
@@ -311,9 +331,11 @@ __global__ void __launch_bounds__(64) k_raster_tiles(FS fs, BinBuffers bb, Raste
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_sync();                        // before this wave restages
         }
     }
+    __syncthreads();                                // every wave's bids are in
+    if (wv != 0) return;
 
     // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store.  Pixels
     // nobody covers get the reference's initial values (rasterize.py:50-58: index -1, weights 0, depth far, inverse

@@ -90,6 +90,7 @@ D3M_EXPORT const char* d3m_error_string(int code) {
 // ---------------------------------------------------------------------------------------------------
 static const int KCAP_DEFAULT = 16;   // a face covering more tiles than this is "large"
 static const int KCAP_MAX = 64;
+static const int RASTER_SMALL_GRID = 8192;   // up to this many tiles a tile gets 4 waves instead of 1 (d3m_forward.h)
 
 struct FwdLayout {
     size_t zero_bytes;   // prefix that must be zeroed per call
@@ -160,7 +161,10 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
-    LAUNCH("k_raster_tiles", k_raster_tiles<FS>, dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
+    if (n_tiles <= RASTER_SMALL_GRID)
+        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
+    else
+        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 1>), dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
@@ -182,7 +186,10 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};
-    LAUNCH("k_raster_tiles", k_raster_tiles<DenseFaces>, dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
+    if (n_tiles <= RASTER_SMALL_GRID)
+        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
+    else
+        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1>), dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
