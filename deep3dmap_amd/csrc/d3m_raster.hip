@@ -90,7 +90,7 @@ D3M_EXPORT const char* d3m_error_string(int code) {
 // ---------------------------------------------------------------------------------------------------
 static const int KCAP_DEFAULT = 16;   // a face covering more tiles than this is "large"
 static const int KCAP_MAX = 64;
-static const int RASTER_SMALL_GRID = 8192;   // up to this many tiles a tile gets 4 waves instead of 1 (d3m_forward.h)
+static const int RASTER_SMALL_GRID = 32768;  // up to this many tiles a tile gets 4 waves instead of 1 (d3m_forward.h)
 
 struct FwdLayout {
     size_t zero_bytes;   // prefix that must be zeroed per call
