@@ -196,24 +196,29 @@ __device__ __forceinline__ SegRef load_ref(const EdgeGradArgs& a, int axis, size
     return r;
 }
 
-// short segment, walked straight from global memory by the owning thread: 8 + 16 bytes per pixel
-__device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMaps& m, size_t view_base, size_t line_base,
-                                            const Segment& sg, int fn, float two_over_is, float& g0, float& g1) {
-    bool have_ref = false;
-    SegRef ref = {0, 0, 0, 0};
+// short segment, walked straight from global memory by the owning thread: 8 + 16 bytes per pixel.  Two pixels per
+// round, both records of both pixels requested before any is used, no branch inside: the walk is a chain of memory
+// round trips and nothing else (the lazy, one-record-at-a-time form cost 0.21 ms of the 0.59 ms emit pass).
+__device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMaps& m, size_t line_base, const Segment& sg,
+                                            const SegRef& ref, int fn, float two_over_is, float& g0, float& g1) {
     const float q0 = sg.f0 ? sg.q0 : 1.0f, q1 = sg.f1 ? sg.q1 : 1.0f;
-    for (int d1 = sg.from; d1 <= sg.to; d1++) {
-        const size_t idx = line_base + d1;
-        const float2 dt = m.dot[idx];
-        if (sg.inward && __float_as_int(dt.y) != fn) continue;
-        if (!have_ref) { ref = load_ref(a, sg.axis, view_base, sg.d0, sg.ref_pos); have_ref = true; }
-        const float4 g = m.grad[idx];
+    auto pixel = [&](const float2 dt, const float4 g, int d1, bool on) {
         float diff = dt.x;
         diff = __builtin_fmaf(-ref.alpha, g.x, diff);
         diff = __builtin_fmaf(-ref.r, g.y, diff);
         diff = __builtin_fmaf(-ref.g, g.z, diff);
         diff = __builtin_fmaf(-ref.b, g.w, diff);
+        // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
+        if (!on || (sg.inward && __float_as_int(dt.y) != fn)) diff = 0.0f;
         visit_pixel(diff, d1, sg.d1_cross, q0, q1, sg.f0 != 0, sg.f1 != 0, two_over_is, a.eps, g0, g1);
+    };
+    for (int d1 = sg.from; d1 <= sg.to; d1 += 2) {
+        const bool two = d1 + 1 <= sg.to;
+        const size_t ia = line_base + d1, ib = two ? ia + 1 : ia;
+        const float2 dta = m.dot[ia], dtb = m.dot[ib];
+        const float4 ga = m.grad[ia], gb = m.grad[ib];
+        pixel(dta, ga, d1, true);
+        pixel(dtb, gb, d1 + 1, two);
     }
 }
 
@@ -473,9 +478,13 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             // this thread walks the segment itself (still correct, just serial)
             bool queued[2];
             GroupedAdd ga[2];
+            SegRef refs[2];
 #pragma unroll
             for (int which = 0; which < 2; which++) {       // 0: outward, 1: inward
                 const long slot = 2 * (cbase + c) + which;
+                // reference values of the segment (one pixel of the original maps): requested before anything waits
+                refs[which] = SegRef{0, 0, 0, 0};
+                if (active && has[which]) refs[which] = load_ref(a, axis, base, sg[which].d0, sg[which].ref_pos);
                 queued[which] = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
                                 (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
                 // the line-cursor atomics of both segments go out now and are only waited for after the work below
@@ -487,7 +496,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 uint4 rec0, rec1, rec2;
                 if (queued[which]) {
                     const Segment& q = sg[which];
-                    const SegRef ref = load_ref(a, axis, base, q.d0, q.ref_pos);
+                    const SegRef& ref = refs[which];
                     const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
                     const float s_t = (float)(q.inward ? -q.dir : q.dir);
                     const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
@@ -502,7 +511,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                                       __float_as_uint(-1.0f / qc1));
                 } else if (active) {
                     float g0 = 0, g1 = 0;
-                    if (has[which]) walk_inline(a, m, base, line_base, sg[which], fn, two_over_is, g0, g1);
+                    if (has[which]) walk_inline(a, m, line_base, sg[which], refs[which], fn, two_over_is, g0, g1);
                     if (slot < (long)w.cap) {
                         w.results[slot] = make_float2(g0, g1);
                     } else if (g0 != 0 || g1 != 0) {        // no slot left: fold into the lane's overflow sum
@@ -528,7 +537,10 @@ constexpr int EG_SORT_CHUNK = 1024;  // segments ordered by length at a time (a 
 __device__ __forceinline__ int from0_clamp(int from, int is) { return min(max(from, 0), is - 1); }
 
 // ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
-template <bool USE_RGB, bool USE_ALPHA>
+// PAD: the LDS image of the line has 2*S + 16 entries (only the first S are filled), so the lanes of a row that has
+// finished -- the four rows of a wave advance in lock step with the longest -- keep reading inside the allocation and
+// the per-iteration address clamp disappears; without PAD (large S) the index is clamped.
+template <bool USE_RGB, bool USE_ALPHA, bool PAD>
 __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     const int is = a.S;
@@ -548,14 +560,17 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
     const uint32_t* recs = w.items + ((size_t)w.line_offset[line] + item_lo) * EG_ITEM_DW;    // contiguous records
-    // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T, owner) with
+    // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
-    // visited pixel, both conflict-free (16- and 8-byte lane strides within a 16-lane row).
+    // visited pixel, both conflict-free (16- and 8-byte lane strides within a 16-lane row).  T is kept halved (exact)
+    // because the two packed fma below start BOTH halves of the sum from it.
+    const int n_lds = PAD ? 2 * is + 16 : is;
     float4* s_grd = (float4*)s_line;
-    float2* s_df = (float2*)(s_grd + is);
+    float2* s_df = (float2*)(s_grd + n_lds);
     for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
         s_grd[p] = m.grad[line_base + p];
-        s_df[p] = m.dot[line_base + p];
+        const float2 d = m.dot[line_base + p];
+        s_df[p] = make_float2(0.5f * d.x, d.y);
     }
     __syncthreads();
     // FOUR segments per wave, one per 16-lane row: the segments are short once clipped (tens of pixels), so a whole
@@ -603,34 +618,63 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
         const uint32_t bits = q0v.x & 63u;
         const int from = (int)(q0v.z & 0xFFFF), to = have ? (int)(q0v.z >> 16) : -1, fn = (int)(q0v.x >> 6);
-        const bool inward = bits & 1;
         const float d1_cross = __uint_as_float(q1v.x);
         const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
         const v2f nref_ar = {USE_ALPHA ? -__uint_as_float(q1v.w) : 0.0f, USE_RGB ? -__uint_as_float(q2v.x) : 0.0f};
         const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
-        // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped), clamped at 0 (KCU:401/:481; NaN passes, as in
-        // the reference); inward walks only count the face's own pixels (KCU:470).  Two packed fma + one add.
-        auto dpos_of = [&](const float4 g, const float2 d, bool on) {
-            v2f p = {d.x, 0.0f};
+        // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped): two packed fma + one add.
+        auto diff_of = [&](const float4 g, const float2 d) {
+            v2f p = {d.x, d.x};
             p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
             p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
-            const float diff = p.x + p.y;
-            const bool keep = on && !(diff <= 0) && (!inward || __float_as_int(d.y) == fn);
-            return keep ? diff : 0.0f;
+            return p.x + p.y;
         };
-        // 16 pixels of each row's segment per iteration; t = d1 - d1_cross advances by exact steps
-        int d1 = from + rl;
-        float t = (float)d1 - d1_cross;
+        // A pixel counts if it lies in the segment, its diff_grad is not <= 0 (KCU:401/:481; NaN passes, as in the
+        // reference) and -- inward walks only -- it belongs to the face (KCU:470).  The three conditions are combined
+        // as wave masks on the scalar unit; the vector unit only issues the compares and ONE select.
+        const unsigned long long m_outward = ~__builtin_amdgcn_ballot_w64((bits & 1u) != 0);
+        // the rows advance together: as many 16-pixel steps as the longest of the four needs (a scalar trip count)
+        const int len = to - from + 1;
+        const int max_len = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                                max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        const int n_iter = (max_len + 15) >> 4;
+        float t = (float)(from + rl) - d1_cross;            // t = d1 - d1_cross advances by exact steps
         v2f acc = {0.0f, 0.0f};
-        while (__any(d1 <= to)) {
-            const bool on = d1 <= to;
-            const int dc = on ? d1 : from0_clamp(from, is);          // keep the LDS address inside the line
-            const float dpos = dpos_of(s_grd[dc], s_df[dc], on);
-            const v2f den = u + t;
-            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
-            d1 += 16;
-            t += 16.0f;
+        if (PAD) {
+            const float4* pg = s_grd + from + rl;
+            const float2* pd = s_df + from + rl;
+            const float4* pg_to = s_grd + to;
+            for (int k = 0; k < n_iter; k++) {
+                const float4 g = *pg;
+                const float2 d = *pd;
+                const float diff = diff_of(g, d);
+                const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
+                const float dpos = __builtin_amdgcn_inverse_ballot_w64(keep) ? diff : 0.0f;
+                const v2f den = u + t;
+                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
+                pg += 16;
+                pd += 16;
+                t += 16.0f;
+            }
+        } else {
+            int d1 = from + rl;
+            for (int k = 0; k < n_iter; k++) {
+                const int dc = min(d1, is - 1);                       // keep the LDS address inside the line
+                const float2 d = s_df[dc];
+                const float diff = diff_of(s_grd[dc], d);
+                const unsigned long long keep = __builtin_amdgcn_ballot_w64(d1 <= to) &
+                                                __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
+                const float dpos = __builtin_amdgcn_inverse_ballot_w64(keep) ? diff : 0.0f;
+                const v2f den = u + t;
+                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
+                d1 += 16;
+                t += 16.0f;
+            }
         }
         // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
         float s0 = acc.x, s1 = acc.y;
@@ -642,7 +686,9 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
             const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
             if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
                 const int df = (bits & 8u) ? from : to;
-                const float dpos = dpos_of(s_grd[df], s_df[df], true);
+                const float2 d = s_df[df];
+                const float diff = diff_of(s_grd[df], d);
+                const float dpos = (!(diff <= 0) && (!(bits & 1u) || __float_as_int(d.y) == fn)) ? diff : 0.0f;
                 if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
                 if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
             }
@@ -934,21 +980,30 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
            EG_FACES_PER_BLOCK, w.alloc);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    const size_t smem = (size_t)6 * S * 4;
+    // the padded LDS image (see k_edge_lines) while four workgroups of it still fit a CU beside their sort arrays
+    const size_t smem_pad = (size_t)(2 * S + 16) * 24;
+    const bool pad = smem_pad <= 36 * 1024;
+    const size_t smem = pad ? smem_pad : (size_t)S * 24;
     const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
-#define D3M_LINES(RGB, ALPHA)                                                                                        \
+#define D3M_LINES1(RGB, ALPHA, PADDED)                                                                               \
     do {                                                                                                             \
         if (smem > 64 * 1024) {                                                                                      \
-            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)smem);                                                                      \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, PADDED>,                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_WAVES * 64), smem, st, a, w);                  \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_WAVES * 64), smem, st, a, w); \
     } while (0)
-    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > ~4500)
+#define D3M_LINES(RGB, ALPHA)                                                                                        \
+    do {                                                                                                             \
+        if (pad) D3M_LINES1(RGB, ALPHA, true);                                                                       \
+        else D3M_LINES1(RGB, ALPHA, false);                                                                          \
+    } while (0)
+    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > ~6800)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
+#undef D3M_LINES1
 #undef D3M_LINES
     LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, grad_faces, vt);
     e = hipGetLastError();
