@@ -151,6 +151,17 @@ struct VertexTarget {
     }
 };
 
+// ---- XCD-contiguous work order ---------------------------------------------------------------------
+// Workgroups i and i + 8 share an XCD (observed dispatch order; a speed matter only).  A kernel that strides a fixed
+// grid (a multiple of 8) over n work units hands XCD x the contiguous range [x*per, (x+1)*per): neighbouring units
+// (neighbouring faces: shared map lines) then meet in ONE L2 instead of being fetched into all eight.
+struct XcdOrder {
+    int per;
+    __device__ __forceinline__ explicit XcdOrder(int n) : per((n + 7) >> 3) {}
+    __device__ __forceinline__ bool more(int i) const { return (i >> 3) < per; }
+    __device__ __forceinline__ int unit(int i) const { return (i & 7) * per + (i >> 3); }
+};
+
 // ---- wave-level primitives -----------------------------------------------------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int lane = lane_id();
@@ -180,52 +191,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
-// Wave-aggregated counter bump: lanes with `has` add 1 to counters[key]; lanes sharing a key are merged
-// into ONE atomic issued by an elected leader.  Group discovery (ballot / shuffle only) comes first, so
-// all leaders' atomics go out in a single wave instruction instead of a chain of dependent round trips.
-// Returns this lane's slot (base + rank among equal keys) when `want_slot`: usable both for counting and
-// for cursor-style list fills.
-struct GroupedAdd {
-    int leader, rank, base;     // base: the counter's old value, valid in the leader lane once the atomic has returned
-};
-
-// Phase 1: group discovery (ballot / readlane only) and ONE atomic per distinct key, issued by the group's leader.
-// Nothing waits for the atomics here: do independent work before wave_grouped_add_end().
-__device__ __forceinline__ GroupedAdd wave_grouped_add_begin(int* counters, size_t key, bool has, bool want_slot,
-                                                             int weight = 1) {
-    unsigned long long pending = __ballot(has);
-    const int lane = lane_id();
-    const uint32_t k32_lo = (uint32_t)key, k32_hi = (uint32_t)((unsigned long long)key >> 32);
-    GroupedAdd g{lane, 0, 0};
-    int my_count = 0;
+// Match-any over a wave: the mask of the `has` lanes that hold the same 32-bit key as this lane (undefined in lanes
+// without `has`).  One pass per DISTINCT key -- readlane, one compare, two selects -- and nothing else inside the
+// loop: ranks, counts and leaders are bit counts on the returned mask.  Used to merge the per-line counter updates of
+// a wave into one atomic per distinct line (neighbouring crossings fall on the same lines).
+__device__ __forceinline__ unsigned long long wave_match_any(uint32_t key, bool has) {
+    unsigned long long pending = __builtin_amdgcn_ballot_w64(has);
+    unsigned long long mine = 0;
     while (pending) {
-        const int leader = __ffsll((long long)pending) - 1;                       // wave-uniform
-        const uint32_t l_lo = (uint32_t)__builtin_amdgcn_readlane((int)k32_lo, leader);
-        const uint32_t l_hi = (uint32_t)__builtin_amdgcn_readlane((int)k32_hi, leader);
-        const bool mine = has && k32_lo == l_lo && k32_hi == l_hi;
-        const unsigned long long same = __ballot(mine);
-        if (mine) {
-            g.leader = leader;
-            g.rank = __popcll(same & ((1ull << lane) - 1ull));
-            my_count = __popcll(same);
-        }
+        const int leader = __builtin_ctzll(pending);                                  // wave-uniform
+        const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const bool eq = key == lk;
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(has && eq);
+        if (eq) mine = same;
         pending &= ~same;
     }
-    if (has && lane == g.leader) {
-        if (want_slot) g.base = atomicAdd(&counters[key], my_count * weight);
-        else atomicAdd(&counters[key], my_count * weight);
-    }
-    return g;
+    return mine;
 }
-
-// Phase 2: this lane's slot = the leader's old counter value + rank among the lanes with the same key.
-__device__ __forceinline__ int wave_grouped_add_end(const GroupedAdd& g) {
-    return __shfl(g.base, g.leader, 64) + g.rank;
-}
-
-__device__ __forceinline__ int wave_grouped_add(int* counters, size_t key, bool has, bool want_slot, int weight = 1) {
-    const GroupedAdd g = wave_grouped_add_begin(counters, key, has, want_slot, weight);
-    return want_slot ? wave_grouped_add_end(g) : 0;
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mask_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 }  // namespace d3m

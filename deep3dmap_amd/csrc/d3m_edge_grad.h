@@ -377,11 +377,13 @@ __device__ __forceinline__ int crossing_lane(const LaneTable& t, int c) {
 // Every crossing yields at most two segments, so 2 x (crossings on the line) bounds the line's record slice without
 // looking at the maps at all (no owner loads, no divisions: those happen once, in k_edge_emit).
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeWork w) {
+__global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgeWork w) {
     __shared__ LaneTable t;
-    const int is = a.S;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {      // fixed grid, uniform trip count per workgroup
+    const XcdOrder xo(n_blocks);
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {              // fixed grid, uniform trip count per workgroup
+        const int blk = xo.unit(i);
+        if (blk >= n_blocks) continue;
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
@@ -389,7 +391,6 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
         if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
             const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
             w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
-            w.lane_partial[lane6] = make_float2(0.0f, 0.0f);
         }
         if (threadIdx.x == 0) w.lane_block[blk] = total;
         for (int c0 = 0; c0 < total; c0 += 256) {
@@ -399,9 +400,10 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, EdgeGradArgs a, EdgeW
                 const int l = crossing_lane(t, c);
                 line = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l] + (c - t.pre[l]);
             }
-            // neighbouring crossings fall on the same lines: merge equal lines within the wave (uniform call site);
-            // every lane stands for the TWO segments its crossing can yield
-            wave_grouped_add(w.line_count, line, c < total, false, 2);
+            // neighbouring crossings fall on the same lines: one atomic per distinct line of the wave (uniform call
+            // site); every lane stands for the TWO segments its crossing can yield
+            const unsigned long long same = wave_match_any((uint32_t)line, c < total);
+            if (c < total && lane_id() == __builtin_ctzll(same)) atomicAdd(&w.line_count[line], 2 * __popcll(same));
         }
         __syncthreads();                                    // the table is rewritten by the next iteration
     }
@@ -446,7 +448,10 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     const int is = a.S;
     const float two_over_is = 2.0f / (float)is;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const XcdOrder xo(n_blocks);
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
+        const int blk = xo.unit(i);
+        if (blk >= n_blocks) continue;
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
@@ -456,19 +461,28 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             const bool active = c < total;
             Segment sg[2];
             bool has[2] = {false, false};
-            int l = 0, fn = 0, axis = 0;
+            int l = 0, fn = 0, axis = 0, d0 = 0;
             size_t base = 0, line = 0;
+            int nz_lo_inv = 0, nz_hi1 = 0;
+            long slice_end = 0;
             if (active) {
                 l = crossing_lane(t, c);
-                const int d0 = t.d0_from[l] + (c - t.pre[l]);
+                d0 = t.d0_from[l] + (c - t.pre[l]);
                 const int bn = t.bn_axis[l] >> 1;
                 axis = t.bn_axis[l] & 1;
                 fn = t.fn[l];
                 base = (size_t)bn * is * is;
-                const AxisMaps& mo = a.ax[axis];
                 line = ((size_t)bn * 2 + axis) * is + d0;
+                nz_lo_inv = a.nz_lo_inv[line];
+                nz_hi1 = a.nz_hi1[line];
+                slice_end = (long)w.line_offset[line] + w.line_count[line];
+            }
+            // the lanes of the wave that share this lane's line (found while the four loads above are in flight)
+            const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
+            if (active) {
+                const AxisMaps& mo = a.ax[axis];
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  is - a.nz_lo_inv[line], a.nz_hi1[line] - 1,
+                                  is - nz_lo_inv, nz_hi1 - 1,
                                   [&](int e0, int e1) { return mo.owner(base + (size_t)e0 * is + e1); }, sg[0], has[0],
                                   sg[1], has[1]);
             }
@@ -477,7 +491,6 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             // queued only if the slot and its line's whole slice fit the capacity the workspace gives; otherwise
             // this thread walks the segment itself (still correct, just serial)
             bool queued[2];
-            GroupedAdd ga[2];
             SegRef refs[2];
 #pragma unroll
             for (int which = 0; which < 2; which++) {       // 0: outward, 1: inward
@@ -486,10 +499,18 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 refs[which] = SegRef{0, 0, 0, 0};
                 if (active && has[which]) refs[which] = load_ref(a, axis, base, sg[which].d0, sg[which].ref_pos);
                 queued[which] = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
-                                (long)w.line_offset[line] + w.line_count[line] <= (long)w.cap;
-                // the line-cursor atomics of both segments go out now and are only waited for after the work below
-                ga[which] = wave_grouped_add_begin(w.line_cursor, line, queued[which], true);     // uniform call site
+                                slice_end <= (long)w.cap;
             }
+            // Record positions: the lanes of the wave that share a line take consecutive places under that line's
+            // cursor (outward segments first) with ONE atomic per distinct line, sent now and only waited for after
+            // the work below.
+            const unsigned long long q_out = same & __builtin_amdgcn_ballot_w64(queued[0]),
+                                     q_in = same & __builtin_amdgcn_ballot_w64(queued[1]);
+            const int n_out = __popcll(q_out), group_leader = active ? __builtin_ctzll(same) : 0;
+            const int rank[2] = {mask_rank(q_out), n_out + mask_rank(q_in)};
+            int cursor_base = 0;
+            if (active && lane_id() == group_leader && n_out + __popcll(q_in) > 0)
+                cursor_base = atomicAdd(&w.line_cursor[line], n_out + __popcll(q_in));
 #pragma unroll
             for (int which = 0; which < 2; which++) {
                 const long slot = 2 * (cbase + c) + which;
@@ -521,7 +542,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                     }
                 }
                 // records are stored in LINE order (the line kernel streams its slice), slots in crossing order
-                const int in_line = wave_grouped_add_end(ga[which]);
+                const int in_line = __shfl(cursor_base, group_leader, 64) + rank[which];
                 if (queued[which]) {
                     uint4* rec = (uint4*)(w.items + ((size_t)w.line_offset[line] + in_line) * EG_ITEM_DW);
                     rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
@@ -705,7 +726,10 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* _
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const XcdOrder xo(n_blocks);
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
+        const int blk = xo.unit(i);
+        if (blk >= n_blocks) continue;
         const int t = threadIdx.x;
         const int pos = blk * EG_FACES_PER_BLOCK + t / 6, ea = t % 6;
         const bool on = t < EG_FACES_PER_BLOCK * 6 && pos < n_vis;
@@ -762,13 +786,19 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
                                                   const float* __restrict__ grgb, float4* __restrict__ grad_row,
                                                   float2* __restrict__ dot_row, float4* __restrict__ grad_col,
                                                   float2* __restrict__ dot_col, int* __restrict__ nz_lo_inv,
-                                                  int* __restrict__ nz_hi1, int S) {
+                                                  int* __restrict__ nz_hi1, int S, float2* __restrict__ lane_partial,
+                                                  const int* __restrict__ n_visible) {
     __shared__ float4 t_grad[32][33];
     __shared__ float2 t_dot[32][33];
     __shared__ int s_col_lo_inv[32], s_col_hi1[32];
     if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
     const int b = blockIdx.z;
+    {   // the overflow sums of the (visible face, edge, axis) lanes start at zero (k_edge_emit adds, k_edge_gather reads)
+        const long n_threads = (long)gridDim.x * gridDim.y * gridDim.z * 256;
+        const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        for (long i = me; i < (long)*n_visible * 6; i += n_threads) lane_partial[i] = make_float2(0.0f, 0.0f);
+    }
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const size_t plane = (size_t)b * S * S;
@@ -862,6 +892,20 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
     return hipGetLastError();
 }
 
+// count -> crossing base per workgroup -> record slice per line
+template <class FS>
+inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, int B, int S, hipStream_t st) {
+    const long nf = (long)B * fs.num_faces(), nl = (long)B * 2 * S;
+    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
+    LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, S, w);
+    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
+           EG_FACES_PER_BLOCK, w.alloc);
+    LAUNCH("k_alloc_ranges", k_alloc_ranges, dim3((unsigned)((nl + 255) / 256)), dim3(256), st, (const int*)w.line_count,
+           w.line_offset, w.alloc + 1, nl);
+    return hipGetLastError();
+}
+
 // ---- host side ----------------------------------------------------------------------------------------
 struct EdgeLayout {
     size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
@@ -912,7 +956,7 @@ template <class FS>
 int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis, int B,
                   float eps, void* ws, size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
-    if (S > 65535 || F > (1 << 26)) return 1;                   // item packing limits (D3M_ERR_INVALID)
+    if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + 1024) return 2;       // D3M_ERR_WORKSPACE
     char* p = (char*)ws;
@@ -941,30 +985,15 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     float4* grad_col = (float4*)(p + L.off_grad_col);
     float2* dot_col = (float2*)(p + L.off_dot_col);
     // per-call counters; the visibility flags too unless the caller brought a d3m_visibility
-    hipError_t e = shared_vis ? zero_async(p + L.off_line_count, L.zero_bytes - (L.off_line_count - L.off_zero), st)
-                              : zero_async(p + L.off_zero, L.zero_bytes, st);
+    const size_t zero_from = shared_vis ? L.off_line_count : L.off_zero;
+    hipError_t e = zero_async(p + zero_from, L.off_zero + L.zero_bytes - zero_from, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     if (shared_vis) {
         w.visible = shared_vis->flags;
         w.visible_list = shared_vis->list;
         w.n_visible = shared_vis->count;
     }
-    LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
-           m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
-           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
-           (int*)(p + L.off_nz_hi), S);
-    EdgeGradArgs a;
-    a.ax[0] = AxisMaps{grad_col, dot_col};
-    a.ax[1] = AxisMaps{grad_row, dot_row};
-    a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
-    a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
-    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
     const long nf = (long)B * F, nl = (long)B * 2 * S;
-    // worst-case grids (every face visible); workgroups past n_visible exit on their first load
-    const dim3 gl((unsigned)((nl + 255) / 256));
-    // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device)
-    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    const dim3 g6((unsigned)(g6_full < 8192 ? g6_full : 8192));
     if (!shared_vis) {
         LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
                m.face_index_map, w.visible, B, F, S);
@@ -975,12 +1004,23 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
         LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.visible_list,
                (const int*)w.vis_block, nf);
     }
-    LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, a, w);
-    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
-           EG_FACES_PER_BLOCK, w.alloc);
-    LAUNCH("k_alloc_ranges", k_alloc_ranges, gl, dim3(256), st, (const int*)w.line_count, w.line_offset, w.alloc + 1, nl);
+    LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
+           m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
+           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
+           (int*)(p + L.off_nz_hi), S, w.lane_partial, (const int*)w.n_visible);
+    EdgeGradArgs a;
+    a.ax[0] = AxisMaps{grad_col, dot_col};
+    a.ax[1] = AxisMaps{grad_row, dot_row};
+    a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
+    a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
+    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
+    // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device);
+    // workgroups past n_visible exit on their first load
+    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
+    e = launch_edge_count(fs, w, B, S, st);
+    if (e != hipSuccess) { *last_err = (int)e; return 3; }
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    // the padded LDS image (see k_edge_lines) while four workgroups of it still fit a CU beside their sort arrays
     const size_t smem_pad = (size_t)(2 * S + 16) * 24;
     const bool pad = smem_pad <= 36 * 1024;
     const size_t smem = pad ? smem_pad : (size_t)S * 24;

@@ -380,7 +380,9 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
     const int sub = threadIdx.x % FM_LANES, slot = threadIdx.x / FM_LANES;
     if (a.list) {
         const int n = *a.n_list;
-        for (long base = (long)blockIdx.x * FM_FACES_PER_BLOCK; base < n; base += (long)gridDim.x * FM_FACES_PER_BLOCK) {
+        const XcdOrder xo((n + FM_FACES_PER_BLOCK - 1) / FM_FACES_PER_BLOCK);       // neighbouring faces share map lines
+        for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
+            const long base = (long)xo.unit(i) * FM_FACES_PER_BLOCK;
             if (base + slot < n) lit_face_backward(a, a.list[base + slot], sub);
         }
     } else {

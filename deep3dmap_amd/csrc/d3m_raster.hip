@@ -286,8 +286,7 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
     VisibilityView vis;
     if (visibility) vis = visibility_view(visibility, (long)batch_size * num_faces);
     return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, batch_size, eps, workspace, workspace_bytes,
-                         (hipStream_t)stream,
-                         &g_last_hip_error);
+                         (hipStream_t)stream, &g_last_hip_error);
 }
 
 // scratch of the gathered (face-major) backward passes: one int per face
@@ -638,7 +637,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps};
         const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
-        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list && all_blocks > 4096 ? 4096 : all_blocks),
+        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
