@@ -588,7 +588,10 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const int n_lds = PAD ? 2 * is + 16 : is;
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + n_lds);
-    for (int p = threadIdx.x; p < is; p += EG_LINE_WAVES * 64) {
+    // only the line's non-zero-gradient extent is staged: every segment was clipped to it (crossing_segments)
+    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
+    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_WAVES * 64) {
         s_grd[p] = m.grad[line_base + p];
         const float2 d = m.dot[line_base + p];
         s_df[p] = make_float2(0.5f * d.x, d.y);
