@@ -28,16 +28,28 @@ struct LaunchTimer {
         }
     }
 };
+// Developer builds only (-DD3M_DEV_SKIP, tools_dev/): kernels whose name appears in $D3M_SKIP are not launched, to
+// see what a kernel costs on the critical path of a captured step.  Results are then wrong by construction.
+#ifdef D3M_DEV_SKIP
+#include <cstdlib>
+#include <cstring>
+inline bool d3m_dev_skip(const char* name) {
+    static const char* list = getenv("D3M_SKIP");
+    return list && strstr(list, name);
+}
+#else
+inline bool d3m_dev_skip(const char*) { return false; }
+#endif
 #define LAUNCH(name, kernel, grid, block, stream, ...)                          \
     do {                                                                        \
         LaunchTimer lt__(name, stream);                                         \
-        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
+        if (!d3m_dev_skip(name)) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
     } while (0)
 
 #define LAUNCH_SMEM(name, kernel, grid, block, smem, stream, ...)               \
     do {                                                                        \
         LaunchTimer lt__(name, stream);                                         \
-        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
+        if (!d3m_dev_skip(name)) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
     } while (0)
 
 // Zero-fill as a KERNEL (not hipMemsetAsync): inside a captured HIP graph a memset becomes a memset node, and on

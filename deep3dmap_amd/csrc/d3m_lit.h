@@ -303,12 +303,20 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     BoxCursor c(x0, x1, y0, sub);
     for (int i = sub; i < area; i += FM_LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
-        if (face_index_map[p] != fn) continue;
-        const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-        const float g0 = grad_rgb_map[3 * p + 0], g1 = grad_rgb_map[3 * p + 1], g2 = grad_rgb_map[3 * p + 2];
-        const float depth = depth_map[p];
+        // Everything the pixel could contribute is requested together with its owner (ONE round trip per step of
+        // the scan instead of two); a pixel of another face then computes on stand-in values with zero gradients
+        // (selected, never multiplied away: its own weights / depth belong to a different triangle).
+        const bool own = face_index_map[p] == fn;
+        const float lw0 = weight_map[3 * p], lw1 = weight_map[3 * p + 1], lw2 = weight_map[3 * p + 2];
+        const float lg0 = grad_rgb_map[3 * p + 0], lg1 = grad_rgb_map[3 * p + 1], lg2 = grad_rgb_map[3 * p + 2];
+        const float ld = depth_map[p], lgd = grad_depth_map ? grad_depth_map[p] : 0.0f;
+        if (!__builtin_amdgcn_ballot_w64(own)) continue;                  // nobody in the wave owns its pixel
+        const float third = 1.0f / 3.0f;
+        const float weight[3] = {own ? lw0 : third, own ? lw1 : third, own ? lw2 : third};
+        const float g0 = own ? lg0 : 0.0f, g1 = own ? lg1 : 0.0f, g2 = own ? lg2 : 0.0f;
+        const float depth = own ? ld : 1.0f;
         if (grad_depth_map) {
-            const float g = grad_depth_map[p], depth2 = depth * depth;
+            const float g = own ? lgd : 0.0f, depth2 = depth * depth;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float z_k = fc[3 * k + 2];
