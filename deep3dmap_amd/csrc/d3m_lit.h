@@ -266,7 +266,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const int S = a.S;
     const float eps = a.eps;
     const int Fp = lt.Fp;
-    if (flags[gi] == FLAG_HIDDEN) return;
+    if (!a.list && flags[gi] == FLAG_HIDDEN) return;              // a listed face is visible: no flag round trip
     const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
     const float* face = faces + (size_t)gi * 9;
     float fc[9];
@@ -300,6 +300,12 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
             for (int l2 = 0; l2 < 3; l2++) dtmp[k] += -finv[3 * l2 + k] / fc[3 * l2 + 2];     // KCU:582
         }
     }
+    // what the epilogue needs, requested now: this lane's texel (sub) of the face's cube and the face's light
+    const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
+    const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
+    const int to = fn >= lt.F ? ((sub & 1) << 2) | (sub & 2) | ((sub >> 2) & 1) : sub;   // (a,b,c) -> (c,b,a) for ts = 2
+    const float* tex = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24 + to * 3;
+    const float tx[3] = {tex[0], tex[1], tex[2]};
     BoxCursor c(x0, x1, y0, sub);
     for (int i = sub; i < area; i += FM_LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
@@ -359,22 +365,20 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
             }
         }
     }
-    if (sub != 0) return;
-    const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
-    const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
-    float gl[3] = {0, 0, 0};
-    const float* tex = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24;
+    // epilogue, one texel per lane (the face's 8 lanes hold all 24 sums after quad_sum): light and texel were requested
+    // before the scan
+    float mine[3] = {0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-        const int to = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float g = acc[t * 3 + c];
-            gt[to * 3 + c] = g * li[c];          // plain store: see the kernel comment
-            gl[c] += g * tex[to * 3 + c];
-        }
+        if (sub == t) { mine[0] = acc[3 * t]; mine[1] = acc[3 * t + 1]; mine[2] = acc[3 * t + 2]; }
     }
-    if (grad_light) {
+    float gl[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        gt[to * 3 + c] = mine[c] * li[c];          // plain store: see the kernel comment
+        gl[c] = quad_sum(mine[c] * tx[c]);
+    }
+    if (grad_light && sub == 0) {
         atomicAdd(&grad_light[3 * (size_t)lrow + 0], gl[0]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 1], gl[1]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 2], gl[2]);
