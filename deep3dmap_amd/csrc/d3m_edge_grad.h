@@ -740,11 +740,19 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* _
         if (on) {
             const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
             g = w.lane_partial[(size_t)pos * 6 + ea];
-            const long first = 2 * ((long)w.lane_block[blk] + lc.x), last = first + 2 * (long)lc.y;
-            for (long k = first; k < last && k < (long)w.cap; k++) {     // slots past cap were folded into lane_partial
-                const float2 r = w.results[k];
-                g.x += r.x;
-                g.y += r.y;
+            // slots (2c, 2c+1) of the lane's crossings c, contiguous and 16-byte aligned: one float4 per crossing, four
+            // crossings requested per round, added in slot order; slots past cap were folded into lane_partial
+            const long c_first = (long)w.lane_block[blk] + lc.x, c_last = min(c_first + (long)lc.y, (long)(w.cap >> 1));
+            const float4* res4 = (const float4*)w.results;
+            for (long c = c_first; c < c_last; c += 4) {
+                float4 r[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) r[j] = c + j < c_last ? res4[c + j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    g.x += r[j].x; g.y += r[j].y;
+                    g.x += r[j].z; g.y += r[j].w;
+                }
             }
         }
         s_g[t] = g;
@@ -966,6 +974,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     size_t cap = (ws_bytes - L.fixed_bytes - 768) / EG_BYTES_PER_ITEM;
     cap = cap > 256 ? cap - 128 : 0;                            // slack for the two 256-byte alignments below
     if (cap > 0x7FFFFF00) cap = 0x7FFFFF00;
+    cap &= ~(size_t)1;                                          // a crossing's two slots stay together (k_edge_gather)
     EdgeWork w;
     w.visible = (int*)(p + L.off_visible);
     w.line_count = (int*)(p + L.off_line_count);
