@@ -135,7 +135,7 @@ __device__ __forceinline__ void crossing_segments(float p00, float p01, float p1
     sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
     sg.q1 = (p10 - p00) / (fd0 - p00);
     // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
-    if (owner(d0, d1_in) == fn) {
+    if (owner(d0, d1_in, direction) == fn) {
         const int d1_limit = (0 < direction) ? is - 1 : 0;
         out = sg;
         out.from = max(max(min(d1_out, d1_limit), 0), nz_lo);
@@ -196,29 +196,33 @@ __device__ __forceinline__ SegRef load_ref(const EdgeGradArgs& a, int axis, size
     return r;
 }
 
+// one pixel of an in-thread walk (record dt = (T, owner), g = gradients); `on` false = not part of the segment
+__device__ __forceinline__ void inline_pixel(const Segment& sg, const SegRef& ref, int fn, const float2 dt, const float4 g,
+                                             int d1, bool on, float two_over_is, float eps, float& g0, float& g1) {
+    float diff = dt.x;
+    diff = __builtin_fmaf(-ref.alpha, g.x, diff);
+    diff = __builtin_fmaf(-ref.r, g.y, diff);
+    diff = __builtin_fmaf(-ref.g, g.z, diff);
+    diff = __builtin_fmaf(-ref.b, g.w, diff);
+    // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
+    if (!on || (sg.inward && __float_as_int(dt.y) != fn)) diff = 0.0f;
+    visit_pixel(diff, d1, sg.d1_cross, sg.f0 ? sg.q0 : 1.0f, sg.f1 ? sg.q1 : 1.0f, sg.f0 != 0, sg.f1 != 0, two_over_is, eps,
+                g0, g1);
+}
+
 // short segment, walked straight from global memory by the owning thread: 8 + 16 bytes per pixel.  Two pixels per
 // round, both records of both pixels requested before any is used, no branch inside: the walk is a chain of memory
 // round trips and nothing else (the lazy, one-record-at-a-time form cost 0.21 ms of the 0.59 ms emit pass).
 __device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMaps& m, size_t line_base, const Segment& sg,
-                                            const SegRef& ref, int fn, float two_over_is, float& g0, float& g1) {
-    const float q0 = sg.f0 ? sg.q0 : 1.0f, q1 = sg.f1 ? sg.q1 : 1.0f;
-    auto pixel = [&](const float2 dt, const float4 g, int d1, bool on) {
-        float diff = dt.x;
-        diff = __builtin_fmaf(-ref.alpha, g.x, diff);
-        diff = __builtin_fmaf(-ref.r, g.y, diff);
-        diff = __builtin_fmaf(-ref.g, g.z, diff);
-        diff = __builtin_fmaf(-ref.b, g.w, diff);
-        // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
-        if (!on || (sg.inward && __float_as_int(dt.y) != fn)) diff = 0.0f;
-        visit_pixel(diff, d1, sg.d1_cross, q0, q1, sg.f0 != 0, sg.f1 != 0, two_over_is, a.eps, g0, g1);
-    };
-    for (int d1 = sg.from; d1 <= sg.to; d1 += 2) {
-        const bool two = d1 + 1 <= sg.to;
+                                            int from, int to, const SegRef& ref, int fn, float two_over_is, float& g0,
+                                            float& g1) {
+    for (int d1 = from; d1 <= to; d1 += 2) {
+        const bool two = d1 + 1 <= to;
         const size_t ia = line_base + d1, ib = two ? ia + 1 : ia;
         const float2 dta = m.dot[ia], dtb = m.dot[ib];
         const float4 ga = m.grad[ia], gb = m.grad[ib];
-        pixel(dta, ga, d1, true);
-        pixel(dtb, gb, d1 + 1, two);
+        inline_pixel(sg, ref, fn, dta, ga, d1, true, two_over_is, a.eps, g0, g1);
+        inline_pixel(sg, ref, fn, dtb, gb, d1 + 1, two, two_over_is, a.eps, g0, g1);
     }
 }
 
@@ -465,6 +469,8 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             size_t base = 0, line = 0;
             int nz_lo_inv = 0, nz_hi1 = 0;
             long slice_end = 0;
+            float2 near_dot[2] = {make_float2(0, 0), make_float2(0, 0)};
+            float4 near_grad[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
             if (active) {
                 l = crossing_lane(t, c);
                 d0 = t.d0_from[l] + (c - t.pre[l]);
@@ -481,10 +487,19 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
             if (active) {
                 const AxisMaps& mo = a.ax[axis];
+                // The owner of the in-pixel decides about the outward walk.  Its record and that of its inward
+                // neighbour -- the first two pixels of the inward walk, which on small faces is the whole walk -- are
+                // requested in the same round trip.
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
                                   is - nz_lo_inv, nz_hi1 - 1,
-                                  [&](int e0, int e1) { return mo.owner(base + (size_t)e0 * is + e1); }, sg[0], has[0],
-                                  sg[1], has[1]);
+                                  [&](int e0, int e1, int dir) {
+                                      const size_t i0 = base + (size_t)e0 * is + e1;
+                                      const size_t i1 = base + (size_t)e0 * is + min(max(e1 - dir, 0), is - 1);
+                                      near_dot[0] = mo.dot[i0]; near_grad[0] = mo.grad[i0];
+                                      near_dot[1] = mo.dot[i1]; near_grad[1] = mo.grad[i1];
+                                      return __float_as_int(near_dot[0].y);
+                                  },
+                                  sg[0], has[0], sg[1], has[1]);
             }
             const AxisMaps& m = a.ax[axis];
             const size_t line_base = base + (line % is) * is;
@@ -532,7 +547,19 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                                       __float_as_uint(-1.0f / qc1));
                 } else if (active) {
                     float g0 = 0, g1 = 0;
-                    if (has[which]) walk_inline(a, m, line_base, sg[which], refs[which], fn, two_over_is, g0, g1);
+                    if (has[which]) {
+                        const Segment& q = sg[which];
+                        int from = q.from, to = q.to;
+                        if (which == 1 && q.oriented) {     // the in-pixel and its inward neighbour are already here
+                            const int n0 = q.d1_in, n1 = q.d1_in - q.dir;
+                            inline_pixel(q, refs[1], fn, near_dot[0], near_grad[0], n0, from <= n0 && n0 <= to, two_over_is,
+                                         a.eps, g0, g1);
+                            inline_pixel(q, refs[1], fn, near_dot[1], near_grad[1], n1, from <= n1 && n1 <= to, two_over_is,
+                                         a.eps, g0, g1);
+                            if (0 < q.dir) to = min(to, n0 - 2); else from = max(from, n0 + 2);
+                        }
+                        walk_inline(a, m, line_base, q, from, to, refs[which], fn, two_over_is, g0, g1);
+                    }
                     if (slot < (long)w.cap) {
                         w.results[slot] = make_float2(g0, g1);
                     } else if (g0 != 0 || g1 != 0) {        // no slot left: fold into the lane's overflow sum
