@@ -87,51 +87,62 @@ __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
 // Also fills the reference's faces_inv scratch (KCU:24-67) when the caller passes it, and -- when the faces come
 // from an indexed mesh -- the dense [B,F,3,3] copy of every front-facing face that the later passes read
 // (vertices_to_faces + fill_back without a pass of its own; culled faces are never read again).
-template <class FS>
+// PAIRED (an indexed mesh with fill_back): face Ft+f is face f with its vertices in reverse order, and at most one
+// of the two is front-facing -- one lane loads the three vertices once and handles both copies, instead of a second
+// lane repeating the index and vertex gathers only to find its copy culled.
+template <class FS, bool PAIRED>
 __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
                                                   float* __restrict__ faces_dense_out) {
     __shared__ TileAgg agg;
     ta_clear(agg);
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int F = bb.F;
-    const bool in_range = i < (long)bb.B * F;
-    const int b = in_range ? (int)(i / F) : 0, f = in_range ? (int)(i % F) : 0;
-    uint2 r = make_uint2(RECT_NONE, 0);
-    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;     // empty
-    bool small = false;
-    if (in_range) {
+    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int F = bb.F, Fl = PAIRED ? F / 2 : F;          // faces per view: all / handled by one lane each
+    const bool in_range = lane_i < (long)bb.B * Fl;
+    const int b = in_range ? (int)(lane_i / Fl) : 0, f0 = in_range ? (int)(lane_i % Fl) : 0;
+    float loaded[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (in_range) fs.load(b, f0, loaded);
+#pragma unroll
+    for (int side = 0; side < (PAIRED ? 2 : 1); side++) {
+        const int f = f0 + side * Fl;
+        const long i = (long)b * F + f;
         float face[9];
-        fs.load(b, f, face);
-        if (!backside(face)) {
-            if (faces_dense_out) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
-            }
-            if (faces_inv) {
-                float fi[9];
-                face_inverse(face, bb.S, fi);
+        for (int k = 0; k < 9; k++) face[k] = side == 0 ? loaded[k] : loaded[(2 - k / 3) * 3 + k % 3];
+        uint2 r = make_uint2(RECT_NONE, 0);
+        int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;     // empty
+        bool small = false;
+        if (in_range) {
+            if (!backside(face)) {
+                if (faces_dense_out) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = fi[k];
-            }
-            int x0, x1, y0, y1;
-            if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
-                tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE;
-                r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
-                small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
-                if (!small) {
-                    const int pos = atomicAdd(&bb.big_count[b], 1);
-                    bb.big_list[(size_t)b * F + pos] = f;
+                    for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
+                }
+                if (faces_inv) {
+                    float fi[9];
+                    face_inverse(face, bb.S, fi);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) faces_inv[i * 9 + k] = fi[k];
+                }
+                int x0, x1, y0, y1;
+                if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
+                    tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE;
+                    r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+                    small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
+                    if (!small) {
+                        const int pos = atomicAdd(&bb.big_count[b], 1);
+                        bb.big_list[(size_t)b * F + pos] = f;
+                    }
                 }
             }
+            bb.rect[i] = r;
         }
-        bb.rect[i] = r;
-    }
-    // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
-    const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
-    for (int s = 0; s < nt; s++) {
-        const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
-        int rank;
-        if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
+        // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
+        const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
+        for (int s = 0; s < nt; s++) {
+            const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
+            int rank;
+            if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)

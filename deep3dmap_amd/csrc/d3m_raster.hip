@@ -156,7 +156,8 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", k_bin_count<FS>, dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv, (float*)nullptr);
+    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv,
+           (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
     LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
@@ -179,8 +180,12 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", k_bin_count<IndexedFaces>, dim3(blocks_for(nf, 256)), dim3(256), st, ifs, bb, (float*)nullptr,
-           faces_out);
+    if (ifs.fill_back)      // one lane per index triple, both copies
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, 256)), dim3(256), st, ifs, bb,
+               (float*)nullptr, faces_out);
+    else
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, 256)), dim3(256), st, ifs, bb,
+               (float*)nullptr, faces_out);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
     LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
