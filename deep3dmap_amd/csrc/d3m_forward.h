@@ -170,20 +170,39 @@ __global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
 }
 
 // ---- pass 3: scatter face ids into the per-tile lists ------------------------------------------
+// PAIRED (fill_back): one lane per (face f, face F/2 + f) pair -- normally exactly one of the two has a rectangle, so
+// every lane has work; should both have one (zero-area faces), the second goes straight to the global cursors.
+template <bool PAIRED>
 __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
     __shared__ TileAgg agg;
     ta_clear(agg);
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Fl = PAIRED ? bb.F / 2 : bb.F;
     int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
-    if (i < (long)bb.B * bb.F) {
-        const uint2 r = bb.rect[i];
+    if (lane_i < (long)bb.B * Fl) {
+        b = (int)(lane_i / Fl);
+        const int f0 = (int)(lane_i % Fl);
+        uint2 r = bb.rect[(size_t)b * bb.F + f0];
+        f = f0;
+        if (PAIRED) {
+            const uint2 r1 = bb.rect[(size_t)b * bb.F + f0 + Fl];
+            if (r.x == RECT_NONE) { r = r1; f = f0 + Fl; }
+            else if (r1.x != RECT_NONE) {             // both copies listed: the second one the plain way
+                const int ax0 = r1.x & 0xFFFF, ay0 = r1.x >> 16, aw = (int)(r1.y & 0xFFFF) - ax0 + 1;
+                const int an = aw * ((int)(r1.y >> 16) - ay0 + 1);
+                for (int s2 = 0; s2 < (an > bb.kcap ? 0 : an); s2++) {
+                    const int tile = b * bb.T + (ay0 + s2 / aw) * bb.tiles_x + ax0 + s2 % aw;
+                    const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
+                    bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f0 + Fl;
+                }
+            }
+        }
         if (r.x != RECT_NONE) {
             tx0 = r.x & 0xFFFF; ty0 = r.x >> 16;
             const int tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
             w = tx1 - tx0 + 1;
             nt = w * (ty1 - ty0 + 1);
             if (nt > bb.kcap) nt = 0;                 // lives in big_list
-            b = (int)(i / bb.F); f = (int)(i % bb.F);
         }
     }
     // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a

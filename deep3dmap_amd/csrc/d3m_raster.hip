@@ -159,7 +159,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv,
            (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     if (n_tiles <= RASTER_SMALL_GRID)
@@ -187,7 +187,8 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, 256)), dim3(256), st, ifs, bb,
                (float*)nullptr, faces_out);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    LAUNCH("k_bin_fill", k_bin_fill, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
+    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, 256)), dim3(256), st, bb);
+    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};
