@@ -267,6 +267,8 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     __shared__ uint32_t s_box_all[W][WAVE];
     __shared__ uint32_t s_zkey_all[W][WAVE];
     __shared__ int s_pre_all[W][WAVE + 1];
+    constexpr int RING = 2 * WAVE;             // survivors of the cheap tests waiting for the expensive ones
+    __shared__ unsigned short s_ring_all[W][RING];
     __shared__ unsigned long long s_z[WAVE];
     __shared__ float s_cx[TILE], s_cy[TILE];
     const int wv = W == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -276,6 +278,7 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     uint32_t (&s_box)[WAVE] = s_box_all[wv];
     uint32_t (&s_zkey)[WAVE] = s_zkey_all[wv];
     int (&s_pre)[WAVE + 1] = s_pre_all[wv];
+    unsigned short (&s_ring)[RING] = s_ring_all[wv];
 
     // XCD-aware order: consecutive blocks are dealt round-robin to the 8 XCDs, so give XCD x the
     // contiguous tile range [x*per, (x+1)*per): neighbouring tiles (shared faces, shared vertex
@@ -335,32 +338,59 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
             s_pre[lane + 1] = incl;
             const int total = __shfl(incl, 63, 64);
             wave_lds_sync();                        // this wave's staging is complete (its own arrays: no block barrier)
-            for (int c = lane; c < total; c += WAVE) {
-                int lo = 0, hi = WAVE;                 // s_pre[lo] <= c < s_pre[hi]
+            // Two phases.  A: every (face, pixel) candidate of the chunk takes the cheap tests (early z, the three
+            // half-plane tests); the ~30 % that pass are appended to a small ring in LDS.  B: whenever the ring holds a
+            // full wave of survivors (and at the end), all 64 lanes do the expensive part -- barycentrics and depth with
+            // their seven correctly-rounded divisions -- instead of a third of them.
+            int head = 0, count = 0;                   // wave-uniform
+            auto resolve = [&](int n) {
+                if (lane < n) {
+                    const uint32_t ent = s_ring[(head + lane) & (RING - 1)];
+                    const int lo = (int)(ent & 63), lx = (int)((ent >> 6) & 7), ly = (int)(ent >> 9);
+                    float face[9], finv[9], w[3], zp;
 #pragma unroll
-                for (int it = 0; it < 6; it++) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_pre[mid] <= c) lo = mid; else hi = mid;
-                }
-                const int local = c - s_pre[lo];
-                const uint32_t box = s_box[lo];
-                const int bw = (box >> 8) & 15;
-                const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
-                const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
-                if (s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32)) continue;      // early z (see above)
-                float face[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) face[k] = s_face[k][lo];
-                if (inside_face(face, s_cx[lx], s_cy[ly])) {
-                    float finv[9], w[3], zp;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) finv[k] = s_finv[k][lo];
+                    for (int k = 0; k < 9; k++) { face[k] = s_face[k][lo]; finv[k] = s_finv[k][lo]; }
                     if (weights_depth(face, finv, px0 + lx, py0 + ly, near, far, w, zp)) {
                         const unsigned long long key = ((unsigned long long)ordered_bits(zp) << 32) | (uint32_t)s_fid[lo];
                         atomicMin(&s_z[ly * TILE + lx], key);
                     }
                 }
+            };
+            for (int c0 = 0; c0 < total; c0 += WAVE) {
+                const int c = c0 + lane;
+                bool pass = false;
+                uint32_t ent = 0;
+                if (c < total) {
+                    int lo = 0, hi = WAVE;                 // s_pre[lo] <= c < s_pre[hi]
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pre[mid] <= c) lo = mid; else hi = mid;
+                    }
+                    const int local = c - s_pre[lo];
+                    const uint32_t box = s_box[lo];
+                    const int bw = (box >> 8) & 15;
+                    const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
+                    const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
+                    if (!(s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32))) {      // early z (see above)
+                        float face[9];
+#pragma unroll
+                        for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : s_face[k][lo];
+                        pass = inside_face(face, s_cx[lx], s_cy[ly]);
+                        ent = (uint32_t)lo | ((uint32_t)lx << 6) | ((uint32_t)ly << 9);
+                    }
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) s_ring[(head + count + mask_rank(m)) & (RING - 1)] = (unsigned short)ent;
+                count += __popcll(m);
+                wave_lds_sync();
+                if (count >= WAVE) {
+                    resolve(WAVE);
+                    head = (head + WAVE) & (RING - 1);
+                    count -= WAVE;
+                }
             }
+            if (count > 0) resolve(count);
             wave_lds_sync();                        // before this wave restages
         }
     }
