@@ -191,6 +191,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Inclusive running maximum over the 64 lanes (unsigned; 0 is the identity): four row_shr steps inside each 16-lane
+// row, then the two row broadcasts -- six DPP moves, no LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32_or0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_max_scan(uint32_t v) {
+    v = max(v, dpp_u32_or0<0x111, 0xF>(v));     // row_shr:1
+    v = max(v, dpp_u32_or0<0x112, 0xF>(v));     // row_shr:2
+    v = max(v, dpp_u32_or0<0x114, 0xF>(v));     // row_shr:4
+    v = max(v, dpp_u32_or0<0x118, 0xF>(v));     // row_shr:8
+    v = max(v, dpp_u32_or0<0x142, 0xA>(v));     // row_bcast:15 -> rows 1 and 3
+    v = max(v, dpp_u32_or0<0x143, 0xC>(v));     // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // Match-any over a wave: the mask of the `has` lanes that hold the same 32-bit key as this lane (undefined in lanes
 // without `has`).  One pass per DISTINCT key -- readlane, one compare, two selects -- and nothing else inside the
 // loop: ranks, counts and leaders are bit counts on the returned mask.  Used to merge the per-line counter updates of

@@ -269,6 +269,8 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     __shared__ int s_pre_all[W][WAVE + 1];
     constexpr int RING = 2 * WAVE;             // survivors of the cheap tests waiting for the expensive ones
     __shared__ unsigned short s_ring_all[W][RING];
+    constexpr int HEADS = 16 * WAVE;           // candidates per window of the owner marks (one uint4 per lane)
+    __shared__ __attribute__((aligned(16))) unsigned char s_head_all[W][HEADS];
     __shared__ unsigned long long s_z[WAVE];
     __shared__ float s_cx[TILE], s_cy[TILE];
     const int wv = W == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -279,6 +281,7 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     uint32_t (&s_zkey)[WAVE] = s_zkey_all[wv];
     int (&s_pre)[WAVE + 1] = s_pre_all[wv];
     unsigned short (&s_ring)[RING] = s_ring_all[wv];
+    unsigned char (&s_head)[HEADS] = s_head_all[wv];
 
     // XCD-aware order: consecutive blocks are dealt round-robin to the 8 XCDs, so give XCD x the
     // contiguous tile range [x*per, (x+1)*per): neighbouring tiles (shared faces, shared vertex
@@ -356,38 +359,48 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                     }
                 }
             };
-            for (int c0 = 0; c0 < total; c0 += WAVE) {
-                const int c = c0 + lane;
-                bool pass = false;
-                uint32_t ent = 0;
-                if (c < total) {
-                    int lo = 0, hi = WAVE;                 // s_pre[lo] <= c < s_pre[hi]
-#pragma unroll
-                    for (int it = 0; it < 6; it++) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_pre[mid] <= c) lo = mid; else hi = mid;
-                    }
-                    const int local = c - s_pre[lo];
-                    const uint32_t box = s_box[lo];
-                    const int bw = (box >> 8) & 15;
-                    const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
-                    const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
-                    if (!(s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32))) {      // early z (see above)
-                        float face[9];
-#pragma unroll
-                        for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : s_face[k][lo];
-                        pass = inside_face(face, s_cx[lx], s_cy[ly]);
-                        ent = (uint32_t)lo | ((uint32_t)lx << 6) | ((uint32_t)ly << 9);
-                    }
-                }
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                if (pass) s_ring[(head + count + mask_rank(m)) & (RING - 1)] = (unsigned short)ent;
-                count += __popcll(m);
+            // Which face a candidate belongs to: every face marks the first of its candidates with its lane number;
+            // the owner of candidate c is then the running maximum of the marks up to c (six DPP steps and a carry)
+            // instead of a binary search through six dependent LDS reads.  Windows of HEADS candidates.
+            int carry = 0;                              // wave-uniform: mark of the last candidate so far
+            for (int w0 = 0; w0 < total; w0 += HEADS) {
+                reinterpret_cast<uint4*>(s_head)[lane] = make_uint4(0, 0, 0, 0);
                 wave_lds_sync();
-                if (count >= WAVE) {
-                    resolve(WAVE);
-                    head = (head + WAVE) & (RING - 1);
-                    count -= WAVE;
+                const int start = incl - cnt;
+                if (cnt > 0 && start >= w0 && start < w0 + HEADS) s_head[start - w0] = (unsigned char)(lane + 1);
+                wave_lds_sync();
+                const int wend = min(total, w0 + HEADS);
+                for (int c0 = w0; c0 < wend; c0 += WAVE) {
+                    const int c = c0 + lane;
+                    uint32_t own = wave_max_scan(c < wend ? (uint32_t)s_head[c - w0] : 0u);
+                    own = max(own, (uint32_t)carry);
+                    carry = __builtin_amdgcn_readlane((int)own, 63);
+                    bool pass = false;
+                    uint32_t ent = 0;
+                    if (c < wend) {
+                        const int lo = (int)own - 1;
+                        const int local = c - s_pre[lo];
+                        const uint32_t box = s_box[lo];
+                        const int bw = (box >> 8) & 15;
+                        const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
+                        const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
+                        if (!(s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32))) {      // early z (see above)
+                            float face[9];
+#pragma unroll
+                            for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : s_face[k][lo];
+                            pass = inside_face(face, s_cx[lx], s_cy[ly]);
+                            ent = (uint32_t)lo | ((uint32_t)lx << 6) | ((uint32_t)ly << 9);
+                        }
+                    }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                    if (pass) s_ring[(head + count + mask_rank(m)) & (RING - 1)] = (unsigned short)ent;
+                    count += __popcll(m);
+                    wave_lds_sync();
+                    if (count >= WAVE) {
+                        resolve(WAVE);
+                        head = (head + WAVE) & (RING - 1);
+                        count -= WAVE;
+                    }
                 }
             }
             if (count > 0) resolve(count);
