@@ -78,7 +78,8 @@ struct EdgeWork {
     float2* lane_partial;// [6*B*F] overflow sums of that lane (segments whose slot did not fit the workspace)
     int* line_count;     // [B*2*S] upper bound (2 per crossing) of the records each line receives = its slice (zeroed per call)
     int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
-    int* line_offset;    // [B*2*S]
+    int4* line_info;     // [B*2*S] what a crossing needs to know about its line, in one load: (S - first pixel of the
+                         //         non-zero-gradient extent, last + 1, first record of the slice, slice length)
     int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
     int* vis_block;      // [ceil(B*F/1024)+1] visible faces per 1024-face chunk, then (in place) their exclusive scan
     int* lane_block;     // [ceil(B*F/42)+1]   crossings per k_edge_count workgroup iteration, then their scan
@@ -413,8 +414,9 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgeWork w) {
     }
 }
 
-// ---- 2. order-free range allocation: offsets[i] = slice start for counts[i] (one atomic per 256) ----
-__global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ counts, int* __restrict__ offsets,
+// ---- 2. order-free range allocation: slice start for counts[i] (one atomic per 256), packed with the line's extent ----
+__global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ counts, const int* __restrict__ nz_lo_inv,
+                                                     const int* __restrict__ nz_hi1, int4* __restrict__ line_info,
                                                      int* __restrict__ cursor, long n) {
     __shared__ int s_wave[4];
     __shared__ int s_base;
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
         s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
     }
     __syncthreads();
-    if (i < n) offsets[i] = s_base + s_wave[wv] + incl - c;
+    if (i < n) line_info[i] = make_int4(nz_lo_inv[i], nz_hi1[i], s_base + s_wave[wv] + incl - c, c);
 }
 
 // ---- 3. walk short segments, emit long ones ------------------------------------------------------------
@@ -467,8 +469,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
             bool has[2] = {false, false};
             int l = 0, fn = 0, axis = 0, d0 = 0;
             size_t base = 0, line = 0;
-            int nz_lo_inv = 0, nz_hi1 = 0;
-            long slice_end = 0;
+            int4 li = make_int4(0, 0, 0, 0);              // the line's extent and record slice
             float2 near_dot[2] = {make_float2(0, 0), make_float2(0, 0)};
             float4 near_grad[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
             if (active) {
@@ -479,11 +480,9 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 fn = t.fn[l];
                 base = (size_t)bn * is * is;
                 line = ((size_t)bn * 2 + axis) * is + d0;
-                nz_lo_inv = a.nz_lo_inv[line];
-                nz_hi1 = a.nz_hi1[line];
-                slice_end = (long)w.line_offset[line] + w.line_count[line];
+                li = w.line_info[line];
             }
-            // the lanes of the wave that share this lane's line (found while the four loads above are in flight)
+            // the lanes of the wave that share this lane's line (found while the load above is in flight)
             const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
             if (active) {
                 const AxisMaps& mo = a.ax[axis];
@@ -491,7 +490,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 // neighbour -- the first two pixels of the inward walk, which on small faces is the whole walk -- are
                 // requested in the same round trip.
                 crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  is - nz_lo_inv, nz_hi1 - 1,
+                                  is - li.x, li.y - 1,
                                   [&](int e0, int e1, int dir) {
                                       const size_t i0 = base + (size_t)e0 * is + e1;
                                       const size_t i1 = base + (size_t)e0 * is + min(max(e1 - dir, 0), is - 1);
@@ -514,7 +513,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 refs[which] = SegRef{0, 0, 0, 0};
                 if (active && has[which]) refs[which] = load_ref(a, axis, base, sg[which].d0, sg[which].ref_pos);
                 queued[which] = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
-                                slice_end <= (long)w.cap;
+                                (long)li.z + li.w <= (long)w.cap;
             }
             // Record positions: the lanes of the wave that share a line take consecutive places under that line's
             // cursor (outward segments first) with ONE atomic per distinct line, sent now and only waited for after
@@ -571,7 +570,7 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
                 // records are stored in LINE order (the line kernel streams its slice), slots in crossing order
                 const int in_line = __shfl(cursor_base, group_leader, 64) + rank[which];
                 if (queued[which]) {
-                    uint4* rec = (uint4*)(w.items + ((size_t)w.line_offset[line] + in_line) * EG_ITEM_DW);
+                    uint4* rec = (uint4*)(w.items + ((size_t)li.z + in_line) * EG_ITEM_DW);
                     rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
                 }
             }
@@ -607,7 +606,8 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
     const size_t line_base = bn * is * is + (size_t)d0 * is;
-    const uint32_t* recs = w.items + ((size_t)w.line_offset[line] + item_lo) * EG_ITEM_DW;    // contiguous records
+    const int4 li = w.line_info[line];
+    const uint32_t* recs = w.items + ((size_t)li.z + item_lo) * EG_ITEM_DW;    // contiguous records
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
     // visited pixel, both conflict-free (16- and 8-byte lane strides within a 16-lane row).  T is kept halved (exact)
@@ -616,8 +616,8 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + n_lds);
     // only the line's non-zero-gradient extent is staged: every segment was clipped to it (crossing_segments)
-    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
-    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    const int p_lo = __builtin_amdgcn_readfirstlane(is - li.x);
+    const int p_hi = __builtin_amdgcn_readfirstlane(li.y - 1);
     for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_WAVES * 64) {
         s_grd[p] = m.grad[line_base + p];
         const float2 d = m.dot[line_base + p];
@@ -932,7 +932,8 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
 
 // count -> crossing base per workgroup -> record slice per line
 template <class FS>
-inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, int B, int S, hipStream_t st) {
+inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, const int* nz_lo_inv, const int* nz_hi1, int B, int S,
+                                    hipStream_t st) {
     const long nf = (long)B * fs.num_faces(), nl = (long)B * 2 * S;
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
@@ -940,7 +941,7 @@ inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, int B, int S, hipS
     LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
            EG_FACES_PER_BLOCK, w.alloc);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, dim3((unsigned)((nl + 255) / 256)), dim3(256), st, (const int*)w.line_count,
-           w.line_offset, w.alloc + 1, nl);
+           nz_lo_inv, nz_hi1, w.line_info, w.alloc + 1, nl);
     return hipGetLastError();
 }
 
@@ -975,7 +976,7 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     // at most half of the faces can be front-facing AND own a pixel only if ... no such bound: size for all
     L.off_lane_cross = o;   o += eg_align(nf * 6 * 8);
     L.off_lane_partial = o; o += eg_align(nf * 6 * 8);
-    L.off_line_offset = o;  o += eg_align(nl * 4);
+    L.off_line_offset = o;  o += eg_align(nl * 16);
     L.off_vis_block = o;    o += eg_align((nf / EG_COMPACT_CHUNK + 2) * 4);
     L.off_lane_block = o;   o += eg_align((nf / EG_FACES_PER_BLOCK + 2) * 4);
     L.off_items = o;
@@ -1011,7 +1012,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     w.visible_list = (int*)(p + L.off_visible_list);
     w.lane_cross = (int2*)(p + L.off_lane_cross);
     w.lane_partial = (float2*)(p + L.off_lane_partial);
-    w.line_offset = (int*)(p + L.off_line_offset);
+    w.line_info = (int4*)(p + L.off_line_offset);
     w.vis_block = (int*)(p + L.off_vis_block);
     w.lane_block = (int*)(p + L.off_lane_block);
     w.items = (uint32_t*)(p + L.off_items);
@@ -1057,7 +1058,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     // workgroups past n_visible exit on their first load
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
-    e = launch_edge_count(fs, w, B, S, st);
+    e = launch_edge_count(fs, w, a.nz_lo_inv, a.nz_hi1, B, S, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
     const size_t smem_pad = (size_t)(2 * S + 16) * 24;
