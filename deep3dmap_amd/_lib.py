@@ -23,6 +23,11 @@ class D3MVertexTarget(ctypes.Structure):
                 ("fill_back", _I)]
 
 
+class D3MFitTargets(ctypes.Structure):
+    _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
+                ("loss", _P)]
+
+
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
 
 _SIGNATURES = {
@@ -57,7 +62,9 @@ _SIGNATURES = {
     "d3m_forward_texture_sampling_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_textures_lit_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
-                                     _P]),
+                                     _P, _P]),
+    "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
+    "d3m_render_fit_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
                                        _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -181,6 +181,13 @@ __global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __res
 // from a zero-initialised rgb_map), alpha = covered; then vertical flip, HWC->CHW and the 2x2 mean when
 // anti-aliasing (rasterize.py:305-326).  rgb_blended / alpha_map are the internal-resolution maps the backward
 // pass reads.
+// The multi-view fit objective (deep3dmap_amd/multiview.py; the composition of photometric_loss on rgb and depth and
+// silhouette_loss that k_fit_loss_* evaluate on finished images) evaluated where the images are produced.
+struct FitTargets {
+    const float *rgb_t, *depth_t, *alpha_t, *mask;   // OUTPUT image layout [B,3,s,s] / [B,s,s]; all NULL = no objective
+    float* partials;                                  // [4 * gridDim.x]: sum |rgb - t| m, sum |depth - t| m, sum m, sum (alpha - t)^2
+};
+
 __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __restrict__ faces, LitTextures lt,
                                                             const int32_t* __restrict__ face_index_map,
                                                             const float* __restrict__ weight_map,
@@ -188,42 +195,113 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
                                                             const float* __restrict__ background, int bg_b,
                                                             float* __restrict__ rgb_blended, float* __restrict__ alpha_map,
                                                             float* __restrict__ rgb_out, float* __restrict__ alpha_out,
-                                                            float* __restrict__ depth_out, int B, int S, int aa, float eps) {
+                                                            float* __restrict__ depth_out, int B, int S, int aa, float eps,
+                                                            FitTargets fit) {
+    __shared__ float s_part[4];
     const int s = aa ? S / 2 : S;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * s * s) return;
-    const int b = (int)(i / ((long)s * s));
-    const int yo = (int)((i / s) % s), xo = (int)(i % s);
-    const int n = aa ? 2 : 1;
-    const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
-    float acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
-    for (int dy = 0; dy < n; dy++) {
-        for (int dx = 0; dx < n; dx++) {
-            const int yi = S - 1 - (yo * n + dy), xi = xo * n + dx;
-            const size_t p = ((size_t)b * S + yi) * S + xi;
-            const int fi = face_index_map[p];
-            const float depth = depth_map[p];
-            float v[3] = {bg[0], bg[1], bg[2]};
-            if (fi >= 0) {
-                const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
-                sample_pixel_lit(faces, lt, B, b, fi, weight, depth, eps, v);
-            }
+    float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
+    if (i < (long)B * s * s) {
+        const int b = (int)(i / ((long)s * s));
+        const int yo = (int)((i / s) % s), xo = (int)(i % s);
+        const int n = aa ? 2 : 1;
+        const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
+        float acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
+        for (int dy = 0; dy < n; dy++) {
+            for (int dx = 0; dx < n; dx++) {
+                const int yi = S - 1 - (yo * n + dy), xi = xo * n + dx;
+                const size_t p = ((size_t)b * S + yi) * S + xi;
+                const int fi = face_index_map[p];
+                const float depth = depth_map[p];
+                float v[3] = {bg[0], bg[1], bg[2]};
+                if (fi >= 0) {
+                    const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                    sample_pixel_lit(faces, lt, B, b, fi, weight, depth, eps, v);
+                }
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                rgb_blended[3 * p + k] = v[k];
-                acc_rgb[k] += v[k];
+                for (int k = 0; k < 3; k++) {
+                    rgb_blended[3 * p + k] = v[k];
+                    acc_rgb[k] += v[k];
+                }
+                const float mask = fi >= 0 ? 1.0f : 0.0f;
+                if (alpha_map) alpha_map[p] = mask;
+                acc_a += mask;
+                acc_d += depth;
             }
-            const float mask = fi >= 0 ? 1.0f : 0.0f;
-            if (alpha_map) alpha_map[p] = mask;
-            acc_a += mask;
-            acc_d += depth;
+        }
+        const float inv = aa ? 0.25f : 1.0f;
+        if (rgb_out) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] = acc_rgb[k] * inv;
+        }
+        if (alpha_out) alpha_out[i] = acc_a * inv;
+        if (depth_out) depth_out[i] = acc_d * inv;
+        if (fit.partials) {                               // same terms as k_fit_loss_reduce
+            const float m = fit.mask[i];
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                t_rgb += fabsf(acc_rgb[k] * inv - fit.rgb_t[(((size_t)b * 3 + k) * s + yo) * s + xo]) * m;
+            t_d = fabsf(acc_d * inv - fit.depth_t[i]) * m;
+            t_m = m;
+            const float d = acc_a * inv - fit.alpha_t[i];
+            t_sse = d * d;
         }
     }
-    const float inv = aa ? 0.25f : 1.0f;
+    if (fit.partials) {
+        t_rgb = block_sum_256(t_rgb, s_part);
+        t_d = block_sum_256(t_d, s_part);
+        t_m = block_sum_256(t_m, s_part);
+        t_sse = block_sum_256(t_sse, s_part);
+        if (threadIdx.x == 0) {
+            float* o = fit.partials + 4 * (size_t)blockIdx.x;
+            o[0] = t_rgb; o[1] = t_d; o[2] = t_m; o[3] = t_sse;
+        }
+    }
+}
+
+// totals[0..3] = the four sums over `n` workgroup partials, totals[4] = *loss = the objective (k_fit_loss_finish for
+// the tens of thousands of partials the fused epilogue leaves: 1024 lanes, 16-byte loads)
+__global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restrict__ partials, int n, float pixels,
+                                                         float* __restrict__ totals, float* __restrict__ loss) {
+    __shared__ float4 s_wave[16];
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float4 v = partials[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+    if (lane_id() == 0) s_wave[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < 16; k++) { t.x += s_wave[k].x; t.y += s_wave[k].y; t.z += s_wave[k].z; t.w += s_wave[k].w; }
+        totals[0] = t.x; totals[1] = t.y; totals[2] = t.z; totals[3] = t.w;
+        const float l = (t.x / (3.0f * t.z) + t.w / pixels) + t.y / t.z;
+        totals[4] = l;
+        *loss = l;
+    }
+}
+
+// The objective's gradient written straight into the internal-resolution maps the backward operators read (no
+// anti-aliasing): k_fit_loss_grad composed with the flip / CHW->HWC of k_output_epilogue_backward.  The image values
+// are those of the maps: rgb_blended, alpha_map, depth_map (k_render_lit_epilogue's outputs without pooling).
+__global__ void __launch_bounds__(256) k_fit_grad_maps(const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
+                                                      const float* __restrict__ depth_map, FitTargets fit,
+                                                      const float* __restrict__ totals, const float* __restrict__ grad_out,
+                                                      float* __restrict__ g_rgb_map, float* __restrict__ g_alpha_map,
+                                                      float* __restrict__ g_depth_map, int B, int S) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)B * S * S) return;
+    const int b = (int)(p / ((long)S * S));
+    const int yi = (int)((p / S) % S), xi = (int)(p % S);
+    const size_t hw = (size_t)S * S, o = (size_t)b * hw + (size_t)(S - 1 - yi) * S + xi;
+    const float go = grad_out ? *grad_out : 1.0f, den = totals[2], m = fit.mask[o];
+    auto sgn = [](float d) { return d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f); };
 #pragma unroll
-    for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] = acc_rgb[k] * inv;
-    if (alpha_out) alpha_out[i] = acc_a * inv;
-    if (depth_out) depth_out[i] = acc_d * inv;
+    for (int c = 0; c < 3; c++)
+        g_rgb_map[3 * p + c] = sgn(rgb_map[3 * p + c] - fit.rgb_t[o + (size_t)(2 * b + c) * hw]) * m / (3.0f * den) * go;
+    if (g_depth_map) g_depth_map[p] = sgn(depth_map[p] - fit.depth_t[o]) * m / den * go;
+    if (g_alpha_map) g_alpha_map[p] = 2.0f * (alpha_map[p] - fit.alpha_t[o]) / (float)hw * go;
 }
 
 // backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of

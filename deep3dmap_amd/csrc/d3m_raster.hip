@@ -565,25 +565,62 @@ D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float*
     return check_launch();
 }
 
+D3M_EXPORT size_t d3m_render_fit_scratch_floats(int batch_size, int image_size) {
+    if (batch_size <= 0 || image_size <= 0) return 0;
+    return 8 + 4 * (size_t)blocks_for((long)batch_size * image_size * image_size, 256);      // totals | partials
+}
+
+static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {
+    ft = FitTargets{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!fit) return D3M_OK;
+    if (!fit->rgb_target || !fit->depth_target || !fit->alpha_target || !fit->mask || !fit->scratch || !fit->loss)
+        return D3M_ERR_INVALID;
+    ft = FitTargets{fit->rgb_target, fit->depth_target, fit->alpha_target, fit->mask, fit->scratch + 8};
+    return D3M_OK;
+}
+
 D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
                                        int light_batch, const int32_t* face_index_map, const float* weight_map,
                                        const float* depth_map, const float* background, int background_batch,
                                        float* rgb_blended, float* alpha_map, float* rgb_out, float* alpha_out,
                                        float* depth_out, int batch_size, int num_tri, int fill_back, int image_size,
-                                       int texture_size, float eps, int anti_aliasing, d3m_stream_t stream) {
-    if (!faces || !face_index_map || !weight_map || !depth_map || !background || !rgb_blended || !rgb_out ||
+                                       int texture_size, float eps, int anti_aliasing, const d3m_fit_targets* fit,
+                                       d3m_stream_t stream) {
+    if (!faces || !face_index_map || !weight_map || !depth_map || !background || !rgb_blended || (!rgb_out && !fit) ||
         batch_size <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
     if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
+    if (fit && (anti_aliasing || !alpha_map)) return D3M_ERR_INVALID;     // the objective reads the maps as the images
     if (background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
     LitTextures lt;
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
     if (rc) return rc;
+    FitTargets ft;
+    if ((rc = to_fit_targets(fit, ft))) return rc;
     const int s = anti_aliasing ? image_size / 2 : image_size;
     const long n = (long)batch_size * s * s;
-    LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, faces, lt,
+    hipStream_t st = (hipStream_t)stream;
+    LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, 256)), dim3(256), st, faces, lt,
            face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
-           depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps);
+           depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
+    if (fit)
+        LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
+               (int)blocks_for(n, 256), (float)((long)s * s), fit->scratch, fit->loss);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_render_fit_backward(const float* rgb_map, const float* alpha_map, const float* depth_map,
+                                       const d3m_fit_targets* fit, const float* grad_loss, float* grad_rgb_map,
+                                       float* grad_alpha_map, float* grad_depth_map, int batch_size, int image_size,
+                                       d3m_stream_t stream) {
+    if (!rgb_map || !alpha_map || !depth_map || !fit || !grad_rgb_map || batch_size <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    FitTargets ft;
+    if (int rc = to_fit_targets(fit, ft)) return rc;
+    const long n = (long)batch_size * image_size * image_size;
+    LAUNCH("k_fit_grad_maps", k_fit_grad_maps, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, rgb_map, alpha_map,
+           depth_map, ft, (const float*)fit->scratch, grad_loss, grad_rgb_map, grad_alpha_map, grad_depth_map, batch_size,
+           image_size);
     return check_launch();
 }
 

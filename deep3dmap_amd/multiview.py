@@ -91,10 +91,20 @@ class MultiViewFit:
         return (photometric_loss(rgb, rgb_t, mask=mask) + silhouette_loss(alpha, alpha_t) / pixels +
                 photometric_loss(depth[:, None], depth_t[:, None], mask=mask))
 
+    def fit_loss(self):
+        """The objective of the current mesh against the targets, evaluated inside the rendering node when the renderer
+        allows it (no images, no image gradients in memory); otherwise render() + loss()."""
+        r = self.renderer
+        if r.lighting_on_the_fly and not r.anti_aliasing:
+            rgb_t, depth_t, alpha_t = self.targets
+            return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
+                                     (rgb_t, depth_t, alpha_t, alpha_t))
+        return self.loss(*self.render())
+
     def _forward_backward(self):
         self.vertices.grad = None
         self.textures.grad = None
-        loss = self.loss(*self.render())
+        loss = self.fit_loss()
         loss.backward()
         return loss.detach()
 

@@ -241,7 +241,7 @@ class _RasterizeLit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
-                far, eps, background_color, return_rgb, return_alpha, return_depth):
+                far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None):
         L = _lib.lib()
         sv, vertices, textures = f32c(screen_vertices), f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
@@ -288,14 +288,29 @@ class _RasterizeLit(torch.autograd.Function):
         s_out = S // 2 if anti_aliasing else S
         m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
         m["alpha_map"] = torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None
-        rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
-        alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
-        depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
+        rgb = alpha = depth = loss = fit_c = None
+        if fit is None:
+            rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
+            alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
+            depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
+        else:
+            # the fit objective is evaluated where the images are produced: they are never written (rasterize_lit_fit)
+            if anti_aliasing or not (return_alpha and return_depth):
+                raise ValueError("the fused fit objective needs rgb, alpha and depth without anti-aliasing")
+            rgb_t, depth_t, alpha_t, mask = (f32c(t) for t in fit)
+            if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
+                raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            scratch = torch.empty(int(L.d3m_render_fit_scratch_floats(B, S)), dtype=torch.float32, device=dev)
+            fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
+                                       _lib.ptr(scratch), _lib.ptr(loss))
+            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss)
         _lib.check(L.d3m_render_lit_epilogue(
             _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
             _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
             _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), B, Ft,
-            int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_render_lit_epilogue")
+            int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
+            ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
         if vis is not None:
             cur.wait_stream(side)
         m["visibility"] = vis
@@ -303,11 +318,14 @@ class _RasterizeLit(torch.autograd.Function):
                    (float(ia), float(idr), ca, cd, direction), Bl)
         ctx.maps = m
         ctx.save_for_backward(faces, vertices, tri, textures, light)
+        if fit is not None:
+            return loss
+        ctx.fit = None
         empty = torch.tensor([])
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
     @staticmethod
-    def backward(ctx, g_rgb, g_alpha, g_depth):
+    def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
         L = _lib.lib()
         faces, vertices, tri, textures, light = ctx.saved_tensors
         S, eps, aa, ra, rd, fill_back, (ia, idr, ca, cd, direction), Bl = ctx.cfg
@@ -319,10 +337,19 @@ class _RasterizeLit(torch.autograd.Function):
         g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
         g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
         g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
-        _lib.check(L.d3m_output_epilogue_backward(
-            _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
-            _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
-            "d3m_output_epilogue_backward")
+        if ctx.fit is None:
+            _lib.check(L.d3m_output_epilogue_backward(
+                _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
+                _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
+                "d3m_output_epilogue_backward")
+        else:       # g_rgb is the gradient of the scalar objective: its gradient maps in one pass over the stored maps
+            rgb_t, depth_t, alpha_t, mask, scratch, loss = ctx.fit
+            fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
+                                       _lib.ptr(scratch), _lib.ptr(loss))
+            _lib.check(L.d3m_render_fit_backward(
+                _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(m["depth_map"]), ctypes.byref(fit_c),
+                _lib.ptr(f32c(g_rgb)), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S,
+                _lib.stream_ptr()), "d3m_render_fit_backward")
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over one compacted list of the faces that own a pixel
         vis = m["visibility"]
@@ -368,7 +395,7 @@ class _RasterizeLit(torch.autograd.Function):
                                    g_depth_map, grad_faces, S)
             _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
                                                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 11
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 12
 
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
@@ -382,6 +409,20 @@ def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back
                                             anti_aliasing, near, far, eps, background_color, True, return_alpha,
                                             return_depth)
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
+
+
+def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
+                      near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR):
+    """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
+
+        photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
+
+    `targets` = (rgb_t [B,3,S,S], depth_t [B,S,S], alpha_t [B,S,S], mask [B,S,S]), evaluated inside the rendering
+    node: the sums are taken where the images are produced and the gradient is written straight into the
+    internal-resolution maps, so the images and their gradients never exist in memory.  Same value and gradients as
+    core.losses.multiview_fit_loss(*rasterize_lit(...), ...)."""
+    return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
+                               far, eps, background_color, True, True, True, tuple(targets))
 
 
 def rasterize_rgbad(

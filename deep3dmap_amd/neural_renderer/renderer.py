@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from . import cameras, mesh_ops
-from .rasterize import rasterize, rasterize_depth, rasterize_lit, rasterize_rgbad, rasterize_silhouettes
+from .rasterize import (rasterize, rasterize_depth, rasterize_lit, rasterize_lit_fit, rasterize_rgbad,
+                        rasterize_silhouettes)
 
 
 class Renderer(nn.Module):
@@ -132,6 +133,16 @@ class Renderer(nn.Module):
         textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
                          self.rasterizer_eps, self.background_color)
+
+    def render_fit_loss(self, vertices, faces, textures, targets, K=None, R=None, t=None, dist_coeffs=None,
+                        orig_size=None):
+        """The multi-view fit objective of render()'s images against `targets` = (rgb, depth, alpha, mask), evaluated
+        inside the rendering node (rasterize_lit_fit); needs lighting_on_the_fly and no anti-aliasing."""
+        if not self.lighting_on_the_fly or self.anti_aliasing:
+            raise ValueError("render_fit_loss needs lighting_on_the_fly and anti_aliasing=False")
+        sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+        return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
+                                 self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self.lighting_on_the_fly:

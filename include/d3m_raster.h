@@ -250,13 +250,34 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
 /* d3m_forward_texture_sampling_lit followed by d3m_output_epilogue in one pass, without the intermediate
  * rgb_map: writes the blended internal-resolution rgb_blended [B,S,S,3] (covered ? sampled : background) and
  * alpha_map [B,S,S] (NULL to skip) that the backward pass reads, and the output images rgb_out [B,3,s,s],
- * alpha_out / depth_out [B,s,s] (NULL to skip; s = S/2 when anti_aliasing), flipped as rasterize.py:305-326. */
+ * alpha_out / depth_out [B,s,s] (NULL to skip; s = S/2 when anti_aliasing), flipped as rasterize.py:305-326.
+ *
+ * `fit` (NULL = none; an ADDITION to the reference's structure, not its interface): the multi-view fit objective
+ *     photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (s*s) + photometric_loss(depth, ...)
+ * (deep3dmap/core/utils/utils.py:105-114 composed as d3m_fit_loss_forward does) evaluated in the same pass, where
+ * the images are produced: *fit->loss receives the value, the images themselves need not be written (rgb_out NULL)
+ * and are not read again.  No anti-aliasing; alpha_map is required.  d3m_render_fit_backward then writes the
+ * objective's gradient (times *grad_loss, NULL = 1) straight into the internal-resolution gradient maps the backward
+ * operators take - d3m_fit_loss_backward followed by d3m_output_epilogue_backward in one pass over the maps. */
+typedef struct {
+    const float* rgb_target;     /* [B,3,S,S]  output image layout (flipped, channel-major) */
+    const float* depth_target;   /* [B,S,S] */
+    const float* alpha_target;   /* [B,S,S] */
+    const float* mask;           /* [B,S,S] */
+    float* scratch;              /* d3m_render_fit_scratch_floats() floats, kept from forward to backward */
+    float* loss;                 /* [1] */
+} d3m_fit_targets;
+size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
                             int light_batch, const int32_t* face_index_map, const float* weight_map,
                             const float* depth_map, const float* background, int background_batch,
                             float* rgb_blended, float* alpha_map, float* rgb_out, float* alpha_out, float* depth_out,
                             int batch_size, int num_tri, int fill_back, int image_size, int texture_size, float eps,
-                            int anti_aliasing, d3m_stream_t stream);
+                            int anti_aliasing, const d3m_fit_targets* fit, d3m_stream_t stream);
+int d3m_render_fit_backward(const float* rgb_map, const float* alpha_map, const float* depth_map,
+                            const d3m_fit_targets* fit, const float* grad_loss, float* grad_rgb_map,
+                            float* grad_alpha_map, float* grad_depth_map, int batch_size, int image_size,
+                            d3m_stream_t stream);
 /* Its backward (replaces backward_textures + the adjoint of lighting and of the fill_back cat):
  * grad_textures [Bx,num_tri,ts^3,3] is WRITTEN (summed over views when Bx = 1); grad_light [Bl,F',3] is
  * written when not NULL.  Sampling weights are recomputed from weight_map / depth_map (no 64 B/pixel

@@ -401,6 +401,48 @@ def test_fused_fit_loss_matches_composed_losses_and_oracle(shape):
                            alpha_t.cuda(), alpha_t.cuda())
 
 
+@pytest.mark.parametrize("ts", [2, 3])
+def test_fit_objective_inside_the_rendering_node(ts):
+    """Renderer.render_fit_loss (objective summed where the images are produced, gradient written straight into the
+    internal maps) against multiview_fit_loss on the rendered images: same value, same vertex / texture gradients,
+    with a non-unit upstream gradient; anti-aliasing is refused."""
+    nr = _nr()
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core import multiview_fit_loss
+    v, tri = synthetic.grid_mesh(14)
+    tex = synthetic.random_textures(tri.shape[0], ts)
+    eyes = torch.from_numpy(synthetic.camera_ring(3)).float().cuda()
+    r = nr.Renderer(image_size=56, anti_aliasing=False, camera_mode="look_at", fill_back=True)
+    r.eye = eyes
+    tri_d = torch.from_numpy(tri).int().cuda()[None]
+    with torch.no_grad():
+        tv = torch.from_numpy(synthetic.perturb(v, 0.04)).float().cuda()
+        rgb_t, depth_t, alpha_t = r(tv[None], tri_d, torch.from_numpy(tex).float().cuda()[None])
+
+    def run(inside):
+        vv = torch.from_numpy(v).float().cuda().requires_grad_(True)
+        tt = torch.from_numpy(tex).float().cuda().requires_grad_(True)
+        if inside:
+            loss = r.render_fit_loss(vv[None], tri_d, tt[None], (rgb_t, depth_t, alpha_t, alpha_t))
+        else:
+            rgb, depth, alpha = r(vv[None], tri_d, tt[None])
+            loss = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t)
+        (loss * 1.75).backward()
+        return loss.detach(), vv.grad, tt.grad
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], rtol=2e-6)
+    assert float(a[1].abs().max()) > 0 and float(a[2].abs().max()) > 0
+    # the two paths differ only in the order the four sums are added up (a factor 1/den on every gradient)
+    for ga, gb in zip(a[1:], b[1:]):
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
+    ra = nr.Renderer(image_size=56, anti_aliasing=True, camera_mode="look_at", fill_back=True)
+    ra.eye = eyes
+    with pytest.raises(ValueError):
+        ra.render_fit_loss(torch.from_numpy(v).float().cuda()[None], tri_d, torch.from_numpy(tex).float().cuda()[None],
+                           (rgb_t, depth_t, alpha_t, alpha_t))
+
+
 @pytest.mark.parametrize("ts", [1, 2, 4])
 @pytest.mark.parametrize("shared", [False, True])
 def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
