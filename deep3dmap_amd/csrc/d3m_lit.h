@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
                                                             float* __restrict__ rgb_out, float* __restrict__ alpha_out,
                                                             float* __restrict__ depth_out, int B, int S, int aa, float eps,
                                                             FitTargets fit) {
-    __shared__ float s_part[4];
+    __shared__ float4 s_part[4];
     const int s = aa ? S / 2 : S;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
@@ -207,6 +207,13 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
         const int n = aa ? 2 : 1;
         const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
         float acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
+        // the objective's targets are requested first: they then arrive under the dependent loads of the sampling
+        float tg[6] = {0, 0, 0, 0, 0, 0};                 // rgb_t x3, depth_t, alpha_t, mask
+        if (fit.partials) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) tg[k] = fit.rgb_t[(((size_t)b * 3 + k) * s + yo) * s + xo];
+            tg[3] = fit.depth_t[i]; tg[4] = fit.alpha_t[i]; tg[5] = fit.mask[i];
+        }
         for (int dy = 0; dy < n; dy++) {
             for (int dx = 0; dx < n; dx++) {
                 const int yi = S - 1 - (yo * n + dy), xi = xo * n + dx;
@@ -237,24 +244,23 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
         if (alpha_out) alpha_out[i] = acc_a * inv;
         if (depth_out) depth_out[i] = acc_d * inv;
         if (fit.partials) {                               // same terms as k_fit_loss_reduce
-            const float m = fit.mask[i];
+            const float m = tg[5];
 #pragma unroll
-            for (int k = 0; k < 3; k++)
-                t_rgb += fabsf(acc_rgb[k] * inv - fit.rgb_t[(((size_t)b * 3 + k) * s + yo) * s + xo]) * m;
-            t_d = fabsf(acc_d * inv - fit.depth_t[i]) * m;
+            for (int k = 0; k < 3; k++) t_rgb += fabsf(acc_rgb[k] * inv - tg[k]) * m;
+            t_d = fabsf(acc_d * inv - tg[3]) * m;
             t_m = m;
-            const float d = acc_a * inv - fit.alpha_t[i];
+            const float d = acc_a * inv - tg[4];
             t_sse = d * d;
         }
     }
-    if (fit.partials) {
-        t_rgb = block_sum_256(t_rgb, s_part);
-        t_d = block_sum_256(t_d, s_part);
-        t_m = block_sum_256(t_m, s_part);
-        t_sse = block_sum_256(t_sse, s_part);
+    if (fit.partials) {                                   // four wave sums (DPP), one exchange through LDS
+        const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
+        if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
+        __syncthreads();
         if (threadIdx.x == 0) {
-            float* o = fit.partials + 4 * (size_t)blockIdx.x;
-            o[0] = t_rgb; o[1] = t_d; o[2] = t_m; o[3] = t_sse;
+            float4 t = s_part[0];
+            for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+            reinterpret_cast<float4*>(fit.partials)[blockIdx.x] = t;
         }
     }
 }
@@ -265,9 +271,15 @@ __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restri
                                                          float* __restrict__ totals, float* __restrict__ loss) {
     __shared__ float4 s_wave[16];
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float4 v = partials[i];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {            // eight loads in flight per lane
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = i0 + j * 1024 + (int)threadIdx.x;
+            v[j] = i < n ? partials[i] : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
     }
     acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
     if (lane_id() == 0) s_wave[threadIdx.x >> 6] = acc;

@@ -600,12 +600,13 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
     const int s = anti_aliasing ? image_size / 2 : image_size;
     const long n = (long)batch_size * s * s;
     hipStream_t st = (hipStream_t)stream;
-    LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, 256)), dim3(256), st, faces, lt,
+    const int threads = 256;
+    LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, threads)), dim3(threads), st, faces, lt,
            face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
            depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
     if (fit)
         LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-               (int)blocks_for(n, 256), (float)((long)s * s), fit->scratch, fit->loss);
+               (int)blocks_for(n, threads), (float)((long)s * s), fit->scratch, fit->loss);
     return check_launch();
 }
 
