@@ -258,15 +258,23 @@ __global__ void __launch_bounds__(1024) k_scan_small(int* __restrict__ counts, i
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int c = i < n ? counts[i] : 0;
-        const int incl = wave_inclusive_scan(c);
+    constexpr int PER = 8;                                  // consecutive entries per lane: 8192 per round
+    for (int base = 0; base < n; base += 1024 * PER) {
+        const int i0 = base + threadIdx.x * PER;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) { c[k] = i0 + k < n ? counts[i0 + k] : 0; sum += c[k]; }
+        const int incl = wave_inclusive_scan(sum);
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
         int before = s_run;
         for (int k = 0; k < wv; k++) before += s_wave[k];
-        if (i < n) counts[i] = before + incl - c;
+        int run = before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (i0 + k < n) counts[i0 + k] = run;
+            run += c[k];
+        }
         __syncthreads();
         if (threadIdx.x == 1023) s_run = before + incl;
         __syncthreads();
