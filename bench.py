@@ -47,8 +47,9 @@ def kernel_bytes(name, V, F, S, ts):
         "k_bin_count": 12 * V + 12 * F,
         "k_bin_fill": 12 * F,
         "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
-        "k_render_lit_epilogue": F * ts ** 3 * 12 + 20 * P + 12 * P + P * (4 + 4 + 12),
-        "k_fit_grad_maps": P * (20 + 24 + 20),                 # value maps + targets -> gradient maps
+        # sampling inputs, blended maps out, then either the images (20 B) or the objective's targets in (24 B) and the
+        # unscaled gradient maps out (20 B)
+        "k_render_lit_epilogue": F * ts ** 3 * 12 + 20 * P + 12 * P + P * (4 + 4 + 12) + P * 24,
         "k_pack_maps": maps + grads,
         "k_edge_lines": maps + grads,
         "k_edge_emit": 12 * V + 12 * F + maps + grads,

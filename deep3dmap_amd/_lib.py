@@ -25,7 +25,7 @@ class D3MVertexTarget(ctypes.Structure):
 
 class D3MFitTargets(ctypes.Structure):
     _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
-                ("loss", _P)]
+                ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P)]
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
@@ -42,7 +42,7 @@ _SIGNATURES = {
     "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
-    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P]),
+    "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _P]),
     "d3m_visibility_bytes": (_SZ, [_I, _I]),
     "d3m_visibility": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),
     "d3m_backward_faces_workspace_bytes": (_SZ, [_I, _I]),
@@ -64,9 +64,8 @@ _SIGNATURES = {
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
                                      _P, _P]),
     "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
-    "d3m_render_fit_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
-                                       _P, _P, _P]),
+                                       _P, _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

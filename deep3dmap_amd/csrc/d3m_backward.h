@@ -55,7 +55,8 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            const float* __restrict__ weight_map,
                                                            const float* __restrict__ grad_depth_map,
                                                            float* __restrict__ grad_faces, int B, int S,
-                                                           const int* __restrict__ only_large, VertexTarget vt) {
+                                                           const int* __restrict__ only_large, VertexTarget vt,
+                                                           GradScale gs = GradScale{nullptr, nullptr, 0.0f}) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fn = face_index_map[i];
@@ -73,7 +74,9 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
     }
     const float depth = depth_map[i];
     const float depth2 = depth * depth;
-    const float g = grad_depth_map[i];
+    float s_rgb, s_alpha, s_depth;
+    gs.get(s_rgb, s_alpha, s_depth);
+    const float g = grad_depth_map[i] * s_depth;
     float tmp[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; k++) {

@@ -151,6 +151,25 @@ struct VertexTarget {
     }
 };
 
+// ---- gradient maps that still lack their scalar factors ---------------------------------------------------
+// The fused fit objective (k_render_lit_epilogue) leaves the objective's gradient in the maps WITHOUT the factors that
+// are only known later -- 1/sum(mask) from the reduction, the incoming gradient of the loss -- so that no pass over the
+// pixels is needed in backward: the operators that read the maps multiply by these three scalars.
+struct GradScale {
+    const float* totals;      // the objective's sums (totals[2] = sum of the mask); NULL: the maps are final
+    const float* grad_out;    // gradient of the scalar objective; NULL = 1
+    float pixels;             // pixels per view
+    __device__ __forceinline__ void get(float& s_rgb, float& s_alpha, float& s_depth) const {
+        s_rgb = s_alpha = s_depth = 1.0f;
+        if (totals) {
+            const float go = grad_out ? *grad_out : 1.0f, den = totals[2];
+            s_rgb = go / (3.0f * den);
+            s_depth = go / den;
+            s_alpha = go / pixels;
+        }
+    }
+};
+
 // ---- XCD-contiguous work order ---------------------------------------------------------------------
 // Workgroups i and i + 8 share an XCD (observed dispatch order; a speed matter only).  A kernel that strides a fixed
 // grid (a multiple of 8) over n work units hands XCD x the contiguous range [x*per, (x+1)*per): neighbouring units

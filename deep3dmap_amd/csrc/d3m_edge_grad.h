@@ -833,13 +833,15 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
                                                   float2* __restrict__ dot_row, float4* __restrict__ grad_col,
                                                   float2* __restrict__ dot_col, int* __restrict__ nz_lo_inv,
                                                   int* __restrict__ nz_hi1, int S, float2* __restrict__ lane_partial,
-                                                  const int* __restrict__ n_visible) {
+                                                  const int* __restrict__ n_visible, GradScale gs) {
     __shared__ float4 t_grad[32][33];
     __shared__ float2 t_dot[32][33];
     __shared__ int s_col_lo_inv[32], s_col_hi1[32];
     if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
     const int b = blockIdx.z;
+    float s_rgb, s_alpha, s_depth;
+    gs.get(s_rgb, s_alpha, s_depth);
     {   // the overflow sums of the (visible face, edge, axis) lanes start at zero (k_edge_emit adds, k_edge_gather reads)
         const long n_threads = (long)gridDim.x * gridDim.y * gridDim.z * 256;
         const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
@@ -855,9 +857,9 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
             const size_t i = plane + (size_t)y * S + x;
             float4 g = make_float4(0, 0, 0, 0);
             float dot = 0;
-            if (alpha) { g.x = galpha[i]; dot += alpha[i] * g.x; }
+            if (alpha) { g.x = galpha[i] * s_alpha; dot += alpha[i] * g.x; }
             if (rgb) {
-                g.y = grgb[3 * i]; g.z = grgb[3 * i + 1]; g.w = grgb[3 * i + 2];
+                g.y = grgb[3 * i] * s_rgb; g.z = grgb[3 * i + 1] * s_rgb; g.w = grgb[3 * i + 2] * s_rgb;
                 dot += rgb[3 * i] * g.y;
                 dot += rgb[3 * i + 1] * g.z;
                 dot += rgb[3 * i + 2] * g.w;
@@ -1000,8 +1002,8 @@ inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
 }
 
 template <class FS>
-int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis, int B,
-                  float eps, void* ws, size_t ws_bytes, hipStream_t st, int* last_err) {
+int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis, GradScale gs,
+                  int B, float eps, void* ws, size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
     const EdgeLayout L = edge_layout(B, F, S);
@@ -1055,7 +1057,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
            m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
            m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
-           (int*)(p + L.off_nz_hi), S, w.lane_partial, (const int*)w.n_visible);
+           (int*)(p + L.off_nz_hi), S, w.lane_partial, (const int*)w.n_visible, gs);
     EdgeGradArgs a;
     a.ax[0] = AxisMaps{grad_col, dot_col};
     a.ax[1] = AxisMaps{grad_row, dot_row};

@@ -186,6 +186,8 @@ __global__ void __launch_bounds__(256) k_texture_sampling_lit(const float* __res
 struct FitTargets {
     const float *rgb_t, *depth_t, *alpha_t, *mask;   // OUTPUT image layout [B,3,s,s] / [B,s,s]; all NULL = no objective
     float* partials;                                  // [4 * gridDim.x]: sum |rgb - t| m, sum |depth - t| m, sum m, sum (alpha - t)^2
+    // the objective's gradient wrt the internal maps, WITHOUT its scalar factors (see GradScale); NULL = not wanted
+    float *g_rgb, *g_alpha, *g_depth;
 };
 
 __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __restrict__ faces, LitTextures lt,
@@ -251,6 +253,14 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
             t_m = m;
             const float d = acc_a * inv - tg[4];
             t_sse = d * d;
+            if (fit.g_rgb) {                              // no anti-aliasing here: the output pixel IS internal pixel p
+                const size_t p = ((size_t)b * S + (S - 1 - yo)) * S + xo;
+                auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
+#pragma unroll
+                for (int k = 0; k < 3; k++) fit.g_rgb[3 * p + k] = sgn(acc_rgb[k] - tg[k]) * m;
+                fit.g_depth[p] = sgn(acc_d - tg[3]) * m;
+                fit.g_alpha[p] = 2.0f * d;
+            }
         }
     }
     if (fit.partials) {                                   // four wave sums (DPP), one exchange through LDS
@@ -294,28 +304,6 @@ __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restri
     }
 }
 
-// The objective's gradient written straight into the internal-resolution maps the backward operators read (no
-// anti-aliasing): k_fit_loss_grad composed with the flip / CHW->HWC of k_output_epilogue_backward.  The image values
-// are those of the maps: rgb_blended, alpha_map, depth_map (k_render_lit_epilogue's outputs without pooling).
-__global__ void __launch_bounds__(256) k_fit_grad_maps(const float* __restrict__ rgb_map, const float* __restrict__ alpha_map,
-                                                      const float* __restrict__ depth_map, FitTargets fit,
-                                                      const float* __restrict__ totals, const float* __restrict__ grad_out,
-                                                      float* __restrict__ g_rgb_map, float* __restrict__ g_alpha_map,
-                                                      float* __restrict__ g_depth_map, int B, int S) {
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= (long)B * S * S) return;
-    const int b = (int)(p / ((long)S * S));
-    const int yi = (int)((p / S) % S), xi = (int)(p % S);
-    const size_t hw = (size_t)S * S, o = (size_t)b * hw + (size_t)(S - 1 - yi) * S + xi;
-    const float go = grad_out ? *grad_out : 1.0f, den = totals[2], m = fit.mask[o];
-    auto sgn = [](float d) { return d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f); };
-#pragma unroll
-    for (int c = 0; c < 3; c++)
-        g_rgb_map[3 * p + c] = sgn(rgb_map[3 * p + c] - fit.rgb_t[o + (size_t)(2 * b + c) * hw]) * m / (3.0f * den) * go;
-    if (g_depth_map) g_depth_map[p] = sgn(depth_map[p] - fit.depth_t[o]) * m / den * go;
-    if (g_alpha_map) g_alpha_map[p] = 2.0f * (alpha_map[p] - fit.alpha_t[o]) / (float)hw * go;
-}
-
 // backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of
 // w * grad_rgb live in LDS, then   grad_textures[view, f, texel] = sum * light   (plain store: within a view
 // at most one of the two copies of a face is front-facing) and  grad_light[face] += sum * texel.
@@ -338,6 +326,7 @@ struct LitFaceArgs {
     const int* n_list;
     int B, S;
     float eps;
+    GradScale gs;
 };
 
 __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi, int sub) {
@@ -356,6 +345,8 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const int S = a.S;
     const float eps = a.eps;
     const int Fp = lt.Fp;
+    float s_rgb, s_alpha, s_depth;
+    a.gs.get(s_rgb, s_alpha, s_depth);
     if (!a.list && flags[gi] == FLAG_HIDDEN) return;              // a listed face is visible: no flag round trip
     const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
     const float* face = faces + (size_t)gi * 9;
@@ -404,8 +395,9 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
         // (selected, never multiplied away: its own weights / depth belong to a different triangle).
         const bool own = face_index_map[p] == fn;
         const float lw0 = weight_map[3 * p], lw1 = weight_map[3 * p + 1], lw2 = weight_map[3 * p + 2];
-        const float lg0 = grad_rgb_map[3 * p + 0], lg1 = grad_rgb_map[3 * p + 1], lg2 = grad_rgb_map[3 * p + 2];
-        const float ld = depth_map[p], lgd = grad_depth_map ? grad_depth_map[p] : 0.0f;
+        const float lg0 = grad_rgb_map[3 * p + 0] * s_rgb, lg1 = grad_rgb_map[3 * p + 1] * s_rgb,
+                    lg2 = grad_rgb_map[3 * p + 2] * s_rgb;
+        const float ld = depth_map[p], lgd = grad_depth_map ? grad_depth_map[p] * s_depth : 0.0f;
         if (!__builtin_amdgcn_ballot_w64(own)) continue;                  // nobody in the wave owns its pixel
         const float third = 1.0f / 3.0f;
         const float weight[3] = {own ? lw0 : third, own ? lw1 : third, own ? lw2 : third};
@@ -502,7 +494,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
                                                                      float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
                                                                      float* __restrict__ grad_light,
                                                                      const int* __restrict__ only_large, int B, int S,
-                                                                     float eps) {
+                                                                     float eps, GradScale gs) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fi = face_index_map[i];
@@ -511,7 +503,9 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
     if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) return;
     const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
     const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
-    const float g[3] = {grad_rgb_map[3 * i], grad_rgb_map[3 * i + 1], grad_rgb_map[3 * i + 2]};
+    float s_rgb, s_alpha, s_depth;
+    gs.get(s_rgb, s_alpha, s_depth);
+    const float g[3] = {grad_rgb_map[3 * i] * s_rgb, grad_rgb_map[3 * i + 1] * s_rgb, grad_rgb_map[3 * i + 2] * s_rgb};
     int fl[3];
     float fr[3];
     sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);

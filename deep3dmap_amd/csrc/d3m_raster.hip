@@ -269,6 +269,12 @@ D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* tex
     return check_launch();
 }
 
+// the scalar factors the unscaled gradient maps of a fused objective still lack (NULL: the maps are final)
+static GradScale to_grad_scale(const d3m_fit_targets* unscaled, int image_size) {
+    if (!unscaled) return GradScale{nullptr, nullptr, 0.0f};
+    return GradScale{unscaled->scratch, unscaled->grad_loss, (float)((long)image_size * image_size)};
+}
+
 D3M_EXPORT size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size) {
     return edge_grad_workspace_bytes(batch_size, num_faces, image_size);
 }
@@ -277,7 +283,9 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                                       float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                                       int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                                      const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream) {
+                                      const d3m_vertex_target* vertex_target, void* visibility,
+                                      const d3m_fit_targets* unscaled, d3m_stream_t stream) {
+    if (unscaled && !unscaled->scratch) return D3M_ERR_INVALID;
     if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -291,8 +299,8 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                 return_alpha != 0};
     VisibilityView vis;
     if (visibility) vis = visibility_view(visibility, (long)batch_size * num_faces);
-    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, batch_size, eps, workspace, workspace_bytes,
-                         (hipStream_t)stream, &g_last_hip_error);
+    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, to_grad_scale(unscaled, image_size), batch_size,
+                         eps, workspace, workspace_bytes, (hipStream_t)stream, &g_last_hip_error);
 }
 
 // scratch of the gathered (face-major) backward passes: one int per face
@@ -571,11 +579,14 @@ D3M_EXPORT size_t d3m_render_fit_scratch_floats(int batch_size, int image_size) 
 }
 
 static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {
-    ft = FitTargets{nullptr, nullptr, nullptr, nullptr, nullptr};
+    ft = FitTargets{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (!fit) return D3M_OK;
     if (!fit->rgb_target || !fit->depth_target || !fit->alpha_target || !fit->mask || !fit->scratch || !fit->loss)
         return D3M_ERR_INVALID;
-    ft = FitTargets{fit->rgb_target, fit->depth_target, fit->alpha_target, fit->mask, fit->scratch + 8};
+    const bool any = fit->grad_rgb_map || fit->grad_alpha_map || fit->grad_depth_map;
+    if (any && !(fit->grad_rgb_map && fit->grad_alpha_map && fit->grad_depth_map)) return D3M_ERR_INVALID;
+    ft = FitTargets{fit->rgb_target, fit->depth_target, fit->alpha_target, fit->mask, fit->scratch + 8,
+                    fit->grad_rgb_map, fit->grad_alpha_map, fit->grad_depth_map};
     return D3M_OK;
 }
 
@@ -610,21 +621,6 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
     return check_launch();
 }
 
-D3M_EXPORT int d3m_render_fit_backward(const float* rgb_map, const float* alpha_map, const float* depth_map,
-                                       const d3m_fit_targets* fit, const float* grad_loss, float* grad_rgb_map,
-                                       float* grad_alpha_map, float* grad_depth_map, int batch_size, int image_size,
-                                       d3m_stream_t stream) {
-    if (!rgb_map || !alpha_map || !depth_map || !fit || !grad_rgb_map || batch_size <= 0 || image_size <= 0)
-        return D3M_ERR_INVALID;
-    FitTargets ft;
-    if (int rc = to_fit_targets(fit, ft)) return rc;
-    const long n = (long)batch_size * image_size * image_size;
-    LAUNCH("k_fit_grad_maps", k_fit_grad_maps, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, rgb_map, alpha_map,
-           depth_map, ft, (const float*)fit->scratch, grad_loss, grad_rgb_map, grad_alpha_map, grad_depth_map, batch_size,
-           image_size);
-    return check_launch();
-}
-
 D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size) {
     if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0) return 0;
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
@@ -639,7 +635,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
                                          float* grad_light, const float* grad_depth_map, float* grad_faces, int batch_size,
                                          int num_tri, int fill_back, int image_size, int texture_size, float eps,
                                          void* workspace, size_t workspace_bytes, const d3m_vertex_target* vertex_target,
-                                         void* visibility, d3m_stream_t stream) {
+                                         void* visibility, const d3m_fit_targets* unscaled, d3m_stream_t stream) {
     if ((grad_depth_map != nullptr) != (grad_faces != nullptr || vertex_target != nullptr)) return D3M_ERR_INVALID;
     VertexTarget vt;
     if (int rcv = to_vertex_target(vertex_target, (fill_back ? 2 : 1) * num_tri, vt)) return rcv;
@@ -653,6 +649,8 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         return D3M_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int B = batch_size, S = image_size;
+    if (unscaled && !unscaled->scratch) return D3M_ERR_INVALID;
+    const GradScale gs = to_grad_scale(unscaled, S);
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
     const size_t view_elems = (size_t)num_tri * ts3 * 3;
     // per-view gradients: straight into grad_textures when every view has its own textures
@@ -679,28 +677,31 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
         if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes, st));
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps};
+                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs};
         const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
-               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps);
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps,
+               gs);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
             DenseFaces fs{faces, lt.Fp};
             LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
                    depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
-                   (const int*)flags, vt);
+                   (const int*)flags, vt, gs);
         }
     } else {
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
-               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps);
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps,
+               gs);
         if (grad_depth_map) {
             DenseFaces fs{faces, lt.Fp};
             if (vt.gv) {
                 LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
                        depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S,
-                       (const int*)nullptr, vt);
+                       (const int*)nullptr, vt, gs);
             } else {
+                if (unscaled) return D3M_ERR_INVALID;      // the dense-array depth path takes final gradient maps only
                 const int rc2 = run_backward_depth(fs, depth_map, face_index_map, (const float*)nullptr, weight_map,
                                                    grad_depth_map, grad_faces, B, S, flags, false, st);
                 if (rc2) return rc2;

@@ -302,9 +302,17 @@ class _RasterizeLit(torch.autograd.Function):
                 raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
             loss = torch.empty((), dtype=torch.float32, device=dev)
             scratch = torch.empty(int(L.d3m_render_fit_scratch_floats(B, S)), dtype=torch.float32, device=dev)
+            # with a backward pass to come, the same pass leaves the objective's gradient in the internal maps, minus
+            # the scalar factors only known later (1 / sum(mask), the gradient of the loss): no pixel pass in backward
+            g_maps = (None, None, None)
+            if any(ctx.needs_input_grad[:4]):
+                g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
+                          torch.empty(B, S, S, dtype=torch.float32, device=dev),
+                          torch.empty(B, S, S, dtype=torch.float32, device=dev))
             fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
-                                       _lib.ptr(scratch), _lib.ptr(loss))
-            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss)
+                                       _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_maps[0]), _lib.ptr(g_maps[1]),
+                                       _lib.ptr(g_maps[2]), None)
+            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps)
         _lib.check(L.d3m_render_lit_epilogue(
             _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
             _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
@@ -334,22 +342,21 @@ class _RasterizeLit(torch.autograd.Function):
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
         grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
         target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
-        g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
-        g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
-        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
+        unscaled = None
         if ctx.fit is None:
+            g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+            g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
+            g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
             _lib.check(L.d3m_output_epilogue_backward(
                 _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
                 _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
                 "d3m_output_epilogue_backward")
-        else:       # g_rgb is the gradient of the scalar objective: its gradient maps in one pass over the stored maps
-            rgb_t, depth_t, alpha_t, mask, scratch, loss = ctx.fit
-            fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
-                                       _lib.ptr(scratch), _lib.ptr(loss))
-            _lib.check(L.d3m_render_fit_backward(
-                _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(m["depth_map"]), ctypes.byref(fit_c),
-                _lib.ptr(f32c(g_rgb)), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S,
-                _lib.stream_ptr()), "d3m_render_fit_backward")
+        else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
+            rgb_t, depth_t, alpha_t, mask, scratch, loss, (g_rgb_map, g_alpha_map, g_depth_map) = ctx.fit
+            grad_loss = f32c(g_rgb).reshape(1)
+            unscaled = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
+                                          _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map),
+                                          _lib.ptr(g_depth_map), _lib.ptr(grad_loss))
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over one compacted list of the faces that own a pixel
         vis = m["visibility"]
@@ -375,10 +382,12 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map),
                     _lib.ptr(grad_textures), _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft,
                     int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None,
-                    _lib.ptr(vis), _lib.stream_ptr()), "d3m_backward_textures_lit")
+                    _lib.ptr(vis), ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
+                    "d3m_backward_textures_lit")
             depth_done = rd
         ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
-                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis)
+                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis,
+                               unscaled=unscaled)
         if side is not None:
             cur.wait_stream(side)
             if need_vert:

@@ -114,11 +114,16 @@ typedef struct {
     const int32_t* tri;     /* [tri_batch, num_tri, 3]; num_faces = (fill_back ? 2 : 1) * num_tri */
     int num_vertices, num_tri, tri_batch, fill_back;
 } d3m_vertex_target;
+/* `unscaled` (NULL = the gradient maps are final): the maps are the unscaled ones a fused fit objective left
+ * (d3m_render_lit_epilogue with fit->grad_*_map, see struct d3m_fit_targets below); their scalar factors are applied
+ * as the maps are read. */
+typedef struct d3m_fit_targets d3m_fit_targets;
 int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                            float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                            int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                           const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream);
+                           const d3m_vertex_target* vertex_target, void* visibility,
+                           const d3m_fit_targets* unscaled, d3m_stream_t stream);
 
 /* Which faces own a pixel depends on face_index_map only.  d3m_visibility builds, once per forward result, the
  * flags and the compacted list of those faces in a caller-owned blob of d3m_visibility_bytes(); backward operators
@@ -256,17 +261,25 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
  *     photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (s*s) + photometric_loss(depth, ...)
  * (deep3dmap/core/utils/utils.py:105-114 composed as d3m_fit_loss_forward does) evaluated in the same pass, where
  * the images are produced: *fit->loss receives the value, the images themselves need not be written (rgb_out NULL)
- * and are not read again.  No anti-aliasing; alpha_map is required.  d3m_render_fit_backward then writes the
- * objective's gradient (times *grad_loss, NULL = 1) straight into the internal-resolution gradient maps the backward
- * operators take - d3m_fit_loss_backward followed by d3m_output_epilogue_backward in one pass over the maps. */
-typedef struct {
+ * and are not read again.  No anti-aliasing; alpha_map is required.
+ * With fit->grad_*_map set the pass also leaves the objective's gradient wrt the internal-resolution maps
+ * (rgb_blended, alpha_map, depth_map) there, WITHOUT the scalar factors that are only known later - sign(rgb - target)
+ * * mask, 2 (alpha - target), sign(depth - target) * mask - so that backward needs no pass over the pixels of its
+ * own: d3m_backward_pixel_map / d3m_backward_textures_lit handed these maps AND the same struct as `unscaled` (with
+ * grad_loss filled in; NULL = 1) multiply by grad_loss / (3 sum(mask)), grad_loss / (s*s), grad_loss / sum(mask)
+ * as they read them.  (d3m_fit_loss_backward followed by d3m_output_epilogue_backward, without either.) */
+struct d3m_fit_targets {
     const float* rgb_target;     /* [B,3,S,S]  output image layout (flipped, channel-major) */
     const float* depth_target;   /* [B,S,S] */
     const float* alpha_target;   /* [B,S,S] */
     const float* mask;           /* [B,S,S] */
     float* scratch;              /* d3m_render_fit_scratch_floats() floats, kept from forward to backward */
     float* loss;                 /* [1] */
-} d3m_fit_targets;
+    float* grad_rgb_map;         /* [B,S,S,3] \                                                        */
+    float* grad_alpha_map;       /* [B,S,S]    > unscaled gradient maps, written by the epilogue; all or none */
+    float* grad_depth_map;       /* [B,S,S]   /                                                         */
+    const float* grad_loss;      /* [1] device scalar, read by the backward operators; NULL = 1 */
+};
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
                             int light_batch, const int32_t* face_index_map, const float* weight_map,
@@ -274,10 +287,6 @@ int d3m_render_lit_epilogue(const float* faces, const float* textures, int textu
                             float* rgb_blended, float* alpha_map, float* rgb_out, float* alpha_out, float* depth_out,
                             int batch_size, int num_tri, int fill_back, int image_size, int texture_size, float eps,
                             int anti_aliasing, const d3m_fit_targets* fit, d3m_stream_t stream);
-int d3m_render_fit_backward(const float* rgb_map, const float* alpha_map, const float* depth_map,
-                            const d3m_fit_targets* fit, const float* grad_loss, float* grad_rgb_map,
-                            float* grad_alpha_map, float* grad_depth_map, int batch_size, int image_size,
-                            d3m_stream_t stream);
 /* Its backward (replaces backward_textures + the adjoint of lighting and of the fill_back cat):
  * grad_textures [Bx,num_tri,ts^3,3] is WRITTEN (summed over views when Bx = 1); grad_light [Bl,F',3] is
  * written when not NULL.  Sampling weights are recomputed from weight_map / depth_map (no 64 B/pixel
@@ -292,7 +301,8 @@ int d3m_backward_textures_lit(const float* faces, const float* textures, int tex
                               const float* depth_map, const float* grad_rgb_map, float* grad_textures, float* grad_light,
                               const float* grad_depth_map, float* grad_faces, int batch_size, int num_tri, int fill_back,
                               int image_size, int texture_size, float eps, void* workspace, size_t workspace_bytes,
-                              const d3m_vertex_target* vertex_target, void* visibility, d3m_stream_t stream);
+                              const d3m_vertex_target* vertex_target, void* visibility,
+                              const d3m_fit_targets* unscaled, d3m_stream_t stream);
 
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.

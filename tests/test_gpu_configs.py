@@ -158,7 +158,7 @@ def test_large_faces_and_small_workspace_against_oracle(S):
         gf = torch.zeros_like(fd)
         rc = L.d3m_backward_pixel_map(_lib.ptr(fd), _lib.ptr(fi), _lib.ptr(rgb_d), _lib.ptr(alpha_d), _lib.ptr(g_rgb_d),
                                       _lib.ptr(g_alpha_d), _lib.ptr(gf), B, F2, S, 1e-3, 1, 1, _lib.ptr(ws2), ws2.numel(),
-                                      None, None, _lib.stream_ptr())
+                                      None, None, None, _lib.stream_ptr())
         assert rc == 0
         torch.cuda.synchronize()
         grads.append(gf)
