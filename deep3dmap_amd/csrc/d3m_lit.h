@@ -327,6 +327,7 @@ struct LitFaceArgs {
     int B, S;
     float eps;
     GradScale gs;
+    int* n_large;                  // [1] zeroed: faces handed to the per-pixel kernels (which leave at once when it stays 0)
 };
 
 __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi, int sub) {
@@ -361,6 +362,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     if (sub == 0 && a.view_mask) atomicOr(&a.view_mask[(size_t)fo * ((a.B + 31) >> 5) + (bn >> 5)], 1u << (bn & 31));
     if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
         flags[gi] = FLAG_LARGE;
+        if (sub == 0) atomicAdd(a.n_large, 1);
         for (int t = sub; t < 24; t += FM_LANES) gt[t] = 0.0f;
         return;
     }
@@ -494,7 +496,9 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
                                                                      float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
                                                                      float* __restrict__ grad_light,
                                                                      const int* __restrict__ only_large, int B, int S,
-                                                                     float eps, GradScale gs) {
+                                                                     float eps, GradScale gs,
+                                                                     const int* __restrict__ n_large) {
+    if (n_large && *n_large == 0) return;          // only_large mode and no such face: nothing to do (uniform exit)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * S * S) return;
     const int fi = face_index_map[i];

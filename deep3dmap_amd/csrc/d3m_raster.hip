@@ -626,7 +626,7 @@ D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int 
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
     return align_up((size_t)batch_size * num_tri * ts3 * 12, 256) +
            align_up((size_t)batch_size * num_tri * (fill_back ? 2 : 1) * 4, 256) +
-           align_up((size_t)num_tri * ((batch_size + 31) / 32) * 4, 256);      // per-view gradients | flags | view masks
+           align_up((size_t)num_tri * ((batch_size + 31) / 32) * 4, 256) + 256;  // per-view gradients | flags | view masks | counter
 }
 
 D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
@@ -659,6 +659,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
     unsigned* view_mask = (unsigned*)((char*)flags + align_up((size_t)nf * 4, 256));
     const size_t mask_bytes = align_up((size_t)num_tri * ((B + 31) / 32) * 4, 256);
+    int* n_large = (int*)((char*)view_mask + mask_bytes);          // zeroed together with the masks (or on its own)
     // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
     const bool skip_zero = texture_size == 2 && textures_batch == 1;
     if (!skip_zero) HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
@@ -675,25 +676,26 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         }
         const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
-        if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes, st));
+        if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes + 256, st));
+        else HIP_TRY(zero_async(n_large, 256, st));
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs};
+                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, n_large};
         const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps,
-               gs);
+               gs, (const int*)n_large);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
             DenseFaces fs{faces, lt.Fp};
             LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
                    depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
-                   (const int*)flags, vt, gs);
+                   (const int*)flags, vt, gs, (const int*)n_large);
         }
     } else {
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps,
-               gs);
+               gs, (const int*)nullptr);
         if (grad_depth_map) {
             DenseFaces fs{faces, lt.Fp};
             if (vt.gv) {
