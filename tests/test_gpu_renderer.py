@@ -443,6 +443,38 @@ def test_fit_objective_inside_the_rendering_node(ts):
                            (rgb_t, depth_t, alpha_t, alpha_t))
 
 
+def test_fit_objective_inside_the_rendering_node_large_faces():
+    """The same comparison on a mesh of a few screen-filling triangles: their bounding boxes exceed the gathered
+    pass's limit, so the texture / depth gradients go through the per-pixel fallback kernels, which must apply the
+    scalar factors of the unscaled gradient maps too."""
+    nr = _nr()
+    from deep3dmap_amd.core import multiview_fit_loss
+    v = np.array([[-0.9, -0.8, 0.1], [0.9, -0.7, -0.1], [0.0, 0.9, 0.2], [0.8, 0.8, -0.2], [-0.8, 0.7, 0.0]], np.float32)
+    tri = np.array([[0, 1, 2], [1, 3, 2], [0, 2, 4]], np.int32)
+    tex = np.random.default_rng(5).uniform(0.1, 1, (3, 2, 2, 2, 3)).astype(np.float32)
+    r = nr.Renderer(image_size=96, anti_aliasing=False, camera_mode="look_at", fill_back=True)
+    r.eye = torch.tensor([[0.3, 0.2, -2.2], [-0.4, 0.5, -2.0]], device="cuda")
+    tri_d = torch.from_numpy(tri).cuda()[None]
+    with torch.no_grad():
+        rgb_t, depth_t, alpha_t = r(torch.from_numpy(v * 0.93).cuda()[None], tri_d, torch.from_numpy(tex).cuda()[None])
+
+    def run(inside):
+        vv = torch.from_numpy(v).cuda().requires_grad_(True)
+        tt = torch.from_numpy(tex).cuda().requires_grad_(True)
+        if inside:
+            loss = r.render_fit_loss(vv[None], tri_d, tt[None], (rgb_t, depth_t, alpha_t, alpha_t))
+        else:
+            loss = multiview_fit_loss(*r(vv[None], tri_d, tt[None]), rgb_t, depth_t, alpha_t, alpha_t)
+        (loss * 0.5).backward()
+        return loss.detach(), vv.grad, tt.grad
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], rtol=2e-6)
+    for ga, gb in zip(a[1:], b[1:]):
+        assert float(gb.abs().max()) > 0
+        assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+
+
 @pytest.mark.parametrize("ts", [1, 2, 4])
 @pytest.mark.parametrize("shared", [False, True])
 def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
