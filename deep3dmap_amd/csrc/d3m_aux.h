@@ -159,29 +159,46 @@ __global__ void __launch_bounds__(256) k_camera_forward(const float* __restrict_
     out[i * 3 + 2] = o[2];
 }
 
-// One lane per (mesh vertex); with a shared mesh (vb == 1) the lane loops over the B views and sums,
-// so the multi-view reduction needs no atomics and is deterministic.
+// Per-view meshes (vb > 1): one lane per (view, vertex).  A shared mesh (vb == 1): EIGHT lanes per vertex, lane s
+// summing views s, s+8, ... and the eight partial sums combined in a fixed DPP tree -- the multi-view reduction needs
+// no atomics, is deterministic, and runs on 8x as many lanes as one-lane-per-vertex (50 k vertices leave most of the
+// chip idle, and each lane's 32 views were a chain of dependent loads).
 __global__ void __launch_bounds__(256) k_camera_backward(const float* __restrict__ vertices, int vb, Cam c,
                                                         const float* __restrict__ grad_out,
                                                         float* __restrict__ grad_vertices, int B, int V) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)(vb > 1 ? B : 1) * V;
-    if (i >= n) return;
-    const int v = (int)(i % V);
-    const int b_lo = vb > 1 ? (int)(i / V) : 0, b_hi = vb > 1 ? b_lo + 1 : B;
-    const float* p = vertices + (size_t)i * 3;
-    const float in[3] = {p[0], p[1], p[2]};
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool shared = vb <= 1;
+    const long i = shared ? t >> 3 : t;
+    const int sub = shared ? (int)(t & 7) : 0;
+    const long n = (long)(shared ? 1 : B) * V;
+    const bool on = i < n;
+    const int v = on ? (int)(i % V) : 0;
+    const int b_lo = shared ? sub : (int)(i / V), b_hi = shared ? B : b_lo + 1, b_step = shared ? 8 : 1;
     float acc[3] = {0, 0, 0};
-    for (int b = b_lo; b < b_hi; b++) {
-        const float* gp = grad_out + ((size_t)b * V + v) * 3;
-        const float g[3] = {gp[0], gp[1], gp[2]};
-        float gv[3];
-        camera_point_adjoint(c, b, in, g, gv);
-        acc[0] += gv[0]; acc[1] += gv[1]; acc[2] += gv[2];
+    if (on) {
+        const float* p = vertices + (size_t)i * 3;
+        const float in[3] = {p[0], p[1], p[2]};
+        for (int b = b_lo; b < b_hi; b += b_step) {
+            const float* gp = grad_out + ((size_t)b * V + v) * 3;
+            const float g[3] = {gp[0], gp[1], gp[2]};
+            float gv[3];
+            camera_point_adjoint(c, b, in, g, gv);
+            acc[0] += gv[0]; acc[1] += gv[1]; acc[2] += gv[2];
+        }
     }
-    grad_vertices[i * 3 + 0] = acc[0];
-    grad_vertices[i * 3 + 1] = acc[1];
-    grad_vertices[i * 3 + 2] = acc[2];
+    if (shared) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            acc[k] += dpp_f32<0xB1>(acc[k]);      // quad_perm [1,0,3,2]
+            acc[k] += dpp_f32<0x4E>(acc[k]);      // quad_perm [2,3,0,1]
+            acc[k] += dpp_f32<0x141>(acc[k]);     // row_half_mirror: the other quad of the 8
+        }
+    }
+    if (on && sub == 0) {
+        grad_vertices[i * 3 + 0] = acc[0];
+        grad_vertices[i * 3 + 1] = acc[1];
+        grad_vertices[i * 3 + 2] = acc[2];
+    }
 }
 
 // vertices_to_faces.py:16-22 + fill_back (renderer.py:86): one lane per output float, coalesced stores

@@ -563,11 +563,19 @@ __global__ void __launch_bounds__(256) k_sum_over_views_ts2(const float4* __rest
     float4 acc = make_float4(0, 0, 0, 0);
     for (int wd = 0; wd < words; wd++) {
         unsigned m = view_mask[(size_t)f * words + wd];
-        while (m) {
-            const int b = (wd << 5) + __ffs((int)m) - 1;
-            m &= m - 1;
-            const float4 v = in[(size_t)b * n4 + j];
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        while (m) {                                       // up to four views' entries requested per round, added in view order
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = make_float4(0, 0, 0, 0);
+                if (m) {
+                    const int b = (wd << 5) + __ffs((int)m) - 1;
+                    m &= m - 1;
+                    v[k] = in[(size_t)b * n4 + j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
         }
     }
     out[j] = acc;

@@ -429,7 +429,7 @@ D3M_EXPORT int d3m_camera_backward(const float* vertices, int vertices_batch, co
     Cam c;
     int rc = to_cam(cam, batch_size, c);
     if (rc) return rc;
-    const long n = (long)(vertices_batch > 1 ? batch_size : 1) * num_vertices;
+    const long n = vertices_batch > 1 ? (long)batch_size * num_vertices : 8l * num_vertices;     // lanes: see the kernel
     LAUNCH("k_camera_backward", k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, vertices,
                        vertices_batch, c, grad_out, grad_vertices, batch_size, num_vertices);
     return check_launch();
