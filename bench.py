@@ -345,7 +345,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
                                    f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "
-                                   f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
+                                   f"+ photometric/silhouette/depth loss + backward (vertex+texture grads); "
+                                   f"the objective is evaluated in the pass that produces the pixel values "
+                                   f"(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps"
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
                        "views_per_gpu": args.views_per_gpu, "triangles": int(F), "image_size": S,
                        "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on,
