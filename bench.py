@@ -233,6 +233,9 @@ def main():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--materialise-images", action="store_true",
+                    help="render() the output images and evaluate the objective on them (multiview_fit_loss) instead of "
+                         "inside the rendering node")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape", "mesh_family"],
                     help="multiview = the headline metric (default); gan2shape = BASELINE config 3 (secondary line)")
@@ -270,7 +273,7 @@ def main():
     tex = synthetic.random_textures(tri.shape[0], args.texture_size)
     eyes = synthetic.camera_ring(n_views)
     fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
-                       world_size=world, device=f"cuda:{local_rank}")
+                       world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images)
     fit.set_targets_from(synthetic.perturb(v))
 
     def barrier():
@@ -345,12 +348,14 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
                                    f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "
-                                   f"+ photometric/silhouette/depth loss + backward (vertex+texture grads); "
-                                   f"the objective is evaluated in the pass that produces the pixel values "
-                                   f"(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps"
+                                   f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
+                                   + ("; output images materialised, objective evaluated on them"
+                                      if args.materialise_images else
+                                      "; the objective is evaluated in the pass that produces the pixel values "
+                                      "(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps")
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
                        "views_per_gpu": args.views_per_gpu, "triangles": int(F), "image_size": S,
-                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on,
+                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}"},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},

@@ -52,7 +52,7 @@ class MultiViewFit:
     """
 
     def __init__(self, vertices, triangles, textures, eyes, image_size=512, anti_aliasing=False, rank=0,
-                 world_size=1, optimise_textures=True, device="cuda"):
+                 world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         lo, hi = shard_views(len(eyes), rank, world_size)
@@ -65,6 +65,7 @@ class MultiViewFit:
                                     fill_back=True)
         self.renderer.eye = self.eyes
         self.image_size = image_size
+        self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.targets = None
         self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
 
@@ -95,7 +96,7 @@ class MultiViewFit:
         """The objective of the current mesh against the targets, evaluated inside the rendering node when the renderer
         allows it (no images, no image gradients in memory); otherwise render() + loss()."""
         r = self.renderer
-        if r.lighting_on_the_fly and not r.anti_aliasing:
+        if self.objective_in_renderer and r.lighting_on_the_fly and not r.anti_aliasing:
             rgb_t, depth_t, alpha_t = self.targets
             return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
                                      (rgb_t, depth_t, alpha_t, alpha_t))
