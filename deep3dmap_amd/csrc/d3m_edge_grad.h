@@ -703,20 +703,36 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
             const float4* pg = s_grd + from + rl;
             const float2* pd = s_df + from + rl;
             const float4* pg_to = s_grd + to;
-            for (int k = 0; k < n_iter; k++) {
-                const float4 g = *pg;
-                const float2 d = *pd;
-                const float diff = diff_of(g, d);
-                const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
-                                                (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                const float dpos = __builtin_amdgcn_inverse_ballot_w64(keep) ? diff : 0.0f;
-                const v2f den = u + t;
-                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
-                pg += 16;
-                pd += 16;
-                t += 16.0f;
+            v2f den = u + t;                                // advances by exact steps of 16 as well
+            if (m_outward == ~0ull) {                       // four outward walks (the common case): no owner test
+                for (int k = 0; k < n_iter; k++) {
+                    const float diff = diff_of(*pg, *pd);
+                    const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                    __builtin_amdgcn_ballot_w64(!(diff <= 0));
+                    const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
+                    // den == 0 (1/0 = inf, 0 * inf = NaN)
+                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                    pg += 16;
+                    pd += 16;
+                    den += 16.0f;
+                }
+            } else {
+                for (int k = 0; k < n_iter; k++) {
+                    const float4 g = *pg;
+                    const float2 d = *pd;
+                    const float diff = diff_of(g, d);
+                    const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                    __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                    (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
+                    const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                    // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
+                    // den == 0 (1/0 = inf, 0 * inf = NaN)
+                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                    pg += 16;
+                    pd += 16;
+                    den += 16.0f;
+                }
             }
         } else {
             int d1 = from + rl;
@@ -727,10 +743,9 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
                 const unsigned long long keep = __builtin_amdgcn_ballot_w64(d1 <= to) &
                                                 __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
                                                 (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                const float dpos = __builtin_amdgcn_inverse_ballot_w64(keep) ? diff : 0.0f;
                 const v2f den = u + t;
                 const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                acc = __builtin_elementwise_fma(v2f{dpos, dpos}, r, acc);
+                if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
                 d1 += 16;
                 t += 16.0f;
             }
