@@ -78,6 +78,21 @@ def measured_traffic(name):
     return k["hbm_bytes_per_launch"] if k else None
 
 
+def measured_valu(name):
+    """Wave-level VALU instructions per launch of `name` from the committed SQ counter summary
+    (profiles/*sq_counters*.csv, tools_dev/sq_counters.sh), or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.csv")),
+                   key=lambda f: ("final" in os.path.basename(f), os.path.basename(f)))
+    if not files:
+        return None
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"] == name and row.get("SQ_INSTS_VALU"):
+            return int(float(row["SQ_INSTS_VALU"]))
+    return None
+
+
 def cpu_baseline(n, image_size, ts, budget_s=25.0):
     """The oracle (this repo's C restatement of the reference algorithm, 'port') timed on the host cores
     on ONE view of the same workload: bounding-box forward + texture sampling + the three backward kernels."""
@@ -342,6 +357,12 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom),
                     "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_count / n_inst,
                     "algorithmic_bytes_per_launch": kb * args.views_per_gpu}
+            # The kernel is not bandwidth-bound: what fraction of its duration the counted VALU
+            # instructions need at one 4-cycle issue slot each on 256 CUs x 4 SIMDs at 2.4 GHz (informational).
+            valu = measured_valu(dom)
+            if valu:
+                roof["valu_wave_instructions"] = valu
+                roof["valu_issue_frac"] = round(valu * 4 / (1024 * 2.4e9) / dom_avg_s, 3)
         out = {
             "metric": "rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
