@@ -213,6 +213,29 @@ def test_full_size_workload_properties():
         assert torch.equal(r1(vt[i:i + 1], ft[i:i + 1], mode="silhouettes")[0], sil[i])
 
 
+def test_full_size_fit_step_fused_objective_equals_materialised_images():
+    """BASELINE headline size (100,352 triangles, 512x512, 4 views): the step bench.py times -- objective evaluated
+    inside the rendering node, unscaled gradient maps, no output images -- against the same step with the images
+    materialised and multiview_fit_loss evaluated on them: same loss, same vertex and texture gradients (they differ
+    only in where the scalar factors of the loss gradient are multiplied in)."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(225)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    eyes = synthetic.camera_ring(32)[[0, 9, 17, 26]]
+    out = []
+    for inside in (True, False):
+        fit = MultiViewFit(v, tri, tex, eyes, image_size=512, objective_in_renderer=inside)
+        fit.set_targets_from(synthetic.perturb(v))
+        loss, gv, gt = fit.step()
+        assert torch.isfinite(gv).all() and torch.isfinite(gt).all()
+        out.append((float(loss), gv.clone(), gt.clone()))
+    (la, gva, gta), (lb, gvb, gtb) = out
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert float(gvb.abs().max()) > 0 and float(gtb.abs().max()) > 0
+    assert _rel_l2(gva, gvb) < 1e-4 and _rel_l2(gta, gtb) < 1e-5
+
+
 def test_graph_replay_with_host_syncs():
     """Regression: replaying the captured step with host synchronisation, read-backs and fresh allocations between
     replays (what a training loop with logging does) must keep reproducing the eager step."""
