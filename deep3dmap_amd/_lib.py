@@ -55,6 +55,8 @@ _SIGNATURES = {
     "d3m_scatter_face_grads": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "d3m_lighting_forward": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
     "d3m_lighting_backward": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
+    "d3m_view_transform": (_I, [_P, _I, _P, _P, _I, _P]),
+    "d3m_view_transform_backward": (_I, [_P, _I, _P, _P, _P, _I, _P]),
     "d3m_depth_to_vertices": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _P]),
     "d3m_depth_to_vertices_backward": (_I, [_P, _P, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_face_light": (_I, [_P, _I, _P, _I, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),

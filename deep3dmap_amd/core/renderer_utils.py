@@ -39,8 +39,41 @@ def get_rotation_matrix(tx, ty, tz):
     return torch.matmul(m_z, torch.matmul(m_y, m_x))
 
 
+class _ViewTransform(torch.autograd.Function):
+    """get_transform_matrices on the device: one HIP launch each way (d3m_view_transform / _backward)."""
+
+    @staticmethod
+    def forward(ctx, view):
+        from .. import _lib
+        v = view.detach().to(torch.float32).contiguous()
+        b, n = v.shape
+        rot = torch.empty(b, 3, 3, dtype=torch.float32, device=v.device)
+        trans = torch.empty(b, 1, 3, dtype=torch.float32, device=v.device)
+        _lib.check(_lib.lib().d3m_view_transform(_lib.ptr(v), n, _lib.ptr(rot), _lib.ptr(trans), b, _lib.stream_ptr()),
+                   "d3m_view_transform")
+        ctx.save_for_backward(v)
+        return rot, trans
+
+    @staticmethod
+    def backward(ctx, g_rot, g_trans):
+        from .. import _lib
+        (v,) = ctx.saved_tensors
+        b, n = v.shape
+        gr = g_rot.to(torch.float32).contiguous() if g_rot is not None else None
+        gt = g_trans.to(torch.float32).contiguous() if g_trans is not None else None
+        g_view = torch.empty_like(v)
+        _lib.check(_lib.lib().d3m_view_transform_backward(_lib.ptr(v), n, _lib.ptr(gr), _lib.ptr(gt), _lib.ptr(g_view), b,
+                                                          _lib.stream_ptr()), "d3m_view_transform_backward")
+        return g_view
+
+
 def get_transform_matrices(view):
-    """view [b,6|5|3] = (rx, ry, rz[, tx, ty[, tz]]) -> (rot [b,3,3], trans [b,1,3]) (utils.py:54-71)."""
+    """view [b,6|5|3] = (rx, ry, rz[, tx, ty[, tz]]) -> (rot [b,3,3], trans [b,1,3]) (utils.py:54-71).  A view on the
+    GPU goes through one HIP launch (and one in backward); host tensors through the reference's tensor algebra."""
+    if view.dim() == 2 and view.size(1) not in (3, 5, 6):
+        raise ValueError("view must have 3, 5 or 6 components")
+    if view.is_cuda and view.dim() == 2:
+        return _ViewTransform.apply(view)
     b = view.size(0)
     if view.size(1) == 6:
         trans_xyz = view[:, 3:].reshape(b, 1, 3)

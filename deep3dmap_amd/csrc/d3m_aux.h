@@ -418,6 +418,73 @@ __global__ void __launch_bounds__(256) k_depth_to_vertices_backward(const float*
     }
 }
 
+// ---- view vector -> (rotation, translation) (deep3dmap/core/renderer/utils.py:34-71) ----------------------------
+// R = Rz(rz) Ry(ry) Rx(rx) with the reference's sign conventions, t = (tx, ty, tz) padded with zeros for 5- and
+// 3-component views: one lane per batch entry instead of ~35 eager kernels (6 trig calls, 27 stacks, 2 batched matmuls)
+// and as many again in backward.  The two 3x3 products are evaluated in the reference's association, Rz (Ry Rx).
+__device__ __forceinline__ void mat3_mul(const float* a, const float* b, float* c) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) c[3 * i + j] = (a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j]) + a[3 * i + 2] * b[6 + j];
+}
+__device__ __forceinline__ void euler_factors(float cx, float sx, float cy, float sy, float cz, float sz, float* mx,
+                                              float* my, float* mz) {
+    const float x[9] = {1, 0, 0, 0, cx, -sx, 0, sx, cx};
+    const float y[9] = {cy, 0, sy, 0, 1, 0, -sy, 0, cy};
+    const float z[9] = {cz, -sz, 0, sz, cz, 0, 0, 0, 1};
+#pragma unroll
+    for (int k = 0; k < 9; k++) { mx[k] = x[k]; my[k] = y[k]; mz[k] = z[k]; }
+}
+
+__global__ void __launch_bounds__(64) k_view_transform(const float* __restrict__ view, int n_comp, float* __restrict__ rot,
+                                                      float* __restrict__ trans, int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* v = view + (size_t)b * n_comp;
+    float mx[9], my[9], mz[9], yx[9], r[9];
+    euler_factors(cosf(v[0]), sinf(v[0]), cosf(v[1]), sinf(v[1]), cosf(v[2]), sinf(v[2]), mx, my, mz);
+    mat3_mul(my, mx, yx);
+    mat3_mul(mz, yx, r);
+#pragma unroll
+    for (int k = 0; k < 9; k++) rot[(size_t)b * 9 + k] = r[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) trans[(size_t)b * 3 + k] = 3 + k < n_comp ? v[3 + k] : 0.0f;
+}
+
+// adjoint: g_view[b, 0..2] = <g_rot, dR/d(rx, ry, rz)>, g_view[b, 3..] = g_trans
+__global__ void __launch_bounds__(64) k_view_transform_backward(const float* __restrict__ view, int n_comp,
+                                                               const float* __restrict__ g_rot,
+                                                               const float* __restrict__ g_trans, float* __restrict__ g_view,
+                                                               int B) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* v = view + (size_t)b * n_comp;
+    const float cx = cosf(v[0]), sx = sinf(v[0]), cy = cosf(v[1]), sy = sinf(v[1]), cz = cosf(v[2]), sz = sinf(v[2]);
+    float mx[9], my[9], mz[9];
+    euler_factors(cx, sx, cy, sy, cz, sz, mx, my, mz);
+    // derivatives of the factors: d/dtheta of (cos, sin) = (-sin, cos), constants -> 0
+    const float dx[9] = {0, 0, 0, 0, -sx, -cx, 0, cx, -sx};
+    const float dy[9] = {-sy, 0, cy, 0, 0, 0, -cy, 0, -sy};
+    const float dz[9] = {-sz, -cz, 0, cz, -sz, 0, 0, 0, 0};
+    float g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (g_rot) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) g[k] = g_rot[(size_t)b * 9 + k];
+    }
+    float t0[9], t1[9];
+    float out[3];
+    mat3_mul(my, dx, t0); mat3_mul(mz, t0, t1);          // dR/drx = Rz Ry Rx'
+    out[0] = 0; for (int k = 0; k < 9; k++) out[0] += g[k] * t1[k];
+    mat3_mul(dy, mx, t0); mat3_mul(mz, t0, t1);          // dR/dry = Rz Ry' Rx
+    out[1] = 0; for (int k = 0; k < 9; k++) out[1] += g[k] * t1[k];
+    mat3_mul(my, mx, t0); mat3_mul(dz, t0, t1);          // dR/drz = Rz' Ry Rx
+    out[2] = 0; for (int k = 0; k < 9; k++) out[2] += g[k] * t1[k];
+    float* o = g_view + (size_t)b * n_comp;
+    o[0] = out[0]; o[1] = out[1]; o[2] = out[2];
+    for (int k = 3; k < n_comp; k++) o[k] = g_trans ? g_trans[(size_t)b * 3 + (k - 3)] : 0.0f;
+}
+
 // ---- output epilogue (rasterize.py:181-195, 305-326) -------------------------------------------------
 // One lane per OUTPUT pixel.  Internal row r is output row S-1-r (vertical flip); with anti-aliasing
 // the output pixel is the mean of its 2x2 internal pixels.

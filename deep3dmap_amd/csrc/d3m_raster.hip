@@ -494,6 +494,24 @@ D3M_EXPORT int d3m_lighting_backward(const float* faces, const float* textures_i
     return check_launch();
 }
 
+D3M_EXPORT int d3m_view_transform(const float* view, int num_components, float* rot, float* trans, int batch_size,
+                                  d3m_stream_t stream) {
+    if (!view || !rot || !trans || batch_size <= 0) return D3M_ERR_INVALID;
+    if (num_components != 3 && num_components != 5 && num_components != 6) return D3M_ERR_INVALID;
+    LAUNCH("k_view_transform", k_view_transform, dim3(blocks_for(batch_size, 64)), dim3(64), (hipStream_t)stream, view,
+           num_components, rot, trans, batch_size);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_view_transform_backward(const float* view, int num_components, const float* grad_rot,
+                                           const float* grad_trans, float* grad_view, int batch_size, d3m_stream_t stream) {
+    if (!view || !grad_view || batch_size <= 0) return D3M_ERR_INVALID;
+    if (num_components != 3 && num_components != 5 && num_components != 6) return D3M_ERR_INVALID;
+    LAUNCH("k_view_transform_backward", k_view_transform_backward, dim3(blocks_for(batch_size, 64)), dim3(64),
+           (hipStream_t)stream, view, num_components, grad_rot, grad_trans, grad_view, batch_size);
+    return check_launch();
+}
+
 D3M_EXPORT int d3m_depth_to_vertices(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
                                      const float* trans, float rot_center_depth, float* vertices, int batch_size,
                                      int height, int width, d3m_stream_t stream) {

@@ -218,6 +218,13 @@ int d3m_lighting_backward(const float* faces, const float* textures_in, const fl
                           float intensity_directional, const float* color_ambient, const float* color_directional,
                           const float* direction, long num_faces_total, int texture_size, d3m_stream_t stream);
 
+/* get_transform_matrices (deep3dmap/core/renderer/utils.py:34-71): view [B,n] = (rx, ry, rz[, tx, ty[, tz]]), n = 3, 5
+ * or 6 -> rot [B,3,3] = Rz Ry Rx and trans [B,3] (missing components 0), and its adjoint (grad_rot / grad_trans may be
+ * NULL = zero).  One launch each way instead of ~35 eager kernels. */
+int d3m_view_transform(const float* view, int num_components, float* rot, float* trans, int batch_size,
+                       d3m_stream_t stream);
+int d3m_view_transform_backward(const float* view, int num_components, const float* grad_rot, const float* grad_trans,
+                                float* grad_view, int batch_size, d3m_stream_t stream);
 /* NrRenderer's depth map -> mesh vertices in one pass (deep3dmap/core/renderer/renderer_nr.py:64-80,95-100:
  * depth_to_3d_grid -> rotate_pts about (0,0,rot_center_depth) -> translate_pts):
  *   vertices[b, y*W+x, :] = R_b (depth[b,y,x] * inv_K (x, y, 1)^T - c) + c + t_b

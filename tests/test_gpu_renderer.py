@@ -443,6 +443,30 @@ def test_fit_objective_inside_the_rendering_node(ts):
                            (rgb_t, depth_t, alpha_t, alpha_t))
 
 
+@pytest.mark.parametrize("n", [3, 5, 6])
+def test_view_transform_kernel_matches_reference_tensor_algebra(n):
+    """get_transform_matrices on the device (one HIP launch each way) against the reference's tensor algebra
+    (utils.py:34-71: stacked Euler factors, Rz (Ry Rx), zero-padded translation) evaluated by torch on the host:
+    values and the gradient of the view through both outputs."""
+    from deep3dmap_amd.core.renderer_utils import get_transform_matrices
+    gen = torch.Generator().manual_seed(n)
+    view = (torch.rand(7, n, generator=gen) - 0.5) * torch.tensor([3.0, 3.0, 3.0, 0.4, 0.4, 0.1][:n])
+    w_r, w_t = torch.randn(7, 3, 3, generator=gen), torch.randn(7, 1, 3, generator=gen)
+
+    def run(dev):
+        v = view.to(dev).clone().requires_grad_(True)
+        rot, trans = get_transform_matrices(v)
+        ((rot * w_r.to(dev)).sum() + (trans * w_t.to(dev)).sum()).backward()
+        return rot.detach().cpu(), trans.detach().cpu(), v.grad.cpu()
+
+    (ra, ta, ga), (rb, tb, gb) = run("cuda"), run("cpu")
+    assert ra.shape == (7, 3, 3) and ta.shape == (7, 1, 3)
+    assert torch.allclose(ra, rb, atol=2e-6) and torch.equal(ta, tb)
+    assert torch.allclose(ga, gb, rtol=1e-5, atol=2e-6)
+    with pytest.raises(ValueError):
+        get_transform_matrices(torch.zeros(2, 4, device="cuda"))
+
+
 def test_fit_objective_inside_the_rendering_node_large_faces():
     """The same comparison on a mesh of a few screen-filling triangles: their bounding boxes exceed the gathered
     pass's limit, so the texture / depth gradients go through the per-pixel fallback kernels, which must apply the
