@@ -84,12 +84,16 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
     BoxCursor c(x0, x1, y0, sub);
     for (int i = sub; i < area; i += FM_LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
-        if (face_index_map[p] != fn) continue;
-        const float depth = depth_map[p], g = grad_depth_map[p];
+        // the pixel's maps are requested together with its owner: one round trip per step of the scan, not two
+        const bool own = face_index_map[p] == fn;
+        const float ld = depth_map[p], lg = grad_depth_map[p];
+        const float lw[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+        if (!__builtin_amdgcn_ballot_w64(own)) continue;
+        const float depth = own ? ld : 1.0f, g = own ? lg : 0.0f;     // selected, not multiplied away
         const float depth2 = depth * depth;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float wk = weight_map[3 * p + k], z_k = face[3 * k + 2];
+            const float wk = own ? lw[k] : 0.0f, z_k = face[3 * k + 2];
             acc[3 * k + 0] += -g * tmp[0] * wk * depth2 * (float)S / 2.0f;          // KCU:588
             acc[3 * k + 1] += -g * tmp[1] * wk * depth2 * (float)S / 2.0f;
             acc[3 * k + 2] += g * wk * depth2 / (z_k * z_k);                        // KCU:575
