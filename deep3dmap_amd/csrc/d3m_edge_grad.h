@@ -18,7 +18,7 @@
 //   4. k_edge_emit    same flattening: every crossing owns two result slots; segments are clipped to the line's
 //                     extent, short ones walked in-thread, long ones written as 48-byte records in LINE order;
 //   5. k_edge_lines   one workgroup per (view, axis, line): the line's records staged in LDS once, the line's
-//                     segments ordered by length, four segments per wave (one per 16-lane row), factored distance;
+//                     segments ordered by length, sixteen segments per wave (four lanes each), factored distance;
 //   6. k_edge_gather  six lanes per visible face add their crossings' slots in order; stored to grad_faces or
 //                     accumulated into the vertex gradient (VertexTarget).
 // Deterministic up to the final vertex atomics.  The reference OVERWRITES the 9 entries of every front-facing face
@@ -587,13 +587,21 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     }
 }
 
-constexpr int EG_SEG_PER_WAVE = 4;   // segments walked concurrently by one wave (one per 16-lane row)
+// Lanes that share one segment (16, 8 or 4: all inside a DPP row).  The per-segment work -- record decode, the
+// trip count, the DPP sum, the result -- is per-LANE vector work shared by all the segments of a wave, so fewer lanes
+// per segment means fewer instructions per segment: 16 -> 8 -> 4 lanes took the kernel from 0.51 to 0.45 to 0.44 ms on
+// the headline step (263 M wave-instructions, 86 % VALU-issue-bound, at 16).
+#ifndef D3M_EG_ROW
+#define D3M_EG_ROW 4
+#endif
+constexpr int EG_ROW = D3M_EG_ROW;
+constexpr int EG_SEG_PER_WAVE = 64 / EG_ROW;   // segments walked concurrently by one wave
 constexpr int EG_SORT_CHUNK = 1024;  // segments ordered by length at a time (a multiple of the workgroup size)
 __device__ __forceinline__ int from0_clamp(int from, int is) { return min(max(from, 0), is - 1); }
 
 // ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
 // PAD: the LDS image of the line has 2*S + 16 entries (only the first S are filled), so the lanes of a row that has
-// finished -- the four rows of a wave advance in lock step with the longest -- keep reading inside the allocation and
+// finished -- the segments of a wave advance in lock step with the longest -- keep reading inside the allocation and
 // the per-iteration address clamp disappears; without PAD (large S) the index is clamped.
 template <bool USE_RGB, bool USE_ALPHA, bool PAD>
 __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
@@ -632,15 +640,15 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         s_df[p] = make_float2(0.5f * d.x, d.y);
     }
     __syncthreads();
-    // FOUR segments per wave, one per 16-lane row: the segments are short once clipped (tens of pixels), so a whole
-    // wave per segment spent most of its time on the per-segment prologue / reduction / epilogue.  Here those are
-    // per-lane vector work shared by four segments, the reduction is four DPP steps inside the row, and a walk
-    // iteration covers 16 pixels of each of the four segments.
+    // EG_SEG_PER_WAVE segments per wave, EG_ROW lanes each: the segments are short once clipped (tens of pixels), so a
+    // whole wave per segment spent most of its time on the per-segment prologue / reduction / epilogue.  Here those
+    // are per-lane vector work shared by all the wave's segments, the reduction is a few DPP steps inside the lane
+    // group, and a walk iteration covers EG_ROW pixels of each segment.
     typedef float v2f __attribute__((ext_vector_type(2)));
-    const int row = lane >> 4, rl = lane & 15;
-    // The four segments of a wave advance in lock step, so they should be about equally long: the workgroup first
+    const int row = lane / EG_ROW, rl = lane % EG_ROW;
+    // The segments of a wave advance in lock step, so they should be about equally long: the workgroup first
     // orders its segments by length (counting sort on length / 16, longest first, in chunks of EG_SORT_CHUNK) and the
-    // waves then take consecutive quadruples of that order.  Unsorted, a quadruple ran at 64 % lane efficiency.
+    // waves then take consecutive groups of that order.  Unsorted, a group of four ran at 64 % lane efficiency.
     __shared__ int s_hist[33];
     __shared__ unsigned short s_order[EG_SORT_CHUNK];
     for (int chunk0 = 0; chunk0 < n_items; chunk0 += EG_SORT_CHUNK) {
@@ -694,9 +702,10 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
         const unsigned long long m_outward = ~__builtin_amdgcn_ballot_w64((bits & 1u) != 0);
         // the rows advance together: as many 16-pixel steps as the longest of the four needs (a scalar trip count)
         const int len = to - from + 1;
-        const int max_len = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
-                                max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
-        const int n_iter = (max_len + 15) >> 4;
+        int max_len = __builtin_amdgcn_readlane(len, 0);
+#pragma unroll
+        for (int r = 1; r < EG_SEG_PER_WAVE; r++) max_len = max(max_len, __builtin_amdgcn_readlane(len, r * EG_ROW));
+        const int n_iter = (max_len + EG_ROW - 1) / EG_ROW;
         float t = (float)(from + rl) - d1_cross;            // t = d1 - d1_cross advances by exact steps
         v2f acc = {0.0f, 0.0f};
         if (PAD) {
@@ -704,7 +713,7 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
             const float2* pd = s_df + from + rl;
             const float4* pg_to = s_grd + to;
             v2f den = u + t;                                // advances by exact steps of 16 as well
-            if (m_outward == ~0ull) {                       // four outward walks (the common case): no owner test
+            if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
                 for (int k = 0; k < n_iter; k++) {
                     const float diff = diff_of(*pg, *pd);
                     const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
@@ -713,9 +722,9 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
                     // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
                     // den == 0 (1/0 = inf, 0 * inf = NaN)
                     if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                    pg += 16;
-                    pd += 16;
-                    den += 16.0f;
+                    pg += EG_ROW;
+                    pd += EG_ROW;
+                    den += (float)EG_ROW;
                 }
             } else {
                 for (int k = 0; k < n_iter; k++) {
@@ -729,9 +738,9 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
                     // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
                     // den == 0 (1/0 = inf, 0 * inf = NaN)
                     if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                    pg += 16;
-                    pd += 16;
-                    den += 16.0f;
+                    pg += EG_ROW;
+                    pd += EG_ROW;
+                    den += (float)EG_ROW;
                 }
             }
         } else {
@@ -746,16 +755,16 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
                 const v2f den = u + t;
                 const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
                 if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                d1 += 16;
-                t += 16.0f;
+                d1 += EG_ROW;
+                t += (float)EG_ROW;
             }
         }
         // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
         float s0 = acc.x, s1 = acc.y;
         s0 += dpp_f32<0xB1>(s0);  s1 += dpp_f32<0xB1>(s1);
         s0 += dpp_f32<0x4E>(s0);  s1 += dpp_f32<0x4E>(s1);
-        s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1);
-        s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1);
+        if (EG_ROW >= 8) { s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1); }
+        if (EG_ROW == 16) { s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1); }
         if (have && rl == 0) {
             const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
             if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
