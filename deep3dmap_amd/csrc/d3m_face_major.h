@@ -20,18 +20,20 @@ constexpr int FM_MAX_BBOX_AREA = 1024;   // larger faces are left to the per-pix
 constexpr int FM_LANES = 8;
 constexpr int FM_FACES_PER_BLOCK = 256 / FM_LANES;
 
-// pixel `i` (row-major) of the box, advanced by FM_LANES per step
-struct BoxCursor {
+// pixel `i` (row-major) of the box, advanced by N (the lanes that share the face) per step
+template <int N>
+struct BoxCursorN {
     int x, y, x0, x1, bw;
-    __device__ __forceinline__ BoxCursor(int x0_, int x1_, int y0_, int start) : x0(x0_), x1(x1_), bw(x1_ - x0_ + 1) {
+    __device__ __forceinline__ BoxCursorN(int x0_, int x1_, int y0_, int start) : x0(x0_), x1(x1_), bw(x1_ - x0_ + 1) {
         y = y0_ + start / bw;
         x = x0_ + start % bw;
     }
     __device__ __forceinline__ void advance() {
-        x += FM_LANES;
+        x += N;
         while (x > x1) { x -= bw; y++; }
     }
 };
+typedef BoxCursorN<FM_LANES> BoxCursor;
 
 // sum over the FM_LANES (= 8) adjacent lanes of a face, in every one of them: two quad swaps and the half-row
 // mirror, all DPP (no LDS crossbar)

@@ -310,6 +310,22 @@ __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restri
 // Entries of faces that own no pixel are NOT written: with shared textures the per-view buffer is scratch and
 // k_sum_over_views skips them by the visibility flags (no 77 MB zero fill per step on the headline workload);
 // a caller-visible per-view gradient is zero-filled by the host wrapper first.
+// Lanes per face in the gathered lit pass.  What is done once per face -- bounding box, inverse, the 24 + 9 DPP sums,
+// the stores -- is per-lane vector work shared by all the faces of a wave, so fewer lanes per face means fewer
+// instructions per face, at the price of more scan steps per lane (each a memory round trip).  Measured on the
+// headline step: 8 lanes 2.135 ms, 4 lanes 2.155 ms.
+#ifndef D3M_LIT_LANES
+#define D3M_LIT_LANES 8
+#endif
+constexpr int LIT_LANES = D3M_LIT_LANES;
+constexpr int LIT_FACES_PER_BLOCK = 256 / LIT_LANES;
+__device__ __forceinline__ float lit_sum(float v) {       // over the LIT_LANES adjacent lanes of a face, in every one
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    if (LIT_LANES == 8) v += dpp_f32<0x141>(v);     // row_half_mirror: the other quad of the 8
+    return v;
+}
+
 struct LitFaceArgs {
     const float* faces;
     LitTextures lt;
@@ -363,7 +379,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
         flags[gi] = FLAG_LARGE;
         if (sub == 0) atomicAdd(a.n_large, 1);
-        for (int t = sub; t < 24; t += FM_LANES) gt[t] = 0.0f;
+        for (int t = sub; t < 24; t += LIT_LANES) gt[t] = 0.0f;
         return;
     }
     // ts == 2: the sample position is clamped below 1 (KCU:222-223), so its integer part is 0 and corner pn of the
@@ -386,11 +402,19 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     // what the epilogue needs, requested now: this lane's texel (sub) of the face's cube and the face's light
     const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
     const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
-    const int to = fn >= lt.F ? ((sub & 1) << 2) | (sub & 2) | ((sub >> 2) & 1) : sub;   // (a,b,c) -> (c,b,a) for ts = 2
-    const float* tex = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24 + to * 3;
-    const float tx[3] = {tex[0], tex[1], tex[2]};
-    BoxCursor c(x0, x1, y0, sub);
-    for (int i = sub; i < area; i += FM_LANES, c.advance()) {
+    constexpr int TPL = 8 / LIT_LANES;                    // texels per lane in the epilogue: sub, sub + LIT_LANES
+    const float* tex_face = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24;
+    int to[TPL];
+    float tx[TPL][3];
+#pragma unroll
+    for (int j = 0; j < TPL; j++) {
+        const int t = sub + j * LIT_LANES;
+        to[j] = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) tx[j][c3] = tex_face[to[j] * 3 + c3];
+    }
+    BoxCursorN<LIT_LANES> c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += LIT_LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
         // Everything the pixel could contribute is requested together with its owner (ONE round trip per step of
         // the scan instead of two); a pixel of another face then computes on stand-in values with zero gradients
@@ -430,10 +454,10 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
         }
     }
 #pragma unroll
-    for (int t = 0; t < 24; t++) acc[t] = quad_sum(acc[t]);
+    for (int t = 0; t < 24; t++) acc[t] = lit_sum(acc[t]);
     if (grad_depth_map) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) dacc[k] = quad_sum(dacc[k]);
+        for (int k = 0; k < 9; k++) dacc[k] = lit_sum(dacc[k]);
         if (sub == 0) {
             if (vt.gv) {
 #pragma unroll
@@ -449,19 +473,24 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
             }
         }
     }
-    // epilogue, one texel per lane (the face's 8 lanes hold all 24 sums after quad_sum): light and texel were requested
-    // before the scan
-    float mine[3] = {0, 0, 0};
+    // epilogue, 8 / LIT_LANES texels per lane (every lane of the face holds all 24 sums after lit_sum): light and
+    // texels were requested before the scan
+    float gl[3] = {0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        if (sub == t) { mine[0] = acc[3 * t]; mine[1] = acc[3 * t + 1]; mine[2] = acc[3 * t + 2]; }
-    }
-    float gl[3];
+    for (int j = 0; j < TPL; j++) {
+        float mine[3] = {0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        gt[to * 3 + c] = mine[c] * li[c];          // plain store: see the kernel comment
-        gl[c] = quad_sum(mine[c] * tx[c]);
+        for (int t = 0; t < 8; t++) {
+            if (sub + j * LIT_LANES == t) { mine[0] = acc[3 * t]; mine[1] = acc[3 * t + 1]; mine[2] = acc[3 * t + 2]; }
+        }
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) {
+            gt[to[j] * 3 + c3] = mine[c3] * li[c3];          // plain store: see the kernel comment
+            gl[c3] += mine[c3] * tx[j][c3];
+        }
     }
+#pragma unroll
+    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_sum(gl[c3]);
     if (grad_light && sub == 0) {
         atomicAdd(&grad_light[3 * (size_t)lrow + 0], gl[0]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 1], gl[1]);
@@ -473,16 +502,16 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
 // a fill_back mesh, i.e. mostly idle waves); with the compacted list of a d3m_visibility only faces that own a pixel
 // do, on a fixed grid that strides over the list.
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs a) {
-    const int sub = threadIdx.x % FM_LANES, slot = threadIdx.x / FM_LANES;
+    const int sub = threadIdx.x % LIT_LANES, slot = threadIdx.x / LIT_LANES;
     if (a.list) {
         const int n = *a.n_list;
-        const XcdOrder xo((n + FM_FACES_PER_BLOCK - 1) / FM_FACES_PER_BLOCK);       // neighbouring faces share map lines
+        const XcdOrder xo((n + LIT_FACES_PER_BLOCK - 1) / LIT_FACES_PER_BLOCK);     // neighbouring faces share map lines
         for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
-            const long base = (long)xo.unit(i) * FM_FACES_PER_BLOCK;
+            const long base = (long)xo.unit(i) * LIT_FACES_PER_BLOCK;
             if (base + slot < n) lit_face_backward(a, a.list[base + slot], sub);
         }
     } else {
-        const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + slot;
+        const long gi = (long)blockIdx.x * LIT_FACES_PER_BLOCK + slot;
         if (gi < (long)a.B * a.lt.Fp) lit_face_backward(a, gi, sub);
     }
 }

@@ -698,7 +698,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         else HIP_TRY(zero_async(n_large, 256, st));
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, n_large};
-        const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
+        const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
