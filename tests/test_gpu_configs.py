@@ -213,6 +213,28 @@ def test_full_size_workload_properties():
         assert torch.equal(r1(vt[i:i + 1], ft[i:i + 1], mode="silhouettes")[0], sil[i])
 
 
+def test_one_wave_per_tile_path_equals_four_waves_per_tile_path():
+    """The tile pass runs one wave per tile when a launch has more than 32768 tiles (the bench.py configuration) and
+    four waves per tile below that (what every other test exercises and the oracle comparisons pin).  Nine views at
+    512x512 (36864 tiles) rendered in one batch must give bit-identical maps to the same views rendered one by one."""
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    from deep3dmap_amd.neural_renderer.mesh_ops import gather_faces
+    from deep3dmap_amd.neural_renderer.rasterize import _raster_forward
+    v, tri = synthetic.grid_mesh(40)
+    eyes = torch.from_numpy(synthetic.camera_ring(9)).cuda()
+    vt = torch.from_numpy(v).cuda()[None].expand(9, -1, -1).contiguous()
+    ft = torch.from_numpy(tri).cuda()[None].expand(9, -1, -1).contiguous()
+    faces = gather_faces(nr.look_at(vt, eyes, _perspective_angle=30), ft, True)
+    tex = torch.rand(9, faces.shape[1], 2, 2, 2, 3, device="cuda")
+    many, _ = _raster_forward(faces, tex, 512, 0.1, 100.0, 1e-3, None, True, True, True, False)
+    assert float((many["face_index_map"] >= 0).float().mean()) > 0.05
+    for i in range(9):
+        one, _ = _raster_forward(faces[i:i + 1].contiguous(), tex[i:i + 1].contiguous(), 512, 0.1, 100.0, 1e-3, None, True,
+                                 True, True, False)
+        for k in ("face_index_map", "weight_map", "depth_map"):
+            assert torch.equal(many[k][i], one[k][0]), (i, k)
+
+
 def test_full_size_fit_step_fused_objective_equals_materialised_images():
     """BASELINE headline size (100,352 triangles, 512x512, 4 views): the step bench.py times -- objective evaluated
     inside the rendering node, unscaled gradient maps, no output images -- against the same step with the images
