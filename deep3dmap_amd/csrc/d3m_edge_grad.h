@@ -626,8 +626,10 @@ __global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs 
     const uint32_t* recs = w.items + ((size_t)li.z + item_lo) * EG_ITEM_DW;    // contiguous records
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
-    // visited pixel, both conflict-free (16- and 8-byte lane strides within a 16-lane row).  T is kept halved (exact)
-    // because the two packed fma below start BOTH halves of the sum from it.
+    // visited pixel, contiguous within a segment's lane group (the groups of a wave start at unrelated offsets, so
+    // bank conflicts between groups do occur; a single 32-byte record per pixel -- one address register instead of
+    // two -- doubled them and was 8 % slower).  T is kept halved (exact) because the two packed fma below start BOTH
+    // halves of the sum from it.
     const int n_lds = PAD ? 2 * is + 16 : is;
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + n_lds);
