@@ -373,6 +373,7 @@ class _RasterizeLit(torch.autograd.Function):
         if side is not None:
             grad_textures = torch.empty_like(textures)
             grad_light = torch.empty_like(light) if need_vert else None
+            grad_vertices = torch.zeros_like(vertices) if need_vert else None
             ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
@@ -384,18 +385,17 @@ class _RasterizeLit(torch.autograd.Function):
                     int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None,
                     _lib.ptr(vis), ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
                     "d3m_backward_textures_lit")
+                if need_vert:       # the light gradient -> world-space vertices through the face normals, same branch
+                    _lib.check(L.d3m_face_light_backward(
+                        _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
+                        _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
+                        Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
             depth_done = rd
         ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
                                g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis,
                                unscaled=unscaled)
         if side is not None:
             cur.wait_stream(side)
-            if need_vert:
-                grad_vertices = torch.zeros_like(vertices)
-                _lib.check(L.d3m_face_light_backward(
-                    _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
-                    _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V, Ft,
-                    int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
             if not need_tex:
                 grad_textures = None
         if rd and not depth_done:           # textures and lighting need no gradient: the depth term on its own
