@@ -124,6 +124,32 @@ def test_algorithmic_byte_model_matches_survey_worked_values():
     assert abs((a_fwd + a_bwd) / 1e6 - 17.86) < 0.02                                      # silhouettes only
 
 
+def test_committed_bench_line_and_profiles_are_consistent():
+    """The committed measurement artefacts: the bench line carries the contract's keys, its roofline object agrees
+    with the committed PMC / SQ summaries that bench.py reads, and the kernel it names is in the rocprofv3 stats."""
+    import csv
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_final.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["unit"] == "Mpix/s" and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert roof["traffic"] == bench.measured_traffic(roof["kernel"])
+    assert roof.get("valu_wave_instructions") == bench.measured_valu(roof["kernel"])
+    assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["cores"] >= 1
+    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_final.csv")))]
+    row = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_final.csv")))
+           if roof["kernel"] in r["Name"]]
+    assert names and row
+    # rocprofv3's average duration of that kernel agrees with the HIP-event average in the bench line
+    assert abs(float(row[0]["AverageNs"]) / 1e3 - roof["avg_launch_us"]) < 0.1 * roof["avg_launch_us"]
+
+
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
