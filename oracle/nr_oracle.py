@@ -8,9 +8,14 @@ cpu_baseline leg.  Nothing under deep3dmap_amd/ imports this module.
 Two kernel back ends with identical signatures are reachable from here:
 
   * "port": oracle/nr_oracle.c (this repo's plain-C restatement; travels to the GPU box),
-  * "ref" : oracle/_ref/libnr_ref.so, the reference's own kernel bodies host-compiled where
-            they lie (oracle/Makefile, target `ref`); only present when it was built in the
-            build container.  Used to validate "port" and to generate tests/golden/.
+  * "hip" : oracle/_ref/libnr_ref_hip.so -- THE REFERENCE'S OWN KERNELS ON THE DEVICE: the text of
+            rasterize_cuda_kernel.cu:22-593 (and of the two texture kernels) compiled where it lies by
+            hipcc against HIP's real headers, -ffp-contract=off (oracle/Makefile, target `ref_hip`;
+            launch drivers in oracle/ref_hipbuild/).  Needs a GPU.  This is the pin of K2/K3/K5/K6: it
+            validates "port", generates tests/golden/*kern*.npz on the GPU box and is what the -m gpu
+            parity tests compare the product with, at fixture and at full size.
+  * "hip_fma": the same text with the compiler's default FMA contraction (what a stock build of the
+            reference would do); compared within north_star's tolerances, not bit for bit.
 
 The torch (CPU) glue below restates, with citations, the Python half of the reference path
 (NR = pnpmodules/neural_renderer/neural_renderer, CR = deep3dmap/core/renderer):
@@ -31,7 +36,8 @@ import torch.nn.functional as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PORT_SO = os.path.join(_HERE, "_build", "libnr_oracle.so")
-_REF_SO = os.path.join(_HERE, "_ref", "libnr_ref.so")
+_HIP_SO = {"hip": os.path.join(_HERE, "_ref", "libnr_ref_hip.so"),
+           "hip_fma": os.path.join(_HERE, "_ref", "libnr_ref_hip_fma.so")}
 
 _f32p = ctypes.POINTER(ctypes.c_float)
 _i32p = ctypes.POINTER(ctypes.c_int32)
@@ -64,11 +70,10 @@ class _Kernels:
         self.backend = backend
         if backend == "port":
             path, prefix = build_port(), "orc_"
-        elif backend == "ref":
-            path, prefix = _REF_SO, "ref_"
+        elif backend in _HIP_SO:
+            path, prefix = _HIP_SO[backend], "refhip_"
             if not os.path.exists(path):
-                raise FileNotFoundError("oracle/_ref/libnr_ref.so not built (run `make -C oracle ref` in the "
-                                        "build container)")
+                raise FileNotFoundError(f"{path} not built (run `make -C oracle ref_hip` in the build container)")
         else:
             raise ValueError(backend)
         self.lib = ctypes.CDLL(path)
@@ -92,8 +97,9 @@ def kernels(backend="port"):
     return _KERNELS[backend]
 
 
-def have_ref():
-    return os.path.exists(_REF_SO)
+def have_ref_hip():
+    """The on-device reference build is present (it was built where /root/reference exists and travels as a .so)."""
+    return all(os.path.exists(p) for p in _HIP_SO.values())
 
 
 def num_threads():

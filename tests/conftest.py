@@ -12,10 +12,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
 
 
+class _Golden(dict):
+    """Both fixture files as one read-only mapping: nr_golden.npz (known answers of the reference's own tests and
+    vectors made by its imported pure-torch modules, tests/golden/make_golden.py) and kern_golden.npz (kern/*: the
+    reference's rasterizer kernels run on the device, tests/golden/make_golden_kern.py)."""
+    @property
+    def files(self):
+        return list(self.keys())
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
-    return np.load(os.path.join(ROOT, "tests", "golden", "nr_golden.npz"))
+    g = _Golden()
+    for name in ("nr_golden.npz", "kern_golden.npz"):
+        with np.load(os.path.join(ROOT, "tests", "golden", name)) as z:
+            g.update({k: z[k] for k in z.files})
+    return g
 
 
 def golden_case(golden, name):

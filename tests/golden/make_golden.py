@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
 """
-Regenerates tests/golden/*.npz.  BUILD CONTAINER ONLY: needs /root/reference.
+Regenerates tests/golden/nr_golden.npz.  BUILD CONTAINER ONLY: needs /root/reference.
+(The kernel-level vectors -- kern_golden.npz, tex_golden.npz -- come from the reference's kernels run ON THE
+DEVICE: tests/golden/make_golden_kern.py, GPU box.)
 
 Sources of truth used here (nothing from them is stored except inputs and numeric outputs):
-  * oracle/_ref/libnr_ref.so -- the reference's six rasterizer kernels
-    (pnpmodules/neural_renderer/neural_renderer/cuda/rasterize_cuda_kernel.cu:22-593) host-compiled
-    where they lie by `make -C oracle ref`;
   * the reference's pure-torch modules, imported by file path from /root/reference
     (NR/{projection,perspective,look_at,vertices_to_faces,lighting,get_points_from_angles}.py,
     deep3dmap/core/renderer/utils.py, deep3dmap/core/utils/utils.py);
@@ -39,81 +38,8 @@ def load_ref(name, path):
     return mod
 
 
-def random_faces(rng, B, Fn, spread=1.2, zlo=0.5, zhi=3.0, size=0.6):
-    """Random triangles in NDC: a centre in [-spread, spread]^2 plus offsets of scale `size`."""
-    c = rng.uniform(-spread, spread, (B, Fn, 1, 2))
-    xy = c + rng.uniform(-size, size, (B, Fn, 3, 2))
-    z = rng.uniform(zlo, zhi, (B, Fn, 3, 1))
-    return np.concatenate([xy, z], -1).astype(np.float32)
-
-
-def kernel_case(rng, B, Fn, S, ts, near, far, eps, faces=None, bg=(0.1, 0.2, 0.3)):
-    """Runs the six reference kernels (ref back end) in full mode and records every map."""
-    faces = random_faces(rng, B, Fn) if faces is None else faces
-    B, Fn = faces.shape[:2]
-    tex = rng.uniform(0, 1, (B, Fn, ts, ts, ts, 3)).astype(np.float32)
-    m = O.raster_forward(faces, tex, S, near, far, eps, bg, True, True, True, backend="ref")
-    g_rgb = rng.normal(0, 1, (B, S, S, 3)).astype(np.float32)
-    g_alpha = rng.normal(0, 1, (B, S, S)).astype(np.float32)
-    g_depth = rng.normal(0, 1, (B, S, S)).astype(np.float32)
-    out = dict(faces=faces, textures=tex, image_size=S, near=near, far=far, eps=eps, background=np.array(bg, np.float32),
-               faces_inv=m["faces_inv"], face_index_map=m["face_index_map"], weight_map=m["weight_map"],
-               depth_map=m["depth_map"], face_inv_map=m["face_inv_map"], rgb_map=m["rgb_map"],
-               alpha_map=m["alpha_map"], sampling_index_map=m["sampling_index_map"],
-               sampling_weight_map=m["sampling_weight_map"], grad_rgb_map=g_rgb, grad_alpha_map=g_alpha,
-               grad_depth_map=g_depth)
-    # the three backward kernels one by one (K4 alone, K5, K6 alone) and the composed order
-    gf_all, gt = O.raster_backward(m, g_rgb, g_alpha, g_depth, True, True, True, backend="ref")
-    gf_pix_rgba, _ = O.raster_backward(m, g_rgb, g_alpha, None, True, True, False, backend="ref")
-    m_a = dict(m)
-    gf_pix_alpha, _ = O.raster_backward(m_a, None, g_alpha, None, False, True, False, backend="ref")
-    gf_depth, _ = O.raster_backward(m, None, None, g_depth, False, False, True, backend="ref")
-    out.update(grad_faces_all=gf_all, grad_textures=gt, grad_faces_pixel_rgba=gf_pix_rgba,
-               grad_faces_pixel_alpha=gf_pix_alpha, grad_faces_depth=gf_depth)
-    return out
-
-
 def main():
-    assert O.have_ref(), "run `make -C oracle ref` first"
-    rng = np.random.default_rng(20261002)
     out = {}
-
-    # ---- 1. kernel-level vectors -----------------------------------------------------------
-    cases = {}
-    cases["rand_b2_f24_s32_ts2"] = kernel_case(rng, 2, 24, 32, 2, 0.1, 100.0, 1e-3)
-    cases["rand_b1_f64_s64_ts4"] = kernel_case(rng, 1, 64, 64, 4, 0.1, 100.0, 1e-4)
-    # ts=1 (NrRenderer's tx_size=1): KCU:222-233 then indexes texels 1..3 of a 1-texel cube, i.e. the
-    # following faces' texels (weights ~ -eps).  The last 3 faces are moved off screen so that this
-    # bleed never leaves the buffer; in-buffer bleed is part of the recorded behaviour.
-    f1 = random_faces(rng, 3, 12)
-    f1[:, -3:, :, 0] += 10.0
-    cases["rand_b3_f12_s16_ts1"] = kernel_case(rng, 3, 12, 16, 1, 0.1, 100.0, 1e-3, faces=f1)
-    # near / far rejects: depth range wider than [near, far]
-    cases["nearfar_b1_f32_s32"] = kernel_case(rng, 1, 32, 32, 2, 1.0, 2.0, 1e-3,
-                                              faces=random_faces(rng, 1, 32, zlo=0.5, zhi=3.0))
-    # ties: every face duplicated (same geometry at index f and f+16) -> lowest index must win;
-    # plus a zero batch entry (all-zero vertices, as the reference's to_minibatch fixture produces)
-    f = random_faces(rng, 1, 16)
-    tie = np.concatenate([f, f], 1)
-    tie = np.concatenate([tie, np.zeros_like(tie)], 0)
-    cases["ties_zero_batch_b2_f32_s32"] = kernel_case(rng, 2, 32, 32, 2, 0.1, 100.0, 1e-3, faces=tie)
-    # fill_back pairs (front + reversed winding), small triangles on a 48x48 raster
-    f = random_faces(rng, 2, 40, size=0.15)
-    cases["fillback_small_b2_f80_s48"] = kernel_case(rng, 2, 80, 48, 2, 0.1, 100.0, 1e-3,
-                                                     faces=np.concatenate([f, f[:, :, ::-1, :]], 1).copy())
-    # grid mesh whose vertices sit exactly on pixel centres / edges (shared-edge ties)
-    n = 9
-    gx, gy = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
-    verts = np.stack([gx, gy, 1.0 + 0.25 * np.sin(3 * gx) * np.cos(2 * gy)], -1).reshape(-1, 3).astype(np.float32)
-    idx = np.arange(n * n).reshape(n, n)
-    tri = np.concatenate([np.stack([idx[:-1, :-1], idx[:-1, 1:], idx[1:, :-1]], -1).reshape(-1, 3),
-                          np.stack([idx[:-1, 1:], idx[1:, 1:], idx[1:, :-1]], -1).reshape(-1, 3)], 0)
-    gf = verts[tri][None]
-    cases["grid_on_pixel_centres_b1_f128_s32"] = kernel_case(rng, 1, gf.shape[1], 32, 2, 0.1, 100.0, 1e-3,
-                                                             faces=np.concatenate([gf, gf[:, :, ::-1, :]], 1).copy())
-    for cname, c in cases.items():
-        for k, v in c.items():
-            out[f"kern/{cname}/{k}"] = np.asarray(v)
 
     # ---- 2. known answers from the reference's own tests -------------------------------------
     out["known/sil1/vertices"] = np.array([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], np.float32)

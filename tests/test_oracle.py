@@ -1,6 +1,7 @@
-"""CPU tests: the oracle (oracle/nr_oracle.c + nr_oracle.py) against the committed golden vectors
-(tests/golden/make_golden.py documents how they were produced from the reference) and against the
-reference's own known-answer tests."""
+"""CPU tests: the oracle (oracle/nr_oracle.c + nr_oracle.py) against the committed golden vectors -- kern/* made by the
+reference's own kernels run on the device (tests/golden/make_golden_kern.py), the rest by its imported pure-torch
+modules (tests/golden/make_golden.py) -- and against the reference's own known-answer tests.  (Fresh random scenes,
+port vs the device reference: tests/test_gpu_reference.py.)"""
 import numpy as np
 import pytest
 import torch
@@ -37,15 +38,21 @@ def test_forward_maps_bit_exact(golden, name, bbox):
 def test_backward_kernels(golden, name):
     c = golden_case(golden, name)
     m = _forward(c)
+    # The vectors come from the device: K5 / K6 add with float atomics there (order of additions not fixed), K4 is
+    # one thread per face.  Hence: same sums up to a few ulps of the tensor's scale, not bit patterns.
+    def close(got, ref):
+        assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+        ok = np.isfinite(ref)
+        return np.abs(got[ok] - ref[ok]).max() <= 2e-6 * max(np.abs(ref[ok]).max(), 1e-30)
     gf, gt = O.raster_backward(m, c["grad_rgb_map"], c["grad_alpha_map"], c["grad_depth_map"], True, True, True)
-    assert np.array_equal(gf, c["grad_faces_all"])
-    assert np.array_equal(gt, c["grad_textures"])
+    assert close(gf, c["grad_faces_all"])
+    assert close(gt, c["grad_textures"])
     gf, _ = O.raster_backward(m, c["grad_rgb_map"], c["grad_alpha_map"], None, True, True, False)
-    assert np.array_equal(gf, c["grad_faces_pixel_rgba"])
+    assert close(gf, c["grad_faces_pixel_rgba"])
     gf, _ = O.raster_backward(m, None, c["grad_alpha_map"], None, False, True, False)
-    assert np.array_equal(gf, c["grad_faces_pixel_alpha"])
+    assert close(gf, c["grad_faces_pixel_alpha"])
     gf, _ = O.raster_backward(m, None, None, c["grad_depth_map"], False, False, True)
-    assert np.array_equal(gf, c["grad_faces_depth"])
+    assert close(gf, c["grad_faces_depth"])
 
 
 def test_ties_pick_lowest_index_and_zero_batch_is_empty(golden):
@@ -142,24 +149,3 @@ def test_deep3dmap_helpers_and_losses(golden):
     assert torch.allclose(O.photometric_loss(a, b, mask=m, conf_sigma=s), t("loss/photometric_mask_sigma"))
     assert torch.allclose(O.smooth_loss(a[:, 0]), t("loss/smooth"))
     assert torch.allclose(O.smooth_loss([a[:, 0], b[:, 0, ::2, ::2]]), t("loss/smooth_pyramid"))
-
-
-@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
-def test_port_equals_reference_hostbuild_on_fresh_random_inputs():
-    """Build-container cross-check beyond the committed vectors: 6 fresh random scenes, all kernels."""
-    rng = np.random.default_rng(99)
-    for trial in range(6):
-        B, Fn, S, ts = int(rng.integers(1, 3)), int(rng.integers(4, 48)), int(rng.choice([16, 24, 40])), int(rng.choice([2, 3]))
-        xy = rng.uniform(-1.3, 1.3, (B, Fn, 1, 2)) + rng.uniform(-0.7, 0.7, (B, Fn, 3, 2))
-        faces = np.concatenate([xy, rng.uniform(0.3, 4.0, (B, Fn, 3, 1))], -1).astype(np.float32)
-        tex = rng.uniform(0, 1, (B, Fn, ts, ts, ts, 3)).astype(np.float32)
-        res = {}
-        for be in ("port", "ref"):
-            m = O.raster_forward(faces, tex, S, 0.5, 3.5, 1e-3, (0, 0, 0), True, True, True, backend=be)
-            grads = [rng.normal(size=s).astype(np.float32) for s in ((B, S, S, 3), (B, S, S), (B, S, S))] \
-                if be == "port" else grads
-            gf, gt = O.raster_backward(m, *grads, True, True, True, backend=be)
-            res[be] = (m, gf, gt)
-        for key in ("face_index_map", "weight_map", "depth_map", "rgb_map", "face_inv_map", "sampling_weight_map"):
-            assert np.array_equal(res["port"][0][key], res["ref"][0][key], equal_nan=True), (trial, key)
-        assert np.array_equal(res["port"][1], res["ref"][1]) and np.array_equal(res["port"][2], res["ref"][2])
