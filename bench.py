@@ -94,31 +94,75 @@ def measured_valu(name):
 
 
 def cpu_baseline(n, image_size, ts, budget_s=25.0):
-    """The oracle (this repo's C restatement of the reference algorithm, 'port') timed on the host cores
-    on ONE view of the same workload: bounding-box forward + texture sampling + the three backward kernels."""
+    """The oracle (this repo's C restatement of the reference algorithm, kind 'port') timed on the host cores on ONE
+    view of the same workload, both variants of SURVEY.md 8(d):
+
+      value (cpu_tiled)   K1 + bounding-box K2 (the loop structure of the reference's own CPU rasterizer,
+                          mesh_cython/render.cpp:333-366) + K3 + K4 + K5 + K6, OpenMP over all host threads;
+      bruteforce          K2 exactly as the reference's kernel (every pixel loops over every face, KCU:105-154),
+                          timed on a bounded band of the view's pixels and scaled linearly to the whole view, + the same
+                          K1, K3..K6; all threads and ONE thread.
+    """
     from deep3dmap_amd import synthetic
     from oracle import nr_oracle as O
     v, tri = synthetic.grid_mesh(n)
     tex = synthetic.random_textures(tri.shape[0], ts)
     eye = synthetic.camera_ring(8)[1]
-    O.OracleRasterizeFunction.backend, O.OracleRasterizeFunction.bbox = "port", True
-    r = O.Renderer(camera_mode="look_at", image_size=image_size, anti_aliasing=False)
+    S = image_size
+    r = O.Renderer(camera_mode="look_at", image_size=S, anti_aliasing=False)
     r.eye = [float(x) for x in eye]
-    vt, trit, text = torch.from_numpy(v)[None], torch.from_numpy(tri)[None], torch.from_numpy(tex)[None]
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 3 and time.perf_counter() - t_all < budget_s:
-        vv = vt.clone().requires_grad_(True)
-        tt = text.clone().requires_grad_(True)
+    vt, trit, text = torch.from_numpy(v)[None], torch.from_numpy(tri)[None].long(), torch.from_numpy(tex)[None]
+    idx, lit = r._lit(vt, trit, text)
+    faces = O.vertices_to_faces(r._camera(vt), idx).numpy()
+    lit = lit.numpy()
+    rng = np.random.default_rng(0)
+    grads = [rng.standard_normal(sh).astype(np.float32) for sh in ((1, S, S, 3), (1, S, S), (1, S, S))]
+    k = O.kernels("port")
+    all_threads = O.num_threads()
+
+    def rest_and_tiled():
+        """(seconds of the tiled K1+K2, seconds of K3..K6) on the current thread count."""
         t0 = time.perf_counter()
-        rgb, depth, alpha = r(vv, trit, tt)
-        (rgb.sum() + alpha.sum() + depth.sum()).backward()
-        times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(image_size * image_size / best / 1e6, 4), "unit": "Mpix/s", "cores": O.num_threads(),
-            "kind": "port",
-            "sample": f"1 view of the same mesh @ {image_size}x{image_size}, render+backward, best of {len(times)} "
-                      f"({best:.2f} s each), OpenMP over {O.num_threads()} threads, per-face bounding-box forward"}
+        m = O.raster_forward(faces, None, S, r.near, r.far, r.rasterizer_eps, None, False, True, True, bbox=True)
+        t_k2 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        m = O.raster_forward(faces, lit, S, r.near, r.far, r.rasterizer_eps, (0, 0, 0), True, True, True, bbox=True)
+        O.raster_backward(m, *grads, True, True, True)
+        return t_k2, time.perf_counter() - t0 - t_k2
+
+    def brute_band(rows):
+        """seconds of the brute-force K2 on `rows` rows in the middle of the view (covered region)."""
+        finv = np.zeros_like(faces)
+        k.face_inverse(O._fp(faces), O._fp(finv), 1, faces.shape[1], S)
+        fi, wm = np.full((1, S, S), -1, np.int32), np.zeros((1, S, S, 3), np.float32)
+        dm, fim = np.full((1, S, S), r.far, np.float32), np.zeros((1, S, S, 9), np.float32)
+        r0 = (S - rows) // 2
+        t0 = time.perf_counter()
+        k.face_index_map_range(O._fp(faces), O._fp(finv), O._ip(fi), O._fp(wm), O._fp(dm), O._fp(fim), 1, faces.shape[1],
+                               S, r.near, r.far, 1, r0 * S, (r0 + rows) * S)
+        return time.perf_counter() - t0
+
+    t_k2, t_rest = min(rest_and_tiled() for _ in range(2))
+    tiled = t_k2 + t_rest
+    rows_all = max(8, S // 8)
+    t_brute_all = brute_band(rows_all) * (S / rows_all)
+    O.set_num_threads(1)
+    try:
+        _, t_rest_1 = rest_and_tiled()
+        rows_1 = max(2, S // 128)
+        t_brute_1 = brute_band(rows_1) * (S / rows_1)
+    finally:
+        O.set_num_threads(all_threads)
+    mpix = lambda t: round(S * S / t / 1e6, 5)
+    return {"value": mpix(tiled), "unit": "Mpix/s", "cores": all_threads, "kind": "port", "variant": "cpu_tiled",
+            "sample": f"1 view of the same mesh @ {S}x{S}, fwd (K1, bounding-box K2, K3) + bwd (K4, K5, K6), "
+                      f"{tiled:.2f} s, OpenMP over {all_threads} threads",
+            "bruteforce": {"value": mpix(t_brute_all + t_rest), "cores": all_threads,
+                           "value_1thread": mpix(t_brute_1 + t_rest_1), "unit": "Mpix/s",
+                           "sample": f"brute-force K2 (KCU:105-154) on {rows_all} of {S} rows with {all_threads} threads "
+                                     f"and on {rows_1} rows with 1 thread, scaled linearly to the view "
+                                     f"({t_brute_all:.1f} s / {t_brute_1:.0f} s per view) + the full view's K1, K3..K6 "
+                                     f"({t_rest:.2f} s / {t_rest_1:.2f} s)"}}
 
 
 def gan2shape_workload(args):
@@ -244,6 +288,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views-per-gpu", type=int, default=32,
                     help="cameras per GPU (weak scaling); 32 = the camera count of BASELINE.json's 100k-triangle config")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --views-per-gpu cameras on every GPU; strong: --total-views cameras in all, "
+                         "split across the GPUs (BASELINE config 4: 32 cameras, 8 per GPU on 4)")
+    ap.add_argument("--total-views", type=int, default=32, help="strong scaling: cameras of the whole job")
     ap.add_argument("--mesh-n", type=int, default=225, help="grid_mesh(n): 225 -> 100,352 triangles")
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
@@ -283,6 +331,9 @@ def main():
     from deep3dmap_amd import _lib, synthetic
     from deep3dmap_amd.multiview import MultiViewFit
 
+    if args.scaling == "strong":
+        assert args.total_views % world == 0, "--total-views must split evenly over the GPUs"
+        args.views_per_gpu = args.total_views // world
     n_views = args.views_per_gpu * world
     v, tri = synthetic.grid_mesh(args.mesh_n)
     tex = synthetic.random_textures(tri.shape[0], args.texture_size)
@@ -366,7 +417,7 @@ def main():
         out = {
             "metric": "rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
                                    f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "
                                    f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
@@ -375,7 +426,8 @@ def main():
                                       "; the objective is evaluated in the pass that produces the pixel values "
                                       "(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps")
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
-                       "views_per_gpu": args.views_per_gpu, "triangles": int(F), "image_size": S,
+                       "api": "render+loss" if args.materialise_images else "render_fit_loss",
+                       "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
                        "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}"},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),

@@ -25,7 +25,8 @@ class D3MVertexTarget(ctypes.Structure):
 
 class D3MFitTargets(ctypes.Structure):
     _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
-                ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P)]
+                ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P),
+                ("mask_sum", _P)]
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
@@ -74,7 +75,7 @@ _SIGNATURES = {
     "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "d3m_smooth_loss_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "d3m_smooth_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_mesh_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "d3m_mesh_render_colors": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),

@@ -69,15 +69,17 @@ def silhouette_loss(image, image_ref):
 
 class _MultiViewFitLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask):
+    def forward(ctx, rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask, mask_sum=None):
         t = [f32c(x) for x in (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)]
+        mask_sum = f32c(mask_sum).reshape(1) if mask_sum is not None else None
         B, C, H, W = t[0].shape
         if C != 3 or any(tuple(x.shape) != (B, H, W) for x in t[2:]) or tuple(t[1].shape) != (B, 3, H, W):
             raise ValueError("multiview_fit_loss: rgb [B,3,H,W]; depth, alpha, mask and their targets [B,H,W]")
         loss = torch.empty((), dtype=torch.float32, device=t[0].device)
         scratch = torch.empty(4104, dtype=torch.float32, device=t[0].device)
-        _lib.check(_lib.lib().d3m_fit_loss_forward(*[_lib.ptr(x) for x in t], _lib.ptr(loss), _lib.ptr(scratch), B, H, W,
-                                                   _lib.stream_ptr()), "d3m_fit_loss_forward")
+        _lib.check(_lib.lib().d3m_fit_loss_forward(*[_lib.ptr(x) for x in t], _lib.ptr(loss), _lib.ptr(scratch),
+                                                   _lib.ptr(mask_sum), B, H, W, _lib.stream_ptr()),
+                   "d3m_fit_loss_forward")
         ctx.save_for_backward(*t, scratch)
         return loss
 
@@ -92,15 +94,17 @@ class _MultiViewFitLoss(torch.autograd.Function):
         _lib.check(_lib.lib().d3m_fit_loss_backward(*[_lib.ptr(x) for x in t], _lib.ptr(scratch), _lib.ptr(f32c(g)),
                                                     _lib.ptr(g_rgb), _lib.ptr(g_depth), _lib.ptr(g_alpha), B, H, W,
                                                     _lib.stream_ptr()), "d3m_fit_loss_backward")
-        return g_rgb, g_depth, g_alpha, None, None, None, None
+        return g_rgb, g_depth, g_alpha, None, None, None, None, None
 
 
-def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask):
+def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum=None):
     """photometric_loss(rgb, rgb_target, mask) + silhouette_loss(alpha, alpha_target) / (H*W) +
     photometric_loss(depth, depth_target, mask): the multi-view fit objective as ONE autograd node (a reduction and a
     finish launch forward, one gradient launch backward) instead of three loss nodes and their eager glue.
-    rgb [B,3,H,W]; depth, alpha, mask and the targets [B,H,W]."""
-    return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask)
+    rgb [B,3,H,W]; depth, alpha, mask and the targets [B,H,W].  `mask_sum` (device scalar, optional) replaces sum(mask)
+    as the normaliser of the two photometric terms: the mask's sum over ALL shards when these views are one rank's share
+    of a camera-sharded objective (deep3dmap_amd/multiview.py)."""
+    return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum)
 
 
 class _SmoothLevel(torch.autograd.Function):

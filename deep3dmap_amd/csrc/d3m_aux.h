@@ -768,6 +768,7 @@ __global__ void __launch_bounds__(256) k_fit_loss_reduce(FitLossArgs a, float* _
 
 // totals[0..3] = the four sums; totals[4] = loss
 __global__ void __launch_bounds__(256) k_fit_loss_finish(const float* __restrict__ partials, int n, float pixels,
+                                                        const float* __restrict__ mask_sum,
                                                         float* __restrict__ totals, float* __restrict__ loss) {
     __shared__ float s_part[4];
     float acc[4] = {0, 0, 0, 0};
@@ -778,6 +779,7 @@ __global__ void __launch_bounds__(256) k_fit_loss_finish(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 4; k++) acc[k] = block_sum_256(acc[k], s_part);
     if (threadIdx.x == 0) {
+        if (mask_sum) acc[2] = *mask_sum;    // this batch is a shard: normalise by the mask of the whole objective
 #pragma unroll
         for (int k = 0; k < 4; k++) totals[k] = acc[k];
         const float l = (acc[0] / (3.0f * acc[2]) + acc[3] / pixels) + acc[1] / acc[2];

@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
 // totals[0..3] = the four sums over `n` workgroup partials, totals[4] = *loss = the objective (k_fit_loss_finish for
 // the tens of thousands of partials the fused epilogue leaves: 1024 lanes, 16-byte loads)
 __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restrict__ partials, int n, float pixels,
+                                                         const float* __restrict__ mask_sum,
                                                          float* __restrict__ totals, float* __restrict__ loss) {
     __shared__ float4 s_wave[16];
     float4 acc = make_float4(0, 0, 0, 0);
@@ -297,6 +298,7 @@ __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restri
     if (threadIdx.x == 0) {
         float4 t = make_float4(0, 0, 0, 0);
         for (int k = 0; k < 16; k++) { t.x += s_wave[k].x; t.y += s_wave[k].y; t.z += s_wave[k].z; t.w += s_wave[k].w; }
+        if (mask_sum) t.z = *mask_sum;       // this batch is a shard: normalise by the mask of the whole objective
         totals[0] = t.x; totals[1] = t.y; totals[2] = t.z; totals[3] = t.w;
         const float l = (t.x / (3.0f * t.z) + t.w / pixels) + t.y / t.z;
         totals[4] = l;

@@ -635,7 +635,7 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
            depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
     if (fit)
         LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-               (int)blocks_for(n, threads), (float)((long)s * s), fit->scratch, fit->loss);
+               (int)blocks_for(n, threads), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
     return check_launch();
 }
 
@@ -848,7 +848,8 @@ static int fit_loss_grid(int batch_size, long hw, dim3& grid) {
 
 D3M_EXPORT int d3m_fit_loss_forward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
                                     const float* alpha, const float* alpha_target, const float* mask, float* loss,
-                                    float* scratch, int batch_size, int height, int width, d3m_stream_t stream) {
+                                    float* scratch, const float* mask_sum, int batch_size, int height, int width,
+                                    d3m_stream_t stream) {
     if (!rgb || !rgb_target || !depth || !depth_target || !alpha || !alpha_target || !mask || !loss || !scratch)
         return D3M_ERR_INVALID;
     dim3 grid;
@@ -859,7 +860,7 @@ D3M_EXPORT int d3m_fit_loss_forward(const float* rgb, const float* rgb_target, c
     FitLossArgs a{rgb, rgb_target, depth, depth_target, alpha, alpha_target, mask, batch_size, (int)hw, (float)hw};
     LAUNCH("k_fit_loss_reduce", k_fit_loss_reduce, grid, dim3(256), st, a, scratch + 8);
     LAUNCH("k_fit_loss_finish", k_fit_loss_finish, dim3(1), dim3(256), st, (const float*)(scratch + 8),
-           (int)(grid.x * grid.y), (float)hw, scratch, loss);
+           (int)(grid.x * grid.y), (float)hw, mask_sum, scratch, loss);
     return check_launch();
 }
 

@@ -23,19 +23,27 @@ def shard_views(n_views, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
-def allreduce_flat(tensors, group=None):
-    """SUM-all-reduce several tensors as one flat buffer (one collective, latency-bound sizes)."""
+def allreduce_sum_(flat, group=None):
+    """In-place SUM-all-reduce of one flat device buffer (one collective per step).  Under "nccl" (= RCCL) the buffer
+    stays on the device and travels over xGMI; under "gloo" (CPU-test / single-GPU debug configuration only) it is
+    staged through the host."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return tensors
-    flat = torch.cat([t.reshape(-1) for t in tensors])
+        return flat
     if flat.is_cuda and dist.get_backend(group) == "gloo":
-        # CPU-test / debug configuration only: gloo reduces on the host.  Under "nccl" (= RCCL) the buffer
-        # stays on the device and travels over xGMI.
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         flat.copy_(host)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+def allreduce_flat(tensors, group=None):
+    """SUM-all-reduce several tensors as one flat buffer (allocates the buffer: for one-off exchanges; the step itself
+    uses the persistent buffer of MultiViewFit)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = allreduce_sum_(torch.cat([t.reshape(-1) for t in tensors]), group)
     out, o = [], 0
     for t in tensors:
         out.append(flat[o:o + t.numel()].view_as(t))
@@ -48,7 +56,12 @@ class MultiViewFit:
 
     vertices [V,3], triangles [F,3] int32, textures [F,ts,ts,ts,3], eyes [n_views,3] (look_at cameras).
     Loss: photometric_loss(rgb, rgb_t, mask=alpha_t) + sum((alpha-alpha_t)^2)/P
-                         + photometric_loss(depth, depth_t, mask=alpha_t),  P = pixels per view.
+                         + photometric_loss(depth, depth_t, mask=alpha_t),  P = pixels per view,
+    taken over ALL n_views cameras.  Sharded over R ranks the objective stays that one: the photometric terms are
+    means over the mask of all cameras, so every rank normalises its sums by the GLOBAL sum(mask) -- a constant of the
+    targets, all-reduced once in set_targets_from() -- and the ranks' values and gradients then simply add up
+    (R ranks x n/R cameras == 1 rank x n cameras, tests/test_gpu_multirank.py).  Per step ONE all-reduce(SUM) of the
+    persistent flat buffer [loss | grad_vertices 3V | grad_textures 3 F ts^3].
     """
 
     def __init__(self, vertices, triangles, textures, eyes, image_size=512, anti_aliasing=False, rank=0,
@@ -67,6 +80,11 @@ class MultiViewFit:
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.targets = None
+        self.mask_sum = None            # [1] device scalar: sum of the mask over ALL ranks' views (world_size > 1 only)
+        self._mask_sum_local = None
+        # the step's results, packed where they are produced (inside the captured step): [loss | grad_v | grad_t]
+        n_t = self.textures.numel() if optimise_textures else 0
+        self._flat = torch.zeros(1 + self.vertices.numel() + n_t, dtype=torch.float32, device=self.device)
         self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
 
     def render(self, vertices=None, textures=None):
@@ -80,17 +98,23 @@ class MultiViewFit:
         tv = torch.as_tensor(target_vertices, dtype=torch.float32).to(self.device)
         rgb, depth, alpha = self.render(vertices=tv)
         self.targets = (rgb.detach(), depth.detach(), alpha.detach())
+        if self.world_size > 1:
+            # the objective's mask is alpha_t: its sum over every rank's cameras is a constant of the targets
+            self._mask_sum_local = self.targets[2].sum().reshape(1)
+            self.mask_sum = allreduce_sum_(self._mask_sum_local.clone())
 
     def loss(self, rgb, depth, alpha, fused=True):
         """The fit objective.  `fused=False` composes it from the three loss operators (the definition; the fused
         node computes the same value and gradients in 3 launches instead of ~11)."""
         rgb_t, depth_t, alpha_t = self.targets
         if fused:
-            return multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t)
+            return multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum)
         mask = alpha_t[:, None]
         pixels = float(self.image_size * self.image_size)
-        return (photometric_loss(rgb, rgb_t, mask=mask) + silhouette_loss(alpha, alpha_t) / pixels +
-                photometric_loss(depth[:, None], depth_t[:, None], mask=mask))
+        # photometric_loss divides by the LOCAL sum(mask); as this rank's part of the global mean it weighs local/global
+        share = 1.0 if self.mask_sum is None else (self._mask_sum_local / self.mask_sum)[0]
+        return (photometric_loss(rgb, rgb_t, mask=mask) * share + silhouette_loss(alpha, alpha_t) / pixels +
+                photometric_loss(depth[:, None], depth_t[:, None], mask=mask) * share)
 
     def fit_loss(self):
         """The objective of the current mesh against the targets, evaluated inside the rendering node when the renderer
@@ -99,7 +123,7 @@ class MultiViewFit:
         if self.objective_in_renderer and r.lighting_on_the_fly and not r.anti_aliasing:
             rgb_t, depth_t, alpha_t = self.targets
             return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
-                                     (rgb_t, depth_t, alpha_t, alpha_t))
+                                     (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum))
         return self.loss(*self.render())
 
     def _forward_backward(self):
@@ -107,7 +131,12 @@ class MultiViewFit:
         self.textures.grad = None
         loss = self.fit_loss()
         loss.backward()
-        return loss.detach()
+        # pack [loss | grad_v | grad_t] into the persistent buffer the collective runs on (part of the captured step)
+        parts = [loss.detach().reshape(1), self.vertices.grad.reshape(-1)]
+        if self.textures.requires_grad:
+            parts.append(self.textures.grad.reshape(-1))
+        torch.cat(parts, out=self._flat)
+        return self._flat
 
     def capture_graph(self, warmup=3):
         """Capture forward + loss + backward of one step into a HIP graph (see deep3dmap_amd/graph.py).
@@ -125,8 +154,10 @@ class MultiViewFit:
         return self._runner.graph is not None
 
     def step(self):
-        """forward + loss + backward + gradient all-reduce.  Returns (loss, grad_vertices, grad_textures)."""
-        loss = self._runner()
-        grads = [self.vertices.grad] + ([self.textures.grad] if self.textures.requires_grad else [])
-        grads = allreduce_flat(grads)
-        return loss, grads[0], (grads[1] if len(grads) > 1 else None)
+        """forward + loss + backward + all-reduce.  Returns (loss, grad_vertices, grad_textures) of the WHOLE objective
+        (all ranks' cameras) as views of the persistent flat buffer, valid until the next step."""
+        flat = allreduce_sum_(self._runner())
+        nv = self.vertices.numel()
+        gv = flat[1:1 + nv].view_as(self.vertices)
+        gt = flat[1 + nv:].view_as(self.textures) if self.textures.requires_grad else None
+        return flat[0], gv, gt

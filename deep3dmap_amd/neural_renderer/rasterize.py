@@ -297,7 +297,8 @@ class _RasterizeLit(torch.autograd.Function):
             # the fit objective is evaluated where the images are produced: they are never written (rasterize_lit_fit)
             if anti_aliasing or not (return_alpha and return_depth):
                 raise ValueError("the fused fit objective needs rgb, alpha and depth without anti-aliasing")
-            rgb_t, depth_t, alpha_t, mask = (f32c(t) for t in fit)
+            rgb_t, depth_t, alpha_t, mask = (f32c(t) for t in fit[:4])
+            mask_sum = f32c(fit[4]).reshape(1) if len(fit) > 4 and fit[4] is not None else None
             if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
                 raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
             loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -311,8 +312,8 @@ class _RasterizeLit(torch.autograd.Function):
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))
             fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
                                        _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_maps[0]), _lib.ptr(g_maps[1]),
-                                       _lib.ptr(g_maps[2]), None)
-            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps)
+                                       _lib.ptr(g_maps[2]), None, _lib.ptr(mask_sum))
+            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps, mask_sum)
         _lib.check(L.d3m_render_lit_epilogue(
             _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
             _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
@@ -352,11 +353,11 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
                 "d3m_output_epilogue_backward")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
-            rgb_t, depth_t, alpha_t, mask, scratch, loss, (g_rgb_map, g_alpha_map, g_depth_map) = ctx.fit
+            rgb_t, depth_t, alpha_t, mask, scratch, loss, (g_rgb_map, g_alpha_map, g_depth_map), mask_sum = ctx.fit
             grad_loss = f32c(g_rgb).reshape(1)
             unscaled = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
                                           _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map),
-                                          _lib.ptr(g_depth_map), _lib.ptr(grad_loss))
+                                          _lib.ptr(g_depth_map), _lib.ptr(grad_loss), _lib.ptr(mask_sum))
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over one compacted list of the faces that own a pixel
         vis = m["visibility"]
@@ -399,6 +400,10 @@ class _RasterizeLit(torch.autograd.Function):
             if not need_tex:
                 grad_textures = None
         if rd and not depth_done:           # textures and lighting need no gradient: the depth term on its own
+            if unscaled is not None:
+                # d3m_backward_depth_map takes final maps: the fused objective left sign(depth - target) * mask, which
+                # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); scratch[2] holds that sum
+                g_depth_map = g_depth_map * (grad_loss / scratch[2])
             grad_faces = torch.zeros_like(faces)
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)
@@ -426,8 +431,9 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
 
-    `targets` = (rgb_t [B,3,S,S], depth_t [B,S,S], alpha_t [B,S,S], mask [B,S,S]), evaluated inside the rendering
-    node: the sums are taken where the images are produced and the gradient is written straight into the
+    `targets` = (rgb_t [B,3,S,S], depth_t [B,S,S], alpha_t [B,S,S], mask [B,S,S][, mask_sum]), evaluated inside the
+    rendering node (the optional device scalar `mask_sum` replaces sum(mask) as the photometric normaliser: the sum over
+    ALL ranks' views when these views are one shard of a camera-sharded fit, so that values and gradients add up): the sums are taken where the images are produced and the gradient is written straight into the
     internal-resolution maps, so the images and their gradients never exist in memory.  Same value and gradients as
     core.losses.multiview_fit_loss(*rasterize_lit(...), ...)."""
     return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,

@@ -286,6 +286,10 @@ struct d3m_fit_targets {
     float* grad_alpha_map;       /* [B,S,S]    > unscaled gradient maps, written by the epilogue; all or none */
     float* grad_depth_map;       /* [B,S,S]   /                                                         */
     const float* grad_loss;      /* [1] device scalar, read by the backward operators; NULL = 1 */
+    const float* mask_sum;       /* [1] device scalar or NULL.  NULL: the photometric terms are normalised by the sum of
+                                  * `mask` over THIS batch.  When the batch is one rank's shard of a larger objective
+                                  * (camera-sharded fit), the sum of the mask over ALL shards: the shard's value is then
+                                  * its additive part of the global objective and gradients add up across ranks. */
 };
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
@@ -358,10 +362,12 @@ int d3m_smooth_loss_backward(const float* pred, const float* grad_loss, float* g
  *             + photometric_loss(depth, depth_target, mask)
  * with rgb [B,3,H,W], depth / alpha / mask [B,H,W].  Same value and gradients as composing the three operators
  * above.  scratch: 4104 floats, written by forward and read by backward (it keeps the reduction totals).
- * grad_loss: device scalar (NULL = 1).  Any of the grad_* outputs may be NULL. */
+ * grad_loss: device scalar (NULL = 1).  Any of the grad_* outputs may be NULL.
+ * mask_sum: device scalar replacing sum(mask) as the photometric terms' normaliser (NULL = sum over this batch; see
+ * struct d3m_fit_targets). */
 int d3m_fit_loss_forward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
                          const float* alpha, const float* alpha_target, const float* mask, float* loss, float* scratch,
-                         int batch_size, int height, int width, d3m_stream_t stream);
+                         const float* mask_sum, int batch_size, int height, int width, d3m_stream_t stream);
 int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float* depth, const float* depth_target,
                           const float* alpha, const float* alpha_target, const float* mask, const float* scratch,
                           const float* grad_loss, float* grad_rgb, float* grad_depth, float* grad_alpha, int batch_size,

@@ -13,9 +13,13 @@
  *   - the reference's hand-written known-answer gradients
  *     (pnpmodules/neural_renderer/tests/test_rasterize_silhouettes.py:37-99,
  *      tests/test_rasterize.py:84-156),
- *   - golden vectors under tests/golden/ produced in the build container by
- *     oracle/ref_hostbuild (the reference kernel bodies compiled where they
- *     lie) and by importing the reference's pure-torch camera modules.
+ *   - golden vectors under tests/golden/: kern_golden.npz / tex_golden.npz
+ *     made by the reference's OWN kernels run on the device
+ *     (oracle/_ref/libnr_ref_hip.so = their text compiled by hipcc where it
+ *     lies, oracle/Makefile `ref_hip`; tests/golden/make_golden_kern.py), and
+ *     nr_golden.npz made by importing the reference's pure-torch modules;
+ *   - on the GPU box, fresh random scenes against that device build
+ *     (tests/test_gpu_reference.py).
  *
  * Arithmetic notes.  The reference is templated on scalar_t; this restates
  * the scalar_t = float instantiation, keeping every place where a double
@@ -136,14 +140,13 @@ static inline float pixel_center(int i, int is) {
  * rasterize.py:50-69); only covered pixels are written.
  * face_inv_map may be NULL (return_depth == 0).
  * ------------------------------------------------------------------------- */
-ORC_API void orc_face_index_map(const float *faces, const float *faces_inv, int32_t *face_index_map,
-                                float *weight_map, float *depth_map, float *face_inv_map,
-                                int batch_size, int num_faces, int image_size, float near, float far,
-                                int return_depth) {
+static void face_index_map_range(const float *faces, const float *faces_inv, int32_t *face_index_map,
+                                 float *weight_map, float *depth_map, float *face_inv_map,
+                                 int num_faces, int image_size, float near, float far,
+                                 int return_depth, long pixel_begin, long pixel_end) {
     const int is = image_size, nf = num_faces;
-    const long npix = (long)batch_size * is * is;
 #pragma omp parallel for schedule(dynamic, 64)
-    for (long i = 0; i < npix; i++) {
+    for (long i = pixel_begin; i < pixel_end; i++) {
         const int bn = (int)(i / ((long)is * is));
         const int pn = (int)(i % ((long)is * is));
         const int yi = pn / is, xi = pn % is;
@@ -172,6 +175,27 @@ ORC_API void orc_face_index_map(const float *faces, const float *faces_inv, int3
             }
         }
     }
+}
+
+ORC_API void orc_face_index_map(const float *faces, const float *faces_inv, int32_t *face_index_map,
+                                float *weight_map, float *depth_map, float *face_inv_map,
+                                int batch_size, int num_faces, int image_size, float near, float far,
+                                int return_depth) {
+    face_index_map_range(faces, faces_inv, face_index_map, weight_map, depth_map, face_inv_map, num_faces,
+                         image_size, near, far, return_depth, 0, (long)batch_size * image_size * image_size);
+}
+
+/* The same brute force over the flat pixel range [pixel_begin, pixel_end) only: a bounded sample of a full-size
+ * workload for bench.py's cpu_baseline (the full loop is O(pixels * faces): ~50 s per 512x512 view and thread). */
+ORC_API void orc_face_index_map_range(const float *faces, const float *faces_inv, int32_t *face_index_map,
+                                      float *weight_map, float *depth_map, float *face_inv_map,
+                                      int batch_size, int num_faces, int image_size, float near, float far,
+                                      int return_depth, long pixel_begin, long pixel_end) {
+    const long npix = (long)batch_size * image_size * image_size;
+    if (pixel_begin < 0) pixel_begin = 0;
+    if (pixel_end > npix) pixel_end = npix;
+    face_index_map_range(faces, faces_inv, face_index_map, weight_map, depth_map, face_inv_map, num_faces,
+                         image_size, near, far, return_depth, pixel_begin, pixel_end);
 }
 
 /* ---------------------------------------------------------------------------

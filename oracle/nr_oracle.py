@@ -84,6 +84,9 @@ class _Kernels:
         if backend == "port":
             self.face_index_map_bbox = self.lib.orc_face_index_map_bbox
             self.face_index_map_bbox.argtypes, self.face_index_map_bbox.restype = _SIGS["face_index_map"], None
+            self.face_index_map_range = self.lib.orc_face_index_map_range
+            self.face_index_map_range.argtypes = _SIGS["face_index_map"] + [ctypes.c_long, ctypes.c_long]
+            self.face_index_map_range.restype = None
             self.lib.orc_num_threads.restype = _I
             self.lib.orc_set_num_threads.argtypes = [_I]
 

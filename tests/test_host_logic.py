@@ -153,7 +153,7 @@ def test_committed_bench_line_and_profiles_are_consistent():
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
-from deep3dmap_amd.multiview import allreduce_flat, shard_views
+from deep3dmap_amd.multiview import allreduce_flat, allreduce_sum_, shard_views
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group(backend="gloo")
 lo, hi = shard_views(8, rank, world)
@@ -163,6 +163,32 @@ gt = sum(torch.arange(4.0).reshape(2, 2) * (v + 1) for v in range(lo, hi))
 out_v, out_t = allreduce_flat([gv, gt])
 assert torch.equal(out_v, torch.full((5, 3), 36.0)), out_v
 assert torch.equal(out_t, torch.arange(4.0).reshape(2, 2) * 36.0), out_t
+
+# The sharded fit objective (MultiViewFit): photometric terms are means over the mask of ALL cameras.  With every
+# rank normalising by the all-reduced sum(mask), shard values and gradients add up to the unsharded objective; with
+# the LOCAL sum (the round-1 defect) they do not.
+g = torch.Generator().manual_seed(5)
+n, hw = 8, 6
+rgb_t, alpha_t = torch.rand(n, 3, hw, hw, generator=g), (torch.rand(n, hw, hw, generator=g) > 0.4).float()
+alpha_t[:4] *= (torch.rand(4, hw, hw, generator=g) > 0.5).float()         # unequal masks across the two shards
+x0 = torch.rand(n, 3, hw, hw, generator=g)
+def objective(x, a, sl, den):
+    return ((x[sl] - rgb_t[sl]).abs() * alpha_t[sl, None]).sum() / (3 * den) + ((a[sl] - alpha_t[sl]) ** 2).sum() / (hw * hw)
+a0 = torch.rand(n, hw, hw, generator=g)
+x, a = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+full = objective(x, a, slice(0, n), alpha_t.sum())
+full.backward()
+xs, as_ = x0.clone().requires_grad_(True), a0.clone().requires_grad_(True)
+den = allreduce_sum_(alpha_t[lo:hi].sum().reshape(1))
+assert torch.allclose(den, alpha_t.sum())
+part = objective(xs, as_, slice(lo, hi), den[0])
+part.backward()
+tot = allreduce_sum_(part.detach().reshape(1).clone())
+assert torch.allclose(tot[0], full.detach(), rtol=1e-6), (tot, full)
+assert torch.allclose(xs.grad[lo:hi], x.grad[lo:hi], rtol=1e-6, atol=1e-9) and torch.allclose(as_.grad[lo:hi], a.grad[lo:hi])
+wrong = objective(x0, a0, slice(lo, hi), alpha_t[lo:hi].sum())
+tot_wrong = allreduce_sum_(wrong.reshape(1).clone())
+assert not torch.allclose(tot_wrong[0], full.detach(), rtol=1e-3)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
