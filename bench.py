@@ -299,6 +299,8 @@ def main():
     ap.add_argument("--materialise-images", action="store_true",
                     help="render() the output images and evaluate the objective on them (multiview_fit_loss) instead of "
                          "inside the rendering node")
+    ap.add_argument("--view-groups", type=int, default=1,
+                    help="run each GPU's views as this many concurrent pipelines inside the rendering node")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape", "mesh_family"],
                     help="multiview = the headline metric (default); gan2shape = BASELINE config 3 (secondary line)")
@@ -339,7 +341,8 @@ def main():
     tex = synthetic.random_textures(tri.shape[0], args.texture_size)
     eyes = synthetic.camera_ring(n_views)
     fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
-                       world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images)
+                       world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images,
+                       view_groups=args.view_groups)
     fit.set_targets_from(synthetic.perturb(v))
 
     def barrier():
@@ -428,7 +431,7 @@ def main():
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
                        "api": "render+loss" if args.materialise_images else "render_fit_loss",
                        "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
-                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "objective_in_renderer": not args.materialise_images,
+                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}"},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},

@@ -5,7 +5,7 @@ import os
 
 import torch
 
-from .build import LIB_PATH
+from .build import LOAD_PATH as LIB_PATH
 
 _c_f32p = ctypes.c_void_p      # device pointers travel as integers
 _I, _F, _SZ, _L = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long

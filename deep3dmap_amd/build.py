@@ -6,6 +6,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_PKG, "csrc")
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libd3m_raster.so")
+# Developer variants (tools_dev/: -D tuning flags, -DD3M_DEV_SKIP) are loaded THROUGH this override, never copied over the
+# product library; build_library() ignores it.
+LOAD_PATH = os.environ.get("D3M_LIB_PATH", LIB_PATH)
 SOURCES = ["d3m_raster.hip"]
 HEADERS = ["d3m_launch.h", "d3m_device.h", "d3m_forward.h", "d3m_backward.h", "d3m_edge_grad.h", "d3m_face_major.h", "d3m_lit.h", "d3m_aux.h", "d3m_textures.h", "d3m_mesh.h",
            os.path.join("..", "..", "include", "d3m_raster.h")]

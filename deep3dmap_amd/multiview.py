@@ -65,7 +65,7 @@ class MultiViewFit:
     """
 
     def __init__(self, vertices, triangles, textures, eyes, image_size=512, anti_aliasing=False, rank=0,
-                 world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True):
+                 world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True, view_groups=1):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         lo, hi = shard_views(len(eyes), rank, world_size)
@@ -77,6 +77,7 @@ class MultiViewFit:
         self.renderer = nr.Renderer(image_size=image_size, anti_aliasing=anti_aliasing, camera_mode="look_at",
                                     fill_back=True)
         self.renderer.eye = self.eyes
+        self.renderer.view_groups = view_groups     # concurrent pipelines over this rank's views (rasterize.py)
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.targets = None

@@ -222,13 +222,26 @@ def _vec3_host(x):
 _side_streams = {}
 
 
-def _side_stream(device):
-    """One extra stream per device for the branch of the lit backward that runs beside the edge gradient."""
+def _side_stream(device, which=0):
+    """Extra streams per (device, forking stream) for the branches a lit render node runs beside its main line: the
+    visibility list / the gathered texture pass of every view group, and the main line of every group but the first."""
     index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(device).cuda_stream)       # one per stream that forks
+    key = (index, torch.cuda.current_stream(device).cuda_stream, which)       # one set per stream that forks
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
+
+
+def _group_bounds(B, groups):
+    g = max(1, min(int(groups), B))
+    return [(B * k // g, B * (k + 1) // g) for k in range(g)]
+
+
+def _bslice(t, lo, hi):
+    """views lo..hi of a tensor whose leading axis is the batch, or the tensor itself when it is shared (batch 1)"""
+    if t is None:
+        return None
+    return t if t.shape[0] == 1 else t[lo:hi]
 
 
 class _RasterizeLit(torch.autograd.Function):
@@ -237,11 +250,19 @@ class _RasterizeLit(torch.autograd.Function):
     cat(textures, permuted) * light array of NR/renderer.py:155-167 is never materialised and textures /
     mesh may be shared by all views (batch 1).  The node starts from the SCREEN-space vertices: the face gather
     (vertices_to_faces + fill_back) happens inside, and backward accumulates the face gradients straight into the
-    gradient of those vertices (d3m_vertex_target) instead of filling a [B,F',3,3] array for a scatter pass."""
+    gradient of those vertices (d3m_vertex_target) instead of filling a [B,F',3,3] array for a scatter pass.
+
+    VIEW GROUPS.  Nothing couples the views of a batch (KCU:92,263), so the node may run them as `view_groups`
+    contiguous groups, each a complete pipeline (binning -> tile pass -> epilogue; edge gradient beside the gathered
+    texture / depth pass) on streams of its own, forked from and joined to the current stream inside this one node --
+    inside a captured step: parallel branches of the graph.  The passes of a pipeline alternate between latency-bound
+    (binning, crossing emit) and issue-bound (tile pass, line walk) kernels; two pipelines out of phase fill each other's
+    gaps.  With a fused fit objective the groups are shards of it: each normalises by the mask sum of ALL views
+    (mask_sum), so the group values and gradients add up exactly as ranks do (multiview.py)."""
 
     @staticmethod
     def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
-                far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None):
+                far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None, view_groups=1):
         L = _lib.lib()
         sv, vertices, textures = f32c(screen_vertices), f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
@@ -262,33 +283,26 @@ class _RasterizeLit(torch.autograd.Function):
                                     float(ia), float(idr), cca, ccd, cdir, Bl, V, Ft, int(bool(fill_back)),
                                     _lib.stream_ptr()), "d3m_face_light")
         background = _background_tensor(background_color, dev)
-        # coverage straight from the indexed mesh: the binning pass reads the faces through `tri` and leaves the dense
-        # copy of the front-facing ones in `faces` (no vertices_to_faces pass); culled entries are never read
+        need_grad = any(ctx.needs_input_grad[:4])
+        groups = _group_bounds(B, view_groups)
+        G = len(groups)
+        # Everything the branches write is allocated here, on the current stream: no tensor changes its owning stream.
+        # Coverage comes straight from the indexed mesh: the binning pass reads the faces through `tri` and leaves the
+        # dense copy of the front-facing ones in `faces` (no vertices_to_faces pass); culled entries are never read.
         faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
         m = {"face_index_map": torch.empty((B, S, S), dtype=torch.int32, device=dev),
              "weight_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
              "depth_map": torch.empty((B, S, S), dtype=torch.float32, device=dev),
-             "face_inv_map": torch.zeros(1, dtype=torch.float32, device=dev)}
-        ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
-        _lib.check(L.d3m_forward_face_index_map_mesh(
-            _lib.ptr(sv), _lib.ptr(tri), tri.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces),
-            _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), None, B, S, float(near),
-            float(far), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
-        # which faces own a pixel is known now and only the backward pass needs it: build that list on the side
-        # stream while the sampling / epilogue pass below runs (its own buffer: this node's backward may run late)
-        vis = None
-        if any(ctx.needs_input_grad[:4]):
-            vis = torch.empty(int(L.d3m_visibility_bytes(B, Fp)), dtype=torch.uint8, device=dev)
-            cur, side = torch.cuda.current_stream(), _side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                _lib.check(L.d3m_visibility(_lib.ptr(m["face_index_map"]), _lib.ptr(vis), vis.numel(), B, Fp, S,
-                                            _lib.stream_ptr()), "d3m_visibility")
-        # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
+             "face_inv_map": torch.zeros(1, dtype=torch.float32, device=dev),
+             "rgb_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
+             "alpha_map": torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None}
+        # which faces own a pixel is only needed by the backward pass: one blob per group (this node's backward may run
+        # late, so they are its own buffers), built beside the sampling / epilogue pass
+        vis = [torch.empty(int(L.d3m_visibility_bytes(hi - lo, Fp)), dtype=torch.uint8, device=dev) for lo, hi in groups] \
+            if need_grad else None
         s_out = S // 2 if anti_aliasing else S
-        m["rgb_map"] = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
-        m["alpha_map"] = torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None
-        rgb = alpha = depth = loss = fit_c = None
+        rgb = alpha = depth = loss_g = None
+        fit_state = None
         if fit is None:
             rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
             alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
@@ -301,35 +315,72 @@ class _RasterizeLit(torch.autograd.Function):
             mask_sum = f32c(fit[4]).reshape(1) if len(fit) > 4 and fit[4] is not None else None
             if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
                 raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
-            loss = torch.empty((), dtype=torch.float32, device=dev)
-            scratch = torch.empty(int(L.d3m_render_fit_scratch_floats(B, S)), dtype=torch.float32, device=dev)
+            if G > 1 and mask_sum is None:          # the groups are shards: they need the normaliser of the whole batch
+                mask_sum = mask.sum().reshape(1)
+            loss_g = torch.empty(G, dtype=torch.float32, device=dev)
+            scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(hi - lo, S)), dtype=torch.float32, device=dev)
+                       for lo, hi in groups]
             # with a backward pass to come, the same pass leaves the objective's gradient in the internal maps, minus
             # the scalar factors only known later (1 / sum(mask), the gradient of the loss): no pixel pass in backward
             g_maps = (None, None, None)
-            if any(ctx.needs_input_grad[:4]):
+            if need_grad:
                 g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
                           torch.empty(B, S, S, dtype=torch.float32, device=dev),
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))
-            fit_c = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
-                                       _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_maps[0]), _lib.ptr(g_maps[1]),
-                                       _lib.ptr(g_maps[2]), None, _lib.ptr(mask_sum))
-            ctx.fit = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps, mask_sum)
-        _lib.check(L.d3m_render_lit_epilogue(
-            _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl, _lib.ptr(m["face_index_map"]),
-            _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(background), background.shape[0],
-            _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"]), _lib.ptr(rgb), _lib.ptr(alpha), _lib.ptr(depth), B, Ft,
-            int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
-            ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
-        if vis is not None:
-            cur.wait_stream(side)
+            fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum)
+        cur = torch.cuda.current_stream()
+        mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
+        auxs = [_side_stream(dev, G + k) for k in range(G)]
+        for k in range(G):
+            if mains[k] is not cur:
+                mains[k].wait_stream(cur)
+            # every branch enters (a capture) from the ORIGIN stream: a stream that joins through another branch's
+            # event -- a fork of a fork -- crashes hipStreamEndCapture on ROCm 7.2
+            if vis is not None and auxs[k] is not cur and auxs[k] is not mains[k]:
+                auxs[k].wait_stream(cur)
+        for k, (lo, hi) in enumerate(groups):
+            Bg = hi - lo
+            with torch.cuda.stream(mains[k]):
+                tri_g, tex_g, light_g, bg_g = (_bslice(t, lo, hi) for t in (tri, textures, light, background))
+                fi_g, wm_g, dm_g = m["face_index_map"][lo:hi], m["weight_map"][lo:hi], m["depth_map"][lo:hi]
+                ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(Bg, Fp, S), dev)
+                _lib.check(L.d3m_forward_face_index_map_mesh(
+                    _lib.ptr(sv[lo:hi]), _lib.ptr(tri_g), tri_g.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces[lo:hi]),
+                    _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), None, Bg, S, float(near), float(far), _lib.ptr(ws),
+                    ws.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+                if vis is not None:
+                    if auxs[k] is not mains[k]:
+                        auxs[k].wait_stream(mains[k])
+                    with torch.cuda.stream(auxs[k]):
+                        _lib.check(L.d3m_visibility(_lib.ptr(fi_g), _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
+                                                    _lib.stream_ptr()), "d3m_visibility")
+                fit_c = None
+                if fit_state is not None:
+                    fit_c = _lib.D3MFitTargets(
+                        _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
+                        _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(_bslice(g_maps[0], lo, hi)),
+                        _lib.ptr(_bslice(g_maps[1], lo, hi)), _lib.ptr(_bslice(g_maps[2], lo, hi)), None, _lib.ptr(mask_sum))
+                # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
+                _lib.check(L.d3m_render_lit_epilogue(
+                    _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
+                    _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(bg_g), bg_g.shape[0],
+                    _lib.ptr(m["rgb_map"][lo:hi]), _lib.ptr(_bslice(m["alpha_map"], lo, hi)),
+                    _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
+                    int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
+                    ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
+        for k in range(G):
+            if mains[k] is not cur:
+                cur.wait_stream(mains[k])
+            if vis is not None and auxs[k] is not cur and auxs[k] is not mains[k]:
+                cur.wait_stream(auxs[k])
         m["visibility"] = vis
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
-                   (float(ia), float(idr), ca, cd, direction), Bl)
+                   (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
+        ctx.fit = fit_state
         ctx.save_for_backward(faces, vertices, tri, textures, light)
         if fit is not None:
-            return loss
-        ctx.fit = None
+            return loss_g.sum() if G > 1 else loss_g.reshape(())
         empty = torch.tensor([])
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
@@ -337,13 +388,12 @@ class _RasterizeLit(torch.autograd.Function):
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
         L = _lib.lib()
         faces, vertices, tri, textures, light = ctx.saved_tensors
-        S, eps, aa, ra, rd, fill_back, (ia, idr, ca, cd, direction), Bl = ctx.cfg
+        S, eps, aa, ra, rd, fill_back, (ia, idr, ca, cd, direction), Bl, groups = ctx.cfg
         m = ctx.maps
-        dev, B = faces.device, faces.shape[0]
+        dev, B, G = faces.device, faces.shape[0], len(groups)
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
         grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
-        target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
-        unscaled = None
+        grad_loss = scratch = mask_sum = None
         if ctx.fit is None:
             g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
             g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
@@ -353,80 +403,116 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
                 "d3m_output_epilogue_backward")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
-            rgb_t, depth_t, alpha_t, mask, scratch, loss, (g_rgb_map, g_alpha_map, g_depth_map), mask_sum = ctx.fit
+            rgb_t, depth_t, alpha_t, mask, scratch, loss_g, (g_rgb_map, g_alpha_map, g_depth_map), mask_sum = ctx.fit
             grad_loss = f32c(g_rgb).reshape(1)
-            unscaled = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask),
-                                          _lib.ptr(scratch), _lib.ptr(loss), _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map),
-                                          _lib.ptr(g_depth_map), _lib.ptr(grad_loss), _lib.ptr(mask_sum))
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
-        # and both passes run over one compacted list of the faces that own a pixel
+        # and both passes run over the compacted list of the faces that own a pixel.  The edge gradient (K4: ~8
+        # latency-bound launches) and the gathered texture / depth pass (K5+K6) are independent -- they only meet in
+        # the float atomics on grad_sv -- so the second runs on a stream of its own, per view group.
         vis = m["visibility"]
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
+        gathered = need_tex or need_vert
         grad_textures = grad_vertices = grad_light = None
-        depth_done = False
-        # The edge gradient (K4: ~8 latency-bound launches) and the gathered texture / depth pass (K5+K6) are
-        # independent -- they only meet in the float atomics on grad_sv -- so the second one runs on a side stream,
-        # forked from and joined to the current one (inside a captured step: a parallel branch of the graph).
-        # Everything it writes is allocated here, on the current stream, so no tensor changes its owning stream.
-        cur = torch.cuda.current_stream()
-        side = _side_stream(dev) if (need_tex or need_vert) else None
-        if side is not None:
-            grad_textures = torch.empty_like(textures)
-            grad_light = torch.empty_like(light) if need_vert else None
+        tex_shared, light_shared = textures.shape[0] == 1, Bl == 1
+        gt_g = gl_g = None
+        if gathered:
             grad_vertices = torch.zeros_like(vertices) if need_vert else None
-            ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
-                _lib.check(L.d3m_backward_textures_lit(
-                    _lib.ptr(faces), _lib.ptr(textures), textures.shape[0], _lib.ptr(light), Bl,
-                    _lib.ptr(m["face_index_map"]), _lib.ptr(m["weight_map"]), _lib.ptr(m["depth_map"]), _lib.ptr(g_rgb_map),
-                    _lib.ptr(grad_textures), _lib.ptr(grad_light), _lib.ptr(g_depth_map) if rd else None, None, B, Ft,
-                    int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None,
-                    _lib.ptr(vis), ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
-                    "d3m_backward_textures_lit")
-                if need_vert:       # the light gradient -> world-space vertices through the face normals, same branch
-                    _lib.check(L.d3m_face_light_backward(
-                        _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
-                        _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
-                        Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
-            depth_done = rd
-        ops.backward_pixel_map(faces, m["face_index_map"], m["rgb_map"], m["alpha_map"] if ra else None, g_rgb_map,
-                               g_alpha_map, None, S, eps, True, ra, vertex_target=target, visibility=vis,
-                               unscaled=unscaled)
-        if side is not None:
-            cur.wait_stream(side)
+            if tex_shared:
+                gt_g = [torch.empty_like(textures) for _ in groups]
+            else:
+                grad_textures = torch.empty_like(textures)
+                gt_g = [grad_textures[lo:hi] for lo, hi in groups]
+            if need_vert:
+                if light_shared:
+                    gl_g = [torch.empty_like(light) for _ in groups]
+                else:
+                    grad_light = torch.empty_like(light)
+                    gl_g = [grad_light[lo:hi] for lo, hi in groups]
+        cur = torch.cuda.current_stream()
+        mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
+        auxs = [_side_stream(dev, G + k) for k in range(G)]
+        for k in range(G):
+            if mains[k] is not cur:
+                mains[k].wait_stream(cur)
+            if gathered and auxs[k] is not cur:
+                auxs[k].wait_stream(cur)
+        for k, (lo, hi) in enumerate(groups):
+            Bg = hi - lo
+            tri_g, tex_g, light_g = (_bslice(t, lo, hi) for t in (tri, textures, light))
+            fi_g, wm_g, dm_g = m["face_index_map"][lo:hi], m["weight_map"][lo:hi], m["depth_map"][lo:hi]
+            target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back))
+            unscaled = None
+            if ctx.fit is not None:
+                unscaled = _lib.D3MFitTargets(
+                    _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
+                    _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(g_rgb_map[lo:hi]), _lib.ptr(g_alpha_map[lo:hi]),
+                    _lib.ptr(g_depth_map[lo:hi]), _lib.ptr(grad_loss), _lib.ptr(mask_sum))
+            if gathered:
+                with torch.cuda.stream(auxs[k]):
+                    ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
+                    # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
+                    _lib.check(L.d3m_backward_textures_lit(
+                        _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
+                        _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(g_rgb_map[lo:hi]), _lib.ptr(gt_g[k]),
+                        _lib.ptr(gl_g[k]) if gl_g is not None else None,
+                        _lib.ptr(g_depth_map[lo:hi]) if rd else None, None, Bg, Ft, int(fill_back), S, ts, eps,
+                        _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis[k]),
+                        ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
+                        "d3m_backward_textures_lit")
+            with torch.cuda.stream(mains[k]):
+                ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
+                                       g_rgb_map[lo:hi], g_alpha_map[lo:hi] if ra else None, None, S, eps, True, ra,
+                                       vertex_target=target, visibility=vis[k], unscaled=unscaled)
+        for k in range(G):
+            if mains[k] is not cur:
+                cur.wait_stream(mains[k])
+            if gathered and auxs[k] is not cur and auxs[k] is not mains[k]:
+                cur.wait_stream(auxs[k])
+        if gathered:
+            # shared textures / light: the groups' sums add up (a group's pass already summed over its views)
+            if tex_shared:
+                grad_textures = gt_g[0] if G == 1 else torch.stack(gt_g).sum(0)
+            if need_vert:
+                if light_shared:
+                    grad_light = gl_g[0] if G == 1 else torch.stack(gl_g).sum(0)
+                # the light gradient -> world-space vertices through the face normals
+                _lib.check(L.d3m_face_light_backward(
+                    _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
+                    _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
+                    Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
             if not need_tex:
                 grad_textures = None
-        if rd and not depth_done:           # textures and lighting need no gradient: the depth term on its own
-            if unscaled is not None:
+        elif rd:                            # textures and lighting need no gradient: the depth term on its own
+            if ctx.fit is not None:
                 # d3m_backward_depth_map takes final maps: the fused objective left sign(depth - target) * mask, which
-                # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); scratch[2] holds that sum
-                g_depth_map = g_depth_map * (grad_loss / scratch[2])
+                # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); totals[2] of the scratch holds that
+                # sum (the same in every group: with more than one the normaliser is the batch's mask_sum)
+                g_depth_map = g_depth_map * (grad_loss / scratch[0][2])
             grad_faces = torch.zeros_like(faces)
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)
             _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
                                                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 12
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 13
 
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
                   anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
-                  background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True):
+                  background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True, view_groups=1):
     """rgb (+alpha, depth) images of the mesh (`screen_vertices` [B,V,3] after the camera transform, triangles
     `tri` [1|B,F,3]) textured with the ORIGINAL `textures` [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face
     light (computed from world-space `vertices`) are applied on the fly.  Same outputs as vertices_to_faces() +
     lighting() + rasterize_rgbad() on the materialised arrays."""
     rgb, alpha, depth = _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size,
                                             anti_aliasing, near, far, eps, background_color, True, return_alpha,
-                                            return_depth)
+                                            return_depth, None, view_groups)
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
 
 
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
-                      near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR):
+                      near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
+                      view_groups=1):
     """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
@@ -437,7 +523,7 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
     internal-resolution maps, so the images and their gradients never exist in memory.  Same value and gradients as
     core.losses.multiview_fit_loss(*rasterize_lit(...), ...)."""
     return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
-                               far, eps, background_color, True, True, True, tuple(targets))
+                               far, eps, background_color, True, True, True, tuple(targets), view_groups)
 
 
 def rasterize_rgbad(

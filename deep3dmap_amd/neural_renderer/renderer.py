@@ -62,6 +62,9 @@ class Renderer(nn.Module):
         # the textures, textures / mesh of batch 1 are shared by all views).  False: the reference's sequence
         # cat -> lighting -> rasterize on materialised arrays.  Same images either way.
         self.lighting_on_the_fly = True
+        # The views of a batch are independent; the on-the-fly path may run them as this many concurrent pipelines
+        # (rasterize._RasterizeLit, "VIEW GROUPS").  1 = one pipeline for the whole batch.
+        self.view_groups = 1
 
     def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
                 orig_size=None):
@@ -128,7 +131,7 @@ class Renderer(nn.Module):
             sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             return rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                  self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                 False, False)['rgb']
+                                 False, False, view_groups=self.view_groups)['rgb']
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
@@ -142,13 +145,15 @@ class Renderer(nn.Module):
             raise ValueError("render_fit_loss needs lighting_on_the_fly and anti_aliasing=False")
         sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
-                                 self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color)
+                                 self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
+                                 view_groups=self.view_groups)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self.lighting_on_the_fly:
             sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
-                                self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color)
+                                self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
+                                view_groups=self.view_groups)
         else:
             f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
             textures = self._lit_textures(vertices, faces, textures)

@@ -309,3 +309,48 @@ def test_graph_capture_with_retained_autograd_state():
         torch.cuda.synchronize()
         assert abs(float(l) - l0) <= 1e-5 * abs(l0)
         assert _rel_l2(depth.grad, gd0) < 1e-4 and _rel_l2(view.grad, gv0) < 1e-4
+
+
+@pytest.mark.parametrize("groups", [2, 3, 5])
+def test_view_groups_equal_one_pipeline(groups):
+    """The lit render node run as concurrent view groups (rasterize._RasterizeLit, "VIEW GROUPS"): the fused fit
+    objective and its gradients (the groups are shards of it), and plain render() with per-view textures -- images
+    bit for bit, gradients to rounding -- against the single pipeline."""
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(30)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    eyes = synthetic.camera_ring(5)
+    res = []
+    for g in (1, groups):
+        fit = MultiViewFit(v, tri, tex, eyes, image_size=96, view_groups=g)
+        fit.set_targets_from(synthetic.perturb(v, 0.03))
+        loss, gv, gt = fit.step()
+        eager = (float(loss), gv.clone(), gt.clone())
+        fit.capture_graph()
+        for _ in range(3):
+            loss, gv, gt = fit.step()
+        assert abs(float(loss) - eager[0]) <= 1e-6 * abs(eager[0]) and _rel_l2(gv, eager[1]) < 1e-5
+        res.append(eager)
+    (l1, gv1, gt1), (lg, gvg, gtg) = res
+    assert abs(lg - l1) <= 1e-5 * abs(l1)
+    assert float((gvg - gv1).abs().max()) <= 1e-5 * float(gv1.abs().max())
+    assert float((gtg - gt1).abs().max()) <= 1e-5 * float(gt1.abs().max())
+    # render(): per-view textures and world vertices with gradients (light gradient path), anti-aliasing on
+    B = 5
+    vt = torch.from_numpy(v).cuda()[None].repeat(B, 1, 1) * torch.linspace(0.9, 1.1, B, device="cuda")[:, None, None]
+    ft = torch.from_numpy(tri).cuda()[None].repeat(B, 1, 1)
+    tx = torch.rand(B, tri.shape[0], 2, 2, 2, 3, device="cuda")
+    outs = []
+    for g in (1, groups):
+        r = nr.Renderer(image_size=48, anti_aliasing=True, camera_mode="look_at")
+        r.eye = torch.from_numpy(eyes).cuda()
+        r.view_groups = g
+        vg, tg = vt.clone().requires_grad_(True), tx.clone().requires_grad_(True)
+        rgb, depth, alpha = r(vg, ft, tg)
+        (rgb.square().sum() + alpha.sum() + depth.clamp(max=5).sum()).backward()
+        outs.append((rgb.detach(), depth.detach(), alpha.detach(), vg.grad, tg.grad))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][3:], outs[1][3:]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
