@@ -9,16 +9,21 @@
 // axis 0), and a line is shared by hundreds of walks.  So:
 //   0. visibility     faces that own no pixel cannot contribute: flags + compacted list (shared with the gathered
 //                     texture / depth pass through d3m_visibility);
-//   1. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- packed in both
+//  THE PLAN (geometry only: faces + face_index_map; d3m_edge_plan can build it right after the forward pass)
+//   1. k_edge_count   a workgroup publishes the crossing ranges of its 42 faces x 6 (edge, axis) lanes in LDS and
+//                     its threads take ONE crossing each per round: crossings per workgroup and per line;
+//   2. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
+//   3. k_edge_scatter same flattening: one 32-byte record per crossing, written in LINE order;
+//  THE GRADIENT (needs the gradient maps)
+//   4. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- packed in both
 //                     orientations (rows, columns), plus each line's non-zero-gradient extent;
-//   2. k_edge_count   a workgroup publishes the crossing ranges of its 42 faces x 6 (edge, axis) lanes in LDS and
-//                     its threads take ONE crossing each per round; bounds the records each line will receive
-//                     (two per crossing) without touching the maps;
-//   3. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
-//   4. k_edge_emit    same flattening: every crossing owns two result slots; segments are clipped to the line's
-//                     extent, short ones walked in-thread, long ones written as 48-byte records in LINE order;
-//   5. k_edge_lines   one workgroup per (view, axis, line): the line's records staged in LDS once, the line's
-//                     segments ordered by length, sixteen segments per wave (four lanes each), factored distance;
+//   5. k_edge_lines   one workgroup per (view, axis, line): the line's per-pixel records staged in LDS once; a thread
+//                     per (crossing, outward | inward) sets the segment up against them (owner test, clip to the
+//                     extent), walks it if short, queues it in LDS if long; the queued segments are ordered by length
+//                     and walked sixteen per wave (four lanes each) with the factored distance.  The walks never
+//                     touch global memory;
+//      k_edge_overflow  crossings that got no record (workspace smaller than the scene needs) are walked from global
+//                     memory by one thread each; leaves at once otherwise;
 //   6. k_edge_gather  six lanes per visible face add their crossings' slots in order; stored to grad_faces or
 //                     accumulated into the vertex gradient (VertexTarget).
 // Deterministic up to the final vertex atomics.  The reference OVERWRITES the 9 entries of every front-facing face
@@ -28,6 +33,7 @@
 // regrouped (see "FACTORED DISTANCE" and k_pack_maps); the divisions inside the walk use v_rcp_f32 (1 ulp), far
 // inside the 1e-3 gradient tolerance.
 #pragma once
+#include <algorithm>
 #include <type_traits>
 #include "d3m_backward.h"
 #include "d3m_face_major.h"
@@ -36,13 +42,9 @@
 namespace d3m {
 
 constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are walked by the owning lane
-#ifndef D3M_EG_LINE_PARTS
-#define D3M_EG_LINE_PARTS 1
-#endif
 #ifndef D3M_EG_LINE_WAVES
 #define D3M_EG_LINE_WAVES 8
 #endif
-constexpr int EG_LINE_PARTS = D3M_EG_LINE_PARTS;   // workgroups per line (items are dealt round-robin to the parts)
 constexpr int EG_LINE_WAVES = D3M_EG_LINE_WAVES;   // waves per workgroup: parts x waves walk one line's items concurrently
 constexpr int EG_ITEM_DW = 12;     // dwords per item
 
@@ -70,24 +72,6 @@ struct EdgeGradArgs {
     unsigned n_lines;   // B*2*S
 };
 
-struct EdgeWork {
-    int* visible;        // [B*F]   1 if the face owns a pixel (zeroed per call, set by k_mark_visible)
-    int* visible_list;   // [B*F]   compacted indices of those faces
-    int* n_visible;      // [1]     (zeroed per call)
-    int2* lane_cross;    // [6*B*F] per (visible face, edge, axis) lane: first crossing within its workgroup, count
-    float2* lane_partial;// [6*B*F] overflow sums of that lane (segments whose slot did not fit the workspace)
-    int* line_count;     // [B*2*S] upper bound (2 per crossing) of the records each line receives = its slice (zeroed per call)
-    int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
-    int4* line_info;     // [B*2*S] what a crossing needs to know about its line, in one load: (S - first pixel of the
-                         //         non-zero-gradient extent, last + 1, first record of the slice, slice length)
-    int* alloc;          // [2] crossings (written by the block scan), line-slice cursor (zeroed per call)
-    int* vis_block;      // [ceil(B*F/1024)+1] visible faces per 1024-face chunk, then (in place) their exclusive scan
-    int* lane_block;     // [ceil(B*F/42)+1]   crossings per k_edge_count workgroup iteration, then their scan
-    uint32_t* items;     // [cap * EG_ITEM_DW] records of the queued segments, grouped by line
-    float2* results;     // [cap]
-    int cap;
-};
-
 struct SegRef {
     float alpha, r, g, b;
 };
@@ -107,60 +91,95 @@ __device__ __forceinline__ void crossing_range(float p00, float p10, int is, int
     d0_to = f2i(fminf(fmaxf(p00, p10), (float)(is - 1)));
 }
 
-// The (at most two) walk segments of ONE crossing d0 of an (edge, axis) pair: KCU:314-362 (outward) and :417-431
-// (inward).  p00..p21 = p[num][dim] of KCU:289-294 for that pair; owner(d0, d1) returns face_index_map at that
-// line position.  has_out / has_in tell which of `out` / `in` were filled.
+// The geometry of ONE crossing d0 of an (edge, axis) pair: everything about its two walks (KCU:314-362 outward,
+// :417-431 inward) that does not depend on the gradient maps.  p00..p21 = p[num][dim] of KCU:289-294 for that pair;
+// owner(d0, d1) returns face_index_map at that line position.  Computed once per crossing (k_edge_scatter) and kept in
+// the crossing's record.
+enum : uint32_t { XG_ALIVE = 1, XG_DIRPOS = 2, XG_F0 = 4, XG_F1 = 8, XG_OWNER = 16, XG_ORIENTED = 32 };
+struct XGeom {
+    float d1_cross, q0, q1;     // crossing position along the line; first factors of `dist` (KCU:404 / :409)
+    int d1_in;                  // the in-pixel next to the crossing
+    int in_from, in_to;         // inward walk, in-pixel .. opposite edge, before clipping to the gradients' extent
+    uint32_t bits;              // XG_ALIVE: both pixels next to the crossing lie in the image (KCU:325-328);
+                                // XG_DIRPOS: walk direction +1 (KCU:297-308); XG_F0/F1: KCU:403/:408 evaluate the term;
+                                // XG_OWNER: the in-pixel belongs to the face, i.e. the outward walk exists (KCU:354);
+                                // XG_ORIENTED: every inward pixel lies on the expected side of the crossing
+};
+
 template <class Owner>
-__device__ __forceinline__ void crossing_segments(float p00, float p01, float p10, float p11, float p20, float p21,
-                                                  int axis, int fn, int is, int d0, int nz_lo, int nz_hi, Owner&& owner,
-                                                  Segment& out, bool& has_out, Segment& in, bool& has_in) {
-    // [nz_lo, nz_hi]: the line's pixels with a non-zero gradient.  Outside it diff_grad is exactly 0 and KCU:401/:481
-    // skip the pixel, so every segment is clipped to it (with a masked loss the gradients vanish outside the object,
-    // and the outward walks, which run to the image BORDER, lose most of their length or disappear).
-    has_out = has_in = false;
-    if (nz_hi < nz_lo) return;
+__device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p10, float p11, float p20, float p21, int axis,
+                                                   int fn, int is, int d0, Owner&& owner) {
+    XGeom g;
     const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
     const float fd0 = (float)d0;
-    const float d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;                 // KCU:317
-    const int d1_in = (0 < direction) ? f2i(floorf(d1_cross)) : f2i(ceilf(d1_cross));
-    const int d1_out = (int)((unsigned)d1_in + (unsigned)direction);
-    if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) return;                   // KCU:325-328
-    Segment sg;
-    sg.axis = axis;
-    sg.d0 = d0;
-    sg.dir = direction;
-    sg.d1_in = d1_in;
-    sg.d1_cross = d1_cross;
-    sg.f0 = p10 != fd0;
-    sg.f1 = p00 != fd0;
-    sg.q0 = (p10 - p00) / (p10 - fd0);      // KCU:404 / :409: first factor of `dist`
-    sg.q1 = (p10 - p00) / (fd0 - p00);
-    // outward: out-pixel .. image border, only if the in-pixel belongs to this face (KCU:354-362)
-    if (owner(d0, d1_in, direction) == fn) {
-        const int d1_limit = (0 < direction) ? is - 1 : 0;
-        out = sg;
-        out.from = max(max(min(d1_out, d1_limit), 0), nz_lo);
-        out.to = min(min(max(d1_out, d1_limit), is - 1), nz_hi);
-        out.inward = 0;
-        out.oriented = 1;
-        out.ref_pos = d1_in;
-        has_out = out.from <= out.to;
-    }
+    g.d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;                           // KCU:317
+    g.d1_in = (0 < direction) ? f2i(floorf(g.d1_cross)) : f2i(ceilf(g.d1_cross));
+    const int d1_out = (int)((unsigned)g.d1_in + (unsigned)direction);
+    g.bits = (0 < direction) ? XG_DIRPOS : 0u;
+    g.q0 = g.q1 = 0.0f;
+    g.in_from = g.in_to = 0;
+    if (g.d1_in < 0 || is <= g.d1_in || d1_out < 0 || is <= d1_out) { g.d1_in = 0; return g; }   // KCU:325-328
+    g.bits |= XG_ALIVE | (p10 != fd0 ? XG_F0 : 0u) | (p00 != fd0 ? XG_F1 : 0u);
+    g.q0 = (p10 - p00) / (p10 - fd0);       // KCU:404 / :409: first factor of `dist`
+    g.q1 = (p10 - p00) / (fd0 - p00);
+    if (owner(d0, g.d1_in) == fn) g.bits |= XG_OWNER;                                       // KCU:354
     // inward: in-pixel .. opposite edge (KCU:417-431)
     float d0_cross2;
     if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
     else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
     const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
-    in = sg;
-    in.from = max(min(d1_in, d1_limit), 0);
-    in.to = min(max(d1_in, d1_limit), is - 1);
+    g.in_from = max(min(g.d1_in, d1_limit), 0);
+    g.in_to = min(max(g.d1_in, d1_limit), is - 1);
     // all pixels on the expected side of the crossing (see "FACTORED DISTANCE"): decided before clipping
-    in.oriented = (0 < direction) ? in.to == d1_in : in.from == d1_in;
-    in.from = max(in.from, nz_lo);
-    in.to = min(in.to, nz_hi);
-    in.inward = 1;
-    in.ref_pos = d1_out;
-    has_in = in.from <= in.to;
+    if ((0 < direction) ? g.in_to == g.d1_in : g.in_from == g.d1_in) g.bits |= XG_ORIENTED;
+    return g;
+}
+
+// record <-> geometry (32 bytes per crossing)
+__device__ __forceinline__ void geometry_to_record(const XGeom& g, int fn, uint32_t crossing, uint32_t line, uint4& r0,
+                                                   uint4& r1) {
+    r0 = make_uint4(__float_as_uint(g.d1_cross), __float_as_uint(g.q0), __float_as_uint(g.q1), g.bits | ((uint32_t)g.d1_in << 8));
+    r1 = make_uint4((uint32_t)g.in_from | ((uint32_t)g.in_to << 16), (uint32_t)fn, crossing, line);
+}
+__device__ __forceinline__ XGeom record_to_geometry(const uint4 r0, const uint4 r1) {
+    XGeom g;
+    g.d1_cross = __uint_as_float(r0.x); g.q0 = __uint_as_float(r0.y); g.q1 = __uint_as_float(r0.z);
+    g.bits = r0.w & 0xFFu; g.d1_in = (int)(r0.w >> 8);
+    g.in_from = (int)(r1.x & 0xFFFFu); g.in_to = (int)(r1.x >> 16);
+    return g;
+}
+
+// Walk `which` (0: outward, 1: inward) of a crossing, clipped to [nz_lo, nz_hi]: the line's pixels with a non-zero
+// gradient.  Outside it diff_grad is exactly 0 and KCU:401/:481 skip the pixel (with a masked loss the gradients vanish
+// outside the object, and the outward walks, which run to the image BORDER, lose most of their length or disappear).
+__device__ __forceinline__ bool geometry_segment(const XGeom& g, int which, int axis, int d0, int is, int nz_lo, int nz_hi,
+                                                 Segment& sg) {
+    if (!(g.bits & XG_ALIVE) || nz_hi < nz_lo || (which == 0 && !(g.bits & XG_OWNER))) return false;
+    const int direction = (g.bits & XG_DIRPOS) ? 1 : -1;
+    const int d1_out = g.d1_in + direction;
+    sg.axis = axis;
+    sg.d0 = d0;
+    sg.dir = direction;
+    sg.d1_in = g.d1_in;
+    sg.d1_cross = g.d1_cross;
+    sg.f0 = (g.bits & XG_F0) != 0;
+    sg.f1 = (g.bits & XG_F1) != 0;
+    sg.q0 = g.q0;
+    sg.q1 = g.q1;
+    sg.inward = which;
+    if (which == 0) {       // out-pixel .. image border (KCU:354-362)
+        const int d1_limit = (0 < direction) ? is - 1 : 0;
+        sg.from = max(max(min(d1_out, d1_limit), 0), nz_lo);
+        sg.to = min(min(max(d1_out, d1_limit), is - 1), nz_hi);
+        sg.oriented = 1;
+        sg.ref_pos = g.d1_in;
+    } else {
+        sg.from = max(g.in_from, nz_lo);
+        sg.to = min(g.in_to, nz_hi);
+        sg.oriented = (g.bits & XG_ORIENTED) != 0;
+        sg.ref_pos = d1_out;
+    }
+    return sg.from <= sg.to;
 }
 
 // A segment is handed to the line kernel when it is long and its pixels lie on the expected side of the crossing
@@ -305,15 +324,16 @@ __global__ void __launch_bounds__(256) k_compact_visible(const int* __restrict__
 constexpr int EG_FACES_PER_BLOCK = 42;
 
 template <class FS>
-__device__ __forceinline__ bool load_face_lane(const FS& fs, const EdgeWork& w, int blk, int is, int& pos, int& ea, long& gi,
+__device__ __forceinline__ bool load_face_lane(const FS& fs, const int* __restrict__ visible_list,
+                                               const int* __restrict__ n_visible, int blk, int is, int& pos, int& ea, long& gi,
                                                int& bn, int& fn, float& p00, float& p01, float& p10, float& p11,
                                                float& p20, float& p21) {
     const int t = threadIdx.x;
     if (t >= EG_FACES_PER_BLOCK * 6) return false;
     pos = blk * EG_FACES_PER_BLOCK + t / 6;
     ea = t % 6;
-    if (pos >= *w.n_visible) return false;
-    gi = w.visible_list[pos];
+    if (pos >= *n_visible) return false;
+    gi = visible_list[pos];
     const int F = fs.num_faces();
     bn = (int)(gi / F);
     fn = (int)(gi % F);
@@ -349,12 +369,13 @@ struct LaneTable {
 };
 
 template <class FS>
-__device__ __forceinline__ int publish_lanes(const FS& fs, const EdgeWork& w, int blk, int is, LaneTable& t, bool& on, int& pos,
-                                             int& ea, int& n_cross) {
+__device__ __forceinline__ int publish_lanes(const FS& fs, const int* __restrict__ visible_list,
+                                             const int* __restrict__ n_visible, int blk, int is, LaneTable& t, bool& on,
+                                             int& pos, int& ea, int& n_cross) {
     int bn = 0, fn = 0;
     long gi = 0;
     float p00 = 0, p01 = 0, p10 = 0, p11 = 0, p20 = 0, p21 = 0;
-    on = load_face_lane(fs, w, blk, is, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21);
+    on = load_face_lane(fs, visible_list, n_visible, blk, is, pos, ea, gi, bn, fn, p00, p01, p10, p11, p20, p21);
     int d0_from = 0, d0_to = -1;
     if (on) crossing_range(p00, p10, is, d0_from, d0_to);
     n_cross = on ? max(d0_to - d0_from + 1, 0) : 0;
@@ -386,11 +407,41 @@ __device__ __forceinline__ int crossing_lane(const LaneTable& t, int c) {
     return lo;
 }
 
-// ---- 1. per workgroup: how many crossings; per line: an upper bound of the segments it will receive ------------
-// Every crossing yields at most two segments, so 2 x (crossings on the line) bounds the line's record slice without
-// looking at the maps at all (no owner loads, no divisions: those happen once, in k_edge_emit).
+// ---- the plan: everything about the crossings that depends on GEOMETRY only --------------------------------
+// faces + face_index_map decide which faces are visible, where their edges cross the pixel grid, and therefore
+// which line every crossing belongs to.  None of that depends on the gradient maps, so the plan can be built as soon
+// as the forward pass has produced face_index_map (d3m_edge_plan: on a side stream, beside the sampling pass) and
+// the backward pass starts with the line kernel.  One record (32 bytes) per crossing, stored in LINE order:
+//   xrec[2*i]   = d1_cross, q0, q1, bits | in-pixel << 8            (struct XGeom)
+//   xrec[2*i+1] = inward walk from | to << 16, face index, crossing index, line
+// The results of record i live at results[2*i + {0: outward, 1: inward}] -- LINE order too, so that the line kernel's
+// stores are contiguous; xpos[crossing index] = i lets k_edge_gather find them (scattered READS of 16 bytes instead of
+// scattered 8-byte writes, which cost the line kernel 0.15 ms of partial-line write traffic).
+struct EdgePlan {
+    int* visible;        // [B*F]   flags of the faces that own a pixel   \  the caller's d3m_visibility blob
+    int* visible_list;   // [B*F]   their compacted indices                > (or one built in the workspace)
+    int* n_visible;      // [1]                                            /
+    int2* lane_cross;    // [6*B*F] per (visible face, edge, axis) lane: first crossing within its workgroup, count
+    int* lane_block;     // [ceil(B*F/42)+1] crossings per k_edge_count workgroup iteration, then (in place) their scan
+    int* line_count;     // [B*2*S] crossings on each line (zeroed per call)
+    int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
+    int2* line_slice;    // [B*2*S] (first record, number of records) of the line's slice of xrec
+    int* alloc;          // [0] total crossings (written by the block scan), [1] slice cursor (zeroed per call)
+    uint4* xrec;         // [2 * cap]
+    float2* results;     // [2 * cap] written by the line kernel (record order) or the overflow kernel (crossing order)
+    int* xpos;           // [cap]     record position of every crossing (plan complete only)
+    int cap;             // crossings the record / result arrays can hold; the rest is walked by k_edge_overflow
+};
+
+// The records are written iff ALL the batch's crossings fit (uniform over a launch): they are then dense and complete,
+// xrec[0 .. alloc[0]), grouped by line.  Otherwise (a workspace smaller than the scene needs) k_edge_overflow walks
+// every crossing the slow way.
+
+__device__ __forceinline__ bool plan_complete(const EdgePlan& w) { return w.alloc[0] <= w.cap; }
+
+// ---- 1. per workgroup: how many crossings; per line: how many records it will receive ------------------------
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgeWork w) {
+__global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgePlan w) {
     __shared__ LaneTable t;
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const XcdOrder xo(n_blocks);
@@ -399,7 +450,7 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgeWork w) {
         if (blk >= n_blocks) continue;
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
-        const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
+        const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
         // every lane of a listed face gets its record (n_cross is 0 for a lane that is not `on`)
         if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
             const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
@@ -413,18 +464,16 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgeWork w) {
                 const int l = crossing_lane(t, c);
                 line = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l] + (c - t.pre[l]);
             }
-            // neighbouring crossings fall on the same lines: one atomic per distinct line of the wave (uniform call
-            // site); every lane stands for the TWO segments its crossing can yield
+            // neighbouring crossings fall on the same lines: one atomic per distinct line of the wave (uniform call site)
             const unsigned long long same = wave_match_any((uint32_t)line, c < total);
-            if (c < total && lane_id() == __builtin_ctzll(same)) atomicAdd(&w.line_count[line], 2 * __popcll(same));
+            if (c < total && lane_id() == __builtin_ctzll(same)) atomicAdd(&w.line_count[line], __popcll(same));
         }
         __syncthreads();                                    // the table is rewritten by the next iteration
     }
 }
 
-// ---- 2. order-free range allocation: slice start for counts[i] (one atomic per 256), packed with the line's extent ----
-__global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ counts, const int* __restrict__ nz_lo_inv,
-                                                     const int* __restrict__ nz_hi1, int4* __restrict__ line_info,
+// ---- 2. order-free range allocation: slice start for counts[i] (one atomic per 256 lines) ---------------------
+__global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ counts, int2* __restrict__ line_slice,
                                                      int* __restrict__ cursor, long n) {
     __shared__ int s_wave[4];
     __shared__ int s_base;
@@ -440,24 +489,64 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
         s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
     }
     __syncthreads();
-    if (i < n) line_info[i] = make_int4(nz_lo_inv[i], nz_hi1[i], s_base + s_wave[wv] + incl - c, c);
+    if (i < n) line_slice[i] = make_int2(s_base + s_wave[wv] + incl - c, c);
 }
 
-// ---- 3. walk short segments, emit long ones ------------------------------------------------------------
-// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] | fn << 6; 1 inv0; 2 from | to<<16; 3 slot;
-// 4 d1_cross; 5 u0; 6 u1; 7..10 reference alpha,r,g,b; 11 inv1.  (line and slots are implied by where the item is
-// indexed.)
-//
-// FACTORED DISTANCE.  Along one queued segment t = d1 - d1_cross keeps its sign s_t (outward: the walk direction;
-// inward: the opposite), so KCU:404-405's  dist = q*t*(2/is) +- eps  is  qc*(t + u)  with qc = q*2/is and the
-// per-item constant u = s_t*eps/|qc|, and the walk's sum  -sum diff/dist  becomes  (-1/qc) * sum diff/(t + u):
-// per pixel one packed add, two v_rcp and one packed fma for both vertices; inv = -1/qc is applied once per item.
-// |t + u| >= |u| > 0, so no quotient is infinite.  The one pixel where t == 0 (an inward walk starting exactly on
-// an integer crossing: the reference's `0 < dist` is false there, i.e. -eps whatever s_t says) is corrected after
-// the loop (fix_at_*; only if that pixel survived the clip to the line's non-zero extent).  Inward segments whose
-// limit lies on the unexpected side of the in-pixel (possible only within rounding of a vertex) are not queued.
+// ---- 3. the crossings' records, written in line order -------------------------------------------------------
+// Same flattening as the count pass.  The lanes of a wave that share a line take consecutive places under that
+// line's cursor with ONE atomic per distinct line.
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWork w) {
+__global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __restrict__ face_index_map, int is, EdgePlan w) {
+    __shared__ LaneTable t;
+    const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const XcdOrder xo(n_blocks);
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
+        const int blk = xo.unit(i);
+        if (blk >= n_blocks) continue;
+        bool on;
+        int pos = 0, ea = 0, n_cross = 0;
+        const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
+        const long cbase = w.lane_block[blk];               // scanned: first crossing of this workgroup
+        for (int c0 = 0; c0 < total; c0 += 256) {
+            const int c = c0 + threadIdx.x;
+            const bool active = c < total;
+            int l = 0;
+            size_t line = 0;
+            int2 slice = make_int2(0, 0);
+            if (active) {
+                l = crossing_lane(t, c);
+                line = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l] + (c - t.pre[l]);
+                slice = w.line_slice[line];
+            }
+            const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
+            const bool fits = active && plan_complete(w);
+            const unsigned long long q = same & __builtin_amdgcn_ballot_w64(fits);
+            const int leader = active ? __builtin_ctzll(same) : 0, n = __popcll(q);
+            int cursor_base = 0;
+            if (active && lane_id() == leader && n > 0) cursor_base = atomicAdd(&w.line_cursor[line], n);
+            const int in_line = __shfl(cursor_base, leader, 64) + mask_rank(q);
+            if (fits) {
+                const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, d0 = t.d0_from[l] + (c - t.pre[l]);
+                const int32_t* view = face_index_map + (size_t)bn * is * is;
+                const XGeom g = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis,
+                                                  t.fn[l], is, d0, [&](int e0, int e1) {
+                                                      return view[axis ? (size_t)e0 * is + e1 : (size_t)e1 * is + e0];
+                                                  });
+                uint4* rec = w.xrec + 2 * ((size_t)slice.x + in_line);
+                geometry_to_record(g, t.fn[l], (uint32_t)(cbase + c), (uint32_t)line, rec[0], rec[1]);
+                w.xpos[cbase + c] = slice.x + in_line;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 4. crossings that have no record: walked by the owning thread, straight from global memory ---------------
+// Only when the workspace is too small for the scene (the default capacity is two crossings per face of the batch).
+// Leaves at once otherwise.  Results: the crossing's own slots when it has them, else the lane's overflow sum.
+template <class FS>
+__global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, EdgePlan w, float2* __restrict__ lane_partial) {
+    if (plan_complete(w)) return;                           // every crossing has a record: k_edge_lines did it all (uniform exit)
     __shared__ LaneTable t;
     const int is = a.S;
     const float two_over_is = 2.0f / (float)is;
@@ -468,118 +557,31 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
         if (blk >= n_blocks) continue;
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
-        const int total = publish_lanes(fs, w, blk, is, t, on, pos, ea, n_cross);
-        const long cbase = w.lane_block[blk];               // scanned: first crossing of this workgroup
-        for (int c0 = 0; c0 < total; c0 += 256) {
-            const int c = c0 + threadIdx.x;
-            const bool active = c < total;
-            Segment sg[2];
-            bool has[2] = {false, false};
-            int l = 0, fn = 0, axis = 0, d0 = 0;
-            size_t base = 0, line = 0;
-            int4 li = make_int4(0, 0, 0, 0);              // the line's extent and record slice
-            float2 near_dot[2] = {make_float2(0, 0), make_float2(0, 0)};
-            float4 near_grad[2] = {make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
-            if (active) {
-                l = crossing_lane(t, c);
-                d0 = t.d0_from[l] + (c - t.pre[l]);
-                const int bn = t.bn_axis[l] >> 1;
-                axis = t.bn_axis[l] & 1;
-                fn = t.fn[l];
-                base = (size_t)bn * is * is;
-                line = ((size_t)bn * 2 + axis) * is + d0;
-                li = w.line_info[line];
-            }
-            // the lanes of the wave that share this lane's line (found while the load above is in flight)
-            const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
-            if (active) {
-                const AxisMaps& mo = a.ax[axis];
-                // The owner of the in-pixel decides about the outward walk.  Its record and that of its inward
-                // neighbour -- the first two pixels of the inward walk, which on small faces is the whole walk -- are
-                // requested in the same round trip.
-                crossing_segments(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                  is - li.x, li.y - 1,
-                                  [&](int e0, int e1, int dir) {
-                                      const size_t i0 = base + (size_t)e0 * is + e1;
-                                      const size_t i1 = base + (size_t)e0 * is + min(max(e1 - dir, 0), is - 1);
-                                      near_dot[0] = mo.dot[i0]; near_grad[0] = mo.grad[i0];
-                                      near_dot[1] = mo.dot[i1]; near_grad[1] = mo.grad[i1];
-                                      return __float_as_int(near_dot[0].y);
-                                  },
-                                  sg[0], has[0], sg[1], has[1]);
-            }
+        const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
+        const long cbase = w.lane_block[blk];
+        for (int c = threadIdx.x; c < total; c += 256) {
+            const int l = crossing_lane(t, c);
+            const int d0 = t.d0_from[l] + (c - t.pre[l]);
+            const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
+            const size_t line = ((size_t)bn * 2 + axis) * is + d0;
+            const size_t base = (size_t)bn * is * is, line_base = base + (size_t)d0 * is;
             const AxisMaps& m = a.ax[axis];
-            const size_t line_base = base + (line % is) * is;
-            // queued only if the slot and its line's whole slice fit the capacity the workspace gives; otherwise
-            // this thread walks the segment itself (still correct, just serial)
-            bool queued[2];
-            SegRef refs[2];
-#pragma unroll
-            for (int which = 0; which < 2; which++) {       // 0: outward, 1: inward
-                const long slot = 2 * (cbase + c) + which;
-                // reference values of the segment (one pixel of the original maps): requested before anything waits
-                refs[which] = SegRef{0, 0, 0, 0};
-                if (active && has[which]) refs[which] = load_ref(a, axis, base, sg[which].d0, sg[which].ref_pos);
-                queued[which] = active && has[which] && segment_queueable(sg[which]) && slot < (long)w.cap &&
-                                (long)li.z + li.w <= (long)w.cap;
-            }
-            // Record positions: the lanes of the wave that share a line take consecutive places under that line's
-            // cursor (outward segments first) with ONE atomic per distinct line, sent now and only waited for after
-            // the work below.
-            const unsigned long long q_out = same & __builtin_amdgcn_ballot_w64(queued[0]),
-                                     q_in = same & __builtin_amdgcn_ballot_w64(queued[1]);
-            const int n_out = __popcll(q_out), group_leader = active ? __builtin_ctzll(same) : 0;
-            const int rank[2] = {mask_rank(q_out), n_out + mask_rank(q_in)};
-            int cursor_base = 0;
-            if (active && lane_id() == group_leader && n_out + __popcll(q_in) > 0)
-                cursor_base = atomicAdd(&w.line_cursor[line], n_out + __popcll(q_in));
+            const XGeom xg = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+                                               [&](int e0, int e1) { return m.owner(base + (size_t)e0 * is + e1); });
 #pragma unroll
             for (int which = 0; which < 2; which++) {
-                const long slot = 2 * (cbase + c) + which;
-                uint4 rec0, rec1, rec2;
-                if (queued[which]) {
-                    const Segment& q = sg[which];
-                    const SegRef& ref = refs[which];
-                    const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
-                    const float s_t = (float)(q.inward ? -q.dir : q.dir);
-                    const float u0 = s_t * (a.eps / fabsf(qc0)), u1 = s_t * (a.eps / fabsf(qc1));
-                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
-                    const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
-                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
-                    rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-1.0f / qc0),
-                                      (uint32_t)q.from | ((uint32_t)q.to << 16), (uint32_t)slot);
-                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
-                                      __float_as_uint(ref.alpha));
-                    rec2 = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
-                                      __float_as_uint(-1.0f / qc1));
-                } else if (active) {
-                    float g0 = 0, g1 = 0;
-                    if (has[which]) {
-                        const Segment& q = sg[which];
-                        int from = q.from, to = q.to;
-                        if (which == 1 && q.oriented) {     // the in-pixel and its inward neighbour are already here
-                            const int n0 = q.d1_in, n1 = q.d1_in - q.dir;
-                            inline_pixel(q, refs[1], fn, near_dot[0], near_grad[0], n0, from <= n0 && n0 <= to, two_over_is,
-                                         a.eps, g0, g1);
-                            inline_pixel(q, refs[1], fn, near_dot[1], near_grad[1], n1, from <= n1 && n1 <= to, two_over_is,
-                                         a.eps, g0, g1);
-                            if (0 < q.dir) to = min(to, n0 - 2); else from = max(from, n0 + 2);
-                        }
-                        walk_inline(a, m, line_base, q, from, to, refs[which], fn, two_over_is, g0, g1);
-                    }
-                    if (slot < (long)w.cap) {
-                        w.results[slot] = make_float2(g0, g1);
-                    } else if (g0 != 0 || g1 != 0) {        // no slot left: fold into the lane's overflow sum
-                        const size_t lane_id6 = ((size_t)blk * EG_FACES_PER_BLOCK) * 6 + l;
-                        atomicAdd(&w.lane_partial[lane_id6].x, g0);
-                        atomicAdd(&w.lane_partial[lane_id6].y, g1);
-                    }
+                float g0 = 0, g1 = 0;
+                Segment sg;
+                if (geometry_segment(xg, which, axis, d0, is, is - a.nz_lo_inv[line], a.nz_hi1[line] - 1, sg)) {
+                    const SegRef ref = load_ref(a, axis, base, sg.d0, sg.ref_pos);
+                    walk_inline(a, m, line_base, sg, sg.from, sg.to, ref, fn, two_over_is, g0, g1);
                 }
-                // records are stored in LINE order (the line kernel streams its slice), slots in crossing order
-                const int in_line = __shfl(cursor_base, group_leader, 64) + rank[which];
-                if (queued[which]) {
-                    uint4* rec = (uint4*)(w.items + ((size_t)li.z + in_line) * EG_ITEM_DW);
-                    rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
+                if (cbase + c < (long)w.cap) {
+                    w.results[2 * (cbase + c) + which] = make_float2(g0, g1);
+                } else if (g0 != 0 || g1 != 0) {
+                    const size_t lane_id6 = ((size_t)blk * EG_FACES_PER_BLOCK) * 6 + l;
+                    atomicAdd(&lane_partial[lane_id6].x, g0);
+                    atomicAdd(&lane_partial[lane_id6].y, g1);
                 }
             }
         }
@@ -587,210 +589,315 @@ __global__ void __launch_bounds__(256) k_edge_emit(FS fs, EdgeGradArgs a, EdgeWo
     }
 }
 
-// Lanes that share one segment (16, 8 or 4: all inside a DPP row).  The per-segment work -- record decode, the
+// Lanes that share one long segment (16, 8 or 4: all inside a DPP row).  The per-segment work -- record decode, the
 // trip count, the DPP sum, the result -- is per-LANE vector work shared by all the segments of a wave, so fewer lanes
-// per segment means fewer instructions per segment: 16 -> 8 -> 4 lanes took the kernel from 0.51 to 0.45 to 0.44 ms on
+// per segment means fewer instructions per segment: 16 -> 8 -> 4 lanes took the walk from 0.51 to 0.45 to 0.44 ms on
 // the headline step (263 M wave-instructions, 86 % VALU-issue-bound, at 16).
 #ifndef D3M_EG_ROW
 #define D3M_EG_ROW 4
 #endif
 constexpr int EG_ROW = D3M_EG_ROW;
 constexpr int EG_SEG_PER_WAVE = 64 / EG_ROW;   // segments walked concurrently by one wave
-constexpr int EG_SORT_CHUNK = 1024;  // segments ordered by length at a time (a multiple of the workgroup size)
-__device__ __forceinline__ int from0_clamp(int from, int is) { return min(max(from, 0), is - 1); }
+constexpr int EG_LINE_THREADS = EG_LINE_WAVES * 64;
+constexpr int EG_CHUNK = EG_LINE_THREADS / 2;  // crossings set up at a time: one thread per (crossing, outward | inward)
+constexpr int EG_QUEUE = EG_LINE_THREADS;      // long segments queued in LDS before they are walked (one sort key per thread)
+static_assert(EG_LINE_THREADS == 512, "the chunk sort below assumes at most one queued segment per thread");
 
-// ---- 4. one workgroup per (view, axis, line, part) ---------------------------------------------------------
-// PAD: the LDS image of the line has 2*S + 16 entries (only the first S are filled), so the lanes of a row that has
+// ---- 5. one workgroup per (view, axis, line): set up the line's crossings, walk their segments ------------------
+// The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a chunk of
+// EG_CHUNK crossing records at a time:
+//   SET-UP   one thread per (crossing, outward | inward): the segment of KCU:314-362 / :417-431 with the owner test
+//            answered from LDS, clipped to the extent; empty segments store their zero, short ones (and the
+//            inward one whose pixels do not all lie on the expected side of the crossing) are walked by the thread
+//            itself from LDS, long ones are queued in LDS as 48-byte items;
+//   WALK     the queued segments ordered by length (counting sort on length / 16, longest first), sixteen per wave,
+//            four lanes each, FACTORED DISTANCE (below).
+// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] | fn << 6; 1 inv0; 2 from | to<<16;
+// 3 result slot; 4 d1_cross; 5 u0; 6 u1; 7..10 reference alpha,r,g,b; 11 inv1.
+//
+// FACTORED DISTANCE.  Along one queued segment t = d1 - d1_cross keeps its sign s_t (outward: the walk direction;
+// inward: the opposite), so KCU:404-405's  dist = q*t*(2/is) +- eps  is  qc*(t + u)  with qc = q*2/is and the
+// per-item constant u = s_t*eps/|qc|, and the walk's sum  -sum diff/dist  becomes  (-1/qc) * sum diff/(t + u):
+// per pixel one packed add, two v_rcp and one packed fma for both vertices; inv = -1/qc is applied once per item.
+// |t + u| >= |u| > 0, so no quotient is infinite.  The one pixel where t == 0 (an inward walk starting exactly on
+// an integer crossing: the reference's `0 < dist` is false there, i.e. -eps whatever s_t says) is corrected after
+// the loop (fix_at_*; only if that pixel survived the clip to the line's non-zero extent).
+//
+// PAD: the LDS image of the line has 2*S + 16 entries (only the extent is filled), so the lanes of a row that has
 // finished -- the segments of a wave advance in lock step with the longest -- keep reading inside the allocation and
 // the per-iteration address clamp disappears; without PAD (large S) the index is clamped.
 template <bool USE_RGB, bool USE_ALPHA, bool PAD>
-__global__ void __launch_bounds__(EG_LINE_WAVES * 64) k_edge_lines(EdgeGradArgs a, EdgeWork w) {
+__global__ void __launch_bounds__(EG_LINE_THREADS) k_edge_lines(EdgeGradArgs a, EdgePlan w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
+    __shared__ __attribute__((aligned(16))) uint32_t s_items[EG_LINE_THREADS * EG_ITEM_DW];
+    __shared__ int s_hist[33];
+    __shared__ unsigned short s_order[EG_LINE_THREADS];
+    __shared__ int s_nitems, s_pass[2];
     const int is = a.S;
-    // (Keeping a line's parts on one XCD for L2 reuse was measured SLOWER: it piles a heavy line's work
-    //  onto one XCD.  Parts of a line are consecutive workgroups, i.e. spread over the XCDs.)
-    const int part = blockIdx.x % EG_LINE_PARTS;
-    const size_t line = blockIdx.x / EG_LINE_PARTS;          // (b*2 + axis)*S + d0
-    const int n_line = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // items queued under this line
-    // this workgroup's share of them: a contiguous range (EG_LINE_PARTS = 1: all)
-    const int item_lo = (int)((long)n_line * part / EG_LINE_PARTS), item_hi = (int)((long)n_line * (part + 1) / EG_LINE_PARTS);
-    const int n_items = item_hi - item_lo;
-    if (n_items <= 0) return;                                 // nothing for this workgroup (uniform exit)
+    const size_t line = blockIdx.x;                           // (b*2 + axis)*S + d0
+    const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // crossing records under this line
+    if (n_x <= 0) return;                                     // nothing to do (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
     const int d0 = (int)(line % is);
     const int axis = (int)((line / is) & 1);
     const size_t bn = line / ((size_t)2 * is);
     const AxisMaps& m = a.ax[axis];
-    const size_t line_base = bn * is * is + (size_t)d0 * is;
-    const int4 li = w.line_info[line];
-    const uint32_t* recs = w.items + ((size_t)li.z + item_lo) * EG_ITEM_DW;    // contiguous records
+    const size_t view_base = bn * is * is, line_base = view_base + (size_t)d0 * is;
+    const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
+    const uint4* xrec = w.xrec + 2 * (size_t)x_first;
+    const float two_over_is = 2.0f / (float)is;
+    // only the line's non-zero-gradient extent is staged: every segment is clipped to it (geometry_segment)
+    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
+    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    // One thread per (crossing, outward | inward): threads 0..EG_CHUNK-1 take the outward walk of crossing t, the others
+    // the inward walk of crossing t - EG_CHUNK (the waves of the first half mostly queue -- long walks to the extent's
+    // end --, those of the second mostly walk 1-3 pixels: no divergence between the two kinds).  A segment's set-up needs
+    // its record, the extent and -- for the reference values -- one pixel of the original maps: all of that is requested
+    // BEFORE the line image is staged, so that a workgroup pays two memory round trips (record -> reference values,
+    // beside the image), not four.
+    struct Setup {
+        bool has;
+        Segment sg;
+        SegRef ref;
+        int fn;
+        long slot;
+    };
+    const int my_x = (int)threadIdx.x & (EG_CHUNK - 1), my_which = (int)threadIdx.x >= EG_CHUNK ? 1 : 0;
+    auto set_up = [&](int ci) {
+        Setup u;
+        u.has = false;
+        u.ref = SegRef{0, 0, 0, 0};
+        u.fn = 0;
+        u.slot = 0;
+        if (ci < n_x) {
+            const uint4 r0 = xrec[2 * (size_t)ci], r1 = xrec[2 * (size_t)ci + 1];
+            u.fn = (int)r1.y;
+            u.slot = 2 * ((long)x_first + ci) + my_which;
+            u.has = geometry_segment(record_to_geometry(r0, r1), my_which, axis, d0, is, p_lo, p_hi, u.sg);
+            if (u.has) u.ref = load_ref(a, axis, view_base, d0, u.sg.ref_pos);
+        }
+        return u;
+    };
+    const Setup first = set_up(my_x);
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
-    // visited pixel, contiguous within a segment's lane group (the groups of a wave start at unrelated offsets, so
-    // bank conflicts between groups do occur; a single 32-byte record per pixel -- one address register instead of
-    // two -- doubled them and was 8 % slower).  T is kept halved (exact) because the two packed fma below start BOTH
-    // halves of the sum from it.
+    // visited pixel, contiguous within a segment's lane group.  T is kept halved (exact) because the two packed fma
+    // below start BOTH halves of the sum from it.
     const int n_lds = PAD ? 2 * is + 16 : is;
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + n_lds);
-    // only the line's non-zero-gradient extent is staged: every segment was clipped to it (crossing_segments)
-    const int p_lo = __builtin_amdgcn_readfirstlane(is - li.x);
-    const int p_hi = __builtin_amdgcn_readfirstlane(li.y - 1);
-    for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_WAVES * 64) {
+    for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_THREADS) {
         s_grd[p] = m.grad[line_base + p];
         const float2 d = m.dot[line_base + p];
         s_df[p] = make_float2(0.5f * d.x, d.y);
     }
-    __syncthreads();
-    // EG_SEG_PER_WAVE segments per wave, EG_ROW lanes each: the segments are short once clipped (tens of pixels), so a
-    // whole wave per segment spent most of its time on the per-segment prologue / reduction / epilogue.  Here those
-    // are per-lane vector work shared by all the wave's segments, the reduction is a few DPP steps inside the lane
-    // group, and a walk iteration covers EG_ROW pixels of each segment.
     typedef float v2f __attribute__((ext_vector_type(2)));
+    // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped) from its LDS records: two packed fma + one add
+    auto diff_of = [](const float4 g, const float2 d, const v2f nref_ar, const v2f nref_gb) {
+        v2f p = {d.x, d.x};
+        p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
+        p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
+        return p.x + p.y;
+    };
     const int row = lane / EG_ROW, rl = lane % EG_ROW;
-    // The segments of a wave advance in lock step, so they should be about equally long: the workgroup first
-    // orders its segments by length (counting sort on length / 16, longest first, in chunks of EG_SORT_CHUNK) and the
-    // waves then take consecutive groups of that order.  Unsorted, a group of four ran at 64 % lane efficiency.
-    __shared__ int s_hist[33];
-    __shared__ unsigned short s_order[EG_SORT_CHUNK];
-    for (int chunk0 = 0; chunk0 < n_items; chunk0 += EG_SORT_CHUNK) {
-    const int nc = min(EG_SORT_CHUNK, n_items - chunk0);
+    // The queue of long segments (EG_QUEUE items in LDS) is filled by as many set-up passes as it takes -- a line of the
+    // headline mesh has ~380 crossings, i.e. two passes, of which ~240 segments are long -- and walked when the next
+    // pass might not fit, and at the end: the walk wants MANY segments at a time (sixteen per wave, ordered by length).
+    auto walk_queue = [&]() {
+        const int nc = s_nitems;                              // (the caller's barrier made it visible)
+        if (nc > 0) {
+            // ---- order the queued segments by length: the segments of a wave advance in lock step, so they should be
+            // about equally long (unsorted, a group ran at 64 % lane efficiency) -----------------------------------------
+            int key = -1, rank_in_key = 0;
+            if ((int)threadIdx.x < nc) {
+                const uint32_t ft = s_items[(size_t)threadIdx.x * EG_ITEM_DW + 2];
+                key = 31 - min(((int)(ft >> 16) - (int)(ft & 0xFFFF) + 1) >> 4, 31);
+                rank_in_key = atomicAdd(&s_hist[key], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int run = 0;
+                for (int k = 0; k < 32; k++) { const int c = s_hist[k]; s_hist[k] = run; run += c; }
+            }
+            __syncthreads();
+            if (key >= 0) s_order[s_hist[key] + rank_in_key] = (unsigned short)threadIdx.x;
+            __syncthreads();
+            // ---- walk: EG_SEG_PER_WAVE segments per wave, EG_ROW lanes each ------------------------------------------
+            constexpr int STRIDE = EG_LINE_WAVES * EG_SEG_PER_WAVE;
+            for (int base = wv * EG_SEG_PER_WAVE; base < nc; base += STRIDE) {
+                const bool have = base + row < nc;
+                const int it = have ? s_order[base + row] : s_order[base];
+                const uint4* q = (const uint4*)(s_items + (size_t)it * EG_ITEM_DW);
+                const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
+                const uint32_t bits = q0v.x & 63u;
+                const int from = (int)(q0v.z & 0xFFFF), to = have ? (int)(q0v.z >> 16) : -1, fn = (int)(q0v.x >> 6);
+                const float d1_cross = __uint_as_float(q1v.x);
+                const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
+                const v2f nref_ar = {USE_ALPHA ? -__uint_as_float(q1v.w) : 0.0f, USE_RGB ? -__uint_as_float(q2v.x) : 0.0f};
+                const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
+                // A pixel counts if it lies in the segment, its diff_grad is not <= 0 (KCU:401/:481; NaN passes, as in the
+                // reference) and -- inward walks only -- it belongs to the face (KCU:470).  The three conditions are combined
+                // as wave masks on the scalar unit; the vector unit only issues the compares and ONE select.
+                const unsigned long long m_outward = ~__builtin_amdgcn_ballot_w64((bits & 1u) != 0);
+                // the rows advance together: as many EG_ROW-pixel steps as the longest needs (a scalar trip count)
+                const int len = to - from + 1;
+                int max_len = __builtin_amdgcn_readlane(len, 0);
+    #pragma unroll
+                for (int r = 1; r < EG_SEG_PER_WAVE; r++) max_len = max(max_len, __builtin_amdgcn_readlane(len, r * EG_ROW));
+                const int n_iter = (max_len + EG_ROW - 1) / EG_ROW;
+                float t = (float)(from + rl) - d1_cross;            // t = d1 - d1_cross advances by exact steps
+                v2f acc = {0.0f, 0.0f};
+                if (PAD) {
+                    const float4* pg = s_grd + from + rl;
+                    const float2* pd = s_df + from + rl;
+                    const float4* pg_to = s_grd + to;
+                    v2f den = u + t;                                // advances by exact steps of EG_ROW as well
+                    if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
+                        for (int k = 0; k < n_iter; k++) {
+                            const float diff = diff_of(*pg, *pd, nref_ar, nref_gb);
+                            const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                            __builtin_amdgcn_ballot_w64(!(diff <= 0));
+                            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                            // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
+                            // den == 0 (1/0 = inf, 0 * inf = NaN)
+                            if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                            pg += EG_ROW;
+                            pd += EG_ROW;
+                            den += (float)EG_ROW;
+                        }
+                    } else {
+                        for (int k = 0; k < n_iter; k++) {
+                            const float4 g = *pg;
+                            const float2 d = *pd;
+                            const float diff = diff_of(g, d, nref_ar, nref_gb);
+                            const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                            __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                            (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
+                            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                            if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                            pg += EG_ROW;
+                            pd += EG_ROW;
+                            den += (float)EG_ROW;
+                        }
+                    }
+                } else {
+                    int d1 = from + rl;
+                    for (int k = 0; k < n_iter; k++) {
+                        const int dc = min(d1, is - 1);                       // keep the LDS address inside the line
+                        const float2 d = s_df[dc];
+                        const float diff = diff_of(s_grd[dc], d, nref_ar, nref_gb);
+                        const unsigned long long keep = __builtin_amdgcn_ballot_w64(d1 <= to) &
+                                                        __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                        (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
+                        const v2f den = u + t;
+                        const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                        if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                        d1 += EG_ROW;
+                        t += (float)EG_ROW;
+                    }
+                }
+                // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
+                float s0 = acc.x, s1 = acc.y;
+                s0 += dpp_f32<0xB1>(s0);  s1 += dpp_f32<0xB1>(s1);
+                s0 += dpp_f32<0x4E>(s0);  s1 += dpp_f32<0x4E>(s1);
+                if (EG_ROW >= 8) { s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1); }
+                if (EG_ROW == 16) { s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1); }
+                if (have && rl == 0) {
+                    const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
+                    if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
+                        const int df = (bits & 8u) ? from : to;
+                        const float2 d = s_df[df];
+                        const float diff = diff_of(s_grd[df], d, nref_ar, nref_gb);
+                        const float dpos = (!(diff <= 0) && (!(bits & 1u) || __float_as_int(d.y) == fn)) ? diff : 0.0f;
+                        if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
+                        if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
+                    }
+                    w.results[(int)q0v.w] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
+                }
+            }
+
+        }
+        __syncthreads();                                      // the queue has been read
+        if (threadIdx.x == 0) s_nitems = 0;
+        if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+    };
+    if (threadIdx.x == 0) { s_nitems = 0; s_pass[0] = 0; s_pass[1] = 0; }
     if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    int my_key[EG_SORT_CHUNK / (EG_LINE_WAVES * 64)], my_rank[EG_SORT_CHUNK / (EG_LINE_WAVES * 64)];
-#pragma unroll
-    for (int j = 0; j < EG_SORT_CHUNK / (EG_LINE_WAVES * 64); j++) {
-        const int i = threadIdx.x + j * EG_LINE_WAVES * 64;
-        my_key[j] = -1;
-        if (i < nc) {
-            const uint32_t ft = recs[(size_t)(chunk0 + i) * EG_ITEM_DW + 2];
-            const int len = (int)(ft >> 16) - (int)(ft & 0xFFFF) + 1;
-            my_key[j] = 31 - min(len >> 4, 31);
-            my_rank[j] = atomicAdd(&s_hist[my_key[j]], 1);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = 0; k < 32; k++) { const int c = s_hist[k]; s_hist[k] = run; run += c; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < EG_SORT_CHUNK / (EG_LINE_WAVES * 64); j++)
-        if (my_key[j] >= 0) s_order[s_hist[my_key[j]] + my_rank[j]] = (unsigned short)(threadIdx.x + j * EG_LINE_WAVES * 64);
-    __syncthreads();
-    constexpr int STRIDE = EG_LINE_WAVES * EG_SEG_PER_WAVE;
-    for (int base = wv * EG_SEG_PER_WAVE; base < nc; base += STRIDE) {
-        const bool have = base + row < nc;
-        const int it = chunk0 + (have ? s_order[base + row] : s_order[base]);
-        const uint4* q = (const uint4*)(recs + (size_t)it * EG_ITEM_DW);
-        const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
-        const uint32_t bits = q0v.x & 63u;
-        const int from = (int)(q0v.z & 0xFFFF), to = have ? (int)(q0v.z >> 16) : -1, fn = (int)(q0v.x >> 6);
-        const float d1_cross = __uint_as_float(q1v.x);
-        const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
-        const v2f nref_ar = {USE_ALPHA ? -__uint_as_float(q1v.w) : 0.0f, USE_RGB ? -__uint_as_float(q2v.x) : 0.0f};
-        const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
-        // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped): two packed fma + one add.
-        auto diff_of = [&](const float4 g, const float2 d) {
-            v2f p = {d.x, d.x};
-            p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
-            p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
-            return p.x + p.y;
-        };
-        // A pixel counts if it lies in the segment, its diff_grad is not <= 0 (KCU:401/:481; NaN passes, as in the
-        // reference) and -- inward walks only -- it belongs to the face (KCU:470).  The three conditions are combined
-        // as wave masks on the scalar unit; the vector unit only issues the compares and ONE select.
-        const unsigned long long m_outward = ~__builtin_amdgcn_ballot_w64((bits & 1u) != 0);
-        // the rows advance together: as many 16-pixel steps as the longest of the four needs (a scalar trip count)
-        const int len = to - from + 1;
-        int max_len = __builtin_amdgcn_readlane(len, 0);
-#pragma unroll
-        for (int r = 1; r < EG_SEG_PER_WAVE; r++) max_len = max(max_len, __builtin_amdgcn_readlane(len, r * EG_ROW));
-        const int n_iter = (max_len + EG_ROW - 1) / EG_ROW;
-        float t = (float)(from + rl) - d1_cross;            // t = d1 - d1_cross advances by exact steps
-        v2f acc = {0.0f, 0.0f};
-        if (PAD) {
-            const float4* pg = s_grd + from + rl;
-            const float2* pd = s_df + from + rl;
-            const float4* pg_to = s_grd + to;
-            v2f den = u + t;                                // advances by exact steps of 16 as well
-            if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
-                for (int k = 0; k < n_iter; k++) {
-                    const float diff = diff_of(*pg, *pd);
-                    const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                    __builtin_amdgcn_ballot_w64(!(diff <= 0));
-                    const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                    // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
-                    // den == 0 (1/0 = inf, 0 * inf = NaN)
-                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                    pg += EG_ROW;
-                    pd += EG_ROW;
-                    den += (float)EG_ROW;
-                }
-            } else {
-                for (int k = 0; k < n_iter; k++) {
-                    const float4 g = *pg;
-                    const float2 d = *pd;
-                    const float diff = diff_of(g, d);
-                    const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                    __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
-                                                    (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                    const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                    // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
-                    // den == 0 (1/0 = inf, 0 * inf = NaN)
-                    if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                    pg += EG_ROW;
-                    pd += EG_ROW;
-                    den += (float)EG_ROW;
+    __syncthreads();                                          // the image is staged
+    for (int chunk0 = 0, pass = 0; chunk0 < n_x; chunk0 += EG_CHUNK, pass ^= 1) {
+        const Setup u = chunk0 == 0 ? first : set_up(chunk0 + my_x);
+        // ---- empty segments store their zero, short ones are walked here, long ones queued ------------------------
+        bool queued = false;
+        uint4 rec0 = make_uint4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+        if (chunk0 + my_x < n_x) {
+            const Segment& q = u.sg;
+            const SegRef& ref = u.ref;
+            const int fn = u.fn;
+            float g0 = 0, g1 = 0;
+            if (u.has) {
+                if (segment_queueable(q)) {
+                    const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
+                    const float s_t = (float)(q.inward ? -q.dir : q.dir);
+                    // 1 / qc by v_rcp_f32 (1 ulp), like every quotient of the walk itself
+                    const float rq0 = __builtin_amdgcn_rcpf(qc0), rq1 = __builtin_amdgcn_rcpf(qc1);
+                    const float u0 = s_t * (a.eps * fabsf(rq0)), u1 = s_t * (a.eps * fabsf(rq1));
+                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
+                    const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
+                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
+                    rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-rq0),
+                                      (uint32_t)q.from | ((uint32_t)q.to << 16), (uint32_t)u.slot);
+                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
+                                      __float_as_uint(ref.alpha));
+                    rec2 = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
+                                      __float_as_uint(-rq1));
+                    queued = true;
+                } else {                                      // short (or not oriented): this thread walks it, from LDS
+                    const v2f nref_ar = {USE_ALPHA ? -ref.alpha : 0.0f, USE_RGB ? -ref.r : 0.0f};
+                    const v2f nref_gb = {USE_RGB ? -ref.g : 0.0f, USE_RGB ? -ref.b : 0.0f};
+                    const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
+                    for (int d1 = q.from; d1 <= q.to; d1++) {
+                        const float2 d = s_df[d1];
+                        float diff = diff_of(s_grd[d1], d, nref_ar, nref_gb);
+                        // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
+                        if (q.inward && __float_as_int(d.y) != fn) diff = 0.0f;
+                        visit_pixel(diff, d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is, a.eps, g0, g1);
+                    }
                 }
             }
-        } else {
-            int d1 = from + rl;
-            for (int k = 0; k < n_iter; k++) {
-                const int dc = min(d1, is - 1);                       // keep the LDS address inside the line
-                const float2 d = s_df[dc];
-                const float diff = diff_of(s_grd[dc], d);
-                const unsigned long long keep = __builtin_amdgcn_ballot_w64(d1 <= to) &
-                                                __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
-                                                (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                const v2f den = u + t;
-                const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                d1 += EG_ROW;
-                t += (float)EG_ROW;
+            if (!queued) w.results[u.slot] = make_float2(g0, g1);
+        }
+        // the pass's long segments: if they do not fit behind what is queued already, that is walked first
+        const unsigned long long qm = __builtin_amdgcn_ballot_w64(queued);
+        if (lane == 0 && qm) atomicAdd(&s_pass[pass], __popcll(qm));
+        __syncthreads();
+        const bool full = s_nitems + s_pass[pass] > EG_QUEUE;     // uniform: read by everyone before anyone appends
+        __syncthreads();
+        if (full) walk_queue();
+        if (threadIdx.x == 0) s_pass[pass ^ 1] = 0;               // (next read: after the next pass's barrier)
+        {   // queue positions: one LDS atomic per wave, ranks from the ballot
+            int base = 0;
+            if (lane == 0 && qm) base = atomicAdd(&s_nitems, __popcll(qm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (queued) {
+                uint4* it = (uint4*)(s_items + (size_t)(base + mask_rank(qm)) * EG_ITEM_DW);
+                it[0] = rec0; it[1] = rec1; it[2] = rec2;
             }
         }
-        // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
-        float s0 = acc.x, s1 = acc.y;
-        s0 += dpp_f32<0xB1>(s0);  s1 += dpp_f32<0xB1>(s1);
-        s0 += dpp_f32<0x4E>(s0);  s1 += dpp_f32<0x4E>(s1);
-        if (EG_ROW >= 8) { s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1); }
-        if (EG_ROW == 16) { s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1); }
-        if (have && rl == 0) {
-            const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
-            if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
-                const int df = (bits & 8u) ? from : to;
-                const float2 d = s_df[df];
-                const float diff = diff_of(s_grd[df], d);
-                const float dpos = (!(diff <= 0) && (!(bits & 1u) || __float_as_int(d.y) == fn)) ? diff : 0.0f;
-                if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
-                if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
-            }
-            w.results[(int)q0v.w] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
-        }
+        __syncthreads();
     }
-    __syncthreads();                                          // s_order / s_hist are rewritten by the next chunk
-    }
+    walk_queue();
 }
 
 // ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* __restrict__ grad_faces, VertexTarget vt) {
+__global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const float2* __restrict__ lane_partial,
+                                                    float* __restrict__ grad_faces, VertexTarget vt) {
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const XcdOrder xo(n_blocks);
+    const bool complete = plan_complete(w);      // results in record order (found through xpos), else in crossing order
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
         const int blk = xo.unit(i);
         if (blk >= n_blocks) continue;
@@ -800,15 +907,18 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgeWork w, float* _
         float2 g = make_float2(0.0f, 0.0f);
         if (on) {
             const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
-            g = w.lane_partial[(size_t)pos * 6 + ea];
+            g = lane_partial[(size_t)pos * 6 + ea];
             // slots (2c, 2c+1) of the lane's crossings c, contiguous and 16-byte aligned: one float4 per crossing, four
-            // crossings requested per round, added in slot order; slots past cap were folded into lane_partial
-            const long c_first = (long)w.lane_block[blk] + lc.x, c_last = min(c_first + (long)lc.y, (long)(w.cap >> 1));
+            // crossings requested per round, added in slot order; crossings past cap were folded into lane_partial
+            const long c_first = (long)w.lane_block[blk] + lc.x, c_last = min(c_first + (long)lc.y, (long)w.cap);
             const float4* res4 = (const float4*)w.results;
             for (long c = c_first; c < c_last; c += 4) {
+                long at[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) at[j] = (complete && c + j < c_last) ? (long)w.xpos[c + j] : c + j;
                 float4 r[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) r[j] = c + j < c_last ? res4[c + j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int j = 0; j < 4; j++) r[j] = c + j < c_last ? res4[at[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     g.x += r[j].x; g.y += r[j].y;
@@ -966,10 +1076,66 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
     return hipGetLastError();
 }
 
-// count -> crossing base per workgroup -> record slice per line
+// count -> crossing base per workgroup -> record slice per line -> records (geometry only: see struct EdgePlan)
+struct EdgePlanLayout {
+    size_t off_line_count, off_line_cursor, off_alloc, zero_bytes;     // the zeroed prefix
+    size_t off_lane_cross, off_lane_block, off_line_slice, off_xrec;   // xrec | results follow, sized by capacity
+    size_t fixed_bytes;
+};
+constexpr size_t EG_BYTES_PER_CROSSING = 32 + 16 + 4;  // record + its two result slots + its position
+constexpr int EG_CROSSINGS_PER_FACE_DEFAULT = 2;       // default capacity per face of the batch (visible or not)
+
+inline EdgePlanLayout edge_plan_layout(int B, int F, int S) {
+    const size_t nf = (size_t)B * F, nl = (size_t)B * 2 * S;
+    EdgePlanLayout L;
+    size_t o = 0;
+    L.off_line_count = o;  o += eg_align(nl * 4);
+    L.off_line_cursor = o; o += eg_align(nl * 4);
+    L.off_alloc = o;       o += 256;
+    L.zero_bytes = o;
+    L.off_lane_cross = o;  o += eg_align(nf * 6 * 8);
+    L.off_lane_block = o;  o += eg_align((nf / EG_FACES_PER_BLOCK + 2) * 4);
+    L.off_line_slice = o;  o += eg_align(nl * 8);
+    L.off_xrec = o;
+    L.fixed_bytes = o;
+    return L;
+}
+
+inline size_t edge_plan_min_bytes(int B, int F, int S) { return edge_plan_layout(B, F, S).fixed_bytes + 1024; }
+inline size_t edge_plan_bytes(int B, int F, int S) {
+    return edge_plan_min_bytes(B, F, S) + eg_align((size_t)EG_CROSSINGS_PER_FACE_DEFAULT * B * F * EG_BYTES_PER_CROSSING);
+}
+
+// the plan as laid out in `blob` (flags / list / count come from a visibility blob)
+inline bool edge_plan_view(void* blob, size_t bytes, const VisibilityView& v, int B, int F, int S, EdgePlan& w) {
+    const EdgePlanLayout L = edge_plan_layout(B, F, S);
+    if (!blob || bytes < L.fixed_bytes + 1024) return false;
+    char* p = (char*)blob;
+    size_t cap = (bytes - L.fixed_bytes - 512) / EG_BYTES_PER_CROSSING;
+    cap = cap > 64 ? cap - 32 : 0;                             // slack for the 256-byte alignments below
+    if (cap > 0x3FFFFF00) cap = 0x3FFFFF00;                    // 2 * cap result slots are indexed with an int
+    w.visible = v.flags; w.visible_list = v.list; w.n_visible = v.count;
+    w.line_count = (int*)(p + L.off_line_count);
+    w.line_cursor = (int*)(p + L.off_line_cursor);
+    w.alloc = (int*)(p + L.off_alloc);
+    w.lane_cross = (int2*)(p + L.off_lane_cross);
+    w.lane_block = (int*)(p + L.off_lane_block);
+    w.line_slice = (int2*)(p + L.off_line_slice);
+    w.xrec = (uint4*)(p + L.off_xrec);
+    w.results = (float2*)(p + eg_align(L.off_xrec + cap * 32));
+    w.xpos = (int*)(p + eg_align(eg_align(L.off_xrec + cap * 32) + cap * 16));
+    w.cap = (int)cap;
+    return true;
+}
+
 template <class FS>
-inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, const int* nz_lo_inv, const int* nz_hi1, int B, int S,
-                                    hipStream_t st) {
+inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const EdgePlan& w, void* blob, int B, int S,
+                                hipStream_t st) {
+    const EdgePlanLayout L = edge_plan_layout(B, fs.num_faces(), S);
+    hipError_t e = zero_async(blob, L.zero_bytes, st);
+    if (e != hipSuccess) return e;
+    // the passes walk the compacted list with a fixed grid (n_visible is only known on the device); workgroups past
+    // it leave on their first load
     const long nf = (long)B * fs.num_faces(), nl = (long)B * 2 * S;
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
@@ -977,20 +1143,20 @@ inline hipError_t launch_edge_count(FS fs, const EdgeWork& w, const int* nz_lo_i
     LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
            EG_FACES_PER_BLOCK, w.alloc);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, dim3((unsigned)((nl + 255) / 256)), dim3(256), st, (const int*)w.line_count,
-           nz_lo_inv, nz_hi1, w.line_info, w.alloc + 1, nl);
+           w.line_slice, w.alloc + 1, nl);
+    LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g6, dim3(256), st, fs, face_index_map, S, w);
     return hipGetLastError();
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
+// Workspace of d3m_backward_pixel_map: the per-pixel walk records, the lines' extents, the lanes' overflow sums, and
+// room for a visibility blob and a plan of its own (used when the caller brings none).
 struct EdgeLayout {
     size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
-    size_t off_zero, zero_bytes;   // visible | line_count | line_cursor | alloc | n_visible
-    size_t off_visible, off_line_count, off_line_cursor, off_nz_lo, off_nz_hi, off_alloc, off_visible_list, off_lane_cross,
-        off_lane_partial, off_line_offset, off_vis_block, off_lane_block;
-    size_t off_items;              // items | results follow, sized by capacity
-    size_t fixed_bytes;
+    size_t off_nz_lo, off_nz_hi, nz_bytes;     // zeroed per call
+    size_t off_lane_partial, off_visibility, off_plan;
+    size_t fixed_bytes;                         // everything but the plan (sized by capacity)
 };
-
 
 inline EdgeLayout edge_layout(int B, int F, int S) {
     const size_t px = (size_t)B * S * S, nf = (size_t)B * F, nl = (size_t)B * 2 * S;
@@ -1000,128 +1166,98 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.off_dot_row = o;  o += eg_align(px * 8);
     L.off_grad_col = o; o += eg_align(px * 16);
     L.off_dot_col = o;  o += eg_align(px * 8);
-    L.off_zero = o;
-    L.off_visible = o;      o += eg_align(nf * 4);
-    L.off_line_count = o;   o += eg_align(nl * 4);
-    L.off_line_cursor = o;  o += eg_align(nl * 4);
-    L.off_nz_lo = o;        o += eg_align(nl * 4);
-    L.off_nz_hi = o;        o += eg_align(nl * 4);
-    L.off_alloc = o;        o += 256;                 // alloc[0], alloc[1], n_visible (alloc[2])
-    L.zero_bytes = o - L.off_zero;
-    L.off_visible_list = o; o += eg_align(nf * 4);
-    // at most half of the faces can be front-facing AND own a pixel only if ... no such bound: size for all
-    L.off_lane_cross = o;   o += eg_align(nf * 6 * 8);
+    L.off_nz_lo = o;    o += eg_align(nl * 4);
+    L.off_nz_hi = o;    o += eg_align(nl * 4);
+    L.nz_bytes = o - L.off_nz_lo;
     L.off_lane_partial = o; o += eg_align(nf * 6 * 8);
-    L.off_line_offset = o;  o += eg_align(nl * 16);
-    L.off_vis_block = o;    o += eg_align((nf / EG_COMPACT_CHUNK + 2) * 4);
-    L.off_lane_block = o;   o += eg_align((nf / EG_FACES_PER_BLOCK + 2) * 4);
-    L.off_items = o;
+    L.off_visibility = o;   o += eg_align(visibility_bytes((long)nf));
+    L.off_plan = o;
     L.fixed_bytes = o;
     return L;
 }
 
-constexpr size_t EG_BYTES_PER_ITEM = EG_ITEM_DW * 4 + 8;
-constexpr int EG_ITEMS_PER_FACE_DEFAULT = 4;
-
+inline size_t edge_grad_workspace_min_bytes(int B, int F, int S) {
+    return edge_layout(B, F, S).fixed_bytes + edge_plan_min_bytes(B, F, S);
+}
 inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
-    return edge_layout(B, F, S).fixed_bytes + eg_align((size_t)EG_ITEMS_PER_FACE_DEFAULT * B * F * EG_BYTES_PER_ITEM) + 1024;
+    return edge_layout(B, F, S).fixed_bytes + edge_plan_bytes(B, F, S);
 }
 
 template <class FS>
-int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis, GradScale gs,
-                  int B, float eps, void* ws, size_t ws_bytes, hipStream_t st, int* last_err) {
+int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis,
+                  void* shared_plan, size_t shared_plan_bytes, GradScale gs, int B, float eps, void* ws, size_t ws_bytes,
+                  hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
+    const size_t smem_pad = (size_t)(2 * S + 16) * 24;
+    const bool pad = smem_pad <= 36 * 1024;
+    const size_t smem = pad ? smem_pad : (size_t)S * 24;
+    if (smem + 28 * 1024 > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
     const EdgeLayout L = edge_layout(B, F, S);
-    if (!ws || ws_bytes < L.fixed_bytes + 1024) return 2;       // D3M_ERR_WORKSPACE
+    if (!ws || ws_bytes < L.fixed_bytes + (shared_plan ? 0 : edge_plan_min_bytes(B, F, S))) return 2;   // D3M_ERR_WORKSPACE
     char* p = (char*)ws;
-    size_t cap = (ws_bytes - L.fixed_bytes - 768) / EG_BYTES_PER_ITEM;
-    cap = cap > 256 ? cap - 128 : 0;                            // slack for the two 256-byte alignments below
-    if (cap > 0x7FFFFF00) cap = 0x7FFFFF00;
-    cap &= ~(size_t)1;                                          // a crossing's two slots stay together (k_edge_gather)
-    EdgeWork w;
-    w.visible = (int*)(p + L.off_visible);
-    w.line_count = (int*)(p + L.off_line_count);
-    w.line_cursor = (int*)(p + L.off_line_cursor);
-    w.alloc = (int*)(p + L.off_alloc);
-    w.n_visible = w.alloc + 2;
-    w.visible_list = (int*)(p + L.off_visible_list);
-    w.lane_cross = (int2*)(p + L.off_lane_cross);
-    w.lane_partial = (float2*)(p + L.off_lane_partial);
-    w.line_info = (int4*)(p + L.off_line_offset);
-    w.vis_block = (int*)(p + L.off_vis_block);
-    w.lane_block = (int*)(p + L.off_lane_block);
-    w.items = (uint32_t*)(p + L.off_items);
-    const size_t off_res = eg_align(L.off_items + cap * EG_ITEM_DW * 4);
-    w.results = (float2*)(p + off_res);
-    w.cap = (int)cap;
-
+    const long nf = (long)B * F, nl = (long)B * 2 * S;
+    hipError_t e;
+    // which faces own a pixel: the caller's d3m_visibility, or one built here
+    VisibilityView vis;
+    if (shared_vis) {
+        vis = *shared_vis;
+    } else {
+        vis = visibility_view(p + L.off_visibility, nf);
+        e = run_visibility(m.face_index_map, vis, B, F, S, st);
+        if (e != hipSuccess) { *last_err = (int)e; return 3; }
+    }
+    // the crossings' records: the caller's d3m_edge_plan, or one built here
+    EdgePlan w;
+    if (shared_plan) {
+        if (!edge_plan_view(shared_plan, shared_plan_bytes, vis, B, F, S, w)) return 2;
+    } else {
+        if (!edge_plan_view(p + L.off_plan, ws_bytes - L.fixed_bytes, vis, B, F, S, w)) return 2;
+        e = run_edge_plan(fs, m.face_index_map, w, p + L.off_plan, B, S, st);
+        if (e != hipSuccess) { *last_err = (int)e; return 3; }
+    }
     float4* grad_row = (float4*)(p + L.off_grad_row);
     float2* dot_row = (float2*)(p + L.off_dot_row);
     float4* grad_col = (float4*)(p + L.off_grad_col);
     float2* dot_col = (float2*)(p + L.off_dot_col);
-    // per-call counters; the visibility flags too unless the caller brought a d3m_visibility
-    const size_t zero_from = shared_vis ? L.off_line_count : L.off_zero;
-    hipError_t e = zero_async(p + zero_from, L.off_zero + L.zero_bytes - zero_from, st);
+    float2* lane_partial = (float2*)(p + L.off_lane_partial);
+    e = zero_async(p + L.off_nz_lo, L.nz_bytes, st);
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
-    if (shared_vis) {
-        w.visible = shared_vis->flags;
-        w.visible_list = shared_vis->list;
-        w.n_visible = shared_vis->count;
-    }
-    const long nf = (long)B * F, nl = (long)B * 2 * S;
-    if (!shared_vis) {
-        LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st,
-               m.face_index_map, w.visible, B, F, S);
-        const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
-        LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.vis_block, nf);
-        LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.vis_block, n_chunks, (const int*)nullptr, 1,
-               w.n_visible);
-        LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)w.visible, w.visible_list,
-               (const int*)w.vis_block, nf);
-    }
     LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
            m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
            m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
-           (int*)(p + L.off_nz_hi), S, w.lane_partial, (const int*)w.n_visible, gs);
+           (int*)(p + L.off_nz_hi), S, lane_partial, (const int*)w.n_visible, gs);
     EdgeGradArgs a;
     a.ax[0] = AxisMaps{grad_col, dot_col};
     a.ax[1] = AxisMaps{grad_row, dot_row};
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
-    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)((long)B * 2 * S);
-    // count / emit / gather walk the compacted list with a fixed grid (n_visible is only known on the device);
-    // workgroups past n_visible exit on their first load
-    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
-    e = launch_edge_count(fs, w, a.nz_lo_inv, a.nz_hi1, B, S, st);
-    if (e != hipSuccess) { *last_err = (int)e; return 3; }
-    LAUNCH("k_edge_emit", k_edge_emit<FS>, g6, dim3(256), st, fs, a, w);
-    const size_t smem_pad = (size_t)(2 * S + 16) * 24;
-    const bool pad = smem_pad <= 36 * 1024;
-    const size_t smem = pad ? smem_pad : (size_t)S * 24;
-    const dim3 glines((unsigned)(nl * EG_LINE_PARTS));
+    a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
+    const dim3 glines((unsigned)nl);
 #define D3M_LINES1(RGB, ALPHA, PADDED)                                                                               \
     do {                                                                                                             \
-        if (smem > 64 * 1024) {                                                                                      \
+        if (smem + 28 * 1024 > 64 * 1024) {                                                                          \
             e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, PADDED>,                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_WAVES * 64), smem, st, a, w); \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_THREADS), smem, st, a, w); \
     } while (0)
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
         if (pad) D3M_LINES1(RGB, ALPHA, true);                                                                       \
         else D3M_LINES1(RGB, ALPHA, false);                                                                          \
     } while (0)
-    if (smem > 160 * 1024) return 1;                            // a line does not fit LDS (S > ~6800)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
 #undef D3M_LINES1
 #undef D3M_LINES
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, grad_faces, vt);
+    const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
+    // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
+    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, g6, dim3(256), st, fs, a, w, lane_partial);
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, grad_faces, vt);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

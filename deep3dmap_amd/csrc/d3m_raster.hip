@@ -283,8 +283,9 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                                       float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                                       int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                                      const d3m_vertex_target* vertex_target, void* visibility,
-                                      const d3m_fit_targets* unscaled, d3m_stream_t stream) {
+                                      const d3m_vertex_target* vertex_target, void* visibility, void* edge_plan,
+                                      size_t edge_plan_size, const d3m_fit_targets* unscaled, d3m_stream_t stream) {
+    if (edge_plan && !visibility) return D3M_ERR_INVALID;      // a plan indexes the list of its visibility blob
     if (unscaled && !unscaled->scratch) return D3M_ERR_INVALID;
     if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
         image_size <= 0)
@@ -299,8 +300,33 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                 return_alpha != 0};
     VisibilityView vis;
     if (visibility) vis = visibility_view(visibility, (long)batch_size * num_faces);
-    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, to_grad_scale(unscaled, image_size), batch_size,
-                         eps, workspace, workspace_bytes, (hipStream_t)stream, &g_last_hip_error);
+    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, edge_plan, edge_plan_size,
+                         to_grad_scale(unscaled, image_size), batch_size, eps, workspace, workspace_bytes,
+                         (hipStream_t)stream, &g_last_hip_error);
+}
+
+D3M_EXPORT size_t d3m_backward_pixel_map_workspace_min_bytes(int batch_size, int num_faces, int image_size) {
+    return edge_grad_workspace_min_bytes(batch_size, num_faces, image_size);
+}
+
+D3M_EXPORT size_t d3m_edge_plan_bytes(int batch_size, int num_faces, int image_size) {
+    if (batch_size <= 0 || num_faces <= 0 || image_size <= 0) return 0;
+    return edge_plan_bytes(batch_size, num_faces, image_size);
+}
+D3M_EXPORT size_t d3m_edge_plan_min_bytes(int batch_size, int num_faces, int image_size) {
+    if (batch_size <= 0 || num_faces <= 0 || image_size <= 0) return 0;
+    return edge_plan_min_bytes(batch_size, num_faces, image_size);
+}
+D3M_EXPORT int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
+                             size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream) {
+    if (!faces || !face_index_map || !visibility || !edge_plan || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if (image_size > 65535 || num_faces > (1 << 26) || (long)batch_size * 2 * image_size >= (1l << 31)) return D3M_ERR_INVALID;
+    const VisibilityView vis = visibility_view(visibility, (long)batch_size * num_faces);
+    EdgePlan w;
+    if (!edge_plan_view(edge_plan, edge_plan_size, vis, batch_size, num_faces, image_size, w)) return D3M_ERR_WORKSPACE;
+    DenseFaces fs{faces, num_faces};
+    HIP_TRY(run_edge_plan(fs, face_index_map, w, edge_plan, batch_size, image_size, (hipStream_t)stream));
+    return check_launch();
 }
 
 // scratch of the gathered (face-major) backward passes: one int per face

@@ -78,6 +78,7 @@ class MultiViewFit:
                                     fill_back=True)
         self.renderer.eye = self.eyes
         self.renderer.view_groups = view_groups     # concurrent pipelines over this rank's views (rasterize.py)
+        self.renderer.defer_plan_join = True        # _forward_backward below runs backward right behind forward
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.targets = None

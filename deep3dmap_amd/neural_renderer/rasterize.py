@@ -262,7 +262,8 @@ class _RasterizeLit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
-                far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None, view_groups=1):
+                far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None, view_groups=1,
+                defer_plan_join=False):
         L = _lib.lib()
         sv, vertices, textures = f32c(screen_vertices), f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
@@ -299,6 +300,10 @@ class _RasterizeLit(torch.autograd.Function):
         # which faces own a pixel is only needed by the backward pass: one blob per group (this node's backward may run
         # late, so they are its own buffers), built beside the sampling / epilogue pass
         vis = [torch.empty(int(L.d3m_visibility_bytes(hi - lo, Fp)), dtype=torch.uint8, device=dev) for lo, hi in groups] \
+            if need_grad else None
+        # ... and so is the edge gradient's plan (where the visible faces' edges cross the pixel grid, by image line):
+        # geometry only, so it is built on the same branch and the backward pass starts with the line walk
+        plan = [torch.empty(int(L.d3m_edge_plan_bytes(hi - lo, Fp, S)), dtype=torch.uint8, device=dev) for lo, hi in groups] \
             if need_grad else None
         s_out = S // 2 if anti_aliasing else S
         rgb = alpha = depth = loss_g = None
@@ -354,6 +359,8 @@ class _RasterizeLit(torch.autograd.Function):
                     with torch.cuda.stream(auxs[k]):
                         _lib.check(L.d3m_visibility(_lib.ptr(fi_g), _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
                                                     _lib.stream_ptr()), "d3m_visibility")
+                        _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
+                                                   plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")
                 fit_c = None
                 if fit_state is not None:
                     fit_c = _lib.D3MFitTargets(
@@ -368,12 +375,24 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
                     int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
                     ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
+        # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
+        # on the same stream and (if captured) in the same capture, may leave that branch open here: backward waits for it
+        # where it first needs it and joins it, and the branch runs on under the loss and the first backward passes.
+        plan_ready = None
+        if vis is not None and defer_plan_join and G == 1:     # (with view groups: capture crashes on ROCm 7.2, as above)
+            plan_ready = []
+            for k in range(G):
+                ev = torch.cuda.Event()
+                ev.record(auxs[k])
+                plan_ready.append(ev)
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
-            if vis is not None and auxs[k] is not cur and auxs[k] is not mains[k]:
+            if vis is not None and plan_ready is None:
                 cur.wait_stream(auxs[k])
         m["visibility"] = vis
+        m["edge_plan"] = plan
+        m["plan_ready"] = plan_ready
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
@@ -432,11 +451,14 @@ class _RasterizeLit(torch.autograd.Function):
         cur = torch.cuda.current_stream()
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k) for k in range(G)]
+        plan_ready = m["plan_ready"]
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
-            if gathered and auxs[k] is not cur:
+            if gathered or plan_ready is not None:
                 auxs[k].wait_stream(cur)
+            if plan_ready is not None:
+                mains[k].wait_event(plan_ready[k])       # the forward's open branch: visibility + plan of this group
         for k, (lo, hi) in enumerate(groups):
             Bg = hi - lo
             tri_g, tex_g, light_g = (_bslice(t, lo, hi) for t in (tri, textures, light))
@@ -463,11 +485,12 @@ class _RasterizeLit(torch.autograd.Function):
             with torch.cuda.stream(mains[k]):
                 ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
                                        g_rgb_map[lo:hi], g_alpha_map[lo:hi] if ra else None, None, S, eps, True, ra,
-                                       vertex_target=target, visibility=vis[k], unscaled=unscaled)
+                                       vertex_target=target, visibility=vis[k], unscaled=unscaled,
+                                       edge_plan=m["edge_plan"][k])
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
-            if gathered and auxs[k] is not cur and auxs[k] is not mains[k]:
+            if gathered or plan_ready is not None:
                 cur.wait_stream(auxs[k])
         if gathered:
             # shared textures / light: the groups' sums add up (a group's pass already summed over its views)
@@ -494,7 +517,7 @@ class _RasterizeLit(torch.autograd.Function):
                                    g_depth_map, grad_faces, S)
             _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
                                                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 13
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 14
 
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
@@ -512,7 +535,7 @@ def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back
 
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
                       near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
-                      view_groups=1):
+                      view_groups=1, defer_plan_join=False):
     """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
@@ -523,7 +546,7 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
     internal-resolution maps, so the images and their gradients never exist in memory.  Same value and gradients as
     core.losses.multiview_fit_loss(*rasterize_lit(...), ...)."""
     return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
-                               far, eps, background_color, True, True, True, tuple(targets), view_groups)
+                               far, eps, background_color, True, True, True, tuple(targets), view_groups, defer_plan_join)
 
 
 def rasterize_rgbad(

@@ -34,6 +34,18 @@ def visibility(face_index_map, num_faces):
     return blob
 
 
+def edge_plan(faces, face_index_map, visibility_blob, image_size, out=None):
+    """Where the visible faces' edges cross the pixel grid, grouped by image line (d3m_edge_plan): geometry only, so it
+    can be built right after the forward pass and handed to backward_pixel_map.  Returns the blob."""
+    L = _lib.lib()
+    B, F = faces.shape[:2]
+    blob = out if out is not None else torch.empty(int(L.d3m_edge_plan_bytes(B, F, int(image_size))), dtype=torch.uint8,
+                                                   device=faces.device)
+    _lib.check(L.d3m_edge_plan(_lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(visibility_blob), _lib.ptr(blob), blob.numel(), B, F,
+                               int(image_size), _lib.stream_ptr()), "d3m_edge_plan")
+    return blob
+
+
 def _opt(t):
     """The reference passes 1-element dummies for disabled outputs (rasterize.py:46,59-69)."""
     return None if (t is None or t.numel() <= 1) else t
@@ -71,10 +83,12 @@ def forward_texture_sampling(faces, textures, face_index_map, weight_map, depth_
 
 
 def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
-                       image_size, eps, return_rgb, return_alpha, vertex_target=None, visibility=None, unscaled=None):
+                       image_size, eps, return_rgb, return_alpha, vertex_target=None, visibility=None, unscaled=None,
+                       edge_plan=None):
     """`vertex_target` (a _lib.D3MVertexTarget, not part of the reference signature) sends the face gradients
     straight into the gradient of the vertices the faces were gathered from; grad_faces may then be None.
-    `unscaled` (a _lib.D3MFitTargets): the gradient maps are the unscaled ones a fused fit objective left."""
+    `unscaled` (a _lib.D3MFitTargets): the gradient maps are the unscaled ones a fused fit objective left.
+    `edge_plan`: the blob edge_plan() built for the same faces / visibility (the op builds its own otherwise)."""
     _lib.require_device(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces,
                         names=["faces", "face_index_map", "rgb_map", "alpha_map", "grad_rgb_map", "grad_alpha_map",
                                "grad_faces"])
@@ -86,7 +100,8 @@ def backward_pixel_map(faces, face_index_map, rgb_map, alpha_map, grad_rgb_map, 
         _lib.ptr(alpha_map if return_alpha else None), _lib.ptr(grad_rgb_map if return_rgb else None),
         _lib.ptr(grad_alpha_map if return_alpha else None), _lib.ptr(grad_faces), B, F, int(image_size), float(eps),
         int(bool(return_rgb)), int(bool(return_alpha)), _lib.ptr(ws), ws.numel(),
-        ctypes.byref(vertex_target) if vertex_target is not None else None, _lib.ptr(visibility),
+        ctypes.byref(vertex_target) if vertex_target is not None else None, _lib.ptr(visibility), _lib.ptr(edge_plan),
+        edge_plan.numel() if edge_plan is not None else 0,
         ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr())
     _lib.check(rc, "backward_pixel_map")
     return grad_faces

@@ -65,6 +65,9 @@ class Renderer(nn.Module):
         # The views of a batch are independent; the on-the-fly path may run them as this many concurrent pipelines
         # (rasterize._RasterizeLit, "VIEW GROUPS").  1 = one pipeline for the whole batch.
         self.view_groups = 1
+        # render_fit_loss only: leave the forward's side branch (visibility list, edge-gradient plan) open for backward
+        # to join.  ONLY for callers that run backward right behind forward on the same stream (MultiViewFit does).
+        self.defer_plan_join = False
 
     def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
                 orig_size=None):
@@ -146,7 +149,7 @@ class Renderer(nn.Module):
         sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                 view_groups=self.view_groups)
+                                 view_groups=self.view_groups, defer_plan_join=self.defer_plan_join)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self.lighting_on_the_fly:

@@ -103,8 +103,11 @@ int d3m_forward_texture_sampling(const float* faces, const float* textures, cons
  * 0).  grad_faces must arrive zero-initialised, as RasterizeFunction.backward provides it
  * (rasterize.py:111): the reference also stores zeros for front-facing faces without pixels and leaves
  * culled faces untouched, which is then identical.  rgb_map/grad_rgb_map may be NULL when return_rgb == 0, alpha
- * likewise.  workspace: d3m_backward_pixel_map_workspace_bytes() bytes of scratch (no init needed). */
+ * likewise.  workspace: d3m_backward_pixel_map_workspace_bytes() bytes of scratch (no init needed); with less -- down to
+ * d3m_backward_pixel_map_workspace_min_bytes() -- the crossings that find no room are walked one thread each (slow,
+ * same result); below that D3M_ERR_WORKSPACE. */
 size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size);
+size_t d3m_backward_pixel_map_workspace_min_bytes(int batch_size, int num_faces, int image_size);
 /* Optional destination of face gradients (an ADDITION to the reference's interface; NULL = the dense grad_faces):
  * when `faces` was gathered from vertices (vertices_to_faces + fill_back, renderer.py:86 / vertices_to_faces.py),
  * the gradient of each face corner is accumulated straight into grad_vertices [B,num_vertices,3] (+=, float
@@ -122,8 +125,8 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
                            float* grad_faces, int batch_size, int num_faces, int image_size, float eps,
                            int return_rgb, int return_alpha, void* workspace, size_t workspace_bytes,
-                           const d3m_vertex_target* vertex_target, void* visibility,
-                           const d3m_fit_targets* unscaled, d3m_stream_t stream);
+                           const d3m_vertex_target* vertex_target, void* visibility, void* edge_plan,
+                           size_t edge_plan_size, const d3m_fit_targets* unscaled, d3m_stream_t stream);
 
 /* Which faces own a pixel depends on face_index_map only.  d3m_visibility builds, once per forward result, the
  * flags and the compacted list of those faces in a caller-owned blob of d3m_visibility_bytes(); backward operators
@@ -131,6 +134,17 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
 size_t d3m_visibility_bytes(int batch_size, int num_faces);
 int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
                    int num_faces, int image_size, d3m_stream_t stream);
+/* Where the edges of the visible faces cross the pixel grid -- every walk of KCU:312-362 / :417-431 starts at such a
+ * crossing -- depends on `faces` and face_index_map only, not on the gradient maps.  d3m_edge_plan builds, once per
+ * forward result, the crossings' records (position, the in-pixel and whether the face owns it, the inward walk's end,
+ * the first factors of KCU:404/:409's `dist`) grouped by image line in a caller-owned blob of d3m_edge_plan_bytes() (less is
+ * accepted down to d3m_edge_plan_min_bytes(): crossings without room are then walked the slow way);
+ * d3m_backward_pixel_map handed the blob (`edge_plan`, NULL = it builds its own in its workspace) starts with the
+ * line walk.  `visibility`: the d3m_visibility blob of the same forward result (required). */
+size_t d3m_edge_plan_bytes(int batch_size, int num_faces, int image_size);
+size_t d3m_edge_plan_min_bytes(int batch_size, int num_faces, int image_size);
+int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
+                  size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream);
 
 /* Scratch for the two entry points below: one int per face.  With it the sums are GATHERED per visible
  * face (no atomics; faces with a very large bounding box still use the per-pixel atomic kernel);
