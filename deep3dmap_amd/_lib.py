@@ -26,7 +26,7 @@ class D3MVertexTarget(ctypes.Structure):
 class D3MFitTargets(ctypes.Structure):
     _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
                 ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P),
-                ("mask_sum", _P)]
+                ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P)]
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3

@@ -159,15 +159,23 @@ struct GradScale {
     const float* totals;      // the objective's sums (totals[2] = sum of the mask); NULL: the maps are final
     const float* grad_out;    // gradient of the scalar objective; NULL = 1
     float pixels;             // pixels per view
+    int records;              // the rgb / alpha gradients come from the edge gradient's per-pixel records
+                              // (k_render_lit_fit_records), which already carry 1 / (3 sum(mask)) and 1 / pixels
     __device__ __forceinline__ void get(float& s_rgb, float& s_alpha, float& s_depth) const {
         s_rgb = s_alpha = s_depth = 1.0f;
         if (totals) {
             const float go = grad_out ? *grad_out : 1.0f, den = totals[2];
-            s_rgb = go / (3.0f * den);
+            s_rgb = records ? go : go / (3.0f * den);
             s_depth = go / den;
-            s_alpha = go / pixels;
+            s_alpha = records ? go : go / pixels;
         }
     }
+};
+// the rgb gradient of a pixel: a [B,S,S,3] map, or the yzw of the [B,S,S] float4 records
+struct RgbGrad {
+    const float* p;
+    int stride, off;
+    __device__ __forceinline__ float get(size_t pixel, int k) const { return p[pixel * stride + off + k]; }
 };
 
 // ---- XCD-contiguous work order ---------------------------------------------------------------------

@@ -48,19 +48,25 @@ constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are w
 constexpr int EG_LINE_WAVES = D3M_EG_LINE_WAVES;   // waves per workgroup: parts x waves walk one line's items concurrently
 constexpr int EG_ITEM_DW = 12;     // dwords per item
 
-// What a walk reads per pixel, as one scan axis sees it: element (line d0, position d1) lives at b*S*S + d0*S + d1.
-// k_pack_maps builds both orientations in one pass over the maps:
+// What a walk reads per pixel, row-major like the maps (pixel (y, x) of view b at b*S*S + y*S + x); k_pack_maps (or
+// the fused fit epilogue, d3m_lit.h) builds it in one pass:
 //   grad[i] = (grad_alpha, grad_r, grad_g, grad_b)              (0 for a disabled output)
 //   dot[i]  = (sum value*grad of the pixel itself, owner face index bits)
 // so that  diff_grad = dot.x - <reference values, grad>  (KCU:385-396 / :473-479 regrouped: 4 fma).
-struct AxisMaps {
+// A row line (axis 1) reads its pixels contiguously, a column line (axis 0) with stride S -- once, into LDS; transposed
+// copies of the records (48 more bytes per pixel written and read) bought nothing measurable.
+// `go` (NULL = 1): a scalar factor the records still lack -- the fused fit objective writes them before the gradient
+// of the loss is known.  The walks are linear in it up to its SIGN (KCU:401/:481 keep a pixel iff diff_grad > 0): the
+// sign is applied where records are read, the magnitude where the sums are gathered.
+struct EdgeGradArgs {
     const float4* grad;
     const float2* dot;
-    __device__ __forceinline__ int owner(size_t i) const { return __float_as_int(dot[i].y); }
-};
-
-struct EdgeGradArgs {
-    AxisMaps ax[2];   // [0]: axis 0 = column walks (transposed records); [1]: axis 1 = row walks
+    const float* go;
+    __device__ __forceinline__ size_t pixel(int axis, size_t view_base, int d0, int d1) const {   // line d0, position d1
+        return view_base + (axis ? (size_t)d0 * S + d1 : (size_t)d1 * S + d0);
+    }
+    __device__ __forceinline__ float go_sign() const { return (go && *go < 0) ? -1.0f : 1.0f; }
+    __device__ __forceinline__ float go_abs() const { return go ? fabsf(*go) : 1.0f; }
     const float* alpha_map;   // original [B,S,S] / [B,S,S,3] maps: reference values of a segment (one pixel each)
     const float* rgb_map;
     // per line (b*2 + axis)*S + d0: extent of the pixels whose gradients are not all zero, built by k_pack_maps with
@@ -233,14 +239,18 @@ __device__ __forceinline__ void inline_pixel(const Segment& sg, const SegRef& re
 // short segment, walked straight from global memory by the owning thread: 8 + 16 bytes per pixel.  Two pixels per
 // round, both records of both pixels requested before any is used, no branch inside: the walk is a chain of memory
 // round trips and nothing else (the lazy, one-record-at-a-time form cost 0.21 ms of the 0.59 ms emit pass).
-__device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, const AxisMaps& m, size_t line_base, const Segment& sg,
+__device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, size_t view_base, const Segment& sg,
                                             int from, int to, const SegRef& ref, int fn, float two_over_is, float& g0,
                                             float& g1) {
+    const float gs = a.go_sign();
     for (int d1 = from; d1 <= to; d1 += 2) {
         const bool two = d1 + 1 <= to;
-        const size_t ia = line_base + d1, ib = two ? ia + 1 : ia;
-        const float2 dta = m.dot[ia], dtb = m.dot[ib];
-        const float4 ga = m.grad[ia], gb = m.grad[ib];
+        const size_t ia = a.pixel(sg.axis, view_base, sg.d0, d1), ib = two ? a.pixel(sg.axis, view_base, sg.d0, d1 + 1) : ia;
+        float2 dta = a.dot[ia], dtb = a.dot[ib];
+        float4 ga = a.grad[ia], gb = a.grad[ib];
+        dta.x *= gs; dtb.x *= gs;
+        ga.x *= gs; ga.y *= gs; ga.z *= gs; ga.w *= gs;
+        gb.x *= gs; gb.y *= gs; gb.z *= gs; gb.w *= gs;
         inline_pixel(sg, ref, fn, dta, ga, d1, true, two_over_is, a.eps, g0, g1);
         inline_pixel(sg, ref, fn, dtb, gb, d1 + 1, two, two_over_is, a.eps, g0, g1);
     }
@@ -564,17 +574,16 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
             const int d0 = t.d0_from[l] + (c - t.pre[l]);
             const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
             const size_t line = ((size_t)bn * 2 + axis) * is + d0;
-            const size_t base = (size_t)bn * is * is, line_base = base + (size_t)d0 * is;
-            const AxisMaps& m = a.ax[axis];
+            const size_t base = (size_t)bn * is * is;
             const XGeom xg = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
-                                               [&](int e0, int e1) { return m.owner(base + (size_t)e0 * is + e1); });
+                                               [&](int e0, int e1) { return __float_as_int(a.dot[a.pixel(axis, base, e0, e1)].y); });
 #pragma unroll
             for (int which = 0; which < 2; which++) {
                 float g0 = 0, g1 = 0;
                 Segment sg;
                 if (geometry_segment(xg, which, axis, d0, is, is - a.nz_lo_inv[line], a.nz_hi1[line] - 1, sg)) {
                     const SegRef ref = load_ref(a, axis, base, sg.d0, sg.ref_pos);
-                    walk_inline(a, m, line_base, sg, sg.from, sg.to, ref, fn, two_over_is, g0, g1);
+                    walk_inline(a, base, sg, sg.from, sg.to, ref, fn, two_over_is, g0, g1);
                 }
                 if (cbase + c < (long)w.cap) {
                     w.results[2 * (cbase + c) + which] = make_float2(g0, g1);
@@ -601,7 +610,11 @@ constexpr int EG_SEG_PER_WAVE = 64 / EG_ROW;   // segments walked concurrently b
 constexpr int EG_LINE_THREADS = EG_LINE_WAVES * 64;
 constexpr int EG_CHUNK = EG_LINE_THREADS / 2;  // crossings set up at a time: one thread per (crossing, outward | inward)
 constexpr int EG_QUEUE = EG_LINE_THREADS;      // long segments queued in LDS before they are walked (one sort key per thread)
-static_assert(EG_LINE_THREADS == 512, "the chunk sort below assumes at most one queued segment per thread");
+constexpr size_t EG_LINE_STATIC_LDS = (size_t)EG_QUEUE * (EG_ITEM_DW * 4 + 2) + 1024;   // queue + order + counters
+static_assert((EG_CHUNK & (EG_CHUNK - 1)) == 0, "threads are split into an outward and an inward half by a mask");
+#ifndef D3M_EG_LINE_MINWAVES
+#define D3M_EG_LINE_MINWAVES 1
+#endif
 
 // ---- 5. one workgroup per (view, axis, line): set up the line's crossings, walk their segments ------------------
 // The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a chunk of
@@ -627,7 +640,7 @@ static_assert(EG_LINE_THREADS == 512, "the chunk sort below assumes at most one 
 // finished -- the segments of a wave advance in lock step with the longest -- keep reading inside the allocation and
 // the per-iteration address clamp disappears; without PAD (large S) the index is clamped.
 template <bool USE_RGB, bool USE_ALPHA, bool PAD>
-__global__ void __launch_bounds__(EG_LINE_THREADS) k_edge_lines(EdgeGradArgs a, EdgePlan w) {
+__global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     __shared__ __attribute__((aligned(16))) uint32_t s_items[EG_LINE_THREADS * EG_ITEM_DW];
     __shared__ int s_hist[33];
@@ -641,8 +654,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS) k_edge_lines(EdgeGradArgs a, 
     const int d0 = (int)(line % is);
     const int axis = (int)((line / is) & 1);
     const size_t bn = line / ((size_t)2 * is);
-    const AxisMaps& m = a.ax[axis];
-    const size_t view_base = bn * is * is, line_base = view_base + (size_t)d0 * is;
+    const size_t view_base = bn * is * is;
     const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
     const uint4* xrec = w.xrec + 2 * (size_t)x_first;
     const float two_over_is = 2.0f / (float)is;
@@ -686,10 +698,14 @@ __global__ void __launch_bounds__(EG_LINE_THREADS) k_edge_lines(EdgeGradArgs a, 
     const int n_lds = PAD ? 2 * is + 16 : is;
     float4* s_grd = (float4*)s_line;
     float2* s_df = (float2*)(s_grd + n_lds);
+    const float go_sign = a.go_sign();
     for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_THREADS) {
-        s_grd[p] = m.grad[line_base + p];
-        const float2 d = m.dot[line_base + p];
-        s_df[p] = make_float2(0.5f * d.x, d.y);
+        const size_t pi = a.pixel(axis, view_base, d0, p);
+        float4 g = a.grad[pi];
+        const float2 d = a.dot[pi];
+        g.x *= go_sign; g.y *= go_sign; g.z *= go_sign; g.w *= go_sign;
+        s_grd[p] = g;
+        s_df[p] = make_float2(0.5f * go_sign * d.x, d.y);
     }
     typedef float v2f __attribute__((ext_vector_type(2)));
     // diff_grad of one pixel (KCU:385-396 / :473-479 regrouped) from its LDS records: two packed fma + one add
@@ -892,12 +908,14 @@ __global__ void __launch_bounds__(EG_LINE_THREADS) k_edge_lines(EdgeGradArgs a, 
 // ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const float2* __restrict__ lane_partial,
-                                                    float* __restrict__ grad_faces, VertexTarget vt) {
+                                                    const float* __restrict__ go, float* __restrict__ grad_faces,
+                                                    VertexTarget vt) {
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const XcdOrder xo(n_blocks);
     const bool complete = plan_complete(w);      // results in record order (found through xpos), else in crossing order
+    const float go_abs = go ? fabsf(*go) : 1.0f; // the magnitude of the factor the records lacked (EdgeGradArgs::go)
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
         const int blk = xo.unit(i);
         if (blk >= n_blocks) continue;
@@ -907,7 +925,7 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
         float2 g = make_float2(0.0f, 0.0f);
         if (on) {
             const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
-            g = lane_partial[(size_t)pos * 6 + ea];
+            if (!complete) g = lane_partial[(size_t)pos * 6 + ea];
             // slots (2c, 2c+1) of the lane's crossings c, contiguous and 16-byte aligned: one float4 per crossing, four
             // crossings requested per round, added in slot order; crossings past cap were folded into lane_partial
             const long c_first = (long)w.lane_block[blk] + lc.x, c_last = min(c_first + (long)lc.y, (long)w.cap);
@@ -933,7 +951,7 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
 #pragma unroll
             for (int e = 0; e < 6; e++) {
                 const int edge = e >> 1, axis = e & 1;
-                const float2 r = s_g[t + e];
+                const float2 r = make_float2(s_g[t + e].x * go_abs, s_g[t + e].y * go_abs);
                 acc[edge * 2 + (1 - axis)] += r.x;                    // vertex pi[0] = edge, component 1 - axis (KCU:406)
                 acc[((edge + 1) % 3) * 2 + (1 - axis)] += r.y;        // vertex pi[1] = edge + 1            (KCU:411)
             }
@@ -961,28 +979,19 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
     }
 }
 
-// Per-pixel walk records in both orientations, one pass over the maps (replaces five transposes): a 32x32 tile per
-// workgroup; the row-major records are written straight away, the column-major ones through an LDS tile.
+// Per-pixel walk records and the lines' non-zero extents, one pass over the five maps: a 32x32 tile per workgroup
+// (the column extents are merged per tile in LDS: one atomic per column and tile).
 __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ fi, const float* __restrict__ alpha,
                                                   const float* __restrict__ galpha, const float* __restrict__ rgb,
                                                   const float* __restrict__ grgb, float4* __restrict__ grad_row,
-                                                  float2* __restrict__ dot_row, float4* __restrict__ grad_col,
-                                                  float2* __restrict__ dot_col, int* __restrict__ nz_lo_inv,
-                                                  int* __restrict__ nz_hi1, int S, float2* __restrict__ lane_partial,
-                                                  const int* __restrict__ n_visible, GradScale gs) {
-    __shared__ float4 t_grad[32][33];
-    __shared__ float2 t_dot[32][33];
+                                                  float2* __restrict__ dot_row, int* __restrict__ nz_lo_inv,
+                                                  int* __restrict__ nz_hi1, int S, GradScale gs) {
     __shared__ int s_col_lo_inv[32], s_col_hi1[32];
     if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
     const int b = blockIdx.z;
     float s_rgb, s_alpha, s_depth;
     gs.get(s_rgb, s_alpha, s_depth);
-    {   // the overflow sums of the (visible face, edge, axis) lanes start at zero (k_edge_emit adds, k_edge_gather reads)
-        const long n_threads = (long)gridDim.x * gridDim.y * gridDim.z * 256;
-        const long me = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-        for (long i = me; i < (long)*n_visible * 6; i += n_threads) lane_partial[i] = make_float2(0.0f, 0.0f);
-    }
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const size_t plane = (size_t)b * S * S;
@@ -1003,8 +1012,6 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
             const float2 d = make_float2(dot, __int_as_float(fi[i]));
             grad_row[i] = g;
             dot_row[i] = d;
-            t_grad[r][tx] = g;
-            t_dot[r][tx] = d;
             nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
         }
         // non-zero extents: this tile's share of row y (one half-wave = one tile row) and of its 32 columns
@@ -1025,14 +1032,6 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
         const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
         atomicMax(&nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
         atomicMax(&nz_hi1[line], s_col_hi1[threadIdx.x]);
-    }
-    for (int r = ty; r < 32; r += 8) {
-        const int x = x0 + r, y = y0 + tx;
-        if (x < S && y < S) {
-            const size_t i = plane + (size_t)x * S + y;
-            grad_col[i] = t_grad[tx][r];
-            dot_col[i] = t_dot[tx][r];
-        }
     }
 }
 
@@ -1152,7 +1151,7 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
 // Workspace of d3m_backward_pixel_map: the per-pixel walk records, the lines' extents, the lanes' overflow sums, and
 // room for a visibility blob and a plan of its own (used when the caller brings none).
 struct EdgeLayout {
-    size_t off_grad_row, off_dot_row, off_grad_col, off_dot_col;
+    size_t off_grad_row, off_dot_row;
     size_t off_nz_lo, off_nz_hi, nz_bytes;     // zeroed per call
     size_t off_lane_partial, off_visibility, off_plan;
     size_t fixed_bytes;                         // everything but the plan (sized by capacity)
@@ -1164,8 +1163,6 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     size_t o = 0;
     L.off_grad_row = o; o += eg_align(px * 16);
     L.off_dot_row = o;  o += eg_align(px * 8);
-    L.off_grad_col = o; o += eg_align(px * 16);
-    L.off_dot_col = o;  o += eg_align(px * 8);
     L.off_nz_lo = o;    o += eg_align(nl * 4);
     L.off_nz_hi = o;    o += eg_align(nl * 4);
     L.nz_bytes = o - L.off_nz_lo;
@@ -1183,16 +1180,32 @@ inline size_t edge_grad_workspace_bytes(int B, int F, int S) {
     return edge_layout(B, F, S).fixed_bytes + edge_plan_bytes(B, F, S);
 }
 
+// per-pixel records the caller already has (the fused fit epilogue wrote them): k_pack_maps is skipped
+struct EdgeRecords {
+    const float4* grad;
+    const float2* dot;
+    const int* nz_lo_inv;
+    const int* nz_hi1;
+    const float* go;       // the factor they still lack (device scalar; NULL = 1)
+};
+
+// the lanes' overflow sums start at zero -- only ever used when the plan is incomplete (leaves at once otherwise)
+__global__ void __launch_bounds__(256) k_zero_lane_partial(EdgePlan w, float2* __restrict__ lane_partial) {
+    if (plan_complete(w)) return;
+    const long n = (long)*w.n_visible * 6;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) lane_partial[i] = make_float2(0.0f, 0.0f);
+}
+
 template <class FS>
 int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis,
-                  void* shared_plan, size_t shared_plan_bytes, GradScale gs, int B, float eps, void* ws, size_t ws_bytes,
-                  hipStream_t st, int* last_err) {
+                  void* shared_plan, size_t shared_plan_bytes, EdgeRecords rec, GradScale gs, int B, float eps, void* ws,
+                  size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
     const size_t smem_pad = (size_t)(2 * S + 16) * 24;
     const bool pad = smem_pad <= 36 * 1024;
     const size_t smem = pad ? smem_pad : (size_t)S * 24;
-    if (smem + 28 * 1024 > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
+    if (smem + EG_LINE_STATIC_LDS > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + (shared_plan ? 0 : edge_plan_min_bytes(B, F, S))) return 2;   // D3M_ERR_WORKSPACE
     char* p = (char*)ws;
@@ -1218,25 +1231,27 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     }
     float4* grad_row = (float4*)(p + L.off_grad_row);
     float2* dot_row = (float2*)(p + L.off_dot_row);
-    float4* grad_col = (float4*)(p + L.off_grad_col);
-    float2* dot_col = (float2*)(p + L.off_dot_col);
     float2* lane_partial = (float2*)(p + L.off_lane_partial);
-    e = zero_async(p + L.off_nz_lo, L.nz_bytes, st);
-    if (e != hipSuccess) { *last_err = (int)e; return 3; }
-    LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
-           m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr, m.use_rgb ? m.rgb_map : nullptr,
-           m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row, grad_col, dot_col, (int*)(p + L.off_nz_lo),
-           (int*)(p + L.off_nz_hi), S, lane_partial, (const int*)w.n_visible, gs);
     EdgeGradArgs a;
-    a.ax[0] = AxisMaps{grad_col, dot_col};
-    a.ax[1] = AxisMaps{grad_row, dot_row};
+    if (rec.grad) {
+        a.grad = rec.grad; a.dot = rec.dot; a.go = rec.go;
+        a.nz_lo_inv = rec.nz_lo_inv; a.nz_hi1 = rec.nz_hi1;
+    } else {
+        e = zero_async(p + L.off_nz_lo, L.nz_bytes, st);
+        if (e != hipSuccess) { *last_err = (int)e; return 3; }
+        LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, m.face_index_map,
+               m.use_alpha ? m.alpha_map : nullptr, m.use_alpha ? m.grad_alpha_map : nullptr,
+               m.use_rgb ? m.rgb_map : nullptr, m.use_rgb ? m.grad_rgb_map : nullptr, grad_row, dot_row,
+               (int*)(p + L.off_nz_lo), (int*)(p + L.off_nz_hi), S, gs);
+        a.grad = grad_row; a.dot = dot_row; a.go = nullptr;
+        a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
+    }
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
-    a.nz_lo_inv = (const int*)(p + L.off_nz_lo); a.nz_hi1 = (const int*)(p + L.off_nz_hi);
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     const dim3 glines((unsigned)nl);
 #define D3M_LINES1(RGB, ALPHA, PADDED)                                                                               \
     do {                                                                                                             \
-        if (smem + 28 * 1024 > 64 * 1024) {                                                                          \
+        if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                          \
             e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, PADDED>,                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
@@ -1256,8 +1271,9 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
-    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, g6, dim3(256), st, fs, a, w, lane_partial);
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, grad_faces, vt);
+    LAUNCH("k_zero_lane_partial", k_zero_lane_partial, dim3(512), dim3(256), st, w, lane_partial);
+    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 2048u)), dim3(256), st, fs, a, w, lane_partial);
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;

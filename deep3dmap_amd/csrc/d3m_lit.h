@@ -275,6 +275,116 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
     }
 }
 
+// The same pass for the fused fit objective WITH the edge gradient's per-pixel records (d3m_edge_grad.h, struct
+// EdgeGradArgs) as its gradient output: no anti-aliasing, so an output pixel is an internal pixel, and with the
+// normaliser of the photometric terms known up front (fit.mask_sum: the mask is a constant of the targets) everything
+// a walk reads per pixel is known here except the gradient of the loss itself, which the readers apply (`go`):
+//   grad = (2 (alpha - alpha_t) / pixels,  sign(rgb - rgb_t) mask / (3 mask_sum))
+//   dot  = (<(alpha, rgb), grad>, owner)
+// plus each line's non-zero extent.  k_pack_maps and the unscaled g_rgb / g_alpha maps (16 B per pixel written here,
+// 36 B read there) disappear from the step; the gathered texture pass reads grad.yzw (one 16-byte load instead of three
+// dwords).  A 32x32 tile per workgroup, so that the column extents are merged in LDS (one atomic per column and tile).
+struct FitRecords {
+    float4* grad;          // [B,S,S]
+    float2* dot;           // [B,S,S]
+    int* nz_lo_inv;        // [B,2,S] zeroed: S - (first pixel with a non-zero record), per line (b*2 + axis)*S + d0
+    int* nz_hi1;           // [B,2,S] zeroed: last such pixel + 1
+    const float* mask_sum; // [1]
+    float* g_depth;        // [B,S,S] sign(depth - target) * mask (the depth gradient stays a map: k_backward_textures_lit)
+};
+
+__global__ void __launch_bounds__(256) k_render_lit_fit_records(const float* __restrict__ faces, LitTextures lt,
+                                                               const int32_t* __restrict__ face_index_map,
+                                                               const float* __restrict__ weight_map,
+                                                               const float* __restrict__ depth_map,
+                                                               const float* __restrict__ background, int bg_b,
+                                                               float* __restrict__ rgb_blended, float* __restrict__ alpha_map,
+                                                               int B, int S, float eps, FitTargets fit, FitRecords rec) {
+    __shared__ float4 s_part[4];
+    __shared__ int s_col_lo_inv[32], s_col_hi1[32];
+    if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
+    __syncthreads();
+    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
+    const float inv_pixels = 1.0f / (float)((long)S * S), inv_3den = 1.0f / (3.0f * *rec.mask_sum);
+    float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
+    auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
+    for (int r = ty; r < 32; r += 8) {
+        const int yi = y0 + r, xi = x0 + tx;                  // internal pixel; row 0 = bottom (rasterize.py:311-317)
+        bool nz = false;
+        if (yi < S && xi < S) {
+            const int yo = S - 1 - yi;                        // output row
+            const size_t p = ((size_t)b * S + yi) * S + xi, o = ((size_t)b * S + yo) * S + xi;
+            // the objective's targets are requested first: they then arrive under the dependent loads of the sampling
+            float tg[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tg[k] = fit.rgb_t[(((size_t)b * 3 + k) * S + yo) * S + xi];
+            tg[3] = fit.depth_t[o]; tg[4] = fit.alpha_t[o]; tg[5] = fit.mask[o];
+            const int fi = face_index_map[p];
+            const float depth = depth_map[p];
+            float v[3] = {bg[0], bg[1], bg[2]};
+            if (fi >= 0) {
+                const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                sample_pixel_lit(faces, lt, B, b, fi, weight, depth, eps, v);
+            }
+            const float alpha = fi >= 0 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) rgb_blended[3 * p + k] = v[k];
+            alpha_map[p] = alpha;
+            const float m = tg[5], d = alpha - tg[4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t_rgb += fabsf(v[k] - tg[k]) * m;      // same terms as k_fit_loss_reduce
+            t_d += fabsf(depth - tg[3]) * m;
+            t_m += m;
+            t_sse += d * d;
+            if (rec.grad) {
+                float4 g;
+                g.x = (2.0f * d) * inv_pixels;
+                g.y = (sgn(v[0] - tg[0]) * m) * inv_3den;
+                g.z = (sgn(v[1] - tg[1]) * m) * inv_3den;
+                g.w = (sgn(v[2] - tg[2]) * m) * inv_3den;
+                float dot = alpha * g.x;
+                dot += v[0] * g.y;
+                dot += v[1] * g.z;
+                dot += v[2] * g.w;
+                rec.grad[p] = g;
+                rec.dot[p] = make_float2(dot, __int_as_float(fi));
+                rec.g_depth[p] = sgn(depth - tg[3]) * m;
+                nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
+            }
+        }
+        if (rec.grad) {     // non-zero extents: this tile's share of row yi (one half-wave = one tile row) and of its 32 columns
+            const unsigned long long ball = __ballot(nz);
+            const unsigned half = (threadIdx.x & 32) ? (unsigned)(ball >> 32) : (unsigned)ball;
+            if (half != 0 && tx == 0) {
+                const size_t line = ((size_t)b * 2 + 1) * S + (y0 + r);
+                atomicMax(&rec.nz_lo_inv[line], S - (x0 + (__ffs((int)half) - 1)));
+                atomicMax(&rec.nz_hi1[line], x0 + (32 - __clz((int)half)));
+            }
+            if (nz) {
+                atomicMax(&s_col_lo_inv[tx], S - (y0 + r));
+                atomicMax(&s_col_hi1[tx], y0 + r + 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (rec.grad && threadIdx.x < 32 && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
+        const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
+        atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
+        atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);
+    }
+    // four wave sums (DPP), one exchange through LDS
+    const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = s_part[0];
+        for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+        reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // totals[0..3] = the four sums over `n` workgroup partials, totals[4] = *loss = the objective (k_fit_loss_finish for
 // the tens of thousands of partials the fused epilogue leaves: 1024 lanes, 16-byte loads)
 __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restrict__ partials, int n, float pixels,
@@ -332,7 +442,8 @@ struct LitFaceArgs {
     const float* faces;
     LitTextures lt;
     const int32_t* face_index_map;
-    const float *weight_map, *depth_map, *grad_rgb_map;
+    const float *weight_map, *depth_map;
+    RgbGrad grad_rgb;
     float* gtex_view;              // [B,F,24]
     float* grad_light;             // [Bm,F',3] zeroed, or NULL
     const float* grad_depth_map;   // or NULL
@@ -354,7 +465,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const int32_t* __restrict__ face_index_map = a.face_index_map;
     const float* __restrict__ weight_map = a.weight_map;
     const float* __restrict__ depth_map = a.depth_map;
-    const float* __restrict__ grad_rgb_map = a.grad_rgb_map;
+    const RgbGrad grad_rgb = a.grad_rgb;
     float* __restrict__ gtex_view = a.gtex_view;
     float* __restrict__ grad_light = a.grad_light;
     const float* __restrict__ grad_depth_map = a.grad_depth_map;
@@ -423,8 +534,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
         // (selected, never multiplied away: its own weights / depth belong to a different triangle).
         const bool own = face_index_map[p] == fn;
         const float lw0 = weight_map[3 * p], lw1 = weight_map[3 * p + 1], lw2 = weight_map[3 * p + 2];
-        const float lg0 = grad_rgb_map[3 * p + 0] * s_rgb, lg1 = grad_rgb_map[3 * p + 1] * s_rgb,
-                    lg2 = grad_rgb_map[3 * p + 2] * s_rgb;
+        const float lg0 = grad_rgb.get(p, 0) * s_rgb, lg1 = grad_rgb.get(p, 1) * s_rgb, lg2 = grad_rgb.get(p, 2) * s_rgb;
         const float ld = depth_map[p], lgd = grad_depth_map ? grad_depth_map[p] * s_depth : 0.0f;
         if (!__builtin_amdgcn_ballot_w64(own)) continue;                  // nobody in the wave owns its pixel
         const float third = 1.0f / 3.0f;
@@ -522,8 +632,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
 __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const float* __restrict__ faces, LitTextures lt,
                                                                      const int32_t* __restrict__ face_index_map,
                                                                      const float* __restrict__ weight_map,
-                                                                     const float* __restrict__ depth_map,
-                                                                     const float* __restrict__ grad_rgb_map,
+                                                                     const float* __restrict__ depth_map, RgbGrad grad_rgb,
                                                                      float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
                                                                      float* __restrict__ grad_light,
                                                                      const int* __restrict__ only_large, int B, int S,
@@ -540,7 +649,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
     const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
     float s_rgb, s_alpha, s_depth;
     gs.get(s_rgb, s_alpha, s_depth);
-    const float g[3] = {grad_rgb_map[3 * i] * s_rgb, grad_rgb_map[3 * i + 1] * s_rgb, grad_rgb_map[3 * i + 2] * s_rgb};
+    const float g[3] = {grad_rgb.get(i, 0) * s_rgb, grad_rgb.get(i, 1) * s_rgb, grad_rgb.get(i, 2) * s_rgb};
     int fl[3];
     float fr[3];
     sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);

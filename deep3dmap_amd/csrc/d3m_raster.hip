@@ -271,8 +271,9 @@ D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* tex
 
 // the scalar factors the unscaled gradient maps of a fused objective still lack (NULL: the maps are final)
 static GradScale to_grad_scale(const d3m_fit_targets* unscaled, int image_size) {
-    if (!unscaled) return GradScale{nullptr, nullptr, 0.0f};
-    return GradScale{unscaled->scratch, unscaled->grad_loss, (float)((long)image_size * image_size)};
+    if (!unscaled) return GradScale{nullptr, nullptr, 0.0f, 0};
+    return GradScale{unscaled->scratch, unscaled->grad_loss, (float)((long)image_size * image_size),
+                     unscaled->edge_grad ? 1 : 0};
 }
 
 D3M_EXPORT size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size) {
@@ -292,15 +293,21 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
         return D3M_ERR_INVALID;
     VertexTarget vt;
     if (int rc = to_vertex_target(vertex_target, num_faces, vt)) return rc;
-    if (return_rgb && (!rgb_map || !grad_rgb_map)) return D3M_ERR_INVALID;
-    if (return_alpha && (!alpha_map || !grad_alpha_map)) return D3M_ERR_INVALID;
+    const bool records = unscaled && unscaled->edge_grad;      // the gradient maps arrive as per-pixel records
+    if (records && !(unscaled->edge_dot && unscaled->edge_nz_lo_inv && unscaled->edge_nz_hi1)) return D3M_ERR_INVALID;
+    if (return_rgb && (!rgb_map || (!grad_rgb_map && !records))) return D3M_ERR_INVALID;
+    if (return_alpha && (!alpha_map || (!grad_alpha_map && !records))) return D3M_ERR_INVALID;
     if (!return_rgb && !return_alpha) return D3M_OK;    // rasterize.py:200-201
     DenseFaces fs{faces, num_faces};
     PixelMaps m{face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb != 0,
                 return_alpha != 0};
     VisibilityView vis;
     if (visibility) vis = visibility_view(visibility, (long)batch_size * num_faces);
-    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, edge_plan, edge_plan_size,
+    EdgeRecords rec{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (records)
+        rec = EdgeRecords{(const float4*)unscaled->edge_grad, (const float2*)unscaled->edge_dot, unscaled->edge_nz_lo_inv,
+                          unscaled->edge_nz_hi1, unscaled->grad_loss};
+    return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, edge_plan, edge_plan_size, rec,
                          to_grad_scale(unscaled, image_size), batch_size, eps, workspace, workspace_bytes,
                          (hipStream_t)stream, &g_last_hip_error);
 }
@@ -628,7 +635,7 @@ static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {
     if (!fit->rgb_target || !fit->depth_target || !fit->alpha_target || !fit->mask || !fit->scratch || !fit->loss)
         return D3M_ERR_INVALID;
     const bool any = fit->grad_rgb_map || fit->grad_alpha_map || fit->grad_depth_map;
-    if (any && !(fit->grad_rgb_map && fit->grad_alpha_map && fit->grad_depth_map)) return D3M_ERR_INVALID;
+    if (any && !fit->edge_grad && !(fit->grad_rgb_map && fit->grad_alpha_map && fit->grad_depth_map)) return D3M_ERR_INVALID;
     ft = FitTargets{fit->rgb_target, fit->depth_target, fit->alpha_target, fit->mask, fit->scratch + 8,
                     fit->grad_rgb_map, fit->grad_alpha_map, fit->grad_depth_map};
     return D3M_OK;
@@ -656,6 +663,19 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
     const long n = (long)batch_size * s * s;
     hipStream_t st = (hipStream_t)stream;
     const int threads = 256;
+    if (fit && fit->edge_grad) {
+        // the objective's gradient leaves as the edge gradient's per-pixel records (and the depth gradient map)
+        if (!fit->edge_dot || !fit->edge_nz_lo_inv || !fit->edge_nz_hi1 || !fit->mask_sum || !fit->grad_depth_map)
+            return D3M_ERR_INVALID;
+        const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
+        FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
+                       fit->grad_depth_map};
+        LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
+               weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, batch_size, image_size, eps, ft, rec);
+        LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
+               (int)(tiles.x * tiles.y * tiles.z), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
+        return check_launch();
+    }
     LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, threads)), dim3(threads), st, faces, lt,
            face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
            depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
@@ -683,9 +703,11 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     if ((grad_depth_map != nullptr) != (grad_faces != nullptr || vertex_target != nullptr)) return D3M_ERR_INVALID;
     VertexTarget vt;
     if (int rcv = to_vertex_target(vertex_target, (fill_back ? 2 : 1) * num_tri, vt)) return rcv;
-    if (!faces || !face_index_map || !weight_map || !depth_map || !grad_rgb_map || !grad_textures || batch_size <= 0 ||
-        image_size <= 0)
+    const bool records = unscaled && unscaled->edge_grad;      // the rgb gradient is the yzw of the fit's per-pixel records
+    if (!faces || !face_index_map || !weight_map || !depth_map || (!grad_rgb_map && !records) || !grad_textures ||
+        batch_size <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
+    const RgbGrad grad_rgb = records ? RgbGrad{(const float*)unscaled->edge_grad, 4, 1} : RgbGrad{grad_rgb_map, 3, 0};
     LitTextures lt;
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
     if (rc) return rc;
@@ -722,13 +744,13 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
         if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes + 256, st));
         else HIP_TRY(zero_async(n_large, 256, st));
-        LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, grad_depth_map,
+        LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, n_large};
         const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
-               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)flags, B, S, eps,
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps,
                gs, (const int*)n_large);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
             DenseFaces fs{faces, lt.Fp};
@@ -738,7 +760,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         }
     } else {
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
-               faces, lt, face_index_map, weight_map, depth_map, grad_rgb_map, gview, grad_light, (const int*)nullptr, B, S, eps,
+               faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)nullptr, B, S, eps,
                gs, (const int*)nullptr);
         if (grad_depth_map) {
             DenseFaces fs{faces, lt.Fp};

@@ -82,7 +82,7 @@ class MultiViewFit:
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.targets = None
-        self.mask_sum = None            # [1] device scalar: sum of the mask over ALL ranks' views (world_size > 1 only)
+        self.mask_sum = None            # [1] device scalar: sum of the mask over ALL ranks' views
         self._mask_sum_local = None
         # the step's results, packed where they are produced (inside the captured step): [loss | grad_v | grad_t]
         n_t = self.textures.numel() if optimise_textures else 0
@@ -100,10 +100,10 @@ class MultiViewFit:
         tv = torch.as_tensor(target_vertices, dtype=torch.float32).to(self.device)
         rgb, depth, alpha = self.render(vertices=tv)
         self.targets = (rgb.detach(), depth.detach(), alpha.detach())
-        if self.world_size > 1:
-            # the objective's mask is alpha_t: its sum over every rank's cameras is a constant of the targets
-            self._mask_sum_local = self.targets[2].sum().reshape(1)
-            self.mask_sum = allreduce_sum_(self._mask_sum_local.clone())
+        # the objective's mask is alpha_t: its sum over every rank's cameras is a constant of the targets (with it known
+        # before the render, the fused objective leaves its gradient ready for the edge gradient: rasterize.py)
+        self._mask_sum_local = self.targets[2].sum().reshape(1)
+        self.mask_sum = allreduce_sum_(self._mask_sum_local.clone())
 
     def loss(self, rgb, depth, alpha, fused=True):
         """The fit objective.  `fused=False` composes it from the three loss operators (the definition; the fused

@@ -320,18 +320,23 @@ class _RasterizeLit(torch.autograd.Function):
             mask_sum = f32c(fit[4]).reshape(1) if len(fit) > 4 and fit[4] is not None else None
             if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
                 raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
-            if G > 1 and mask_sum is None:          # the groups are shards: they need the normaliser of the whole batch
+            if mask_sum is None and (G > 1 or need_grad):
+                # view groups are shards of the objective and need the normaliser of the whole batch; and with it known
+                # up front the pass below can leave the gradient as the edge gradient's per-pixel records
                 mask_sum = mask.sum().reshape(1)
             loss_g = torch.empty(G, dtype=torch.float32, device=dev)
             scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(hi - lo, S)), dtype=torch.float32, device=dev)
                        for lo, hi in groups]
-            # with a backward pass to come, the same pass leaves the objective's gradient in the internal maps, minus
-            # the scalar factors only known later (1 / sum(mask), the gradient of the loss): no pixel pass in backward
-            g_maps = (None, None, None)
+            # with a backward pass to come, the same pass leaves the objective's gradient behind -- minus the gradient of the
+            # loss, only known later -- in the form its readers want: the edge gradient's per-pixel records (what
+            # d3m_backward_pixel_map would otherwise pack from gradient maps: no pixel pass in backward at all), the
+            # lines' non-zero extents, and the depth gradient as a map
+            g_maps = None
             if need_grad:
-                g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
-                          torch.empty(B, S, S, dtype=torch.float32, device=dev),
-                          torch.empty(B, S, S, dtype=torch.float32, device=dev))
+                g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
+                          torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
+                          torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev),          # nz_lo_inv | nz_hi1
+                          torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum)
         cur = torch.cuda.current_stream()
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
@@ -363,10 +368,7 @@ class _RasterizeLit(torch.autograd.Function):
                                                    plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")
                 fit_c = None
                 if fit_state is not None:
-                    fit_c = _lib.D3MFitTargets(
-                        _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
-                        _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(_bslice(g_maps[0], lo, hi)),
-                        _lib.ptr(_bslice(g_maps[1], lo, hi)), _lib.ptr(_bslice(g_maps[2], lo, hi)), None, _lib.ptr(mask_sum))
+                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None)
                 # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
                 _lib.check(L.d3m_render_lit_epilogue(
                     _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -404,6 +406,19 @@ class _RasterizeLit(torch.autograd.Function):
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
     @staticmethod
+    def _fit_struct(fit_state, k, lo, hi, grad_loss):
+        """d3m_fit_targets of view group k (views lo..hi): forward's `fit` (grad_loss None) / backward's `unscaled`."""
+        rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum = fit_state
+        eg = ed = nz_lo = nz_hi = gd = None
+        if g_maps is not None:
+            eg, ed, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
+            nz_lo, nz_hi = g_maps[2][0, lo:hi], g_maps[2][1, lo:hi]
+        return _lib.D3MFitTargets(
+            _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
+            _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), None, None, _lib.ptr(gd), _lib.ptr(grad_loss),
+            _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi))
+
+    @staticmethod
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
         L = _lib.lib()
         faces, vertices, tri, textures, light = ctx.saved_tensors
@@ -422,7 +437,8 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
                 "d3m_output_epilogue_backward")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
-            rgb_t, depth_t, alpha_t, mask, scratch, loss_g, (g_rgb_map, g_alpha_map, g_depth_map), mask_sum = ctx.fit
+            scratch, g_depth_map = ctx.fit[4], ctx.fit[6][3]
+            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (ctx.fit[6][:3])
             grad_loss = f32c(g_rgb).reshape(1)
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over the compacted list of the faces that own a pixel.  The edge gradient (K4: ~8
@@ -466,17 +482,14 @@ class _RasterizeLit(torch.autograd.Function):
             target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back))
             unscaled = None
             if ctx.fit is not None:
-                unscaled = _lib.D3MFitTargets(
-                    _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
-                    _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(g_rgb_map[lo:hi]), _lib.ptr(g_alpha_map[lo:hi]),
-                    _lib.ptr(g_depth_map[lo:hi]), _lib.ptr(grad_loss), _lib.ptr(mask_sum))
+                unscaled = _RasterizeLit._fit_struct(ctx.fit, k, lo, hi, grad_loss)
             if gathered:
                 with torch.cuda.stream(auxs[k]):
                     ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
                     # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
                     _lib.check(L.d3m_backward_textures_lit(
                         _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
-                        _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(g_rgb_map[lo:hi]), _lib.ptr(gt_g[k]),
+                        _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(_bslice(g_rgb_map, lo, hi)), _lib.ptr(gt_g[k]),
                         _lib.ptr(gl_g[k]) if gl_g is not None else None,
                         _lib.ptr(g_depth_map[lo:hi]) if rd else None, None, Bg, Ft, int(fill_back), S, ts, eps,
                         _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis[k]),
@@ -484,7 +497,8 @@ class _RasterizeLit(torch.autograd.Function):
                         "d3m_backward_textures_lit")
             with torch.cuda.stream(mains[k]):
                 ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
-                                       g_rgb_map[lo:hi], g_alpha_map[lo:hi] if ra else None, None, S, eps, True, ra,
+                                       _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S, eps,
+                                       True, ra,
                                        vertex_target=target, visibility=vis[k], unscaled=unscaled,
                                        edge_plan=m["edge_plan"][k])
         for k in range(G):

@@ -304,6 +304,17 @@ struct d3m_fit_targets {
                                   * `mask` over THIS batch.  When the batch is one rank's shard of a larger objective
                                   * (camera-sharded fit), the sum of the mask over ALL shards: the shard's value is then
                                   * its additive part of the global objective and gradients add up across ranks. */
+    /* The gradient wrt rgb_blended / alpha_map in the form the edge gradient reads it (all four or none; needs mask_sum
+     * and grad_depth_map; grad_rgb_map / grad_alpha_map are then not written and may be NULL): per pixel
+     *   edge_grad = (2 (alpha - target) / (S*S), sign(rgb - target) mask / (3 mask_sum))      float4 [B,S,S]
+     *   edge_dot  = (<(alpha, rgb), edge_grad>, face index bits)                               float2 [B,S,S]
+     * and per image line (b*2 + axis)*S + d0 the extent of its non-zero records (caller-zeroed int [B,2,S] each:
+     * S - first, last + 1).  Everything but grad_loss is in there; d3m_backward_pixel_map / d3m_backward_textures_lit
+     * handed the struct as `unscaled` read the records instead of packing the maps (no pass over the pixels). */
+    void* edge_grad;
+    void* edge_dot;
+    int* edge_nz_lo_inv;
+    int* edge_nz_hi1;
 };
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,

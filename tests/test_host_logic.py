@@ -33,7 +33,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     L = _lib.lib()
     assert b"gfx950" in L.d3m_version()
     assert L.d3m_forward_workspace_bytes(8, 200704, 512) > L.d3m_forward_workspace_min_bytes(8, 200704, 512) > 0
-    assert L.d3m_backward_pixel_map_workspace_bytes(1, 10, 64) > 64 * 64 * 36
+    # per-pixel walk records (24 B) + plan; the minimum leaves out only the per-crossing room
+    assert L.d3m_backward_pixel_map_workspace_bytes(1, 10, 64) > L.d3m_backward_pixel_map_workspace_min_bytes(1, 10, 64) > 64 * 64 * 24
+    assert L.d3m_edge_plan_bytes(1, 10, 64) > L.d3m_edge_plan_min_bytes(1, 10, 64) > 0
     assert L.d3m_error_string(2) == b"workspace missing or too small"
 
 
