@@ -26,7 +26,7 @@ class D3MVertexTarget(ctypes.Structure):
 class D3MFitTargets(ctypes.Structure):
     _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
                 ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P),
-                ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P)]
+                ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P), ("defer_finish", _I)]
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
@@ -71,6 +71,7 @@ _SIGNATURES = {
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
                                      _P, _P]),
     "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
+    "d3m_fit_finish": (_I, [ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
                                        _P, _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            const float* __restrict__ grad_depth_map,
                                                            float* __restrict__ grad_faces, int B, int S,
                                                            const int* __restrict__ only_large, VertexTarget vt,
-                                                           GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0},
+                                                           GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0, nullptr},
                                                            const int* __restrict__ n_large = nullptr) {
     if (n_large && *n_large == 0) return;          // no face was left to this kernel (uniform exit)
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

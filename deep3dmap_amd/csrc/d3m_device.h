@@ -161,10 +161,12 @@ struct GradScale {
     float pixels;             // pixels per view
     int records;              // the rgb / alpha gradients come from the edge gradient's per-pixel records
                               // (k_render_lit_fit_records), which already carry 1 / (3 sum(mask)) and 1 / pixels
+    const float* den_given;   // the photometric normaliser when it was known before the render (fit->mask_sum): the
+                              // backward pass then does not depend on the objective's reduction having finished
     __device__ __forceinline__ void get(float& s_rgb, float& s_alpha, float& s_depth) const {
         s_rgb = s_alpha = s_depth = 1.0f;
         if (totals) {
-            const float go = grad_out ? *grad_out : 1.0f, den = totals[2];
+            const float go = grad_out ? *grad_out : 1.0f, den = den_given ? *den_given : totals[2];
             s_rgb = records ? go : go / (3.0f * den);
             s_depth = go / den;
             s_alpha = records ? go : go / pixels;

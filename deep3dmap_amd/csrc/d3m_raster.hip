@@ -271,9 +271,9 @@ D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* tex
 
 // the scalar factors the unscaled gradient maps of a fused objective still lack (NULL: the maps are final)
 static GradScale to_grad_scale(const d3m_fit_targets* unscaled, int image_size) {
-    if (!unscaled) return GradScale{nullptr, nullptr, 0.0f, 0};
+    if (!unscaled) return GradScale{nullptr, nullptr, 0.0f, 0, nullptr};
     return GradScale{unscaled->scratch, unscaled->grad_loss, (float)((long)image_size * image_size),
-                     unscaled->edge_grad ? 1 : 0};
+                     unscaled->edge_grad ? 1 : 0, unscaled->mask_sum};
 }
 
 D3M_EXPORT size_t d3m_backward_pixel_map_workspace_bytes(int batch_size, int num_faces, int image_size) {
@@ -672,16 +672,29 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
                        fit->grad_depth_map};
         LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
                weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, batch_size, image_size, eps, ft, rec);
-        LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-               (int)(tiles.x * tiles.y * tiles.z), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
+        if (!fit->defer_finish)
+            LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
+                   (int)(tiles.x * tiles.y * tiles.z), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
         return check_launch();
     }
+    if (fit && fit->defer_finish) return D3M_ERR_INVALID;      // only the records form splits the reduction off
     LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, threads)), dim3(threads), st, faces, lt,
            face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
            depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
     if (fit)
         LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
                (int)blocks_for(n, threads), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
+    return check_launch();
+}
+
+// The last step of the fused objective (partial sums -> *fit->loss) for a d3m_render_lit_epilogue call made with
+// fit->defer_finish: a one-workgroup kernel.  Behind a pass that fills the chip it waits for a free slot, so a caller
+// whose backward pass does not need the value (records + mask_sum: see GradScale) runs it on another stream.
+D3M_EXPORT int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream) {
+    if (!fit || !fit->scratch || !fit->loss || !fit->edge_grad || batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    const int tiles = ((image_size + 31) / 32) * ((image_size + 31) / 32) * batch_size;
+    LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), (hipStream_t)stream, (const float4*)(fit->scratch + 8),
+           tiles, (float)((long)image_size * image_size), fit->mask_sum, fit->scratch, fit->loss);
     return check_launch();
 }
 

@@ -341,6 +341,11 @@ class _RasterizeLit(torch.autograd.Function):
         cur = torch.cuda.current_stream()
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k) for k in range(G)]
+        # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
+        # on the same stream and (if captured) in the same capture, may leave that branch open at the end of forward
+        # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
+        # under the loss and the first backward passes.  The outputs are then only valid after backward.
+        plan_ready = [] if (vis is not None and defer_plan_join and G == 1) else None   # (G > 1: capture crashes, as above)
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
@@ -366,9 +371,14 @@ class _RasterizeLit(torch.autograd.Function):
                                                     _lib.stream_ptr()), "d3m_visibility")
                         _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
                                                    plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")
+                        if plan_ready is not None:
+                            plan_ready.append(torch.cuda.Event())
+                            plan_ready[k].record(auxs[k])
                 fit_c = None
                 if fit_state is not None:
-                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None)
+                    # with records the backward pass does not read the objective's value: its one-workgroup last step
+                    # (which would wait for a free slot behind the plan's kernels) goes to the end of the side branch
+                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None, defer_finish=vis is not None)
                 # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
                 _lib.check(L.d3m_render_lit_epilogue(
                     _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -377,16 +387,10 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
                     int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
                     ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
-        # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
-        # on the same stream and (if captured) in the same capture, may leave that branch open here: backward waits for it
-        # where it first needs it and joins it, and the branch runs on under the loss and the first backward passes.
-        plan_ready = None
-        if vis is not None and defer_plan_join and G == 1:     # (with view groups: capture crashes on ROCm 7.2, as above)
-            plan_ready = []
-            for k in range(G):
-                ev = torch.cuda.Event()
-                ev.record(auxs[k])
-                plan_ready.append(ev)
+                if fit_c is not None and vis is not None:
+                    auxs[k].wait_stream(mains[k])
+                    with torch.cuda.stream(auxs[k]):
+                        _lib.check(L.d3m_fit_finish(ctypes.byref(fit_c), Bg, S, _lib.stream_ptr()), "d3m_fit_finish")
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
@@ -406,7 +410,7 @@ class _RasterizeLit(torch.autograd.Function):
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
     @staticmethod
-    def _fit_struct(fit_state, k, lo, hi, grad_loss):
+    def _fit_struct(fit_state, k, lo, hi, grad_loss, defer_finish=False):
         """d3m_fit_targets of view group k (views lo..hi): forward's `fit` (grad_loss None) / backward's `unscaled`."""
         rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum = fit_state
         eg = ed = nz_lo = nz_hi = gd = None
@@ -416,7 +420,7 @@ class _RasterizeLit(torch.autograd.Function):
         return _lib.D3MFitTargets(
             _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
             _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), None, None, _lib.ptr(gd), _lib.ptr(grad_loss),
-            _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi))
+            _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi), int(defer_finish))
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
@@ -525,7 +529,7 @@ class _RasterizeLit(torch.autograd.Function):
                 # d3m_backward_depth_map takes final maps: the fused objective left sign(depth - target) * mask, which
                 # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); totals[2] of the scratch holds that
                 # sum (the same in every group: with more than one the normaliser is the batch's mask_sum)
-                g_depth_map = g_depth_map * (grad_loss / scratch[0][2])
+                g_depth_map = g_depth_map * (grad_loss / ctx.fit[7])          # mask_sum: set whenever gradients are wanted
             grad_faces = torch.zeros_like(faces)
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)

@@ -315,8 +315,11 @@ struct d3m_fit_targets {
     void* edge_dot;
     int* edge_nz_lo_inv;
     int* edge_nz_hi1;
+    int defer_finish;            /* records form only: d3m_render_lit_epilogue leaves the partial sums in `scratch` and the
+                                  * caller completes *loss with d3m_fit_finish (on any stream ordered behind the pass) */
 };
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
+int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
                             int light_batch, const int32_t* face_index_map, const float* weight_map,
                             const float* depth_map, const float* background, int background_batch,
