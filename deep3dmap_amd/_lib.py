@@ -64,6 +64,12 @@ _SIGNATURES = {
     "d3m_view_transform_backward": (_I, [_P, _I, _P, _P, _P, _I, _P]),
     "d3m_depth_to_vertices": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _P]),
     "d3m_depth_to_vertices_backward": (_I, [_P, _P, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_grid_warp": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "d3m_grid_warp_backward": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_depth_normals": (_I, [_P, _P, _I, _P, _I, _I, _I, _P]),
+    "d3m_depth_normals_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "d3m_textures_from_im": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "d3m_textures_from_im_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "d3m_face_light": (_I, [_P, _I, _P, _I, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_face_light_backward": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_forward_texture_sampling_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

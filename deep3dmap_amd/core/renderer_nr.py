@@ -1,5 +1,13 @@
 """NrRenderer: deep3dmap's adapter from a canonical depth map to the mesh renderer
-(deep3dmap/core/renderer/renderer_nr.py:12-277), same constructor keys, attributes and methods."""
+(deep3dmap/core/renderer/renderer_nr.py:12-277; "CR" below), same constructor keys, attributes and methods.
+
+Built differently from the reference's chain of eager tensor ops: every "back-project the depth map, move the points
+rigidly, maybe project them again" of the class is ONE pass of d3m_grid_warp over the pixels.  Rigid moves about the
+rotation centre c = (0, 0, rot_center_depth) -- rotate_pts, translate_pts, their inverses and chains of them -- are
+composed on [B,3,3] / [B,1,3] into a single `Rigid` first (tiny tensors; the view's gradient flows through that
+composition), normals are one pass (d3m_depth_normals), image -> face textures one pass (d3m_textures_from_im), and the
+view sweeps of render_yaw / render_view / render_given_view share one frame loop."""
+import ctypes
 import math
 
 import torch
@@ -8,47 +16,97 @@ import torch.nn as nn
 from .. import _lib
 from .. import neural_renderer as nr
 from ..neural_renderer._util import const_tensor, f32c
-from .renderer_utils import get_face_idx, get_grid, get_textures_from_im, get_transform_matrices
+from .renderer_utils import get_face_idx, get_textures_from_im, get_transform_matrices
+
+EPS = 1e-7
 
 
-class _DepthToVertices(torch.autograd.Function):
-    """depth_to_3d_grid -> rotate_pts -> translate_pts (renderer_nr.py:64-80,95-100) as one HIP pass with an
-    analytic adjoint for the depth map and for the view's rotation / translation."""
+class Rigid:
+    """p -> A (p - c) + c + t with A [B,3,3], t [B,1,3] (row vectors, as CR stores trans_xyz) about the centre c."""
+
+    def __init__(self, A, t):
+        self.A, self.t = A, t
 
     @staticmethod
-    def forward(ctx, depth, inv_K, rot_mat, trans_xyz, center_z):
-        d, iK, R, t = f32c(depth), f32c(inv_K), f32c(rot_mat), f32c(trans_xyz).reshape(-1, 3)
+    def identity(device):
+        return Rigid(torch.eye(3, dtype=torch.float32, device=device)[None], torch.zeros(1, 1, 3, dtype=torch.float32, device=device))
+
+    @staticmethod
+    def of_view(view):
+        """rotate_pts(rot_mat) then translate_pts(trans_xyz) of a view vector (CR:95-100)."""
+        return Rigid(*get_transform_matrices(view))
+
+    def inverse(self):
+        """translate_pts(-t) then rotate_pts(A^T) (CR:102-107): A^T (p - t - c) + c."""
+        return Rigid(self.A.transpose(2, 1), -self.t.matmul(self.A))
+
+    def then(self, other):
+        """self first, `other` second: other.A (self.A (p-c) + self.t) + c + other.t."""
+        return Rigid(other.A.matmul(self.A), self.t.matmul(other.A.transpose(2, 1)) + other.t)
+
+
+class _GridWarp(torch.autograd.Function):
+    """d3m_grid_warp: depth [B,H,W] -> Q = A (depth Kinv (x,y,1) - c) + c + t as points [B,H*W,3], or with K as the
+    normalised sampling grid [B,H,W,2] (CR:74-88); analytic adjoint for the depth map, A and t."""
+
+    @staticmethod
+    def forward(ctx, depth, inv_K, A, t, center_z, K, crop):
+        d, iK = f32c(depth), f32c(inv_K)
         B, H, W = d.shape
-        if R.shape[0] != B or t.shape[0] != B:
-            R, t = R.expand(B, 3, 3).contiguous(), t.expand(B, 3).contiguous()
-        out = torch.empty(B, H * W, 3, dtype=torch.float32, device=d.device)
-        _lib.check(_lib.lib().d3m_depth_to_vertices(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(R), _lib.ptr(t),
-                                                    float(center_z), _lib.ptr(out), B, H, W, _lib.stream_ptr()),
-                   "d3m_depth_to_vertices")
-        ctx.save_for_backward(d, iK, R)
+        A_b = f32c(A.expand(B, 3, 3))
+        t_b = f32c(t.reshape(-1, 3).expand(B, 3))
+        Kc = f32c(K) if K is not None else None
+        out = torch.empty((B, H, W, 2) if Kc is not None else (B, H * W, 3), dtype=torch.float32, device=d.device)
+        crop_c = (ctypes.c_int * 4)(*[int(v) for v in crop]) if crop is not None else None
+        _lib.check(_lib.lib().d3m_grid_warp(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(A_b), _lib.ptr(t_b),
+                                            float(center_z), _lib.ptr(Kc), Kc.shape[0] if Kc is not None else 1, crop_c,
+                                            _lib.ptr(out), B, H, W, _lib.stream_ptr()), "d3m_grid_warp")
+        if crop is not None and any(ctx.needs_input_grad[:4]):
+            raise NotImplementedError("crop_mesh is a visualisation option (CR:145-158): no gradient through it")
+        ctx.save_for_backward(d, iK, A_b, t_b, Kc)
         ctx.center_z = float(center_z)
-        ctx.shapes = (tuple(rot_mat.shape), tuple(trans_xyz.shape))
+        ctx.shapes = (tuple(A.shape), tuple(t.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        d, iK, R = ctx.saved_tensors
+        d, iK, A_b, t_b, Kc = ctx.saved_tensors
         B, H, W = d.shape
-        g = f32c(g)
         gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
-        gR = torch.empty(B, 3, 3, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[2] else None
+        gA = torch.empty(B, 3, 3, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[2] else None
         gt = torch.empty(B, 3, dtype=torch.float32, device=d.device) if ctx.needs_input_grad[3] else None
-        _lib.check(_lib.lib().d3m_depth_to_vertices_backward(
-            _lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(R), ctx.center_z, _lib.ptr(g), _lib.ptr(gd), _lib.ptr(gR),
-            _lib.ptr(gt), B, H, W, _lib.stream_ptr()), "d3m_depth_to_vertices_backward")
-        rot_shape, trans_shape = ctx.shapes
-        if gR is not None and rot_shape[0] != B:
-            gR = gR.sum(0, keepdim=True)
+        _lib.check(_lib.lib().d3m_grid_warp_backward(
+            _lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(A_b), _lib.ptr(t_b), ctx.center_z, _lib.ptr(Kc),
+            Kc.shape[0] if Kc is not None else 1, _lib.ptr(f32c(g)), _lib.ptr(gd), _lib.ptr(gA), _lib.ptr(gt), B, H, W,
+            _lib.stream_ptr()), "d3m_grid_warp_backward")
+        A_shape, t_shape = ctx.shapes
+        if gA is not None and A_shape[0] != B:
+            gA = gA.sum(0, keepdim=True)
         if gt is not None:
-            gt = (gt.sum(0, keepdim=True) if trans_shape[0] != B else gt).reshape(trans_shape)
-        return gd, None, gR, gt, None
+            gt = (gt.sum(0, keepdim=True) if t_shape[0] != B else gt).reshape(t_shape)
+        return gd, None, gA, gt, None, None, None
 
-EPS = 1e-7
+
+class _DepthNormals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        d, iK = f32c(depth), f32c(inv_K)
+        B, H, W = d.shape
+        out = torch.empty(B, H, W, 3, dtype=torch.float32, device=d.device)
+        _lib.check(_lib.lib().d3m_depth_normals(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(out), B, H, W,
+                                                _lib.stream_ptr()), "d3m_depth_normals")
+        ctx.save_for_backward(d, iK)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d, iK = ctx.saved_tensors
+        B, H, W = d.shape
+        gd = torch.empty_like(d)
+        _lib.check(_lib.lib().d3m_depth_normals_backward(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(f32c(g)),
+                                                         _lib.ptr(gd), B, H, W, _lib.stream_ptr()),
+                   "d3m_depth_normals_backward")
+        return gd, None
 
 
 class NrRenderer():
@@ -63,14 +121,16 @@ class NrRenderer():
         self.renderer_min_depth = cfgs.get('renderer_min_depth', 0.1)
         self.renderer_max_depth = cfgs.get('renderer_max_depth', 10.)
 
-        # camera intrinsics: d * K^-1 (u, v, 1)^T = (x, y, z)^T  (renderer_nr.py:24-46)
+        # camera intrinsics: d * K^-1 (u, v, 1)^T = (x, y, z)^T  (CR:24-46)
         R = torch.eye(3, dtype=torch.float32)[None].cuda()
         t = torch.zeros(1, 3, dtype=torch.float32).cuda()
         fx = fy = (self.image_size - 1) / 2 / (math.tan(self.fov / 2 * math.pi / 180))
         cx = cy = (self.image_size - 1) / 2
-        K = torch.tensor([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]], dtype=torch.float32).cuda()
-        self.inv_K_origin = torch.inverse(K).unsqueeze(0)
-        self.K_origin = K.unsqueeze(0)
+        K = torch.tensor([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]], dtype=torch.float32)
+        # (inverted on the host: a 3x3 inverse is the same few flops anywhere, and the host's LAPACK is the one the CPU
+        #  oracle uses -- identical bits in inv_K mean identical back-projected vertices)
+        self.inv_K_origin = torch.inverse(K).unsqueeze(0).cuda()
+        self.K_origin = K.unsqueeze(0).cuda()
         self.inv_K = self.inv_K_origin.clone()
         self.K = self.K_origin.clone()
         self.renderer = nr.Renderer(camera_mode='projection',
@@ -85,164 +145,113 @@ class NrRenderer():
     def downscale_K(self, downscale):
         if downscale > 1:
             self.K = torch.cat((self.K_origin[:, 0:2] / downscale, self.K_origin[:, 2:]), dim=1)
-            self.inv_K = torch.inverse(self.K[0]).unsqueeze(0)
+            self.inv_K = torch.inverse(self.K[0].cpu()).unsqueeze(0).to(self.K.device)
 
     def set_transform_matrices(self, view):
         self.rot_mat, self.trans_xyz = get_transform_matrices(view)
 
+    # ---- the one pass everything below goes through ---------------------------------------------------------------
+    def _warp(self, depth, rigid, project=False, crop=None):
+        """depth [b,h,w] -> rigidly moved back-projection: points [b,h*w,3], or (project) the sampling grid [b,h,w,2]."""
+        dev = depth.device
+        return _GridWarp.apply(depth, self.inv_K.to(dev), rigid.A.to(dev), rigid.t.to(dev), self.rot_center_depth,
+                               self.K.to(dev) if project else None, crop)
+
+    def _current(self):
+        return Rigid(self.rot_mat, self.trans_xyz)
+
+    # ---- point-wise helpers of the reference's public surface (CR:64-72, 82-88) -----------------------------------
     def rotate_pts(self, pts, rot_mat):
         centroid = const_tensor([0., 0., self.rot_center_depth], pts.device, (1, 1, 3))
-        return (pts - centroid).matmul(rot_mat.transpose(2, 1)) + centroid
+        return torch.baddbmm(centroid.expand(pts.shape[0], 1, 3), pts - centroid, rot_mat.transpose(2, 1).expand(pts.shape[0], 3, 3))
 
     def translate_pts(self, pts, trans_xyz):
         return pts + trans_xyz
 
+    def grid_3d_to_2d(self, grid_3d):
+        """camera-space points [b,h,w,3] -> normalised image coordinates in -1..1 (CR:82-88)."""
+        b, h, w, _ = grid_3d.shape
+        K = self.K.to(grid_3d.device)
+        ndc = grid_3d[..., :2] / grid_3d[..., 2:]
+        uv = ndc.matmul(K[:, :2, :2].transpose(2, 1)) + K[:, :2, 2].reshape(-1, 1, 1, 2)
+        return uv * const_tensor([2. / (w - 1), 2. / (h - 1)], grid_3d.device, (1, 1, 1, 2)) - 1.
+
+    # ---- grids (CR:74-114) ------------------------------------------------------------------------------------------
     def depth_to_3d_grid(self, depth):
         b, h, w = depth.shape
-        grid_2d = get_grid(b, h, w, normalize=False, device=depth.device)  # Nxhxwx2
-        depth = depth.unsqueeze(-1)
-        grid_3d = torch.cat((grid_2d, torch.ones_like(depth)), dim=3)
-        return grid_3d.matmul(self.inv_K.to(depth.device).transpose(2, 1)) * depth
-
-    def grid_3d_to_2d(self, grid_3d):
-        b, h, w, _ = grid_3d.shape
-        grid_2d = grid_3d / grid_3d[..., 2:]
-        grid_2d = grid_2d.matmul(self.K.to(grid_3d.device).transpose(2, 1))[:, :, :, :2]
-        WH = const_tensor([w - 1, h - 1], grid_3d.device, (1, 1, 1, 2))
-        return grid_2d / WH * 2. - 1.  # normalize to -1~1
+        return self._warp(depth, Rigid.identity(depth.device)).reshape(b, h, w, 3)
 
     def get_warped_3d_grid(self, depth):
         b, h, w = depth.shape
-        # depth_to_3d_grid -> rotate_pts -> translate_pts, fused (one kernel each way)
-        grid_3d = _DepthToVertices.apply(depth, self.inv_K.to(depth.device), self.rot_mat, self.trans_xyz,
-                                         self.rot_center_depth)
-        return grid_3d.reshape(b, h, w, 3)
+        return self._warp(depth, self._current()).reshape(b, h, w, 3)
 
     def get_inv_warped_3d_grid(self, depth):
         b, h, w = depth.shape
-        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
-        grid_3d = self.translate_pts(grid_3d, -self.trans_xyz)
-        grid_3d = self.rotate_pts(grid_3d, self.rot_mat.transpose(2, 1))
-        return grid_3d.reshape(b, h, w, 3)
+        return self._warp(depth, self._current().inverse()).reshape(b, h, w, 3)
 
     def get_warped_2d_grid(self, depth):
-        return self.grid_3d_to_2d(self.get_warped_3d_grid(depth))
+        return self._warp(depth, self._current(), project=True)
 
     def get_inv_warped_2d_grid(self, depth):
-        return self.grid_3d_to_2d(self.get_inv_warped_3d_grid(depth))
+        return self._warp(depth, self._current().inverse(), project=True)
 
     def warp_canon_depth(self, canon_depth):
         b, h, w = canon_depth.shape
-        grid_3d = self.get_warped_3d_grid(canon_depth).reshape(b, -1, 3)
-        faces = get_face_idx(b, h, w, canon_depth.device)
-        warped_depth = self.renderer.render_depth(grid_3d, faces)
-        # allow some margin out of valid range
-        margin = (self.max_depth - self.min_depth) / 2
+        warped_depth = self.renderer.render_depth(self._warp(canon_depth, self._current()),
+                                                  get_face_idx(b, h, w, canon_depth.device))
+        margin = (self.max_depth - self.min_depth) / 2          # allow some margin out of valid range (CR:122-124)
         return warped_depth.clamp(min=self.min_depth - margin, max=self.max_depth + margin)
 
     def get_normal_from_depth(self, depth):
-        b, h, w = depth.shape
-        grid_3d = self.depth_to_3d_grid(depth)
-        tu = grid_3d[:, 1:-1, 2:] - grid_3d[:, 1:-1, :-2]
-        tv = grid_3d[:, 2:, 1:-1] - grid_3d[:, :-2, 1:-1]
-        normal = tu.cross(tv, dim=3)
-        zero = const_tensor([0., 0., 1.], depth.device)
-        normal = torch.cat([zero.repeat(b, h - 2, 1, 1), normal, zero.repeat(b, h - 2, 1, 1)], 2)
-        normal = torch.cat([zero.repeat(b, 1, w, 1), normal, zero.repeat(b, 1, w, 1)], 1)
-        return normal / (((normal ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)
+        return _DepthNormals.apply(depth, self.inv_K.to(depth.device))
 
-    # ---- view synthesis helpers (renderer_nr.py:141-277) ------------------------------------------------
-    def _render_textured(self, im, grid_3d, b, h, w):
-        faces = get_face_idx(b, h, w, im.device)
-        textures = get_textures_from_im(im, tx_size=self.tex_cube_size)
-        return self.renderer.render_rgb(grid_3d, faces, textures).clamp(min=-1., max=1.)
+    # ---- view synthesis (CR:141-277): one frame loop for the three public sweeps ----------------------------------------
+    def _frame_mesh(self, images, depth, rigid, crop=None):
+        """render the depth's grid mesh, moved by `rigid`, textured with each image of `images` (CR:196-198)."""
+        b, _, h, w = images[0].shape
+        vertices = self._warp(depth, rigid, crop=crop)
+        faces = get_face_idx(b, h, w, depth.device)
+        return [self.renderer.render_rgb(vertices, faces, get_textures_from_im(im, tx_size=self.tex_cube_size))
+                .clamp(min=-1., max=1.) for im in images]
 
-    def _warp_by_grid_sample(self, im, depth, view):
+    def _frame_resample(self, im, depth, view, mask=None):
+        """the grid_sample form (CR:180-184): warp the depth to `view`, look every target pixel up in the source image."""
         self.set_transform_matrices(view)
-        recon_depth = self.warp_canon_depth(depth)
-        grid_2d_from_canon = self.get_inv_warped_2d_grid(recon_depth)
-        return nn.functional.grid_sample(im, grid_2d_from_canon, mode='bilinear'), grid_2d_from_canon
+        grid = self.get_inv_warped_2d_grid(self.warp_canon_depth(depth))
+        out = nn.functional.grid_sample(im, grid, mode='bilinear')
+        return out if mask is None else (out, nn.functional.grid_sample(mask, grid, mode='nearest'))
+
+    def _sweep(self, im, depth, euler_angles, v_before, v_after, grid_sample, crop=None):
+        dev = im.device
+        undo = Rigid.of_view(v_before).inverse() if v_before is not None else None          # the "inverse warp" (CR:163-167)
+        frames = []
+        for i, angles in enumerate(euler_angles):
+            if grid_sample:
+                view = torch.tensor(list(angles) + [0., 0., 0.], dtype=torch.float32, device=dev).view(1, 6)
+                frames.append(self._frame_resample(im, depth, view - v_before if v_before is not None else view))
+                continue
+            turn = Rigid.of_view(torch.tensor(list(angles), dtype=torch.float32, device=dev).view(1, 3))
+            rigid = undo.then(turn) if undo is not None else turn
+            if v_after is not None:
+                rigid = rigid.then(Rigid.of_view(v_after[i] if v_after.dim() == 3 else v_after))
+            frames.append(self._frame_mesh([im], depth, rigid, crop)[0])
+        return torch.stack(frames, 1)  # b x t x c x h x w
 
     def render_yaw(self, im, depth, v_before=None, v_after=None, rotations=None, maxr=90, nsample=9,
                    grid_sample=False, crop_mesh=None):
-        b, c, h, w = im.shape
-        grid_3d = self.depth_to_3d_grid(depth)
-        if crop_mesh is not None:
-            top, bottom, left, right = crop_mesh  # pixels from border to be cropped
-            if top > 0:
-                grid_3d[:, :top, :, 1] = grid_3d[:, top:top + 1, :, 1].repeat(1, top, 1)
-                grid_3d[:, :top, :, 2] = grid_3d[:, top:top + 1, :, 2].repeat(1, top, 1)
-            if bottom > 0:
-                grid_3d[:, -bottom:, :, 1] = grid_3d[:, -bottom - 1:-bottom, :, 1].repeat(1, bottom, 1)
-                grid_3d[:, -bottom:, :, 2] = grid_3d[:, -bottom - 1:-bottom, :, 2].repeat(1, bottom, 1)
-            if left > 0:
-                grid_3d[:, :, :left, 0] = grid_3d[:, :, left:left + 1, 0].repeat(1, 1, left)
-                grid_3d[:, :, :left, 2] = grid_3d[:, :, left:left + 1, 2].repeat(1, 1, left)
-            if right > 0:
-                grid_3d[:, :, -right:, 0] = grid_3d[:, :, -right - 1:-right, 0].repeat(1, 1, right)
-                grid_3d[:, :, -right:, 2] = grid_3d[:, :, -right - 1:-right, 2].repeat(1, 1, right)
-        grid_3d = grid_3d.reshape(b, -1, 3)
-        if v_before is not None:        # inverse warp
-            rot_mat, trans_xyz = get_transform_matrices(v_before)
-            grid_3d = self.rotate_pts(self.translate_pts(grid_3d, -trans_xyz), rot_mat.transpose(2, 1))
         if rotations is None:
             rotations = torch.linspace(-math.pi / 180 * maxr, math.pi / 180 * maxr, nsample)
-        im_trans = []
-        for i, ri in enumerate(rotations):
-            if grid_sample:
-                view = torch.tensor([0, float(ri), 0, 0, 0, 0], dtype=torch.float32, device=im.device).view(1, 6)
-                if v_before is not None:
-                    view = view - v_before
-                warped_images, _ = self._warp_by_grid_sample(im, depth, view)
-            else:
-                rvec = torch.tensor([0, float(ri), 0], dtype=torch.float32, device=im.device).view(1, 3)
-                rot_mat_i, _ = get_transform_matrices(rvec)
-                grid_3d_i = self.rotate_pts(grid_3d, rot_mat_i.repeat(b, 1, 1))
-                if v_after is not None:
-                    v_after_i = v_after[i] if len(v_after.shape) == 3 else v_after
-                    rot_mat, trans_xyz = get_transform_matrices(v_after_i)
-                    grid_3d_i = self.translate_pts(self.rotate_pts(grid_3d_i, rot_mat), trans_xyz)
-                warped_images = self._render_textured(im, grid_3d_i, b, h, w)
-            im_trans += [warped_images]
-        return torch.stack(im_trans, 1)  # b x t x c x h x w
+        crop = None if (crop_mesh is None or grid_sample) else tuple(int(v) for v in crop_mesh)
+        return self._sweep(im, depth, [(0., float(r), 0.) for r in rotations], v_before, v_after, grid_sample, crop)
 
     def render_view(self, im, depth, v_before=None, rotations=None, maxr=[20, 90], nsample=[5, 9], grid_sample=False):
-        b, c, h, w = im.shape
-        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
-        if v_before is not None:
-            rot_mat, trans_xyz = get_transform_matrices(v_before)
-            grid_3d = self.rotate_pts(self.translate_pts(grid_3d, -trans_xyz), rot_mat.transpose(2, 1))
-        rotations_p = torch.linspace(-math.pi / 180 * maxr[0], math.pi / 180 * maxr[0], nsample[0])
-        rotations_y = torch.linspace(-math.pi / 180 * maxr[1], math.pi / 180 * maxr[1], nsample[1])
-        im_trans = []
-        for axis, angles in ((1, rotations_y), (0, rotations_p)):     # yaw sweep first, then pitch
-            for ang in angles:
-                rvec = [0., 0., 0.]
-                rvec[axis] = float(ang)
-                if grid_sample:
-                    view = torch.tensor(rvec + [0, 0, 0], dtype=torch.float32, device=im.device).view(1, 6)
-                    if v_before is not None:
-                        view = view - v_before
-                    warped_images, _ = self._warp_by_grid_sample(im, depth, view)
-                else:
-                    rot_mat_i, _ = get_transform_matrices(torch.tensor(rvec, dtype=torch.float32, device=im.device).view(1, 3))
-                    warped_images = self._render_textured(im, self.rotate_pts(grid_3d, rot_mat_i.repeat(b, 1, 1)), b, h, w)
-                im_trans += [warped_images]
-        return torch.stack(im_trans, 1)  # b x t x c x h x w
+        pitch = torch.linspace(-math.pi / 180 * maxr[0], math.pi / 180 * maxr[0], nsample[0])
+        yaw = torch.linspace(-math.pi / 180 * maxr[1], math.pi / 180 * maxr[1], nsample[1])
+        angles = [(0., float(a), 0.) for a in yaw] + [(float(a), 0., 0.) for a in pitch]     # yaw sweep, then pitch (CR:214,232)
+        return self._sweep(im, depth, angles, v_before, None, grid_sample)
 
     def render_given_view(self, im, depth, view, mask=None, grid_sample=True):
-        b, c, h, w = im.shape
-        grid_3d = self.depth_to_3d_grid(depth).reshape(b, -1, 3)
         if grid_sample:
-            warped_images, grid_2d_from_canon = self._warp_by_grid_sample(im, depth, view)
-            if mask is not None:
-                warped_mask = nn.functional.grid_sample(mask, grid_2d_from_canon, mode='nearest')
-                return warped_images, warped_mask
-        else:
-            rot_mat, trans_xyz = get_transform_matrices(view)
-            grid_3d = self.translate_pts(self.rotate_pts(grid_3d, rot_mat), trans_xyz)
-            warped_images = self._render_textured(im, grid_3d, b, h, w)
-            if mask is not None:
-                warped_mask = self._render_textured(mask, grid_3d, b, h, w)
-                return warped_images, warped_mask
-        return warped_images  # b x c x h x w
+            return self._frame_resample(im, depth, view, mask)
+        frames = self._frame_mesh([im] if mask is None else [im, mask], depth, Rigid.of_view(view))
+        return frames[0] if mask is None else (frames[0], frames[1])  # b x c x h x w

@@ -114,14 +114,38 @@ def vcolor_to_texture_cube(vcolors):
     return coeffs.matmul(vcolors.permute(0, 2, 3, 1)).reshape(b, n, 2, 2, 2, c)
 
 
+class _TexturesFromIm(torch.autograd.Function):
+    """d3m_textures_from_im / _backward: one pass each way instead of the reference's slices, stacks and matmul."""
+
+    @staticmethod
+    def forward(ctx, im, tx_size):
+        from .. import _lib
+        x = im.detach().to(torch.float32).contiguous()
+        b, c, h, w = x.shape
+        tex = torch.empty(b, 2 * (h - 1) * (w - 1), tx_size, tx_size, tx_size, c, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().d3m_textures_from_im(_lib.ptr(x), _lib.ptr(tex), b, c, h, w, tx_size, _lib.stream_ptr()),
+                   "d3m_textures_from_im")
+        ctx.dims = (b, c, h, w, tx_size)
+        return tex
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        b, c, h, w, tx_size = ctx.dims
+        g = g.to(torch.float32).contiguous()
+        g_im = torch.empty(b, c, h, w, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().d3m_textures_from_im_backward(_lib.ptr(g), _lib.ptr(g_im), b, c, h, w, tx_size,
+                                                            _lib.stream_ptr()), "d3m_textures_from_im_backward")
+        return g_im, None
+
+
 def get_textures_from_im(im, tx_size=1):
-    """Per-face textures of the implicit grid mesh from an image [b,c,h,w] (utils.py:97-107)."""
-    b, c, h, w = im.shape
-    if tx_size == 1:
-        textures = torch.cat([im[:, :, :h - 1, :w - 1].reshape(b, c, -1), im[:, :, 1:, 1:].reshape(b, c, -1)], 2)
-        return textures.transpose(2, 1).reshape(b, -1, 1, 1, 1, c)
-    if tx_size == 2:
-        t1 = torch.stack([im[:, :, :h - 1, :w - 1], im[:, :, :h - 1, 1:], im[:, :, 1:, :w - 1]], -1).reshape(b, c, -1, 3)
-        t2 = torch.stack([im[:, :, 1:, :w - 1], im[:, :, :h - 1, 1:], im[:, :, 1:, 1:]], -1).reshape(b, c, -1, 3)
-        return vcolor_to_texture_cube(torch.cat([t1, t2], 2))
-    raise NotImplementedError("Currently support texture size of 1 or 2 only.")
+    """Per-face textures [b, 2(h-1)(w-1), ts, ts, ts, c] of the implicit grid mesh from an image [b,c,h,w]
+    (utils.py:97-107): cell (y, x) carries the faces with vertex colours (im[y,x], im[y,x+1], im[y+1,x]) and
+    (im[y+1,x], im[y,x+1], im[y+1,x+1]); tx_size 2 expands them to 2x2x2 cubes (vcolor_to_texture_cube), tx_size 1
+    keeps the colour of the first / last vertex."""
+    if tx_size not in (1, 2):
+        raise NotImplementedError("Currently support texture size of 1 or 2 only.")
+    if not im.is_cuda:
+        raise RuntimeError("get_textures_from_im: im must be a CUDA tensor")
+    return _TexturesFromIm.apply(im, tx_size)

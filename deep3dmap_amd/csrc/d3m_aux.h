@@ -418,6 +418,278 @@ __global__ void __launch_bounds__(256) k_depth_to_vertices_backward(const float*
     }
 }
 
+// ---- NrRenderer's depth -> warped pixel grid (renderer_nr.py:74-114, 141-158) ----------------------------------
+// One pass for every variant of "depth_to_3d_grid, then rigid transforms, then maybe grid_3d_to_2d":
+//   P(b, y, x) = depth * Kinv * (x, y, 1)                      (renderer_nr.py:74-80)
+//   crop_mesh (renderer_nr.py:145-158, render_yaw): the top / bottom rows take the y and z of the first kept row, the
+//                 left / right columns then take the x and z of the first kept column (of the row-adjusted grid), i.e.
+//                 P.x from (y, cx), P.y from (ry, x), P.z from (ry, cx) with ry / cx the clamped row / column;
+//   Q = A_b (P - c) + c + t_b,  c = (0, 0, center_z)          (rotate_pts + translate_pts; the callers compose inverse
+//                                                              warps and chains of them into one (A, t) on [B,3,3])
+//   out = Q                                         [B,H*W,3]   or, with K (grid_3d_to_2d, renderer_nr.py:82-88):
+//   out = ((K (Q / Q.z)).xy / (W-1, H-1)) * 2 - 1   [B,H,W,2]   the sampling grid F.grid_sample takes.
+struct GridWarp {
+    const float* depth;
+    const float* inv_K; int invK_b;
+    const float* rot;                 // [B,3,3]
+    const float* trans;               // [B,3]
+    float center_z;
+    const float* K; int K_b;          // NULL: 3-D output
+    int crop_top, crop_bottom, crop_left, crop_right;
+    int B, H, W;
+};
+
+__device__ __forceinline__ void gw_ray(const float* iK, float x, float y, float* ray) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) ray[k] = x * iK[3 * k] + y * iK[3 * k + 1] + iK[3 * k + 2];        // renderer_nr.py:79
+}
+
+__global__ void __launch_bounds__(256) k_grid_warp(GridWarp g, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)g.B * g.H * g.W) return;
+    const int b = (int)(i / ((long)g.H * g.W)), pix = (int)(i % ((long)g.H * g.W));
+    const int xi = pix % g.W, yi = pix / g.W;
+    const float* iK = cam_ptr(g.inv_K, g.invK_b, b, 9);
+    const float* dview = g.depth + (size_t)b * g.H * g.W;
+    float p[3];
+    const bool crop = (g.crop_top | g.crop_bottom | g.crop_left | g.crop_right) != 0;
+    if (!crop) {
+        float ray[3];
+        gw_ray(iK, (float)xi, (float)yi, ray);
+        const float d = dview[pix];
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] = ray[k] * d;
+    } else {
+        const int ry = min(max(yi, g.crop_top), g.H - 1 - g.crop_bottom), cx = min(max(xi, g.crop_left), g.W - 1 - g.crop_right);
+        float r0[3], r1[3], r2[3];
+        gw_ray(iK, (float)cx, (float)yi, r0);      // x component: (y, cx)
+        gw_ray(iK, (float)xi, (float)ry, r1);      // y component: (ry, x)
+        gw_ray(iK, (float)cx, (float)ry, r2);      // z component: (ry, cx)
+        p[0] = r0[0] * dview[yi * g.W + cx];
+        p[1] = r1[1] * dview[ry * g.W + xi];
+        p[2] = r2[2] * dview[ry * g.W + cx];
+    }
+    p[2] -= g.center_z;                                                                       // renderer_nr.py:66
+    const float* R = g.rot + (size_t)b * 9;
+    const float* t = g.trans + (size_t)b * 3;
+    float q[3];
+    q[0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];                                    // :67-68, :71
+    q[1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
+    q[2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + g.center_z + t[2];
+    if (!g.K) {
+        out[3 * i + 0] = q[0]; out[3 * i + 1] = q[1]; out[3 * i + 2] = q[2];
+        return;
+    }
+    const float* K = cam_ptr(g.K, g.K_b, b, 9);
+    const float xn = q[0] / q[2], yn = q[1] / q[2];                                           // :84
+    const float u = xn * K[0] + yn * K[1] + K[2], v = xn * K[3] + yn * K[4] + K[5];           // :85
+    out[2 * i + 0] = u / (float)(g.W - 1) * 2.0f - 1.0f;                                      // :86-87
+    out[2 * i + 1] = v / (float)(g.H - 1) * 2.0f - 1.0f;
+}
+
+// adjoint (no crop): one workgroup per batch entry; grad_depth per pixel, grad_rot [B,3,3] and grad_trans [B,3] by a
+// workgroup reduction over the H*W pixels.
+__global__ void __launch_bounds__(256) k_grid_warp_backward(GridWarp g, const float* __restrict__ g_out,
+                                                           float* __restrict__ g_depth, float* __restrict__ g_rot,
+                                                           float* __restrict__ g_trans) {
+    __shared__ float s_part[4];
+    const int b = blockIdx.x, H = g.H, W = g.W;
+    const long base = (long)b * H * W;
+    const float* iK = cam_ptr(g.inv_K, g.invK_b, b, 9);
+    const float* R = g.rot + (size_t)b * 9;
+    const float* t = g.trans + (size_t)b * 3;
+    const float* K = g.K ? cam_ptr(g.K, g.K_b, b, 9) : nullptr;
+    float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int pix = threadIdx.x; pix < H * W; pix += 256) {
+        float ray[3], p[3];
+        gw_ray(iK, (float)(pix % W), (float)(pix / W), ray);
+        const float d = g.depth[base + pix];
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] = ray[k] * d;
+        p[2] -= g.center_z;
+        float gq[3];
+        if (!K) {
+            gq[0] = g_out[3 * (base + pix)]; gq[1] = g_out[3 * (base + pix) + 1]; gq[2] = g_out[3 * (base + pix) + 2];
+        } else {
+            float q[3];
+            q[0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];
+            q[1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
+            q[2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + g.center_z + t[2];
+            const float gu = g_out[2 * (base + pix)] * 2.0f / (float)(W - 1), gv = g_out[2 * (base + pix) + 1] * 2.0f / (float)(H - 1);
+            const float gxn = gu * K[0] + gv * K[3], gyn = gu * K[1] + gv * K[4];
+            const float iz = 1.0f / q[2];
+            gq[0] = gxn * iz;
+            gq[1] = gyn * iz;
+            gq[2] = -(gxn * q[0] + gyn * q[1]) * iz * iz;
+        }
+        float gp[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) gp[j] = gq[0] * R[j] + gq[1] * R[3 + j] + gq[2] * R[6 + j];
+        if (g_depth) g_depth[base + pix] = gp[0] * ray[0] + gp[1] * ray[1] + gp[2] * ray[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[3 * k + j] += gq[k] * p[j];
+            acc[9 + k] += gq[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const float v = block_sum_256(acc[k], s_part);
+        if (threadIdx.x == 0) {
+            if (k < 9) { if (g_rot) g_rot[b * 9 + k] = v; }
+            else if (g_trans) g_trans[b * 3 + (k - 9)] = v;
+        }
+    }
+}
+
+// ---- NrRenderer.get_normal_from_depth (renderer_nr.py:127-139) -----------------------------------------------------
+//   tu = P(y, x+1) - P(y, x-1),  tv = P(y+1, x) - P(y-1, x),  n = tu x tv,  normal = n / (|n| + 1e-7)   (interior)
+//   normal = (0, 0, 1) / (1 + 1e-7) on the one-pixel border;  P = depth * Kinv (x, y, 1).
+__device__ __forceinline__ void dn_point(const float* __restrict__ dview, const float* iK, int W, int x, int y, float* p) {
+    float ray[3];
+    gw_ray(iK, (float)x, (float)y, ray);
+    const float d = dview[y * W + x];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = ray[k] * d;
+}
+__device__ __forceinline__ void cross3f(const float* a, const float* b, float* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+constexpr float DN_EPS = 1e-7f;
+
+__global__ void __launch_bounds__(256) k_depth_normals(const float* __restrict__ depth, const float* __restrict__ inv_K,
+                                                      int invK_b, float* __restrict__ normal, int B, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W) return;
+    const int b = (int)(i / ((long)H * W)), pix = (int)(i % ((long)H * W));
+    const int x = pix % W, y = pix / W;
+    float n[3] = {0.0f, 0.0f, 1.0f};
+    if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+        const float* iK = cam_ptr(inv_K, invK_b, b, 9);
+        const float* dview = depth + (size_t)b * H * W;
+        float pr[3], pl[3], pd[3], pu[3], tu[3], tv[3];
+        dn_point(dview, iK, W, x + 1, y, pr); dn_point(dview, iK, W, x - 1, y, pl);
+        dn_point(dview, iK, W, x, y + 1, pd); dn_point(dview, iK, W, x, y - 1, pu);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { tu[k] = pr[k] - pl[k]; tv[k] = pd[k] - pu[k]; }
+        cross3f(tu, tv, n);
+    }
+    const float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) + DN_EPS;
+    normal[3 * i + 0] = n[0] / len; normal[3 * i + 1] = n[1] / len; normal[3 * i + 2] = n[2] / len;
+}
+
+// adjoint, gathered: the depth of pixel (y, x) enters the normals of its four neighbours (as their right / left /
+// lower / upper point), so each lane recomputes those four normals' tangent gradients and adds up what reaches its own
+// point -- no atomics, no scratch.
+__device__ __forceinline__ void dn_tangent_grads(const float* __restrict__ dview, const float* iK,
+                                                 const float* __restrict__ g_normal_view, int H, int W, int x, int y,
+                                                 float* g_tu, float* g_tv) {
+    g_tu[0] = g_tu[1] = g_tu[2] = g_tv[0] = g_tv[1] = g_tv[2] = 0.0f;
+    if (!(x > 0 && x < W - 1 && y > 0 && y < H - 1)) return;      // border normals are constants
+    float pr[3], pl[3], pd[3], pu[3], tu[3], tv[3], n[3];
+    dn_point(dview, iK, W, x + 1, y, pr); dn_point(dview, iK, W, x - 1, y, pl);
+    dn_point(dview, iK, W, x, y + 1, pd); dn_point(dview, iK, W, x, y - 1, pu);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { tu[k] = pr[k] - pl[k]; tv[k] = pd[k] - pu[k]; }
+    cross3f(tu, tv, n);
+    const float norm = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), len = norm + DN_EPS;
+    const float* go = g_normal_view + 3 * ((size_t)y * W + x);
+    // out = n / len, len = |n| + eps:  g_n = go / len - n * (go . n) / (len^2 |n|)
+    const float dot = go[0] * n[0] + go[1] * n[1] + go[2] * n[2];
+    const float c = norm > 0.0f ? dot / (len * len * norm) : 0.0f;
+    float gn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gn[k] = go[k] / len - n[k] * c;
+    cross3f(tv, gn, g_tu);      // n = tu x tv:  g_tu = tv x g_n,  g_tv = g_n x tu
+    cross3f(gn, tu, g_tv);
+}
+
+__global__ void __launch_bounds__(256) k_depth_normals_backward(const float* __restrict__ depth, const float* __restrict__ inv_K,
+                                                               int invK_b, const float* __restrict__ g_normal,
+                                                               float* __restrict__ g_depth, int B, int H, int W) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W) return;
+    const int b = (int)(i / ((long)H * W)), pix = (int)(i % ((long)H * W));
+    const int x = pix % W, y = pix / W;
+    const float* iK = cam_ptr(inv_K, invK_b, b, 9);
+    const float* dview = depth + (size_t)b * H * W;
+    const float* gview = g_normal + (size_t)b * H * W * 3;
+    float gp[3] = {0, 0, 0}, a[3], c[3];
+    if (x - 1 >= 0) { dn_tangent_grads(dview, iK, gview, H, W, x - 1, y, a, c); for (int k = 0; k < 3; k++) gp[k] += a[k]; }   // its right point
+    if (x + 1 < W)  { dn_tangent_grads(dview, iK, gview, H, W, x + 1, y, a, c); for (int k = 0; k < 3; k++) gp[k] -= a[k]; }   // its left point
+    if (y - 1 >= 0) { dn_tangent_grads(dview, iK, gview, H, W, x, y - 1, a, c); for (int k = 0; k < 3; k++) gp[k] += c[k]; }   // its lower point
+    if (y + 1 < H)  { dn_tangent_grads(dview, iK, gview, H, W, x, y + 1, a, c); for (int k = 0; k < 3; k++) gp[k] -= c[k]; }   // its upper point
+    float ray[3];
+    gw_ray(iK, (float)x, (float)y, ray);
+    g_depth[i] = gp[0] * ray[0] + gp[1] * ray[1] + gp[2] * ray[2];
+}
+
+// ---- get_textures_from_im (deep3dmap/core/renderer/utils.py:81-107) ----------------------------------------------
+// Per-face textures of the implicit grid mesh from an image [B,C,H,W]: cell (y, x) holds two faces,
+//   n = y (W-1) + x              vertex colours (im[y,x],   im[y,x+1], im[y+1,x])      (utils.py:102)
+//   n + (H-1)(W-1)               vertex colours (im[y+1,x], im[y,x+1], im[y+1,x+1])    (utils.py:103)
+// tx_size 2: texel idx of the 2x2x2 cube = sum_j CUBE[idx][j] * colour_j (utils.py:84-94) -> [B, 2 cells, 8, C];
+// tx_size 1: the colour of im[y,x] / im[y+1,x+1] (utils.py:99-100) -> [B, 2 cells, 1, C].  One lane per (face, texel).
+__constant__ float TFI_CUBE[8][3] = {{0.5f, 0.5f, 0.5f}, {0.f, 0.f, 1.f}, {0.f, 1.f, 0.f}, {-0.5f, 0.5f, 0.5f},
+                                     {1.f, 0.f, 0.f}, {0.5f, -0.5f, 0.5f}, {0.5f, 0.5f, -0.5f}, {0.f, 0.f, 0.f}};
+__device__ __forceinline__ void tfi_vertices(int second, int y, int x, int W, int* v) {     // pixel offsets in the image
+    if (!second) { v[0] = y * W + x; v[1] = y * W + x + 1; v[2] = (y + 1) * W + x; }
+    else         { v[0] = (y + 1) * W + x; v[1] = y * W + x + 1; v[2] = (y + 1) * W + x + 1; }
+}
+
+__global__ void __launch_bounds__(256) k_textures_from_im(const float* __restrict__ im, float* __restrict__ tex, int B, int C,
+                                                         int H, int W, int ts) {
+    const int cells = (H - 1) * (W - 1), per = ts == 2 ? 8 : 1;
+    const long n = (long)B * 2 * cells * per;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int idx = (int)(i % per);
+    const long f = i / per;
+    const int b = (int)(f / (2 * cells)), fn = (int)(f % (2 * cells));
+    const int second = fn >= cells, cell = second ? fn - cells : fn;
+    const int y = cell / (W - 1), x = cell % (W - 1);
+    const float* img = im + (size_t)b * C * H * W;
+    float* o = tex + (size_t)i * C;
+    if (ts == 2) {
+        int v[3];
+        tfi_vertices(second, y, x, W, v);
+        for (int c = 0; c < C; c++) {
+            const float* ch = img + (size_t)c * H * W;
+            // the three products in the order of the reference's matmul row (coeffs . colours)
+            o[c] = (TFI_CUBE[idx][0] * ch[v[0]] + TFI_CUBE[idx][1] * ch[v[1]]) + TFI_CUBE[idx][2] * ch[v[2]];
+        }
+    } else {
+        const int px = second ? (y + 1) * W + x + 1 : y * W + x;
+        for (int c = 0; c < C; c++) o[c] = img[(size_t)c * H * W + px];
+    }
+}
+
+// adjoint, gathered per image pixel: it is a vertex of at most six faces (fixed pattern)
+__global__ void __launch_bounds__(256) k_textures_from_im_backward(const float* __restrict__ g_tex, float* __restrict__ g_im,
+                                                                  int B, int C, int H, int W, int ts) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * C * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H), c = (int)((i / ((long)W * H)) % C), b = (int)(i / ((long)W * H * C));
+    const int cells = (H - 1) * (W - 1), per = ts == 2 ? 8 : 1;
+    const float* gt = g_tex + (size_t)b * 2 * cells * per * C;
+    float acc = 0.0f;
+    auto add = [&](int second, int cy, int cx, int slot) {     // pixel (y, x) is vertex `slot` of that face of cell (cy, cx)
+        if (cy < 0 || cy >= H - 1 || cx < 0 || cx >= W - 1) return;
+        const size_t f = (size_t)(second ? cells : 0) + (size_t)cy * (W - 1) + cx;
+        if (ts == 2) {
+            for (int idx = 0; idx < 8; idx++) acc += TFI_CUBE[idx][slot] * gt[(f * 8 + idx) * C + c];
+        } else if (slot == (second ? 2 : 0)) {
+            acc += gt[f * C + c];
+        }
+    };
+    add(0, y, x, 0); add(0, y, x - 1, 1); add(0, y - 1, x, 2);
+    add(1, y - 1, x, 0); add(1, y, x - 1, 1); add(1, y - 1, x - 1, 2);
+    g_im[i] = acc;
+}
+
 // ---- view vector -> (rotation, translation) (deep3dmap/core/renderer/utils.py:34-71) ----------------------------
 // R = Rz(rz) Ry(ry) Rx(rx) with the reference's sign conventions, t = (tx, ty, tz) padded with zeros for 5- and
 // 3-component views: one lane per batch entry instead of ~35 eager kernels (6 trig calls, 27 stacks, 2 batched matmuls)

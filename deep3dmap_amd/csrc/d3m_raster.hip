@@ -568,6 +568,84 @@ D3M_EXPORT int d3m_depth_to_vertices_backward(const float* depth, const float* i
     return check_launch();
 }
 
+static int to_grid_warp(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
+                        float rot_center_depth, const float* K, int K_batch, const int* crop, int B, int H, int W, GridWarp& g) {
+    if (!depth || !inv_K || !rot || !trans || B <= 0 || H <= 0 || W <= 0) return D3M_ERR_INVALID;
+    if ((inv_K_batch != 1 && inv_K_batch != B) || (K && K_batch != 1 && K_batch != B)) return D3M_ERR_INVALID;
+    g = GridWarp{depth, inv_K, inv_K_batch, rot, trans, rot_center_depth, K, K_batch, 0, 0, 0, 0, B, H, W};
+    if (crop) {
+        if (crop[0] < 0 || crop[1] < 0 || crop[2] < 0 || crop[3] < 0 || crop[0] + crop[1] >= H || crop[2] + crop[3] >= W)
+            return D3M_ERR_INVALID;
+        g.crop_top = crop[0]; g.crop_bottom = crop[1]; g.crop_left = crop[2]; g.crop_right = crop[3];
+    }
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_grid_warp(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
+                             float rot_center_depth, const float* K, int K_batch, const int* crop, float* out,
+                             int batch_size, int height, int width, d3m_stream_t stream) {
+    GridWarp g;
+    if (int rc = to_grid_warp(depth, inv_K, inv_K_batch, rot, trans, rot_center_depth, K, K_batch, crop, batch_size, height,
+                              width, g))
+        return rc;
+    if (!out) return D3M_ERR_INVALID;
+    LAUNCH("k_grid_warp", k_grid_warp, dim3(blocks_for((long)batch_size * height * width, 256)), dim3(256),
+           (hipStream_t)stream, g, out);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_grid_warp_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
+                                      const float* trans, float rot_center_depth, const float* K, int K_batch,
+                                      const float* grad_out, float* grad_depth, float* grad_rot, float* grad_trans,
+                                      int batch_size, int height, int width, d3m_stream_t stream) {
+    GridWarp g;
+    if (int rc = to_grid_warp(depth, inv_K, inv_K_batch, rot, trans, rot_center_depth, K, K_batch, nullptr, batch_size,
+                              height, width, g))
+        return rc;
+    if (!grad_out) return D3M_ERR_INVALID;
+    LAUNCH("k_grid_warp_backward", k_grid_warp_backward, dim3(batch_size), dim3(256), (hipStream_t)stream, g, grad_out,
+           grad_depth, grad_rot, grad_trans);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_depth_normals(const float* depth, const float* inv_K, int inv_K_batch, float* normal, int batch_size,
+                                 int height, int width, d3m_stream_t stream) {
+    if (!depth || !inv_K || !normal || batch_size <= 0 || height <= 0 || width <= 0) return D3M_ERR_INVALID;
+    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
+    LAUNCH("k_depth_normals", k_depth_normals, dim3(blocks_for((long)batch_size * height * width, 256)), dim3(256),
+           (hipStream_t)stream, depth, inv_K, inv_K_batch, normal, batch_size, height, width);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_depth_normals_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* grad_normal,
+                                          float* grad_depth, int batch_size, int height, int width, d3m_stream_t stream) {
+    if (!depth || !inv_K || !grad_normal || !grad_depth || batch_size <= 0 || height <= 0 || width <= 0) return D3M_ERR_INVALID;
+    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
+    LAUNCH("k_depth_normals_backward", k_depth_normals_backward, dim3(blocks_for((long)batch_size * height * width, 256)),
+           dim3(256), (hipStream_t)stream, depth, inv_K, inv_K_batch, grad_normal, grad_depth, batch_size, height, width);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_textures_from_im(const float* im, float* textures, int batch_size, int channels, int height, int width,
+                                    int texture_size, d3m_stream_t stream) {
+    if (!im || !textures || batch_size <= 0 || channels <= 0 || height < 2 || width < 2) return D3M_ERR_INVALID;
+    if (texture_size != 1 && texture_size != 2) return D3M_ERR_INVALID;        // utils.py:106
+    const long n = (long)batch_size * 2 * (height - 1) * (width - 1) * (texture_size == 2 ? 8 : 1);
+    LAUNCH("k_textures_from_im", k_textures_from_im, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, im, textures,
+           batch_size, channels, height, width, texture_size);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_textures_from_im_backward(const float* grad_textures, float* grad_im, int batch_size, int channels,
+                                             int height, int width, int texture_size, d3m_stream_t stream) {
+    if (!grad_textures || !grad_im || batch_size <= 0 || channels <= 0 || height < 2 || width < 2) return D3M_ERR_INVALID;
+    if (texture_size != 1 && texture_size != 2) return D3M_ERR_INVALID;
+    LAUNCH("k_textures_from_im_backward", k_textures_from_im_backward,
+           dim3(blocks_for((long)batch_size * channels * height * width, 256)), dim3(256), (hipStream_t)stream, grad_textures,
+           grad_im, batch_size, channels, height, width, texture_size);
+    return check_launch();
+}
+
 // ---- lit sampling: fill_back and lighting on the fly, shared textures (d3m_lit.h) ----------------------
 D3M_EXPORT int d3m_face_light(const float* vertices, int vertices_batch, const int32_t* tri, int tri_batch, float* light,
                               float intensity_ambient, float intensity_directional, const float* color_ambient,

@@ -252,6 +252,34 @@ int d3m_depth_to_vertices_backward(const float* depth, const float* inv_K, int i
                                    float* grad_rot, float* grad_trans, int batch_size, int height, int width,
                                    d3m_stream_t stream);
 
+/* The general form (deep3dmap/core/renderer/renderer_nr.py:74-114,141-158): every "depth_to_3d_grid, then rigid
+ * transforms, then maybe grid_3d_to_2d" of NrRenderer in one pass.
+ *   P = depth * inv_K (x, y, 1)^T;   Q = rot_b (P - c) + c + trans_b,  c = (0, 0, rot_center_depth)
+ *   K == NULL: out [B,H*W,3] = Q;    K [1|B,3,3]: out [B,H,W,2] = ((K (Q / Q.z)).xy / (W-1, H-1)) * 2 - 1, the sampling
+ *   grid of F.grid_sample (renderer_nr.py:82-88).
+ * crop (NULL or {top, bottom, left, right}: render_yaw's crop_mesh, renderer_nr.py:145-158): border rows / columns take
+ * the y,z / x,z of the first kept row / column.  Inverse warps and chains of transforms are composed into (rot, trans)
+ * by the caller.  The adjoint (no crop) WRITES grad_depth [B,H,W], grad_rot [B,3,3], grad_trans [B,3] (each may be NULL). */
+int d3m_grid_warp(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
+                  float rot_center_depth, const float* K, int K_batch, const int* crop, float* out, int batch_size,
+                  int height, int width, d3m_stream_t stream);
+int d3m_grid_warp_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
+                           float rot_center_depth, const float* K, int K_batch, const float* grad_out, float* grad_depth,
+                           float* grad_rot, float* grad_trans, int batch_size, int height, int width, d3m_stream_t stream);
+/* NrRenderer.get_normal_from_depth (renderer_nr.py:127-139): normal [B,H,W,3] of the back-projected depth map, central
+ * differences, (0,0,1) on the one-pixel border, normalised with EPS = 1e-7; and its adjoint (grad_depth WRITTEN). */
+int d3m_depth_normals(const float* depth, const float* inv_K, int inv_K_batch, float* normal, int batch_size, int height,
+                      int width, d3m_stream_t stream);
+int d3m_depth_normals_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* grad_normal,
+                               float* grad_depth, int batch_size, int height, int width, d3m_stream_t stream);
+/* get_textures_from_im (deep3dmap/core/renderer/utils.py:81-107): textures [B, 2(H-1)(W-1), ts^3, C] of the implicit
+ * grid mesh from im [B,C,H,W], ts = 1 or 2 (anything else: D3M_ERR_INVALID, as utils.py:106 raises); and its adjoint
+ * (grad_im WRITTEN). */
+int d3m_textures_from_im(const float* im, float* textures, int batch_size, int channels, int height, int width,
+                         int texture_size, d3m_stream_t stream);
+int d3m_textures_from_im_backward(const float* grad_textures, float* grad_im, int batch_size, int channels, int height,
+                                  int width, int texture_size, d3m_stream_t stream);
+
 /* --- lighting and fill_back applied on the fly (instead of renderer.py:155-167,203-215 materialising
  * cat(textures, textures.permute(0,1,4,3,2,5)) * light per view) ---------------------------------------
  * light [Bl,F',3]: per-face light of the fill_back'd face array on WORLD vertices [Bv,V,3] / tri [Bt,F,3];

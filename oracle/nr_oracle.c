@@ -643,3 +643,108 @@ ORC_API void orc_create_texture_image(const float *vertices_all, const float *te
             for (int k = 0; k < 3; k++) image[i * 3 + k] = image[((long)y * tile_width * tso + (x - 1)) * 3 + k];
     }
 }
+
+/* ===========================================================================
+ * Camera transforms and NrRenderer's depth -> mesh vertices, in plain f32 with
+ * every operation rounded once (-ffp-contract=off), written out operation by
+ * operation.  The reference evaluates these formulas through torch (matmul,
+ * broadcasting), i.e. in whatever association the tensor library picks; any
+ * fixed f32 association is an equally valid restatement.  This one uses the
+ * same association as the HIP kernels (csrc/d3m_aux.h camera_point /
+ * k_camera_basis / k_grid_warp), so that the oracle and the product hand
+ * BIT-IDENTICAL screen-space vertices to their rasterizers: coverage then
+ * matches pixel for pixel and gradients can be compared at 1e-3 instead of
+ * the few per cent that flipped edge pixels cost.  Checked against the
+ * reference modules' own outputs in tests/test_oracle.py (cam/..., d3m/...).
+ *   look_at / look     NR/look_at.py:47-60, NR/look.py:39-51
+ *   perspective        NR/perspective.py:15-20
+ *   projection         NR/projection.py:19-42
+ *   depth -> vertices  deep3dmap/core/renderer/renderer_nr.py:64-80,95-100
+ * ========================================================================= */
+static void orc_normalize3(float *v) {                    /* F.normalize(eps=1e-5): v / max(|v|, 1e-5) */
+    const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float d = fmaxf(n, 1e-5f);
+    v[0] /= d; v[1] /= d; v[2] /= d;
+}
+static void orc_cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static const float *orc_bptr(const float *p, int nb, int b, int stride) { return p + (size_t)(nb > 1 ? b : 0) * stride; }
+
+/* rows (x, y, z) of the camera frame: z = normalize(at - eye) or normalize(direction) */
+ORC_API void orc_camera_basis(const float *eye, int eye_b, const float *at_or_dir, int at_b, const float *up, int up_b,
+                              int is_look_at, float *rot, int B) {
+    for (int b = 0; b < B; b++) {
+        const float *e = orc_bptr(eye, eye_b, b, 3), *a = orc_bptr(at_or_dir, at_b, b, 3), *u = orc_bptr(up, up_b, b, 3);
+        float z[3], x[3], y[3];
+        for (int k = 0; k < 3; k++) z[k] = is_look_at ? a[k] - e[k] : a[k];
+        orc_normalize3(z);
+        orc_cross3(u, z, x);
+        orc_normalize3(x);
+        orc_cross3(z, x, y);
+        orc_normalize3(y);
+        for (int k = 0; k < 3; k++) { rot[b * 9 + k] = x[k]; rot[b * 9 + 3 + k] = y[k]; rot[b * 9 + 6 + k] = z[k]; }
+    }
+}
+
+/* mode 1: look_at / look (rot = frame, eye_or_t = eye, optional perspective division by z and `width`);
+ * mode 3: projection (rot = R, eye_or_t = t, K, dist, orig).  vertices [vb,V,3] -> out [B,V,3]. */
+ORC_API void orc_camera_points(const float *vertices, int vb, int mode, int perspective, float width, float orig,
+                               const float *rot, int rot_b, const float *eye_or_t, int eye_b, const float *K, int K_b,
+                               const float *dist, int dist_b, float *out, int B, int V) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)B * V; i++) {
+        const int b = (int)(i / V), vi = (int)(i % V);
+        const float *v = vertices + ((size_t)(vb > 1 ? b : 0) * V + vi) * 3;
+        const float *r = orc_bptr(rot, rot_b, b, 9), *e = orc_bptr(eye_or_t, eye_b, b, 3);
+        float *o = out + 3 * i;
+        if (mode == 1) {
+            const float d0 = v[0] - e[0], d1 = v[1] - e[1], d2 = v[2] - e[2];
+            float x = d0 * r[0] + d1 * r[1] + d2 * r[2];
+            float y = d0 * r[3] + d1 * r[4] + d2 * r[5];
+            const float z = d0 * r[6] + d1 * r[7] + d2 * r[8];
+            if (perspective) { x = x / z / width; y = y / z / width; }
+            o[0] = x; o[1] = y; o[2] = z;
+        } else {
+            const float *Kb = orc_bptr(K, K_b, b, 9), *dc = orc_bptr(dist, dist_b, b, 5);
+            const float cx = v[0] * r[0] + v[1] * r[1] + v[2] * r[2] + e[0];
+            const float cy = v[0] * r[3] + v[1] * r[4] + v[2] * r[5] + e[1];
+            const float cz = v[0] * r[6] + v[1] * r[7] + v[2] * r[8] + e[2];
+            const float zz = cz + 1e-9f;
+            const float x_ = cx / zz, y_ = cy / zz;
+            const float k1 = dc[0], k2 = dc[1], p1 = dc[2], p2 = dc[3], k3 = dc[4];
+            const float rr = sqrtf(x_ * x_ + y_ * y_);
+            const float r2 = rr * rr, r4 = r2 * r2, r6 = r4 * r2;
+            const float radial = 1 + k1 * r2 + k2 * r4 + k3 * r6;
+            const float x__ = x_ * radial + 2 * p1 * x_ * y_ + p2 * (r2 + 2 * x_ * x_);
+            const float y__ = y_ * radial + p1 * (r2 + 2 * y_ * y_) + 2 * p2 * x_ * y_;
+            const float u = x__ * Kb[0] + y__ * Kb[1] + Kb[2];
+            float vv = x__ * Kb[3] + y__ * Kb[4] + Kb[5];
+            vv = orig - vv;
+            o[0] = 2 * (u - orig / 2.f) / orig;
+            o[1] = 2 * (vv - orig / 2.f) / orig;
+            o[2] = cz;
+        }
+    }
+}
+
+/* vertices[b, y*W+x] = rot_b (depth * inv_K (x, y, 1) - c) + c + trans_b, c = (0, 0, center_z) */
+ORC_API void orc_depth_to_vertices(const float *depth, const float *inv_K, int invK_b, const float *rot, const float *trans,
+                                   float center_z, float *out, int B, int H, int W) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)B * H * W; i++) {
+        const int b = (int)(i / ((long)H * W)), pix = (int)(i % ((long)H * W));
+        const float x = (float)(pix % W), y = (float)(pix / W);
+        const float *iK = orc_bptr(inv_K, invK_b, b, 9);
+        const float d = depth[i];
+        float p[3];
+        for (int k = 0; k < 3; k++) p[k] = (x * iK[3 * k] + y * iK[3 * k + 1] + iK[3 * k + 2]) * d;
+        p[2] -= center_z;
+        const float *R = rot + (size_t)b * 9, *t = trans + (size_t)b * 3;
+        out[3 * i + 0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];
+        out[3 * i + 1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
+        out[3 * i + 2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + center_z + t[2];
+    }
+}

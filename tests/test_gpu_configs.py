@@ -32,21 +32,25 @@ def test_gan2shape_step_warp_canon_depth_against_oracle():
     depth0 = torch.nn.functional.avg_pool2d(depth0[:, None], 5, 1, 2)[:, 0]
     view = torch.from_numpy(rng.uniform(-1, 1, (b, 6)).astype(np.float32)) * torch.tensor([0.3, 0.5, 0.2, 0.05, 0.05, 0.02])
     target = torch.full((b, 64, 64), 1.0)
+    # gan2shape learns the view (gan2shape.py:440-444).  Euler angles -> (R, t) goes through sin / cos, whose last bits
+    # differ between libm and the device; that map has its own tests (d3m_view_transform vs the reference's vectors and
+    # autograd), so here both sides start from the SAME (R, t) -- the oracle's grid warp computes in the HIP kernel's f32
+    # association -- and gradients are held to 1e-3 with respect to the depth map, R and t.
+    rot0, trans0 = O.get_transform_matrices(view)
     outs = []
     for r, dev, P, S in ((ro, "cpu", O.photometric_loss, O.smooth_loss), (rg, "cuda", photometric_loss, smooth_loss)):
         d = depth0.clone().to(dev).requires_grad_(True)
-        vw = view.clone().to(dev).requires_grad_(True)          # gan2shape learns the view (gan2shape.py:440-444)
-        r.set_transform_matrices(vw)
+        r.rot_mat = rot0.clone().to(dev).requires_grad_(True)
+        r.trans_xyz = trans0.clone().to(dev).requires_grad_(True)
         warped = r.warp_canon_depth(d)
         loss = P(warped[:, None], target.to(dev)[:, None]) + 0.01 * S(d)
         loss.backward()
-        outs.append((warped.detach().cpu(), float(loss.detach()), d.grad.cpu(), vw.grad.cpu()))
-    (w0, l0, g0, v0), (w1, l1, g1, v1) = outs
+        outs.append((warped.detach().cpu(), float(loss.detach()), d.grad.cpu(), r.rot_mat.grad.cpu(), r.trans_xyz.grad.cpu()))
+    (w0, l0, g0, r0, t0), (w1, l1, g1, r1, t1) = outs
     assert w0.shape == w1.shape == (b, 64, 64)
-    assert _rel_l2(w1, w0) < 2e-3
-    assert abs(l1 - l0) < 2e-3 * abs(l0)
-    assert _rel_l2(g1, g0) < 5e-2
-    assert _rel_l2(v1, v0) < 5e-2
+    rel_max = lambda a, b_: float((a - b_).abs().max() / b_.abs().max())
+    assert rel_max(w1, w0) < 1e-5 and abs(l1 - l0) < 1e-5 * abs(l0)
+    assert rel_max(g1, g0) < 1e-3 and rel_max(r1, r0) < 1e-3 and rel_max(t1, t0) < 1e-3
 
 
 def test_pt3d_demo_plumbing_silhouette_fit_decreases_loss():
@@ -100,8 +104,10 @@ def test_multiview_fit_gradients_against_oracle_and_graph_replay():
     lo = (O.photometric_loss(rgb, targets[0], mask=mask) + ((alpha - targets[2]) ** 2).sum() / (64 * 64) +
           O.photometric_loss(depth[:, None], targets[1][:, None], mask=mask))
     lo.backward()
-    assert abs(float(loss) - float(lo)) < 5e-3 * abs(float(lo))
-    assert _rel_l2(gv.cpu(), vt.grad) < 6e-2 and _rel_l2(gt.cpu(), tt.grad) < 2e-2
+    # (the oracle's cameras compute in the HIP kernels' f32 association: same coverage, north_star's 1e-3 on gradients)
+    rel_max = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5 * abs(float(lo.detach()))
+    assert rel_max(gv.cpu(), vt.grad) < 1e-3 and rel_max(gt.cpu(), tt.grad) < 1e-3
     fit.capture_graph()
     assert fit.graph_captured
     for _ in range(2):

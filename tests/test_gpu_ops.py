@@ -23,7 +23,10 @@ def _dev(a):
 
 
 def _grad_close(got, ref):
-    scale = max(1.0, float(np.abs(ref).max()))
+    """north_star: 1e-3 on backward gradients -- of the tensor's own scale (its largest entry), no absolute floor"""
+    scale = float(np.abs(ref).max())
+    if scale == 0.0:
+        return not np.any(got)
     return np.abs(got - ref).max() <= GRAD_RTOL * scale
 
 
@@ -221,7 +224,7 @@ def test_backward_operators_differential_fuzz(seed):
     ops.backward_depth_map(fd, dm, fi, _dev(m["face_inv_map"]), wm, _dev(g_depth), gf, S)
     assert np.isfinite(gf_ref).all() == np.isfinite(gf.cpu().numpy()).all()
     ok = np.isfinite(gf_ref)
-    scale = max(1.0, float(np.abs(gf_ref[ok]).max())) if ok.any() else 1.0
+    scale = float(np.abs(gf_ref[ok]).max()) if ok.any() else 0.0
     assert np.abs(gf.cpu().numpy()[ok] - gf_ref[ok]).max() <= GRAD_RTOL * scale, (B, S, Fn, size, mode, gmode)
     assert _grad_close(gt.cpu().numpy(), gt_ref)
     # and the forward maps of the same scene, bit for bit

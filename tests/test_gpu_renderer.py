@@ -145,6 +145,17 @@ def _rel_l2(a, b):
     return float(torch.linalg.norm(a - b) / (torch.linalg.norm(b) + 1e-12))
 
 
+def _rel_max(a, b):
+    """largest deviation relative to the reference tensor's largest entry (north_star: 1e-3 on backward gradients)"""
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+# The oracle's cameras produce their forward VALUES in the same f32 association as the HIP kernels (oracle/nr_oracle.py
+# "EXACT"), so both rasterize bit-identical screen-space vertices: silhouettes must be EQUAL, images agree to rounding of
+# the shading arithmetic, gradients to north_star's 1e-3.
+IMG_TOL, GRAD_TOL = 2e-6, 1e-3
+
+
 @pytest.mark.parametrize("camera", ["look_at", "look", "projection"])
 @pytest.mark.parametrize("aa", [False, True])
 def test_renderer_end_to_end_against_oracle(camera, aa):
@@ -180,13 +191,11 @@ def test_renderer_end_to_end_against_oracle(camera, aa):
         return [x.detach().cpu() for x in (rgb, depth, alpha, loss, vv.grad, tt.grad)]
 
     ref, got = run(ro, "cpu"), run(rg, "cuda")
-    # camera arithmetic differs in the last bits between torch-CPU and the HIP kernel, which may flip a
-    # few edge pixels: compare image-level agreement, then losses and gradients in norm.
-    assert (ref[2] != got[2]).float().mean() < 2e-3
-    assert _rel_l2(got[0], ref[0]) < 1e-2 and _rel_l2(got[1], ref[1]) < 1e-2
-    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 2e-3
-    assert _rel_l2(got[5], ref[5]) < 1e-2
-    assert _rel_l2(got[4], ref[4]) < 5e-2
+    assert torch.equal(ref[2], got[2])
+    assert _rel_max(got[0], ref[0]) < IMG_TOL and _rel_max(got[1], ref[1]) < IMG_TOL
+    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 1e-5
+    assert _rel_max(got[5], ref[5]) < GRAD_TOL
+    assert _rel_max(got[4], ref[4]) < GRAD_TOL
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -230,11 +239,11 @@ def test_renderer_differential_fuzz(seed):
         return [x.detach().cpu() for x in (rgb, depth, alpha, loss, gv, gt)]
 
     ref, got = run(O, "cpu", False), run(nr, "cuda", shared)
-    assert (ref[2] != got[2]).float().mean() < 4e-3
-    assert _rel_l2(got[0], ref[0]) < 2e-2 and _rel_l2(got[1], ref[1]) < 2e-2
-    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 4e-3
-    assert _rel_l2(got[5], ref[5]) < 2e-2
-    assert _rel_l2(got[4], ref[4]) < 6e-2
+    assert torch.equal(ref[2], got[2])
+    assert _rel_max(got[0], ref[0]) < IMG_TOL and _rel_max(got[1], ref[1]) < IMG_TOL
+    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 1e-5
+    assert _rel_max(got[5], ref[5]) < GRAD_TOL
+    assert _rel_max(got[4], ref[4]) < GRAD_TOL
 
 
 @pytest.mark.parametrize("mode", ["silhouettes", "depth", "rgb"])
@@ -251,8 +260,8 @@ def test_single_output_modes_against_oracle(mode):
         img.clamp(max=5.0).sum().backward()
         outs.append((img.detach().cpu(), vv.grad.cpu()))
     assert outs[0][0].shape == outs[1][0].shape
-    assert _rel_l2(outs[1][0].clamp(max=5.0), outs[0][0].clamp(max=5.0)) < 1e-2
-    assert _rel_l2(outs[1][1], outs[0][1]) < 5e-2
+    assert _rel_max(outs[1][0].clamp(max=5.0), outs[0][0].clamp(max=5.0)) < IMG_TOL
+    assert _rel_max(outs[1][1], outs[0][1]) < GRAD_TOL
 
 
 def test_rasterize_module_matches_reference_layout():
