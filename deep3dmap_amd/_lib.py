@@ -62,14 +62,14 @@ _SIGNATURES = {
     "d3m_lighting_backward": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),
     "d3m_view_transform": (_I, [_P, _I, _P, _P, _I, _P]),
     "d3m_view_transform_backward": (_I, [_P, _I, _P, _P, _P, _I, _P]),
-    "d3m_depth_to_vertices": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _P]),
-    "d3m_depth_to_vertices_backward": (_I, [_P, _P, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_grid_warp": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _P, _P, _I, _I, _I, _P]),
     "d3m_grid_warp_backward": (_I, [_P, _P, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_depth_normals": (_I, [_P, _P, _I, _P, _I, _I, _I, _P]),
     "d3m_depth_normals_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "d3m_textures_from_im": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "d3m_textures_from_im_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "d3m_uv_unwrap": (_I, [_P] * 11 + [_I] * 7 + [_P]),
+    "d3m_uv_unwrap_backward": (_I, [_P] * 12 + [_I] * 7 + [_P]),
     "d3m_face_light": (_I, [_P, _I, _P, _I, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_face_light_backward": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_forward_texture_sampling_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
@@ -146,7 +146,11 @@ def ptr(t):
 
 
 def require_device(*tensors, names=None):
-    """The reference's CHECK_INPUT (rasterize_cuda.cpp:66-68): CUDA + contiguous, else RuntimeError."""
+    """The reference's CHECK_INPUT (rasterize_cuda.cpp:66-68): CUDA + contiguous, else RuntimeError.
+    Dtypes: the reference's launchers dispatch on faces' type (rasterize_cuda_kernel.cu:614, float and double) and then
+    read every map with .data<scalar_t>() / .data<int32_t>(), which raises for a tensor of another type; its Python side
+    only ever allocates float32 / int32 maps (rasterize.py:50-69), so scalar_t = double cannot get past the first map.
+    This library instantiates scalar_t = float only and raises the same kind of error up front."""
     for i, t in enumerate(tensors):
         if t is None:
             continue
@@ -155,6 +159,10 @@ def require_device(*tensors, names=None):
             raise RuntimeError(f"{n} must be a CUDA tensor")
         if not t.is_contiguous():
             raise RuntimeError(f"{n} must be contiguous")
+        if t.is_floating_point() and t.dtype != torch.float32:
+            raise RuntimeError(f"{n}: expected scalar type Float but found {t.dtype}; "
+                               "libd3m_raster is built for float32 (the reference's float64 dispatch, "
+                               "rasterize_cuda_kernel.cu:614, is not reachable from its own Python either)")
 
 
 def kernel_timing(enable):

@@ -62,15 +62,14 @@ def load_config(path):
 def build_renderer(cfg):
     """The renderer adapter a framework of `cfg.model.type` constructs, with the same arguments:
     Gan2Shape -> NrRenderer(model_cfgs, image_size) (models/frameworks/gan2shape.py:99).
-    imgs2mesh uses Pt3dRenderer (pytorch3d; third party, out of scope: see DESIGN.md) -- for that config
-    the plumbing-level stand-in `MeshViewRenderer` is returned."""
+    imgs2mesh -> Pt3dRenderer(device, texture_size, lookview=(0,0,1)) (models/frameworks/imgs2mesh.py:62)."""
     model_cfgs = cfg["model"]["model_cfgs"]
     kind = cfg["model"].get("type")
     if kind == "Gan2Shape":
         from .core.renderer_nr import NrRenderer
         return NrRenderer(model_cfgs, model_cfgs.get("image_size", 64))
     if kind == "imgs2mesh":
-        from .core.mesh_view import MeshViewRenderer
-        return MeshViewRenderer(image_size=model_cfgs.get("image_size", 256),
-                                texture_size=model_cfgs.get("texture_size", 256))
+        import torch
+        from .core.renderer_pt3d import Pt3dRenderer
+        return Pt3dRenderer("cuda", model_cfgs.get("texture_size", 256), lookview=torch.tensor([0., 0., 1.]))
     raise ValueError(f"no renderer adapter for model type {kind!r}")

@@ -351,73 +351,6 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_part) {
     return r;
 }
 
-// ---- NrRenderer's depth -> mesh vertices (deep3dmap/core/renderer/renderer_nr.py:64-80,95-100) ------------
-// vertex(b, y, x) = R_b * (d * Kinv * (x, y, 1) - c) + c + t_b,   c = (0, 0, rot_center_depth)
-// i.e. depth_to_3d_grid -> rotate_pts -> translate_pts in one pass (the reference runs ~10 eager ops).
-__global__ void __launch_bounds__(256) k_depth_to_vertices(const float* __restrict__ depth, const float* __restrict__ inv_K,
-                                                          int invK_b, const float* __restrict__ rot,
-                                                          const float* __restrict__ trans, float center_z,
-                                                          float* __restrict__ out, int B, int H, int W) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * H * W) return;
-    const int b = (int)(i / ((long)H * W)), pix = (int)(i % ((long)H * W));
-    const float x = (float)(pix % W), y = (float)(pix / W);
-    const float* iK = cam_ptr(inv_K, invK_b, b, 9);
-    const float d = depth[i];
-    float p[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) p[k] = (x * iK[3 * k] + y * iK[3 * k + 1] + iK[3 * k + 2]) * d;   // renderer_nr.py:79
-    p[2] -= center_z;                                                                          // :66
-    const float* R = rot + (size_t)b * 9;
-    const float* t = trans + (size_t)b * 3;
-    out[3 * i + 0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];                            // :67-68, :71
-    out[3 * i + 1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
-    out[3 * i + 2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + center_z + t[2];
-}
-
-// adjoint: one workgroup per batch entry; grad_depth per pixel, grad_rot [B,3,3] and grad_trans [B,3] by a
-// workgroup reduction over the H*W vertices.
-__global__ void __launch_bounds__(256) k_depth_to_vertices_backward(const float* __restrict__ depth,
-                                                                   const float* __restrict__ inv_K, int invK_b,
-                                                                   const float* __restrict__ rot, float center_z,
-                                                                   const float* __restrict__ g_out,
-                                                                   float* __restrict__ g_depth, float* __restrict__ g_rot,
-                                                                   float* __restrict__ g_trans, int H, int W) {
-    __shared__ float s_part[4];
-    const int b = blockIdx.x;
-    const long base = (long)b * H * W;
-    const float* iK = cam_ptr(inv_K, invK_b, b, 9);
-    const float* R = rot + (size_t)b * 9;
-    float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int pix = threadIdx.x; pix < H * W; pix += 256) {
-        const float x = (float)(pix % W), y = (float)(pix / W);
-        const float d = depth[base + pix];
-        float ray[3], p[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { ray[k] = x * iK[3 * k] + y * iK[3 * k + 1] + iK[3 * k + 2]; p[k] = ray[k] * d; }
-        p[2] -= center_z;
-        const float g[3] = {g_out[3 * (base + pix)], g_out[3 * (base + pix) + 1], g_out[3 * (base + pix) + 2]};
-        float gp[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) gp[j] = g[0] * R[j] + g[1] * R[3 + j] + g[2] * R[6 + j];
-        if (g_depth) g_depth[base + pix] = gp[0] * ray[0] + gp[1] * ray[1] + gp[2] * ray[2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) acc[3 * k + j] += g[k] * p[j];
-            acc[9 + k] += g[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const float v = block_sum_256(acc[k], s_part);
-        if (threadIdx.x == 0) {
-            if (k < 9) { if (g_rot) g_rot[b * 9 + k] = v; }
-            else if (g_trans) g_trans[b * 3 + (k - 9)] = v;
-        }
-    }
-}
-
 // ---- NrRenderer's depth -> warped pixel grid (renderer_nr.py:74-114, 141-158) ----------------------------------
 // One pass for every variant of "depth_to_3d_grid, then rigid transforms, then maybe grid_3d_to_2d":
 //   P(b, y, x) = depth * Kinv * (x, y, 1)                      (renderer_nr.py:74-80)

@@ -10,6 +10,7 @@
 #include "d3m_aux.h"
 #include "d3m_textures.h"
 #include "d3m_mesh.h"
+#include "d3m_uv.h"
 #include "d3m_backward.h"
 #include "d3m_device.h"
 #include "d3m_edge_grad.h"
@@ -545,29 +546,6 @@ D3M_EXPORT int d3m_view_transform_backward(const float* view, int num_components
     return check_launch();
 }
 
-D3M_EXPORT int d3m_depth_to_vertices(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
-                                     const float* trans, float rot_center_depth, float* vertices, int batch_size,
-                                     int height, int width, d3m_stream_t stream) {
-    if (!depth || !inv_K || !rot || !trans || !vertices || batch_size <= 0 || height <= 0 || width <= 0)
-        return D3M_ERR_INVALID;
-    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
-    const long n = (long)batch_size * height * width;
-    LAUNCH("k_depth_to_vertices", k_depth_to_vertices, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, depth, inv_K,
-           inv_K_batch, rot, trans, rot_center_depth, vertices, batch_size, height, width);
-    return check_launch();
-}
-
-D3M_EXPORT int d3m_depth_to_vertices_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
-                                              float rot_center_depth, const float* grad_vertices, float* grad_depth,
-                                              float* grad_rot, float* grad_trans, int batch_size, int height,
-                                              int width, d3m_stream_t stream) {
-    if (!depth || !inv_K || !rot || !grad_vertices || batch_size <= 0 || height <= 0 || width <= 0) return D3M_ERR_INVALID;
-    if (inv_K_batch != 1 && inv_K_batch != batch_size) return D3M_ERR_INVALID;
-    LAUNCH("k_depth_to_vertices_backward", k_depth_to_vertices_backward, dim3(batch_size), dim3(256), (hipStream_t)stream,
-           depth, inv_K, inv_K_batch, rot, rot_center_depth, grad_vertices, grad_depth, grad_rot, grad_trans, height, width);
-    return check_launch();
-}
-
 static int to_grid_warp(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
                         float rot_center_depth, const float* K, int K_batch, const int* crop, int B, int H, int W, GridWarp& g) {
     if (!depth || !inv_K || !rot || !trans || B <= 0 || H <= 0 || W <= 0) return D3M_ERR_INVALID;
@@ -643,6 +621,47 @@ D3M_EXPORT int d3m_textures_from_im_backward(const float* grad_textures, float* 
     LAUNCH("k_textures_from_im_backward", k_textures_from_im_backward,
            dim3(blocks_for((long)batch_size * channels * height * width, 256)), dim3(256), (hipStream_t)stream, grad_textures,
            grad_im, batch_size, channels, height, width, texture_size);
+    return check_launch();
+}
+
+// ---- Pt3dRenderer.sample's per-pixel pass (d3m_uv.h) ------------------------------------------------------------------
+static int to_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
+                        const float* vnormals, const float* uvs, const float* imgs, const int32_t* used, const float* light,
+                        int B, int T, int F, int V, int C, int H, int W, UvUnwrap& a) {
+    if (!face_index_map || !weight_map || !tri || !verts || !vnormals || !uvs || !imgs || !used || !light || B <= 0 ||
+        T <= 0 || F <= 0 || V <= 0 || C <= 0 || C > 3 || H <= 0 || W <= 0)
+        return D3M_ERR_INVALID;
+    a = UvUnwrap{face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, {light[0], light[1], light[2]},
+                 B, T, F, V, C, H, W};
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
+                             const float* vnormals, const float* uvs, const float* imgs, const int32_t* used,
+                             const float* light, float* out_img, float* out_mask, int batch_size, int texture_size,
+                             int num_tri, int num_vertices, int channels, int height, int width, d3m_stream_t stream) {
+    UvUnwrap a;
+    if (int rc = to_uv_unwrap(face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, light, batch_size,
+                              texture_size, num_tri, num_vertices, channels, height, width, a))
+        return rc;
+    if (!out_img || !out_mask) return D3M_ERR_INVALID;
+    LAUNCH("k_uv_unwrap", k_uv_unwrap, dim3(blocks_for((long)batch_size * texture_size * texture_size, 256)), dim3(256),
+           (hipStream_t)stream, a, out_img, out_mask);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_uv_unwrap_backward(const int32_t* face_index_map, const float* weight_map, const int32_t* tri,
+                                      const float* verts, const float* vnormals, const float* uvs, const float* imgs,
+                                      const int32_t* used, const float* light, const float* grad_img, float* grad_imgs,
+                                      float* grad_uvs, int batch_size, int texture_size, int num_tri, int num_vertices,
+                                      int channels, int height, int width, d3m_stream_t stream) {
+    UvUnwrap a;
+    if (int rc = to_uv_unwrap(face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, light, batch_size,
+                              texture_size, num_tri, num_vertices, channels, height, width, a))
+        return rc;
+    if (!grad_img) return D3M_ERR_INVALID;
+    LAUNCH("k_uv_unwrap_backward", k_uv_unwrap_backward, dim3(blocks_for((long)batch_size * texture_size * texture_size, 256)),
+           dim3(256), (hipStream_t)stream, a, grad_img, grad_imgs, grad_uvs);
     return check_launch();
 }
 

@@ -232,8 +232,12 @@ def _side_stream(device, which=0):
     return _side_streams[key]
 
 
+MAX_VIEW_GROUPS = 3       # every group brings two streams; a captured step with ten concurrent branches made hipGraphLaunch
+                          # segfault on ROCm 7.2 (2 and 3 groups replay fine), and more groups were slower anyway
+
+
 def _group_bounds(B, groups):
-    g = max(1, min(int(groups), B))
+    g = max(1, min(int(groups), B, MAX_VIEW_GROUPS))
     return [(B * k // g, B * (k + 1) // g) for k in range(g)]
 
 
@@ -378,7 +382,9 @@ class _RasterizeLit(torch.autograd.Function):
                 if fit_state is not None:
                     # with records the backward pass does not read the objective's value: its one-workgroup last step
                     # (which would wait for a free slot behind the plan's kernels) goes to the end of the side branch
-                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None, defer_finish=vis is not None)
+                    # (one pipeline only: a second cross-stream edge into a group's side branch makes graph REPLAY
+                    #  segfault on ROCm 7.2, like the fork of a fork above)
+                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None, defer_finish=vis is not None and G == 1)
                 # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
                 _lib.check(L.d3m_render_lit_epilogue(
                     _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -387,7 +393,7 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
                     int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
                     ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
-                if fit_c is not None and vis is not None:
+                if fit_c is not None and vis is not None and G == 1:
                     auxs[k].wait_stream(mains[k])
                     with torch.cuda.stream(auxs[k]):
                         _lib.check(L.d3m_fit_finish(ctypes.byref(fit_c), Bg, S, _lib.stream_ptr()), "d3m_fit_finish")

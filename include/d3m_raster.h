@@ -239,21 +239,8 @@ int d3m_view_transform(const float* view, int num_components, float* rot, float*
                        d3m_stream_t stream);
 int d3m_view_transform_backward(const float* view, int num_components, const float* grad_rot, const float* grad_trans,
                                 float* grad_view, int batch_size, d3m_stream_t stream);
-/* NrRenderer's depth map -> mesh vertices in one pass (deep3dmap/core/renderer/renderer_nr.py:64-80,95-100:
- * depth_to_3d_grid -> rotate_pts about (0,0,rot_center_depth) -> translate_pts):
- *   vertices[b, y*W+x, :] = R_b (depth[b,y,x] * inv_K (x, y, 1)^T - c) + c + t_b
- * depth [B,H,W], inv_K [1|B,3,3], rot [B,3,3], trans [B,3] -> vertices [B,H*W,3]. */
-int d3m_depth_to_vertices(const float* depth, const float* inv_K, int inv_K_batch, const float* rot, const float* trans,
-                          float rot_center_depth, float* vertices, int batch_size, int height, int width,
-                          d3m_stream_t stream);
-/* adjoint: grad_depth [B,H,W], grad_rot [B,3,3], grad_trans [B,3] are WRITTEN (each may be NULL). */
-int d3m_depth_to_vertices_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* rot,
-                                   float rot_center_depth, const float* grad_vertices, float* grad_depth,
-                                   float* grad_rot, float* grad_trans, int batch_size, int height, int width,
-                                   d3m_stream_t stream);
-
-/* The general form (deep3dmap/core/renderer/renderer_nr.py:74-114,141-158): every "depth_to_3d_grid, then rigid
- * transforms, then maybe grid_3d_to_2d" of NrRenderer in one pass.
+/* NrRenderer's depth map -> warped pixel grid (deep3dmap/core/renderer/renderer_nr.py:74-114,141-158): every
+ * "depth_to_3d_grid, then rigid transforms, then maybe grid_3d_to_2d" of the class in one pass.
  *   P = depth * inv_K (x, y, 1)^T;   Q = rot_b (P - c) + c + trans_b,  c = (0, 0, rot_center_depth)
  *   K == NULL: out [B,H*W,3] = Q;    K [1|B,3,3]: out [B,H,W,2] = ((K (Q / Q.z)).xy / (W-1, H-1)) * 2 - 1, the sampling
  *   grid of F.grid_sample (renderer_nr.py:82-88).
@@ -279,6 +266,24 @@ int d3m_textures_from_im(const float* im, float* textures, int batch_size, int c
                          int texture_size, d3m_stream_t stream);
 int d3m_textures_from_im_backward(const float* grad_textures, float* grad_im, int batch_size, int channels, int height,
                                   int width, int texture_size, d3m_stream_t stream);
+
+/* Pt3dRenderer.sample's per-pixel pass (deep3dmap/core/renderer/renderer_pt3d.py:75-97; the reference runs it through
+ * pytorch3d 0.6.1's TexturesUV + SoftPhongShader): for the template mesh rasterized in UV space -- face_index_map /
+ * weight_map [B,T,T(,3)] of d3m_forward_face_index_map on its fill_back faces -- every covered pixel samples
+ * imgs [B,C<=3,H,W] bilinearly (align_corners, border padding, v up) at the barycentric mix of its face's per-vertex
+ * image coordinates uvs [B,V,2] and multiplies by the diffuse term of a point light at `light` against the interpolated
+ * vertex normals vnormals [V,3] at the interpolated position verts [V,3].  out_img / out_mask [B,T,T,4] (row 0 = top):
+ * rgb = texel * diffuse / diffuse, alpha = coverage; zeros where nothing covers or used[b] == 0.
+ * The adjoint ADDS into grad_imgs [B,C,H,W] and grad_uvs [B,V,2] (either may be NULL; caller zeroes). */
+int d3m_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
+                  const float* vnormals, const float* uvs, const float* imgs, const int32_t* used, const float* light,
+                  float* out_img, float* out_mask, int batch_size, int texture_size, int num_tri, int num_vertices,
+                  int channels, int height, int width, d3m_stream_t stream);
+int d3m_uv_unwrap_backward(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
+                           const float* vnormals, const float* uvs, const float* imgs, const int32_t* used,
+                           const float* light, const float* grad_img, float* grad_imgs, float* grad_uvs, int batch_size,
+                           int texture_size, int num_tri, int num_vertices, int channels, int height, int width,
+                           d3m_stream_t stream);
 
 /* --- lighting and fill_back applied on the fly (instead of renderer.py:155-167,203-215 materialising
  * cat(textures, textures.permute(0,1,4,3,2,5)) * light per view) ---------------------------------------

@@ -60,7 +60,7 @@ def test_pt3d_demo_plumbing_silhouette_fit_decreases_loss():
     from deep3dmap_amd.config import build_renderer, load_config
     cfg = load_config(os.path.join(ROOT, "tests", "fixtures", "pt3d_like.py"))
     mv = build_renderer(cfg)
-    assert mv.image_size == 64
+    assert mv.texture_size == 64
     v, f = synthetic.icosphere(1)
     faces = torch.from_numpy(f).cuda()
     target_v = torch.from_numpy(v * np.array([1.0, 0.7, 1.0], np.float32) * 0.8).cuda()
@@ -321,7 +321,7 @@ def test_graph_capture_with_retained_autograd_state():
         assert _rel_l2(depth.grad, gd0) < 1e-4 and _rel_l2(view.grad, gv0) < 1e-4
 
 
-@pytest.mark.parametrize("groups", [2, 3, 5])
+@pytest.mark.parametrize("groups", [2, 3])
 def test_view_groups_equal_one_pipeline(groups):
     """The lit render node run as concurrent view groups (rasterize._RasterizeLit, "VIEW GROUPS"): the fused fit
     objective and its gradients (the groups are shards of it), and plain render() with per-view textures -- images

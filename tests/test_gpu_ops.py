@@ -233,3 +233,14 @@ def test_backward_operators_differential_fuzz(seed):
     ops.forward_face_index_map(fd, fi2, wm2, dm2, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), S, 0.5, 3.5, 1, 1, 0)
     assert np.array_equal(fi2.cpu().numpy(), m["face_index_map"]) and np.array_equal(dm2.cpu().numpy(), m["depth_map"])
     assert np.array_equal(wm2.cpu().numpy(), m["weight_map"])
+
+
+def test_ops_reject_float64_like_the_reference_extension():
+    """rasterize_cuda_kernel.cu:614 dispatches float and double, but every map is read with .data<scalar_t>(): a double
+    `faces` with the float32 maps rasterize.py:50-69 allocates raises there.  Same error class here, before any launch."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    f = torch.zeros(1, 2, 3, 3, device="cuda", dtype=torch.float64)
+    fi = torch.zeros(1, 8, 8, device="cuda", dtype=torch.int32)
+    m = torch.zeros(1, 8, 8, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="Float"):
+        ops.forward_face_index_map(f, fi, m, m[..., 0].contiguous(), m, m, 8, 0.1, 100.0, 0, 1, 1)
