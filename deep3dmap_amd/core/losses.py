@@ -11,6 +11,13 @@ EPS = 1e-7
 class _Photometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, im1, im2, mask, conf_sigma):
+        # the reference's loss is plain tensor algebra: gradients would also reach im2, mask and conf_sigma.  This
+        # kernel differentiates with respect to im1 only -- say so instead of silently dropping a gradient
+        for name, t, need in (("im2", im2, ctx.needs_input_grad[1]), ("mask", mask, ctx.needs_input_grad[2]),
+                              ("conf_sigma", conf_sigma, ctx.needs_input_grad[3])):
+            if t is not None and need:
+                raise NotImplementedError(f"photometric_loss: no gradient with respect to {name} (detach it, or compose "
+                                          "the loss from tensor ops)")
         a, b = f32c(im1), f32c(im2)
         B, C, H, W = a.shape
         m = f32c(mask) if mask is not None else None
@@ -46,6 +53,8 @@ def photometric_loss(im1, im2, mask=None, conf_sigma=None):
 class _SumSquaredError(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("silhouette_loss: no gradient with respect to the reference image (detach it)")
         a, b = f32c(a), f32c(b)
         loss = torch.empty((), dtype=torch.float32, device=a.device)
         grad = torch.empty_like(a) if ctx.needs_input_grad[0] else None
@@ -70,6 +79,8 @@ def silhouette_loss(image, image_ref):
 class _MultiViewFitLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask, mask_sum=None):
+        if any(ctx.needs_input_grad[3:]):
+            raise NotImplementedError("multiview_fit_loss: targets, mask and mask_sum are constants (detach them)")
         t = [f32c(x) for x in (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)]
         mask_sum = f32c(mask_sum).reshape(1) if mask_sum is not None else None
         B, C, H, W = t[0].shape

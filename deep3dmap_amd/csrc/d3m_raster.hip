@@ -132,6 +132,9 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
     if (ws_bytes < L.fixed_bytes + (size_t)B * F * 4) return D3M_ERR_WORKSPACE;
     long kcap = (long)((ws_bytes - L.fixed_bytes) / ((size_t)B * F * 4));
     if (kcap > KCAP_MAX) kcap = KCAP_MAX;
+    // tile_offset / the cursors index `pairs` with an int
+    while (kcap > 1 && kcap * (long)B * F >= (1l << 31)) kcap--;
+    if ((long)B * F >= (1l << 31)) return D3M_ERR_INVALID;
     char* p = (char*)ws;
     bb.B = B; bb.F = F; bb.S = S;
     bb.tiles_x = (S + TILE - 1) / TILE;

@@ -122,7 +122,7 @@ class MultiViewFit:
         """The objective of the current mesh against the targets, evaluated inside the rendering node when the renderer
         allows it (no images, no image gradients in memory); otherwise render() + loss()."""
         r = self.renderer
-        if self.objective_in_renderer and r.lighting_on_the_fly and not r.anti_aliasing:
+        if self.objective_in_renderer and r._on_the_fly() and not r.anti_aliasing:
             rgb_t, depth_t, alpha_t = self.targets
             return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
                                      (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum))

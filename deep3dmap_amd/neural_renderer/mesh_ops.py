@@ -96,10 +96,39 @@ class _Lighting(torch.autograd.Function):
         return gf, gt, None, None, None, None, None
 
 
+def per_batch_light(*params):
+    """True when a light colour / direction is given per batch entry ([bs,3], NR/lighting.py:25-30) rather than once."""
+    for x in params:
+        n = x.numel() if torch.is_tensor(x) else np.asarray(x).size
+        if n != 3:
+            return True
+    return False
+
+
+def _light_rows(x, bs, device):
+    t = x.to(device=device, dtype=torch.float32) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, np.float32), device=device)
+    return t.reshape(-1, 3).expand(bs, 3)
+
+
+def _lighting_per_batch(faces, textures, ia, idr, ca, cd, direction):
+    """The same light with one colour / direction per batch entry: a device-side tensor composition (a few small
+    launches; the fused kernel takes one light for the whole batch)."""
+    bs = faces.shape[0]
+    ca, cd, direction = (_light_rows(x, bs, faces.device) for x in (ca, cd, direction))
+    normal = torch.linalg.cross(faces[:, :, 0] - faces[:, :, 1], faces[:, :, 2] - faces[:, :, 1], dim=2)
+    normal = normal / normal.norm(dim=2, keepdim=True).clamp_min(1e-5)                      # F.normalize(eps=1e-5)
+    cosine = (normal * direction[:, None, :]).sum(2).clamp_min(0)                            # relu(n . dir)
+    light = ia * ca[:, None, :] + idr * cd[:, None, :] * cosine[:, :, None]
+    return textures * light[:, :, None, None, None, :]
+
+
 def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1),
              color_directional=(1, 1, 1), direction=(0, 1, 0)):
     """Per-face ambient + directional light applied to the texture cubes (NR/lighting.py:5-57).
     faces [bs,nf,3,3] (world space), textures [bs,nf,ts,ts,ts,3]; returns the lit textures (the reference
-    multiplies in place and returns the same tensor)."""
+    multiplies in place and returns the same tensor).  Colours / direction: one 3-vector, or [bs,3]."""
+    if per_batch_light(color_ambient, color_directional, direction):
+        return _lighting_per_batch(faces, textures, intensity_ambient, intensity_directional, color_ambient,
+                                   color_directional, direction)
     return _Lighting.apply(faces, textures, intensity_ambient, intensity_directional, color_ambient,
                            color_directional, direction)

@@ -129,8 +129,14 @@ class Renderer(nn.Module):
         return (self.light_intensity_ambient, self.light_intensity_directional, self.light_color_ambient,
                 self.light_color_directional, self.light_direction)
 
+    def _on_the_fly(self):
+        # one light for the whole batch goes through the fused sampler; per-batch colours / directions
+        # (NR/lighting.py:25-30) through the materialised sequence
+        return self.lighting_on_the_fly and not mesh_ops.per_batch_light(
+            self.light_color_ambient, self.light_color_directional, self.light_direction)
+
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        if self.lighting_on_the_fly:
+        if self._on_the_fly():
             sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             return rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                  self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
@@ -144,15 +150,15 @@ class Renderer(nn.Module):
                         orig_size=None):
         """The multi-view fit objective of render()'s images against `targets` = (rgb, depth, alpha, mask), evaluated
         inside the rendering node (rasterize_lit_fit); needs lighting_on_the_fly and no anti-aliasing."""
-        if not self.lighting_on_the_fly or self.anti_aliasing:
-            raise ValueError("render_fit_loss needs lighting_on_the_fly and anti_aliasing=False")
+        if not self._on_the_fly() or self.anti_aliasing:
+            raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch) and anti_aliasing=False")
         sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
                                  view_groups=self.view_groups, defer_plan_join=self.defer_plan_join)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        if self.lighting_on_the_fly:
+        if self._on_the_fly():
             sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,

@@ -571,3 +571,60 @@ def test_obj_round_trip_tetrahedron(tmp_path):
     assert sil.shape == (1, 32, 32) and 0.01 < float(sil.mean()) < 0.9
     with pytest.raises(Exception, match="Failed to load textures"):      # no mtllib line (load_obj.py:150-151)
         nr.load_obj(str(path), load_texture=True)
+
+
+def test_fit_objective_with_frozen_textures_and_ambient_light_only():
+    """render_fit_loss when neither the textures nor the light need a gradient (textures frozen, directional intensity
+    0): the depth term then goes through d3m_backward_depth_map on its own, whose gradient map must carry the
+    objective's 1 / sum(mask) like every other reader -- against the materialised objective on the same renderer."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(16)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    res = []
+    for inside in (True, False):
+        fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=64, optimise_textures=False,
+                           objective_in_renderer=inside)
+        fit.renderer.light_intensity_directional = 0.0
+        fit.renderer.light_intensity_ambient = 1.0
+        fit.set_targets_from(synthetic.perturb(v, 0.03))
+        loss, gv, gt = fit.step()
+        assert gt is None
+        res.append((float(loss), gv.clone()))
+    (la, ga), (lb, gb) = res
+    assert abs(la - lb) <= 1e-5 * abs(lb) and float(gb.abs().max()) > 0
+    assert _rel_max(ga, gb) < 1e-4
+
+
+def test_per_batch_lights_fall_back_to_the_materialised_sequence():
+    """NR/lighting.py:25-30 accepts one colour / direction per batch entry; the fused sampler takes one light, so such
+    renderers go through cat -> lighting -> rasterize, against the oracle."""
+    nr = _nr()
+    from oracle import nr_oracle as O
+    v, tri, tex = _scene()
+    ca = torch.tensor([[1.0, 0.9, 0.8], [0.6, 0.7, 1.0]])
+    dr = torch.tensor([[0.0, 1.0, 0.0], [0.5, 0.5, -0.7]])
+    outs = []
+    for mod, dev in ((O, "cpu"), (nr, "cuda")):
+        r = mod.Renderer(camera_mode="look_at", image_size=40, anti_aliasing=False, light_color_ambient=ca.to(dev),
+                         light_direction=dr.to(dev))
+        vv = v.clone().to(dev).requires_grad_(True)
+        rgb = r(vv, tri.to(dev), tex.to(dev), mode="rgb")
+        rgb.square().sum().backward()
+        outs.append((rgb.detach().cpu(), vv.grad.cpu()))
+    assert _rel_max(outs[1][0], outs[0][0]) < IMG_TOL * 5 and _rel_max(outs[1][1], outs[0][1]) < GRAD_TOL
+
+
+def test_losses_refuse_gradients_they_do_not_compute():
+    from deep3dmap_amd.core import photometric_loss, silhouette_loss
+    a = torch.rand(1, 3, 8, 8, device="cuda", requires_grad=True)
+    b = torch.rand(1, 3, 8, 8, device="cuda", requires_grad=True)
+    sig = torch.rand(1, 1, 8, 8, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        photometric_loss(a, b)
+    with pytest.raises(NotImplementedError):
+        photometric_loss(a, b.detach(), conf_sigma=sig)
+    with pytest.raises(NotImplementedError):
+        silhouette_loss(a[:, 0], b[:, 0])
+    photometric_loss(a, b.detach(), conf_sigma=sig.detach()).backward()
+    assert a.grad is not None
