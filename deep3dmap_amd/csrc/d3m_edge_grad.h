@@ -46,7 +46,7 @@ constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are w
 #define D3M_EG_LINE_WAVES 8
 #endif
 constexpr int EG_LINE_WAVES = D3M_EG_LINE_WAVES;   // waves per workgroup: parts x waves walk one line's items concurrently
-constexpr int EG_ITEM_DW = 12;     // dwords per item
+constexpr int EG_ITEM_DW = 8;      // dwords per item
 
 // What a walk reads per pixel, row-major like the maps (pixel (y, x) of view b at b*S*S + y*S + x); k_pack_maps (or
 // the fused fit epilogue, d3m_lit.h) builds it in one pass:
@@ -265,12 +265,46 @@ __device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, size_t view_b
 // the 6272 of the old per-256-faces cursor cost 43 us, the 9200 per-wave ones of k_edge_count 130 us).
 constexpr int EG_COMPACT_CHUNK = 1024;      // faces per workgroup (4 per lane)
 
-__global__ void __launch_bounds__(256) k_count_visible(const int* __restrict__ visible, int* __restrict__ vis_block, long n) {
+// Which faces own a pixel, as ONE BYTE per face: a face's pixels form a small blob, and only the pixels of it that have
+// neither the same face to their left nor above them speak up (one or two plain byte stores per face, where a store per
+// covered pixel into a dense int array cost 58 us plus 19 us for zeroing it; one BIT per face needs atomics: 78 us).
+__global__ void __launch_bounds__(256) k_mark_visible_bytes(const int32_t* __restrict__ face_index_map,
+                                                           unsigned char* __restrict__ marks, int B, int F, int S) {
+    // a fixed grid striding over the pixels, four independent pixels in flight per lane: with one pixel per lane the
+    // 131 k workgroups of the headline batch are bound by workgroup dispatch, not by memory
+    const long n = (long)B * S * S, stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        int fi[4], left[4], up[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long i = i0 + k * stride;
+            fi[k] = left[k] = up[k] = -1;
+            if (i < n) {
+                const int x = (int)(i % S), y = (int)((i / S) % S);
+                fi[k] = face_index_map[i];
+                if (x > 0) left[k] = face_index_map[i - 1];
+                if (y > 0) up[k] = face_index_map[i - S];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (fi[k] < 0 || fi[k] == left[k] || fi[k] == up[k]) continue;
+            marks[(size_t)((i0 + k * stride) / ((long)S * S)) * F + fi[k]] = 1;
+        }
+    }
+}
+
+// the four faces i0 .. i0+3 (i0 a multiple of 4) of the marks, as a 4-bit mask
+__device__ __forceinline__ unsigned visible_nibble(const unsigned char* __restrict__ marks, long i0, long n) {
+    if (i0 >= n) return 0u;
+    const unsigned m = *(const unsigned*)(marks + i0);          // 0 or 1 per byte
+    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 15u;
+}
+
+__global__ void __launch_bounds__(256) k_count_visible(const unsigned char* __restrict__ bits, int* __restrict__ vis_block, long n) {
     __shared__ int s_wave[4];
     const long i0 = (long)blockIdx.x * EG_COMPACT_CHUNK + threadIdx.x * 4;
-    int c = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) c += (i0 + k < n && visible[i0 + k] != 0) ? 1 : 0;
+    const int c = __popc(visible_nibble(bits, i0, n));
     const int incl = wave_inclusive_scan(c);
     if (lane_id() == 63) s_wave[threadIdx.x >> 6] = incl;
     __syncthreads();
@@ -311,14 +345,18 @@ __global__ void __launch_bounds__(1024) k_scan_small(int* __restrict__ counts, i
     if (threadIdx.x == 0) { counts[n] = s_run; *total = s_run; }
 }
 
-__global__ void __launch_bounds__(256) k_compact_visible(const int* __restrict__ visible, int* __restrict__ list,
-                                                        const int* __restrict__ vis_block, long n) {
+// The compacted list, and the dense flags (FLAG_HIDDEN / FLAG_VISIBLE for EVERY face: 16 contiguous bytes per lane).
+// n is padded to a multiple of 4 by the caller's allocation (eg_align).
+__global__ void __launch_bounds__(256) k_compact_visible(const unsigned char* __restrict__ bits, int* __restrict__ flags,
+                                                        int* __restrict__ list, const int* __restrict__ vis_block, long n) {
     __shared__ int s_wave[4];
     const long i0 = (long)blockIdx.x * EG_COMPACT_CHUNK + threadIdx.x * 4;
+    const unsigned nib = visible_nibble(bits, i0, n);
     bool v[4];
-    int c = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = i0 + k < n && visible[i0 + k] != 0; c += v[k] ? 1 : 0; }
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < n && ((nib >> k) & 1u);
+    const int c = __popc(nib);
+    if (i0 < n) *(int4*)(flags + i0) = make_int4((int)(nib & 1u), (int)((nib >> 1) & 1u), (int)((nib >> 2) & 1u), (int)((nib >> 3) & 1u));
     const int incl = wave_inclusive_scan(c);
     const int wv = threadIdx.x >> 6;
     if (lane_id() == 63) s_wave[wv] = incl;
@@ -625,8 +663,13 @@ static_assert((EG_CHUNK & (EG_CHUNK - 1)) == 0, "threads are split into an outwa
 //            itself from LDS, long ones are queued in LDS as 48-byte items;
 //   WALK     the queued segments ordered by length (counting sort on length / 16, longest first), sixteen per wave,
 //            four lanes each, FACTORED DISTANCE (below).
-// Item (12 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] | fn << 6; 1 inv0; 2 from | to<<16;
-// 3 result slot; 4 d1_cross; 5 u0; 6 u1; 7..10 reference alpha,r,g,b; 11 inv1.
+// Item (8 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] s_t>0[5] | fn << 6; 1 inv0;
+// 2 from | to<<16; 3 result slot; 4 d1_cross; 5 inv1; 6 position of the reference pixel; 7 unused.
+//
+// REFERENCE VALUES.  The pixel whose (alpha, rgb) a walk compares against (KCU:365-381 / :436-452) lies on the walk's
+// own line, next to the crossing -- so the line's VALUES are staged in LDS as well (16 bytes per pixel, the whole
+// line: that pixel need not lie inside the non-zero-gradient extent) and a segment's set-up is one memory round trip
+// (its record), not two (record -> a 16-byte gather from the maps, 25 M of them per headline step).
 //
 // FACTORED DISTANCE.  Along one queued segment t = d1 - d1_cross keeps its sign s_t (outward: the walk direction;
 // inward: the opposite), so KCU:404-405's  dist = q*t*(2/is) +- eps  is  qc*(t + u)  with qc = q*2/is and the
@@ -636,9 +679,12 @@ static_assert((EG_CHUNK & (EG_CHUNK - 1)) == 0, "threads are split into an outwa
 // an integer crossing: the reference's `0 < dist` is false there, i.e. -eps whatever s_t says) is corrected after
 // the loop (fix_at_*; only if that pixel survived the clip to the line's non-zero extent).
 //
-// PAD: the LDS image of the line has 2*S + 16 entries (only the extent is filled), so the lanes of a row that has
-// finished -- the segments of a wave advance in lock step with the longest -- keep reading inside the allocation and
-// the per-iteration address clamp disappears; without PAD (large S) the index is clamped.
+// PAD: the lanes of a row that has finished -- the segments of a wave advance in lock step with the longest -- keep
+// reading, up to entry 2*S + 16 of the image arrays; what they read is never used (their lanes are masked), it only
+// has to lie inside the workgroup's LDS allocation.  The arrays are therefore laid out pairs | gradients | values |
+// tail: an overrun of the 8-byte pairs ends in the gradients, one of the 16-byte gradients in the values and the
+// tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  Without
+// PAD (large S) the index is clamped.
 template <bool USE_RGB, bool USE_ALPHA, bool PAD>
 __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
@@ -670,7 +716,6 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
     struct Setup {
         bool has;
         Segment sg;
-        SegRef ref;
         int fn;
         long slot;
     };
@@ -678,7 +723,6 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
     auto set_up = [&](int ci) {
         Setup u;
         u.has = false;
-        u.ref = SegRef{0, 0, 0, 0};
         u.fn = 0;
         u.slot = 0;
         if (ci < n_x) {
@@ -686,7 +730,6 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
             u.fn = (int)r1.y;
             u.slot = 2 * ((long)x_first + ci) + my_which;
             u.has = geometry_segment(record_to_geometry(r0, r1), my_which, axis, d0, is, p_lo, p_hi, u.sg);
-            if (u.has) u.ref = load_ref(a, axis, view_base, d0, u.sg.ref_pos);
         }
         return u;
     };
@@ -695,10 +738,17 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
     // visited pixel, contiguous within a segment's lane group.  T is kept halved (exact) because the two packed fma
     // below start BOTH halves of the sum from it.
-    const int n_lds = PAD ? 2 * is + 16 : is;
-    float4* s_grd = (float4*)s_line;
-    float2* s_df = (float2*)(s_grd + n_lds);
+    float2* s_df = (float2*)s_line;                            // [is] (T/2, owner)
+    float4* s_grd = (float4*)(s_df + is + (is & 1));           // [is] gradients (alpha, r, g, b)
+    float4* s_val = s_grd + is;                                // [is] values (alpha, r, g, b), then the PAD tail
     const float go_sign = a.go_sign();
+    for (int p = (int)threadIdx.x; p < is; p += EG_LINE_THREADS) {
+        const size_t pi = a.pixel(axis, view_base, d0, p);
+        float4 v = make_float4(0, 0, 0, 0);
+        if (USE_ALPHA) v.x = a.alpha_map[pi];
+        if (USE_RGB) { v.y = a.rgb_map[3 * pi]; v.z = a.rgb_map[3 * pi + 1]; v.w = a.rgb_map[3 * pi + 2]; }
+        s_val[p] = v;
+    }
     for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_THREADS) {
         const size_t pi = a.pixel(axis, view_base, d0, p);
         float4 g = a.grad[pi];
@@ -744,13 +794,16 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                 const bool have = base + row < nc;
                 const int it = have ? s_order[base + row] : s_order[base];
                 const uint4* q = (const uint4*)(s_items + (size_t)it * EG_ITEM_DW);
-                const uint4 q0v = q[0], q1v = q[1], q2v = q[2];
+                const uint4 q0v = q[0], q1v = q[1];
+                const float4 rv = s_val[q1v.z];
                 const uint32_t bits = q0v.x & 63u;
                 const int from = (int)(q0v.z & 0xFFFF), to = have ? (int)(q0v.z >> 16) : -1, fn = (int)(q0v.x >> 6);
                 const float d1_cross = __uint_as_float(q1v.x);
-                const v2f u = {__uint_as_float(q1v.y), __uint_as_float(q1v.z)};
-                const v2f nref_ar = {USE_ALPHA ? -__uint_as_float(q1v.w) : 0.0f, USE_RGB ? -__uint_as_float(q2v.x) : 0.0f};
-                const v2f nref_gb = {USE_RGB ? -__uint_as_float(q2v.y) : 0.0f, USE_RGB ? -__uint_as_float(q2v.z) : 0.0f};
+                const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q1v.y);
+                const float s_t = (bits & 32u) ? 1.0f : -1.0f;
+                const v2f u = {s_t * (a.eps * fabsf(inv0)), s_t * (a.eps * fabsf(inv1))};      // see FACTORED DISTANCE
+                const v2f nref_ar = {USE_ALPHA ? -rv.x : 0.0f, USE_RGB ? -rv.y : 0.0f};
+                const v2f nref_gb = {USE_RGB ? -rv.z : 0.0f, USE_RGB ? -rv.w : 0.0f};
                 // A pixel counts if it lies in the segment, its diff_grad is not <= 0 (KCU:401/:481; NaN passes, as in the
                 // reference) and -- inward walks only -- it belongs to the face (KCU:470).  The three conditions are combined
                 // as wave masks on the scalar unit; the vector unit only issues the compares and ONE select.
@@ -819,7 +872,6 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                 if (EG_ROW >= 8) { s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1); }
                 if (EG_ROW == 16) { s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1); }
                 if (have && rl == 0) {
-                    const float inv0 = __uint_as_float(q0v.y), inv1 = __uint_as_float(q2v.w);
                     if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
                         const int df = (bits & 8u) ? from : to;
                         const float2 d = s_df[df];
@@ -845,10 +897,9 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
         const Setup u = chunk0 == 0 ? first : set_up(chunk0 + my_x);
         // ---- empty segments store their zero, short ones are walked here, long ones queued ------------------------
         bool queued = false;
-        uint4 rec0 = make_uint4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+        uint4 rec0 = make_uint4(0, 0, 0, 0), rec1 = rec0;
         if (chunk0 + my_x < n_x) {
             const Segment& q = u.sg;
-            const SegRef& ref = u.ref;
             const int fn = u.fn;
             float g0 = 0, g1 = 0;
             if (u.has) {
@@ -857,20 +908,18 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                     const float s_t = (float)(q.inward ? -q.dir : q.dir);
                     // 1 / qc by v_rcp_f32 (1 ulp), like every quotient of the walk itself
                     const float rq0 = __builtin_amdgcn_rcpf(qc0), rq1 = __builtin_amdgcn_rcpf(qc1);
-                    const float u0 = s_t * (a.eps * fabsf(rq0)), u1 = s_t * (a.eps * fabsf(rq1));
                     const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
                     const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
-                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u);
+                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u) |
+                                          (0 < s_t ? 32u : 0u);
                     rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-rq0),
                                       (uint32_t)q.from | ((uint32_t)q.to << 16), (uint32_t)u.slot);
-                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(u0), __float_as_uint(u1),
-                                      __float_as_uint(ref.alpha));
-                    rec2 = make_uint4(__float_as_uint(ref.r), __float_as_uint(ref.g), __float_as_uint(ref.b),
-                                      __float_as_uint(-rq1));
+                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(-rq1), (uint32_t)q.ref_pos, 0u);
                     queued = true;
                 } else {                                      // short (or not oriented): this thread walks it, from LDS
-                    const v2f nref_ar = {USE_ALPHA ? -ref.alpha : 0.0f, USE_RGB ? -ref.r : 0.0f};
-                    const v2f nref_gb = {USE_RGB ? -ref.g : 0.0f, USE_RGB ? -ref.b : 0.0f};
+                    const float4 rv = s_val[q.ref_pos];
+                    const v2f nref_ar = {USE_ALPHA ? -rv.x : 0.0f, USE_RGB ? -rv.y : 0.0f};
+                    const v2f nref_gb = {USE_RGB ? -rv.z : 0.0f, USE_RGB ? -rv.w : 0.0f};
                     const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
                     for (int d1 = q.from; d1 <= q.to; d1++) {
                         const float2 d = s_df[d1];
@@ -897,7 +946,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
             base = __builtin_amdgcn_readfirstlane(base);
             if (queued) {
                 uint4* it = (uint4*)(s_items + (size_t)(base + mask_rank(qm)) * EG_ITEM_DW);
-                it[0] = rec0; it[1] = rec1; it[2] = rec2;
+                it[0] = rec0; it[1] = rec1;
             }
         }
         __syncthreads();
@@ -1045,10 +1094,12 @@ struct VisibilityView {
     int* list;         // [B*F]  ascending indices of the faces with flags != 0
     int* vis_block;    // [B*F/1024 + 2]
     int* count;        // [1]
+    unsigned char* marks;   // [B*F] one byte per face, the intermediate the three arrays above are built from
 };
 
 inline size_t visibility_bytes(long nf) {
-    return eg_align((size_t)nf * 4) * 2 + eg_align(((size_t)nf / EG_COMPACT_CHUNK + 2) * 4) + 256;
+    return eg_align((size_t)nf * 4) * 2 + eg_align(((size_t)nf / EG_COMPACT_CHUNK + 2) * 4) + 256 +
+           eg_align((size_t)nf + 4);
 }
 
 inline VisibilityView visibility_view(void* blob, long nf) {
@@ -1057,20 +1108,24 @@ inline VisibilityView visibility_view(void* blob, long nf) {
     v.flags = (int*)p;                        p += eg_align((size_t)nf * 4);
     v.list = (int*)p;                         p += eg_align((size_t)nf * 4);
     v.vis_block = (int*)p;                    p += eg_align(((size_t)nf / EG_COMPACT_CHUNK + 2) * 4);
-    v.count = (int*)p;
+    v.count = (int*)p;                        p += 256;
+    v.marks = (unsigned char*)p;
     return v;
 }
 
 inline hipError_t run_visibility(const int32_t* face_index_map, const VisibilityView& v, int B, int F, int S, hipStream_t st) {
     const long nf = (long)B * F;
-    hipError_t e = zero_async(v.flags, eg_align((size_t)nf * 4), st);
-    if (e != hipSuccess) return e;
-    LAUNCH("k_mark_visible", k_mark_visible, dim3((unsigned)(((long)B * S * S + 255) / 256)), dim3(256), st, face_index_map,
-           v.flags, B, F, S);
+    if (face_index_map) {       // NULL: the marks were left by the forward pass (d3m_forward_face_index_map_mesh)
+        hipError_t e = zero_async(v.marks, eg_align((size_t)nf + 4), st);
+        if (e != hipSuccess) return e;
+        const long px_blocks = ((long)B * S * S + 255) / 256;
+        LAUNCH("k_mark_visible", k_mark_visible_bytes, dim3((unsigned)std::min(px_blocks, 4096l)), dim3(256), st,
+               face_index_map, v.marks, B, F, S);
+    }
     const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
-    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const int*)v.flags, v.vis_block, nf);
+    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const unsigned char*)v.marks, v.vis_block, nf);
     LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, v.vis_block, n_chunks, (const int*)nullptr, 1, v.count);
-    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const int*)v.flags, v.list,
+    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const unsigned char*)v.marks, v.flags, v.list,
            (const int*)v.vis_block, nf);
     return hipGetLastError();
 }
@@ -1196,15 +1251,22 @@ __global__ void __launch_bounds__(256) k_zero_lane_partial(EdgePlan w, float2* _
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) lane_partial[i] = make_float2(0.0f, 0.0f);
 }
 
+// dynamic LDS of k_edge_lines: pairs [S] (8 B, padded to 16), gradients [S] and values [S] (16 B); with PAD the
+// gradients must be readable up to entry 2*S + 16
+inline size_t edge_lines_lds(int S, bool pad) {
+    const size_t pairs = (size_t)(S + (S & 1)) * 8, body = pairs + (size_t)S * 32;
+    return pad ? std::max(body, pairs + (size_t)(2 * S + 16) * 16) : body;
+}
+
 template <class FS>
 int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const VisibilityView* shared_vis,
                   void* shared_plan, size_t shared_plan_bytes, EdgeRecords rec, GradScale gs, int B, float eps, void* ws,
                   size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
-    const size_t smem_pad = (size_t)(2 * S + 16) * 24;
-    const bool pad = smem_pad <= 36 * 1024;
-    const size_t smem = pad ? smem_pad : (size_t)S * 24;
+    const size_t smem_pad = edge_lines_lds(S, true);
+    const bool pad = smem_pad <= 28 * 1024;
+    const size_t smem = pad ? smem_pad : edge_lines_lds(S, false);
     if (smem + EG_LINE_STATIC_LDS > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + (shared_plan ? 0 : edge_plan_min_bytes(B, F, S))) return 2;   // D3M_ERR_WORKSPACE

@@ -56,7 +56,17 @@ __device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& 
 // (face, tile) pair, the pairs are first counted in a small LDS hash table keyed by the tile (LDS atomics), and each
 // distinct tile then costs ONE global atomic per workgroup.  The wave-merged form spent ~110 us per binning pass on
 // its serial group-discovery loops.
-constexpr int TA_SLOTS = 512;            // power of two; a workgroup touches far fewer distinct tiles
+#ifndef D3M_BIN_THREADS
+#define D3M_BIN_THREADS 1024
+#endif
+#ifndef D3M_BIN_FPT
+#define D3M_BIN_FPT 1
+#endif
+constexpr int BIN_THREADS = D3M_BIN_THREADS;      // threads per binning workgroup,
+constexpr int BIN_FPT = D3M_BIN_FPT;              // each taking this many faces (face pairs with fill_back)
+constexpr int BIN_FACES = BIN_THREADS * BIN_FPT;  // -> faces per workgroup: its tile counters cost one global atomic each
+constexpr int TA_BITS = BIN_FACES >= 4096 ? 12 : BIN_FACES >= 1024 ? 11 : BIN_FACES >= 512 ? 10 : 9;
+constexpr int TA_SLOTS = 1 << TA_BITS;   // a workgroup touches far fewer distinct tiles
 constexpr int TA_PROBES = 12;
 struct TileAgg {
     int key[TA_SLOTS];                   // tile id + 1, 0 = empty
@@ -71,7 +81,7 @@ __device__ __forceinline__ void ta_clear(TileAgg& t) {
 
 // slot of `tile` (inserted if new) and this pair's rank among the workgroup's pairs of that tile; -1: table too full
 __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
-    unsigned h = ((unsigned)tile * 2654435761u) >> 23;                 // top 9 bits
+    unsigned h = ((unsigned)tile * 2654435761u) >> (32 - TA_BITS);
     for (int p = 0; p < TA_PROBES; p++, h = (h + 1) & (TA_SLOTS - 1)) {
         int k = t.key[h];
         if (k == 0) k = atomicCAS(&t.key[h], 0, tile + 1);
@@ -91,12 +101,14 @@ __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
 // of the two is front-facing -- one lane loads the three vertices once and handles both copies, instead of a second
 // lane repeating the index and vertex gathers only to find its copy culled.
 template <class FS, bool PAIRED>
-__global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
-                                                  float* __restrict__ faces_dense_out) {
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
+                                                  float* __restrict__ faces_dense_out,
+                                                  unsigned char* __restrict__ marks = nullptr) {
     __shared__ TileAgg agg;
     ta_clear(agg);
-    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int F = bb.F, Fl = PAIRED ? F / 2 : F;          // faces per view: all / handled by one lane each
+    for (int it = 0; it < BIN_FPT; it++) {
+    const long lane_i = ((long)blockIdx.x * BIN_FPT + it) * blockDim.x + threadIdx.x;
     const bool in_range = lane_i < (long)bb.B * Fl;
     const int b = in_range ? (int)(lane_i / Fl) : 0, f0 = in_range ? (int)(lane_i % Fl) : 0;
     float loaded[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -135,6 +147,7 @@ __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* 
                 }
             }
             bb.rect[i] = r;
+            if (marks) marks[i] = 0;                  // "owns a pixel": set by the tile pass (RasterOut::marks)
         }
         // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
         const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
@@ -143,6 +156,7 @@ __global__ void __launch_bounds__(256) k_bin_count(FS fs, BinBuffers bb, float* 
             int rank;
             if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
         }
+    }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
@@ -173,11 +187,15 @@ __global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
 // PAIRED (fill_back): one lane per (face f, face F/2 + f) pair -- normally exactly one of the two has a rectangle, so
 // every lane has work; should both have one (zero-area faces), the second goes straight to the global cursors.
 template <bool PAIRED>
-__global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
+__global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
     __shared__ TileAgg agg;
     ta_clear(agg);
-    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Fl = PAIRED ? bb.F / 2 : bb.F;
+    constexpr int TA_LOCAL = 4;
+    int packed[BIN_FPT][TA_LOCAL], face_of[BIN_FPT];
+#pragma unroll
+    for (int it = 0; it < BIN_FPT; it++) {
+    const long lane_i = ((long)blockIdx.x * BIN_FPT + it) * blockDim.x + threadIdx.x;
     int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
     if (lane_i < (long)bb.B * Fl) {
         b = (int)(lane_i / Fl);
@@ -207,21 +225,21 @@ __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
     }
     // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a
     // full table go straight to the global cursor), one cursor atomic per distinct tile, then the scatter
-    constexpr int TA_LOCAL = 4;
-    int packed[TA_LOCAL];
 #pragma unroll
-    for (int s = 0; s < TA_LOCAL; s++) packed[s] = -1;
+    for (int s = 0; s < TA_LOCAL; s++) packed[it][s] = -1;
+    face_of[it] = f;
     for (int s = 0; s < nt; s++) {
         const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
         int rank = 0, slot = -1;
         if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
         if (slot >= 0) {
 #pragma unroll
-            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[q] = (slot << 16) | rank;
+            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[it][q] = (slot << 16) | rank;
         } else {
             const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
             bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
         }
+    }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
@@ -231,8 +249,12 @@ __global__ void __launch_bounds__(256) k_bin_fill(BinBuffers bb) {
         }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < TA_LOCAL; s++)
-        if (packed[s] >= 0) bb.pairs[(size_t)agg.base[packed[s] >> 16] + (packed[s] & 0xFFFF)] = f;
+    for (int it = 0; it < BIN_FPT; it++) {
+#pragma unroll
+        for (int s = 0; s < TA_LOCAL; s++)
+            if (packed[it][s] >= 0)
+                bb.pairs[(size_t)agg.base[packed[it][s] >> 16] + (packed[it][s] & 0xFFFF)] = face_of[it];
+    }
 }
 
 // ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------
@@ -253,6 +275,7 @@ struct RasterOut {
     float* weight_map;
     float* depth_map;
     float* face_inv_map;   // NULL unless the caller wants the reference's [B,S,S,3,3] map
+    unsigned char* marks;  // NULL, or [B*F] zeroed by k_bin_count: marks[b*F + f] = 1 for every face that owns a pixel
 };
 
 // W waves per tile: W = 1 when there are enough tiles to fill the chip; W = 4 for small rasters (a few thousand
@@ -415,6 +438,13 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     // 0), so the caller's pre-fill is not relied upon: every pixel of every map is written here.
     const unsigned long long key = s_z[lane];
     const int xi = px0 + (lane & 7), yi = py0 + (lane >> 3);
+    if (out.marks) {
+        // which faces own a pixel (d3m_visibility's first step, for free here): a face's pixels form a small blob, and
+        // only those of them that have neither the same face to their left nor above them within the tile speak up
+        const int fid = key != ~0ull ? (int)(uint32_t)(key & 0xFFFFFFFFull) : -1;
+        const int left = __shfl(fid, lane - 1, 64), up = __shfl(fid, lane - 8, 64);
+        if (fid >= 0 && !((lane & 7) && left == fid) && !(lane >= 8 && up == fid)) out.marks[(size_t)b * bb.F + fid] = 1;
+    }
     if (xi < S && yi < S) {
         const size_t i = ((size_t)b * S + yi) * S + xi;
         if (key != ~0ull) {

@@ -160,10 +160,10 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, 256)), dim3(256), st, fs, bb, faces_inv,
+    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, fs, bb, faces_inv,
            (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     if (n_tiles <= RASTER_SMALL_GRID)
@@ -177,6 +177,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
 // copy (front-facing faces only) that the tile pass and every later operator use.
 static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, float near, float far, RasterOut out, void* ws,
                             size_t ws_bytes, hipStream_t st) {
+    // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
     BinBuffers bb;
@@ -185,14 +186,14 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
     if (ifs.fill_back)      // one lane per index triple, both copies
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, 256)), dim3(256), st, ifs, bb,
-               (float*)nullptr, faces_out);
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, BIN_FACES)), dim3(BIN_THREADS), st, ifs, bb,
+               (float*)nullptr, faces_out, out.marks);
     else
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, 256)), dim3(256), st, ifs, bb,
-               (float*)nullptr, faces_out);
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, ifs, bb,
+               (float*)nullptr, faces_out, out.marks);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, 256)), dim3(256), st, bb);
-    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, 256)), dim3(256), st, bb);
+    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, BIN_FACES)), dim3(BIN_THREADS), st, bb);
+    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};
@@ -210,7 +211,7 @@ D3M_EXPORT size_t d3m_visibility_bytes(int batch_size, int num_faces) {
 
 D3M_EXPORT int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
                               int num_faces, int image_size, d3m_stream_t stream) {
-    if (!face_index_map || !visibility || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if (!visibility || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
     if (visibility_size < d3m_visibility_bytes(batch_size, num_faces)) return D3M_ERR_WORKSPACE;
     const VisibilityView v = visibility_view(visibility, (long)batch_size * num_faces);
     HIP_TRY(run_visibility(face_index_map, v, batch_size, num_faces, image_size, (hipStream_t)stream));
@@ -247,13 +248,19 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
                                                int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
                                                float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                                int image_size, float near, float far, void* workspace,
-                                               size_t workspace_bytes, d3m_stream_t stream) {
+                                               size_t workspace_bytes, void* visibility, size_t visibility_size,
+                                               d3m_stream_t stream) {
     if (!vertices || !tri || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
         num_vertices <= 0 || num_tri <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
     if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
     IndexedFaces ifs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, batch_size};
-    RasterOut out{face_index_map, weight_map, depth_map, face_inv_map};
+    RasterOut out{face_index_map, weight_map, depth_map, face_inv_map, nullptr};
+    if (visibility) {       // the first step of d3m_visibility rides along: finish it with d3m_visibility(NULL, ...)
+        const long nf = (long)batch_size * ifs.num_faces();
+        if (visibility_size < visibility_bytes(nf)) return D3M_ERR_WORKSPACE;
+        out.marks = visibility_view(visibility, nf).marks;
+    }
     return run_forward_mesh(ifs, faces_out, batch_size, image_size, near, far, out, workspace, workspace_bytes,
                             (hipStream_t)stream);
 }

@@ -366,12 +366,14 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.check(L.d3m_forward_face_index_map_mesh(
                     _lib.ptr(sv[lo:hi]), _lib.ptr(tri_g), tri_g.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces[lo:hi]),
                     _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), None, Bg, S, float(near), float(far), _lib.ptr(ws),
-                    ws.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+                    ws.numel(), _lib.ptr(vis[k]) if vis is not None else None, vis[k].numel() if vis is not None else 0,
+                    _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
                 if vis is not None:
                     if auxs[k] is not mains[k]:
                         auxs[k].wait_stream(mains[k])
                     with torch.cuda.stream(auxs[k]):
-                        _lib.check(L.d3m_visibility(_lib.ptr(fi_g), _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
+                        # (its first step -- which faces own a pixel -- was left by the tile pass above)
+                        _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
                                                     _lib.stream_ptr()), "d3m_visibility")
                         _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
                                                    plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")

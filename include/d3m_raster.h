@@ -87,7 +87,10 @@ int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, i
                                     int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                     int image_size, float near, float far, void* workspace, size_t workspace_bytes,
-                                    d3m_stream_t stream);
+                                    void* visibility, size_t visibility_size, d3m_stream_t stream);
+/* `visibility` (NULL, or a blob of d3m_visibility_bytes(B, num_faces)): the tile pass then also leaves the first step
+ * of d3m_visibility -- which faces own a pixel -- in the blob, and d3m_visibility(NULL, blob, ...) finishes it without a
+ * pass over face_index_map. */
 
 /* Replaces forward_texture_sampling (KCPP:97-124 -> KCU:172-242).
  *   textures [B,F,ts,ts,ts,3] f32 in; rgb_map [B,S,S,3] f32 i/o; sampling_index_map [B,S,S,8] i32 i/o;
@@ -130,7 +133,8 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
 
 /* Which faces own a pixel depends on face_index_map only.  d3m_visibility builds, once per forward result, the
  * flags and the compacted list of those faces in a caller-owned blob of d3m_visibility_bytes(); backward operators
- * that are handed the blob (`visibility`, NULL = each builds its own) skip that work and run over the list. */
+ * that are handed the blob (`visibility`, NULL = each builds its own) skip that work and run over the list.
+ * face_index_map NULL: the blob went through d3m_forward_face_index_map_mesh, which left the first step in it. */
 size_t d3m_visibility_bytes(int batch_size, int num_faces);
 int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
                    int num_faces, int image_size, d3m_stream_t stream);
