@@ -101,7 +101,11 @@ __device__ __forceinline__ void crossing_range(float p00, float p10, int is, int
 // :417-431 inward) that does not depend on the gradient maps.  p00..p21 = p[num][dim] of KCU:289-294 for that pair;
 // owner(d0, d1) returns face_index_map at that line position.  Computed once per crossing (k_edge_scatter) and kept in
 // the crossing's record.
-enum : uint32_t { XG_ALIVE = 1, XG_DIRPOS = 2, XG_F0 = 4, XG_F1 = 8, XG_OWNER = 16, XG_ORIENTED = 32 };
+enum : uint32_t { XG_ALIVE = 1, XG_DIRPOS = 2, XG_F0 = 4, XG_F1 = 8, XG_OWNER = 16, XG_ORIENTED = 32, XG_IDLE = 64 };
+#ifndef D3M_XG_DEAD_SCAN
+#define D3M_XG_DEAD_SCAN 6
+#endif
+constexpr int XG_DEAD_SCAN = D3M_XG_DEAD_SCAN;   // inward ranges of fewer pixels than this are checked for an owned pixel
 struct XGeom {
     float d1_cross, q0, q1;     // crossing position along the line; first factors of `dist` (KCU:404 / :409)
     int d1_in;                  // the in-pixel next to the crossing
@@ -110,6 +114,7 @@ struct XGeom {
                                 // XG_DIRPOS: walk direction +1 (KCU:297-308); XG_F0/F1: KCU:403/:408 evaluate the term;
                                 // XG_OWNER: the in-pixel belongs to the face, i.e. the outward walk exists (KCU:354);
                                 // XG_ORIENTED: every inward pixel lies on the expected side of the crossing
+                                // XG_IDLE: alive, but neither walk can contribute (no record is written)
 };
 
 template <class Owner>
@@ -138,6 +143,14 @@ __device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p
     g.in_to = min(max(g.d1_in, d1_limit), is - 1);
     // all pixels on the expected side of the crossing (see "FACTORED DISTANCE"): decided before clipping
     if ((0 < direction) ? g.in_to == g.d1_in : g.in_from == g.d1_in) g.bits |= XG_ORIENTED;
+    // NEITHER WALK CAN CONTRIBUTE: the outward walk only exists when the in-pixel is the face's (KCU:354), and the inward
+    // walk only counts pixels of the face (KCU:470).  A short inward range is looked through here (owners only, no
+    // gradients needed); a crossing that fails both needs no record, no set-up and no result.
+    if (!(g.bits & XG_OWNER) && g.in_to - g.in_from < XG_DEAD_SCAN) {
+        bool own = false;
+        for (int d1 = g.in_from; d1 <= g.in_to; d1++) own = own || owner(d0, d1) == fn;
+        if (!own) g.bits |= XG_IDLE;
+    }
     return g;
 }
 
@@ -487,6 +500,90 @@ struct EdgePlan {
 
 __device__ __forceinline__ bool plan_complete(const EdgePlan& w) { return w.alloc[0] <= w.cap; }
 
+// ---- the lines of one workgroup iteration, counted in LDS ---------------------------------------------------------
+// A (face, edge, axis) lane crosses the CONSECUTIVE lines d0_from .. d0_to of its axis, and the 42 neighbouring faces of
+// a workgroup iteration meet on a few hundred lines of one view.  So the lanes add +1 / -1 at the ends of their ranges
+// in a per-axis LDS array indexed by the line (two LDS atomics per LANE), two waves turn the touched window into
+// per-line counts with a running sum, and every line with a count costs the workgroup ONE global atomic -- instead of
+// flattening the crossings and merging the counter updates of each wave by key (one global atomic per distinct line
+// of every wave: 2.3 M per pass of the headline batch, which bounded both passes -- doubling them took k_edge_count
+// from 0.110 to 0.157 ms -- after ~90 instructions of key matching per wave and round).
+// Lanes of another view than the iteration's first face (a view boundary inside the 42 faces) update the global
+// counters directly.  S <= EG_WINDOW_MAX_S (LDS: 16 bytes per line); beyond it the by-key kernels below are used.
+constexpr int EG_WINDOW_MAX_S = 2048;
+struct LineWindow {
+    int* cnt[2];        // [S + 1] per axis: range ends -> counts; all zero between iterations
+};
+__device__ __forceinline__ void window_open(LineWindow& win, int* lds, int is) {
+    win.cnt[0] = lds; win.cnt[1] = lds + (is + 1);
+    for (int k = threadIdx.x; k < 2 * (is + 1); k += blockDim.x) lds[k] = 0;
+}
+// the lanes' range ends; returns after the barrier that makes them (and the window bounds) visible.  s_lo / s_hi:
+// shared ints [2] each.
+__device__ __forceinline__ void window_ranges(const LineWindow& win, const LaneTable& t, int is, bool on, int n_cross, int view,
+                                              int* s_lo, int* s_hi) {
+    if (threadIdx.x < 2) { s_lo[threadIdx.x] = is; s_hi[threadIdx.x] = -1; }
+    __syncthreads();
+    const int l = threadIdx.x;
+    if (on && n_cross > 0 && (t.bn_axis[l] >> 1) == view) {
+        const int axis = t.bn_axis[l] & 1, from = t.d0_from[l], to1 = from + n_cross;    // to + 1 <= is
+        atomicAdd(&win.cnt[axis][from], 1);
+        atomicAdd(&win.cnt[axis][to1], -1);
+        atomicMin(&s_lo[axis], from);
+        atomicMax(&s_hi[axis], to1);
+    }
+    __syncthreads();
+}
+
+// ---- 1. per workgroup: how many crossings; per line: how many records it will receive ------------------------
+template <class FS>
+__global__ void __launch_bounds__(256) k_edge_count_window(FS fs, int is, EdgePlan w) {
+    extern __shared__ int s_window[];
+    __shared__ LaneTable t;
+    __shared__ int s_lo[2], s_hi[2];
+    LineWindow win;
+    window_open(win, s_window, is);
+    const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    const XcdOrder xo(n_blocks);
+    const int wv = threadIdx.x >> 6, lane = lane_id();
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {              // fixed grid, uniform trip count per workgroup
+        const int blk = xo.unit(i);
+        if (blk >= n_blocks) continue;
+        bool on;
+        int pos = 0, ea = 0, n_cross = 0;
+        const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
+        // every lane of a listed face gets its record (n_cross is 0 for a lane that is not `on`)
+        if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
+            const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
+            w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
+        }
+        if (threadIdx.x == 0) w.lane_block[blk] = total;
+        const int view = t.bn_axis[0] >> 1;
+        window_ranges(win, t, is, on, n_cross, view, s_lo, s_hi);
+        if (wv < 2) {                                       // wave `axis`: running sum over the window, 64 lines per round
+            const int axis = wv;
+            int run = 0;
+            for (int d0 = s_lo[axis] + lane; d0 - lane <= s_hi[axis]; d0 += 64) {
+                const bool in = d0 <= s_hi[axis];
+                const int v = in ? win.cnt[axis][d0] : 0;
+                const int incl = wave_inclusive_scan(v) + run;
+                run = __builtin_amdgcn_readlane(incl, 63);
+                if (in) {
+                    win.cnt[axis][d0] = 0;
+                    if (incl > 0) atomicAdd(&w.line_count[((size_t)view * 2 + axis) * is + d0], incl);
+                }
+            }
+        }
+        // a lane of another view (a view boundary inside the iteration): straight to the global counters
+        if (on && n_cross > 0 && (t.bn_axis[threadIdx.x] >> 1) != view) {
+            const int l = threadIdx.x;
+            const size_t line0 = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l];
+            for (int k = 0; k < n_cross; k++) atomicAdd(&w.line_count[line0 + k], 1);
+        }
+        __syncthreads();                                    // the tables are rewritten by the next iteration
+    }
+}
+
 // ---- 1. per workgroup: how many crossings; per line: how many records it will receive ------------------------
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgePlan w) {
@@ -566,20 +663,23 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
                 line = ((size_t)(t.bn_axis[l] >> 1) * 2 + (t.bn_axis[l] & 1)) * is + t.d0_from[l] + (c - t.pre[l]);
                 slice = w.line_slice[line];
             }
-            const unsigned long long same = wave_match_any((uint32_t)line, active);     // uniform call site
-            const bool fits = active && plan_complete(w);
-            const unsigned long long q = same & __builtin_amdgcn_ballot_w64(fits);
-            const int leader = active ? __builtin_ctzll(same) : 0, n = __popcll(q);
-            int cursor_base = 0;
-            if (active && lane_id() == leader && n > 0) cursor_base = atomicAdd(&w.line_cursor[line], n);
-            const int in_line = __shfl(cursor_base, leader, 64) + mask_rank(q);
-            if (fits) {
+            // the geometry first: a crossing that is outside the image or whose walks cannot contribute takes no place
+            XGeom g;
+            bool wants = false;
+            if (active && plan_complete(w)) {
                 const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, d0 = t.d0_from[l] + (c - t.pre[l]);
                 const int32_t* view = face_index_map + (size_t)bn * is * is;
-                const XGeom g = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis,
-                                                  t.fn[l], is, d0, [&](int e0, int e1) {
-                                                      return view[axis ? (size_t)e0 * is + e1 : (size_t)e1 * is + e0];
-                                                  });
+                g = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, t.fn[l], is, d0,
+                                      [&](int e0, int e1) { return view[axis ? (size_t)e0 * is + e1 : (size_t)e1 * is + e0]; });
+                wants = (g.bits & XG_ALIVE) && !(g.bits & XG_IDLE);
+                if (!wants) w.xpos[cbase + c] = -1;
+            }
+            const unsigned long long same = wave_match_any((uint32_t)line, wants);      // uniform call site
+            const int leader = wants ? __builtin_ctzll(same) : 0, n = wants ? __popcll(same) : 0;
+            int cursor_base = 0;
+            if (wants && lane_id() == leader) cursor_base = atomicAdd(&w.line_cursor[line], n);
+            const int in_line = __shfl(cursor_base, leader, 64) + mask_rank(same);
+            if (wants) {
                 uint4* rec = w.xrec + 2 * ((size_t)slice.x + in_line);
                 geometry_to_record(g, t.fn[l], (uint32_t)(cbase + c), (uint32_t)line, rec[0], rec[1]);
                 w.xpos[cbase + c] = slice.x + in_line;
@@ -765,6 +865,16 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
         p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
         return p.x + p.y;
     };
+    // both quotients of a pixel from ONE v_rcp_f32 (a quarter-rate instruction): 1/a = b * 1/(a*b).  Two more roundings
+    // (~1.5 ulp); |a*b| stays far inside the float range for distances of at most S pixels and |u| >= eps*S/2^k
+#ifdef D3M_EG_TWO_RCP
+    auto rcp2 = [](const v2f den) { return v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}; };
+#else
+    auto rcp2 = [](const v2f den) {
+        const float r = __builtin_amdgcn_rcpf(den.x * den.y);
+        return v2f{r, r} * v2f{den.y, den.x};
+    };
+#endif
     const int row = lane / EG_ROW, rl = lane % EG_ROW;
     // The queue of long segments (EG_QUEUE items in LDS) is filled by as many set-up passes as it takes -- a line of the
     // headline mesh has ~380 crossings, i.e. two passes, of which ~240 segments are long -- and walked when the next
@@ -822,11 +932,12 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                     const float4* pg_to = s_grd + to;
                     v2f den = u + t;                                // advances by exact steps of EG_ROW as well
                     if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
+#pragma unroll 2
                         for (int k = 0; k < n_iter; k++) {
                             const float diff = diff_of(*pg, *pd, nref_ar, nref_gb);
                             const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
                                                             __builtin_amdgcn_ballot_w64(!(diff <= 0));
-                            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                            const v2f r = rcp2(den);
                             // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
                             // den == 0 (1/0 = inf, 0 * inf = NaN)
                             if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
@@ -835,6 +946,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                             den += (float)EG_ROW;
                         }
                     } else {
+#pragma unroll 2
                         for (int k = 0; k < n_iter; k++) {
                             const float4 g = *pg;
                             const float2 d = *pd;
@@ -842,7 +954,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                             const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
                                                             __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
                                                             (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                            const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                            const v2f r = rcp2(den);
                             if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
                             pg += EG_ROW;
                             pd += EG_ROW;
@@ -985,7 +1097,8 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
                 for (int j = 0; j < 4; j++) at[j] = (complete && c + j < c_last) ? (long)w.xpos[c + j] : c + j;
                 float4 r[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) r[j] = c + j < c_last ? res4[at[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int j = 0; j < 4; j++)       // (at < 0: the crossing got no record because its walks cannot contribute)
+                    r[j] = (c + j < c_last && at[j] >= 0) ? res4[at[j]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     g.x += r[j].x; g.y += r[j].y;
@@ -1193,11 +1306,14 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
     const long nf = (long)B * fs.num_faces(), nl = (long)B * 2 * S;
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
-    LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, S, w);
+    const bool window = S <= EG_WINDOW_MAX_S;               // the workgroups' lines fit LDS
+    if (window) LAUNCH_SMEM("k_edge_count", k_edge_count_window<FS>, g6, dim3(256), (size_t)2 * (S + 1) * 4, st, fs, S, w);
+    else LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, S, w);
     LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
            EG_FACES_PER_BLOCK, w.alloc);
     LAUNCH("k_alloc_ranges", k_alloc_ranges, dim3((unsigned)((nl + 255) / 256)), dim3(256), st, (const int*)w.line_count,
            w.line_slice, w.alloc + 1, nl);
+    // (the scatter pass keeps the by-key form: with the ranks taken from LDS cursors it was slower, 0.173 vs 0.150 ms)
     LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g6, dim3(256), st, fs, face_index_map, S, w);
     return hipGetLastError();
 }

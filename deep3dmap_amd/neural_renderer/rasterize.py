@@ -2,6 +2,7 @@
 signatures and semantics as pnpmodules/neural_renderer/neural_renderer/rasterize.py (NR/rasterize.py),
 running on the HIP operators of libd3m_raster.so.  CUDA(=HIP)-device tensors only, like the reference."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -225,6 +226,8 @@ _side_streams = {}
 def _side_stream(device, which=0):
     """Extra streams per (device, forking stream) for the branches a lit render node runs beside its main line: the
     visibility list / the gathered texture pass of every view group, and the main line of every group but the first."""
+    if os.environ.get("D3M_SERIAL_BRANCHES"):        # measurement aid: every branch on the forking stream (kernels run alone)
+        return torch.cuda.current_stream(device)
     index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     key = (index, torch.cuda.current_stream(device).cuda_stream, which)       # one set per stream that forks
     if key not in _side_streams:
