@@ -59,13 +59,13 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0, nullptr},
                                                            const int* __restrict__ n_large = nullptr) {
     if (n_large && *n_large == 0) return;          // no face was left to this kernel (uniform exit)
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * S * S) return;
+    // (a fixed grid striding over the pixels: see k_backward_textures_lit_pixels)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * blockDim.x) {
     const int fn = face_index_map[i];
-    if (fn < 0) return;
+    if (fn < 0) continue;
     const int bn = (int)(i / ((long)S * S));
     const int F = fs.num_faces();
-    if (only_large && only_large[(size_t)bn * F + fn] != 2) return;   // the rest was gathered per face
+    if (only_large && only_large[(size_t)bn * F + fn] != 2) continue;   // the rest was gathered per face
     float face[9], finv[9];
     fs.load(bn, fn, face);
     if (face_inv_map) {
@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
         atomicAdd(&gk[0], -g * tmp[0] * wk * depth2 * (float)S / 2.0f);
         atomicAdd(&gk[1], -g * tmp[1] * wk * depth2 * (float)S / 2.0f);
         atomicAdd(&gk[2], g * wk * depth2 / (z_k * z_k));
+    }
     }
 }
 

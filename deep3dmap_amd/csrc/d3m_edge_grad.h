@@ -786,8 +786,15 @@ static_assert((EG_CHUNK & (EG_CHUNK - 1)) == 0, "threads are split into an outwa
 // tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  Without
 // PAD (large S) the index is clamped.
 template <bool USE_RGB, bool USE_ALPHA, bool PAD>
-__global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w) {
+__global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w,
+                                                                                      float2* __restrict__ lane_partial) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
+    if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
+        const long n = (long)*w.n_visible * 6;
+        for (long i = (long)blockIdx.x * EG_LINE_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EG_LINE_THREADS)
+            lane_partial[i] = make_float2(0.0f, 0.0f);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) uint32_t s_items[EG_LINE_THREADS * EG_ITEM_DW];
     __shared__ int s_hist[33];
     __shared__ unsigned short s_order[EG_LINE_THREADS];
@@ -1361,12 +1368,6 @@ struct EdgeRecords {
 };
 
 // the lanes' overflow sums start at zero -- only ever used when the plan is incomplete (leaves at once otherwise)
-__global__ void __launch_bounds__(256) k_zero_lane_partial(EdgePlan w, float2* __restrict__ lane_partial) {
-    if (plan_complete(w)) return;
-    const long n = (long)*w.n_visible * 6;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) lane_partial[i] = make_float2(0.0f, 0.0f);
-}
-
 // dynamic LDS of k_edge_lines: pairs [S] (8 B, padded to 16), gradients [S] and values [S] (16 B); with PAD the
 // gradients must be readable up to entry 2*S + 16
 inline size_t edge_lines_lds(int S, bool pad) {
@@ -1434,7 +1435,8 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_THREADS), smem, st, a, w); \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_THREADS), smem, st, a, w, \
+                    lane_partial);                                                                                   \
     } while (0)
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
@@ -1449,7 +1451,6 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
-    LAUNCH("k_zero_lane_partial", k_zero_lane_partial, dim3(512), dim3(256), st, w, lane_partial);
     LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 2048u)), dim3(256), st, fs, a, w, lane_partial);
     LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt);
     e = hipGetLastError();

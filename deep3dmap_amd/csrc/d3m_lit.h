@@ -639,12 +639,13 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
                                                                      float eps, GradScale gs,
                                                                      const int* __restrict__ n_large) {
     if (n_large && *n_large == 0) return;          // only_large mode and no such face: nothing to do (uniform exit)
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * S * S) return;
+    // a fixed grid striding over the pixels: in only_large mode the launch normally has nothing to do, and 32 k
+    // workgroups that leave at once still cost 12 us of dispatch
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * 256) {
     const int fi = face_index_map[i];
-    if (fi < 0) return;
+    if (fi < 0) continue;
     const int bn = (int)(i / ((long)S * S));
-    if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) return;
+    if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) continue;
     const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
     const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
     float s_rgb, s_alpha, s_depth;
@@ -670,6 +671,7 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
             atomicAdd(&gt[k], w * g[k] * lt.light[3 * (size_t)lrow + k]);
             if (grad_light) atomicAdd(&grad_light[3 * (size_t)lrow + k], w * g[k] * lt.textures[off + k]);
         }
+    }
     }
 }
 

@@ -151,6 +151,13 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
     return D3M_OK;
 }
 
+// grid of the per-pixel backward kernels (they stride): `sparse` = only the pixels of a few large faces have work, and
+// normally there are none
+static inline unsigned px_grid(long n, bool sparse) {
+    const long b = (n + 255) / 256, cap = sparse ? 1024 : 16384;
+    return (unsigned)(b < cap ? b : cap);
+}
+
 template <class FS>
 static int run_forward(FS fs, int B, int F, int S, float near, float far, RasterOut out, float* faces_inv, void* ws,
                        size_t ws_bytes, hipStream_t st) {
@@ -389,7 +396,7 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
         LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S);
     }
-    LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(blocks_for(n, 256)), dim3(256), st, fs, depth_map,
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags,
            VertexTarget{nullptr, nullptr, 0, 0, 1});
     return check_launch();
@@ -869,23 +876,23 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
-        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
+        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, true)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps,
                gs, (const int*)n_large);
         if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
             DenseFaces fs{faces, lt.Fp};
-            LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
+            LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, true)), dim3(256), st, fs,
                    depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
                    (const int*)flags, vt, gs, (const int*)n_large);
         }
     } else {
-        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(blocks_for(n, 256)), dim3(256), st,
+        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, false)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)nullptr, B, S, eps,
                gs, (const int*)nullptr);
         if (grad_depth_map) {
             DenseFaces fs{faces, lt.Fp};
             if (vt.gv) {
-                LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(blocks_for(n, 256)), dim3(256), st, fs,
+                LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, false)), dim3(256), st, fs,
                        depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S,
                        (const int*)nullptr, vt, gs);
             } else {

@@ -301,7 +301,7 @@ class _RasterizeLit(torch.autograd.Function):
         m = {"face_index_map": torch.empty((B, S, S), dtype=torch.int32, device=dev),
              "weight_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
              "depth_map": torch.empty((B, S, S), dtype=torch.float32, device=dev),
-             "face_inv_map": torch.zeros(1, dtype=torch.float32, device=dev),
+             "face_inv_map": const_tensor([0.0], dev),       # the 1-element stand-in of a disabled map (no fill launch)
              "rgb_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
              "alpha_map": torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None}
         # which faces own a pixel is only needed by the backward pass: one blob per group (this node's backward may run
