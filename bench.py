@@ -50,10 +50,14 @@ def kernel_bytes(name, V, F, S, ts):
         # sampling inputs, blended maps out, then either the images (20 B) or the objective's targets in (24 B) and the
         # unscaled gradient maps out (20 B)
         "k_render_lit_epilogue": F * ts ** 3 * 12 + 20 * P + 12 * P + P * (4 + 4 + 12) + P * 24,
+        # the same pass when it also leaves the objective's gradient as the edge gradient's per-pixel records
+        # (16 + 8 B) and the depth gradient map (4 B) instead of images
+        "k_render_lit_fit_records": F * ts ** 3 * 12 + 20 * P + 12 * P + P * 24 + P * (16 + 8 + 4),
         "k_pack_maps": maps + grads,
         "k_edge_lines": maps + grads,
         "k_edge_emit": 12 * V + 12 * F + maps + grads,
-        "k_edge_count": 12 * V + 12 * F + 4 * P,
+        "k_edge_count": 12 * V + 12 * F,
+        "k_edge_scatter": 12 * V + 12 * F + 4 * P,
         "k_edge_gather": 12 * F + 12 * V,
         "k_backward_textures_lit_faces": 12 * V + 12 * F + P * (20 + 12 + 4) + F * ts ** 3 * 12 + 12 * V,
         "k_backward_textures_faces": 12 * V + 12 * F + P * (4 + 12 + 12) + F * ts ** 3 * 12,
@@ -66,31 +70,36 @@ def kernel_bytes(name, V, F, S, ts):
     return table.get(name)
 
 
-def measured_traffic(name):
-    """HBM bytes per launch of `name` from the newest committed PMC summary (profiles/*pmc_traffic*.json, made by
-    profiles/pmc_traffic.py from two rocprofv3 --pmc passes of this same command), or None."""
+def _newest_profile(pattern):
+    """the committed summary of the latest round (profiles/rNN_...), 'final' before anything else of that round"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")),
-                   key=lambda f: ("final" in os.path.basename(f), os.path.basename(f)))
-    if not files:
-        return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(name)
-    return k["hbm_bytes_per_launch"] if k else None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)),
+                   key=lambda f: (os.path.basename(f)[:3], "final" in os.path.basename(f), os.path.basename(f)))
+    return files[-1] if files else None
+
+
+def measured_traffic(name):
+    """(HBM bytes per launch of `name`, file) from the newest committed PMC summary (profiles/*pmc_traffic*.json, made
+    by profiles/pmc_traffic.py from two rocprofv3 --pmc passes of this same command), or (None, None).  NOT measured by
+    this run: PMC counters need the profiler."""
+    f = _newest_profile("*pmc_traffic*.json")
+    if not f:
+        return None, None
+    k = json.load(open(f)).get("kernels", {}).get(name)
+    return (k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)) if k else (None, None)
 
 
 def measured_valu(name):
     """Wave-level VALU instructions per launch of `name` from the committed SQ counter summary
     (profiles/*sq_counters*.csv, tools_dev/sq_counters.sh), or None."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.csv")),
-                   key=lambda f: ("final" in os.path.basename(f), os.path.basename(f)))
-    if not files:
-        return None
-    for row in csv.DictReader(open(files[-1])):
+    f = _newest_profile("*sq_counters*.csv")
+    if not f:
+        return None, None
+    for row in csv.DictReader(open(f)):
         if row["kernel"] == name and row.get("SQ_INSTS_VALU"):
-            return int(float(row["SQ_INSTS_VALU"]))
-    return None
+            return int(float(row["SQ_INSTS_VALU"])), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def cpu_baseline(n, image_size, ts, budget_s=25.0):
@@ -407,15 +416,20 @@ def main():
         roof = None
         if kb is not None:
             ach = kb * args.views_per_gpu / dom_avg_s / 1e9
+            traffic, traffic_src = measured_traffic(dom)
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,     # a committed profiler summary of this command, not this run
                     "avg_launch_us": round(dom_avg_s * 1e6, 2), "launches_per_step": dom_count / n_inst,
+                    "duration_source": "HIP events around every launch of an eager pass of the same step, after the "
+                                       "timed region (a replayed graph cannot carry events)",
                     "algorithmic_bytes_per_launch": kb * args.views_per_gpu}
             # The kernel is not bandwidth-bound: what fraction of its duration the counted VALU
             # instructions need at one 4-cycle issue slot each on 256 CUs x 4 SIMDs at 2.4 GHz (informational).
-            valu = measured_valu(dom)
+            valu, valu_src = measured_valu(dom)
             if valu:
                 roof["valu_wave_instructions"] = valu
+                roof["valu_source"] = valu_src
                 roof["valu_issue_frac"] = round(valu * 4 / (1024 * 2.4e9) / dom_avg_s, 3)
         out = {
             "metric": "rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512", "value": round(value, 2), "unit": "Mpix/s",

@@ -800,7 +800,17 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
     __shared__ unsigned short s_order[EG_LINE_THREADS];
     __shared__ int s_nitems, s_pass[2];
     const int is = a.S;
-    const size_t line = blockIdx.x;                           // (b*2 + axis)*S + d0
+    // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs, and neighbouring COLUMN lines share
+    // their pixels' cache lines (a 64-byte line holds the records of 4 neighbouring columns, the pairs of 8, the alphas
+    // of 16) -- dealt to different XCDs every one of them is fetched into up to 8 L2s (1.74 GB of HBM-side traffic per
+    // launch for 0.3 GB of maps).  XCD x takes the contiguous lines [x*per, (x+1)*per).
+#ifndef D3M_EG_LINES_PLAIN_ORDER
+    const XcdOrder xo((int)a.n_lines);
+    const size_t line = (size_t)xo.unit((int)blockIdx.x);     // (b*2 + axis)*S + d0
+    if (line >= a.n_lines) return;
+#else
+    const size_t line = blockIdx.x;
+#endif
     const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // crossing records under this line
     if (n_x <= 0) return;                                     // nothing to do (uniform exit)
     const int wv = threadIdx.x >> 6, lane = lane_id();
@@ -1427,7 +1437,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     }
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
-    const dim3 glines((unsigned)nl);
+    const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
 #define D3M_LINES1(RGB, ALPHA, PADDED)                                                                               \
     do {                                                                                                             \
         if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                          \

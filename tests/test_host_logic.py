@@ -133,7 +133,7 @@ def test_committed_bench_line_and_profiles_are_consistent():
     import json
     sys.path.insert(0, ROOT)
     import bench
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_final.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_final.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -141,11 +141,13 @@ def test_committed_bench_line_and_profiles_are_consistent():
     assert "workload" in line["config"] and "model" not in line["config"]
     roof = line["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
-    assert roof["traffic"] == bench.measured_traffic(roof["kernel"])
-    assert roof.get("valu_wave_instructions") == bench.measured_valu(roof["kernel"])
+    traffic, traffic_src = bench.measured_traffic(roof["kernel"])
+    assert roof["traffic"] == traffic and roof["traffic_source"] == traffic_src and traffic_src.startswith("profiles/r02_")
+    valu, valu_src = bench.measured_valu(roof["kernel"])
+    assert roof.get("valu_wave_instructions") == valu and roof.get("valu_source") == valu_src
     assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["cores"] >= 1
-    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_final.csv")))]
-    row = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats_final.csv")))
+    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_final.csv")))]
+    row = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_final.csv")))
            if roof["kernel"] in r["Name"]]
     assert names and row
     # rocprofv3's average duration of that kernel agrees with the HIP-event average in the bench line
