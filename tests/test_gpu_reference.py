@@ -141,6 +141,32 @@ def test_product_operators_against_device_reference_fuzz(seed):
         assert _rel_max(gt, gt_ref) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_sliver_faces_against_device_reference(seed):
+    """The binned forward's one theoretical deviation: a (near-)zero-area face selected by brute force at
+    a pixel outside its dilated bounding box.  800 slivers per scene -- collinear up to rounding, thin, and exactly
+    collinear through pixel centres -- product vs the reference's kernels: counted, and the count must be zero."""
+    rng = np.random.default_rng(seed)
+    S, Fn = int(rng.choice([32, 64, 128])), 400
+    p0 = rng.uniform(-1.1, 1.1, (1, Fn, 1, 2))
+    d = rng.uniform(-1, 1, (1, Fn, 1, 2)) * float(rng.choice([0.05, 0.3, 1.5]))
+    xy = p0 + d * rng.uniform(0, 1, (1, Fn, 3, 1))
+    if seed % 3 == 0:
+        xy = xy + rng.normal(size=xy.shape) * 1e-7
+    elif seed % 3 == 1:
+        xy = xy + rng.normal(size=xy.shape) * 1e-4
+    else:
+        c = (2 * rng.integers(0, S, (1, Fn, 1, 2)) + 1 - S) / S
+        xy = c + rng.integers(-3, 4, (1, Fn, 1, 2)) * 2.0 / S * rng.integers(0, 6, (1, Fn, 3, 1))
+    faces = np.concatenate([xy, rng.uniform(0.6, 3.0, (1, Fn, 3, 1))], -1).astype(np.float32)
+    fd = torch.from_numpy(np.concatenate([faces, faces[:, :, ::-1]], 1).copy()).cuda()
+    td = torch.rand(1, fd.shape[1], 2, 2, 2, 3, device="cuda")
+    ref = RH.forward(fd, td, S, 0.5, 3.5, 1e-3, (0, 0, 0))
+    m = _product_forward(fd, td, S, 0.5, 3.5, 1e-3, (0, 0, 0))
+    assert int((m["face_index_map"] != ref["face_index_map"]).sum()) == 0
+    _assert_maps_equal(m, ref, ("weight_map", "depth_map", "rgb_map"))
+
+
 # ------------------------------------------------------------------------------------------------------------
 # 3. BASELINE.json's configurations at FULL SIZE
 # ------------------------------------------------------------------------------------------------------------
