@@ -59,13 +59,10 @@ __device__ __forceinline__ bool pixel_bbox(const float* f, int S, int& x0, int& 
 #ifndef D3M_BIN_THREADS
 #define D3M_BIN_THREADS 1024
 #endif
-#ifndef D3M_BIN_FPT
-#define D3M_BIN_FPT 1
-#endif
-constexpr int BIN_THREADS = D3M_BIN_THREADS;      // threads per binning workgroup,
-constexpr int BIN_FPT = D3M_BIN_FPT;              // each taking this many faces (face pairs with fill_back)
-constexpr int BIN_FACES = BIN_THREADS * BIN_FPT;  // -> faces per workgroup: its tile counters cost one global atomic each
-constexpr int TA_BITS = BIN_FACES >= 4096 ? 12 : BIN_FACES >= 1024 ? 11 : BIN_FACES >= 512 ? 10 : 9;
+constexpr int BIN_THREADS = D3M_BIN_THREADS;      // faces (face pairs with fill_back) per binning workgroup, at most: its
+                                                  // tile counters cost one global atomic each per distinct tile
+constexpr int BIN_THREADS_SMALL = 256;            // ... when 1024 per workgroup would leave most of the chip idle
+constexpr int TA_BITS = BIN_THREADS >= 1024 ? 11 : BIN_THREADS >= 512 ? 10 : 9;
 constexpr int TA_SLOTS = 1 << TA_BITS;   // a workgroup touches far fewer distinct tiles
 constexpr int TA_PROBES = 12;
 struct TileAgg {
@@ -107,8 +104,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
     __shared__ TileAgg agg;
     ta_clear(agg);
     const int F = bb.F, Fl = PAIRED ? F / 2 : F;          // faces per view: all / handled by one lane each
-    for (int it = 0; it < BIN_FPT; it++) {
-    const long lane_i = ((long)blockIdx.x * BIN_FPT + it) * blockDim.x + threadIdx.x;
+    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = lane_i < (long)bb.B * Fl;
     const int b = in_range ? (int)(lane_i / Fl) : 0, f0 = in_range ? (int)(lane_i % Fl) : 0;
     float loaded[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -157,7 +153,6 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
             if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
         }
     }
-    }
     __syncthreads();
     for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
         if (agg.key[k]) atomicAdd(&bb.tile_count[agg.key[k] - 1], agg.cnt[k]);
@@ -192,10 +187,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
     ta_clear(agg);
     const int Fl = PAIRED ? bb.F / 2 : bb.F;
     constexpr int TA_LOCAL = 4;
-    int packed[BIN_FPT][TA_LOCAL], face_of[BIN_FPT];
-#pragma unroll
-    for (int it = 0; it < BIN_FPT; it++) {
-    const long lane_i = ((long)blockIdx.x * BIN_FPT + it) * blockDim.x + threadIdx.x;
+    int packed[TA_LOCAL];
+    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
     if (lane_i < (long)bb.B * Fl) {
         b = (int)(lane_i / Fl);
@@ -226,20 +219,18 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
     // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a
     // full table go straight to the global cursor), one cursor atomic per distinct tile, then the scatter
 #pragma unroll
-    for (int s = 0; s < TA_LOCAL; s++) packed[it][s] = -1;
-    face_of[it] = f;
+    for (int s = 0; s < TA_LOCAL; s++) packed[s] = -1;
     for (int s = 0; s < nt; s++) {
         const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
         int rank = 0, slot = -1;
         if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
         if (slot >= 0) {
 #pragma unroll
-            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[it][q] = (slot << 16) | rank;
+            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[q] = (slot << 16) | rank;
         } else {
             const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
             bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
         }
-    }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
@@ -249,12 +240,8 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
         }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < BIN_FPT; it++) {
-#pragma unroll
-        for (int s = 0; s < TA_LOCAL; s++)
-            if (packed[it][s] >= 0)
-                bb.pairs[(size_t)agg.base[packed[it][s] >> 16] + (packed[it][s] & 0xFFFF)] = face_of[it];
-    }
+    for (int s = 0; s < TA_LOCAL; s++)
+        if (packed[s] >= 0) bb.pairs[(size_t)agg.base[packed[s] >> 16] + (packed[s] & 0xFFFF)] = f;
 }
 
 // ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------

@@ -151,6 +151,9 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
     return D3M_OK;
 }
 
+// binning workgroup: 1024 lanes (fewest global atomics on the tile counters) once that still fills the chip
+static inline unsigned bin_threads(long lanes) { return lanes >= 1024l * 1024 ? BIN_THREADS : BIN_THREADS_SMALL; }
+
 // grid of the per-pixel backward kernels (they stride): `sparse` = only the pixels of a few large faces have work, and
 // normally there are none
 static inline unsigned px_grid(long n, bool sparse) {
@@ -167,10 +170,10 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, fs, bb, faces_inv,
+    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, fs, bb, faces_inv,
            (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, bb);
+    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     if (n_tiles <= RASTER_SMALL_GRID)
@@ -193,14 +196,14 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
     if (ifs.fill_back)      // one lane per index triple, both copies
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, BIN_FACES)), dim3(BIN_THREADS), st, ifs, bb,
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks);
     else
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, ifs, bb,
+        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, BIN_FACES)), dim3(BIN_THREADS), st, bb);
-    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, BIN_FACES)), dim3(BIN_THREADS), st, bb);
+    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, bb);
+    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, bb);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};

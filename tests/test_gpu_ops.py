@@ -175,6 +175,32 @@ def test_edge_gradient_crowded_lines_and_clipped_walks(masked):
     assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
 
 
+def test_edge_gradient_on_an_image_wider_than_the_line_window():
+    """K4 at S = 2304: above 2048 pixels per line the plan's count pass merges its line counters by key instead of in
+    the LDS line window, and the line kernel clamps instead of padding -- small and large faces, two views, against
+    the oracle's per-face walk."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    S, n = 2304, 48
+    rng = np.random.default_rng(23)
+    xy = rng.uniform(-0.9, 0.9, (2, n, 1, 2)) + rng.uniform(-1, 1, (2, n, 3, 2)) * rng.choice([0.004, 0.05, 0.4], (2, n, 1, 1))
+    faces = np.concatenate([xy, rng.uniform(1.0, 2.0, (2, n, 3, 1))], -1).astype(np.float32)
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
+    m = O.raster_forward(faces, rng.uniform(0, 1, (2, 2 * n, 2, 2, 2, 3)).astype(np.float32), S, 0.1, 100.0, 1e-3,
+                         (0.1, 0.2, 0.3), True, True, False)
+    assert (m["face_index_map"] >= 0).sum() > 20000
+    band = np.zeros((2, S, S), np.float32)
+    band[:, 300:2100, 200:2000] = 1.0
+    g_rgb = rng.normal(size=(2, S, S, 3)).astype(np.float32) * band[..., None]
+    g_alpha = rng.normal(size=(2, S, S)).astype(np.float32) * band
+    gf_ref, _ = O.raster_backward(m, g_rgb, g_alpha, None, True, True, False)
+    fd = _dev(faces)
+    gf = torch.zeros_like(fd)
+    ops.backward_pixel_map(fd, _dev(m["face_index_map"]), _dev(m["rgb_map"]), _dev(m["alpha_map"]), _dev(g_rgb), _dev(g_alpha),
+                           gf, S, 1e-3, True, True)
+    assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_backward_operators_differential_fuzz(seed):
     """Random small scenes through K4 / K5 / K6 against the oracle: triangle sizes from sub-pixel to screen-filling,

@@ -35,12 +35,16 @@ print("crossings", total, "per view", total / B, "lines with crossings", int((cu
 act = cursor[cursor > 0]
 print("crossings per active line: mean %.1f median %d p90 %d max %d" % (act.mean(), np.median(act), np.percentile(act, 90), act.max()))
 print("chunks of 256:", int(np.ceil(act / 256).sum()), " thread-slots used in set-up: %.2f" % (2 * act.sum() / (np.ceil(act / 256).sum() * 512)))
-x = raw[off_xrec:off_xrec + total * 32].view(np.uint32).reshape(total, 8)
+slices = raw[off_slice:off_slice + nl * 8].view(np.int32).reshape(nl, 2)
+idx = np.concatenate([np.arange(c) + s0 for (s0, n0), c in zip(slices, cursor) if c > 0])
+print("records written %d of %d crossings (%.3f): the rest is outside the image or cannot contribute" % (len(idx), total, len(idx) / total))
+cap_bytes = len(raw) - off_xrec
+x = raw[off_xrec:off_xrec + (idx.max() + 1) * 32].view(np.uint32).reshape(-1, 8)[idx]
 bits = x[:, 3] & 0xFF
 d1_in = (x[:, 3] >> 8).astype(np.int64)
 alive, owner, oriented = (bits & 1) != 0, (bits & 16) != 0, (bits & 32) != 0
 in_from, in_to = (x[:, 4] & 0xFFFF).astype(np.int64), (x[:, 4] >> 16).astype(np.int64)
-print("alive %.3f  outward walks (owner) %.3f  inward oriented %.3f" % (alive.mean(), (alive & owner).mean(), (alive & oriented).mean()))
+print("of the records: outward walks (owner) %.3f  inward oriented %.3f" % ((alive & owner).mean(), (alive & oriented).mean()))
 il = (in_to - in_from + 1)[alive]
 print("inward length (unclipped): mean %.2f  <=6: %.3f  max %d" % (il.mean(), (il <= 6).mean(), il.max()))
 dirpos = (bits & 2) != 0
