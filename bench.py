@@ -308,6 +308,9 @@ def main():
     ap.add_argument("--materialise-images", action="store_true",
                     help="render() the output images and evaluate the objective on them (multiview_fit_loss) instead of "
                          "inside the rendering node")
+    ap.add_argument("--fit-with-images", action="store_true",
+                    help="the fused objective, and the same pass also writes the output images (Renderer.render_fit_loss "
+                         "images_out): what keeping the images costs on top of the headline line")
     ap.add_argument("--view-groups", type=int, default=1,
                     help="run each GPU's views as this many concurrent pipelines inside the rendering node")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
@@ -353,6 +356,7 @@ def main():
                        world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images,
                        view_groups=args.view_groups)
     fit.set_targets_from(synthetic.perturb(v))
+    fit.keep_images = args.fit_with_images
 
     def barrier():
         if world > 1:
@@ -443,7 +447,8 @@ def main():
                                       "; the objective is evaluated in the pass that produces the pixel values "
                                       "(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps")
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
-                       "api": "render+loss" if args.materialise_images else "render_fit_loss",
+                       "api": "render+loss" if args.materialise_images else
+                              ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"),
                        "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
                        "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}"},

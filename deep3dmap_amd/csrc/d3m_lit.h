@@ -299,6 +299,8 @@ __global__ void __launch_bounds__(256) k_render_lit_fit_records(const float* __r
                                                                const float* __restrict__ depth_map,
                                                                const float* __restrict__ background, int bg_b,
                                                                float* __restrict__ rgb_blended, float* __restrict__ alpha_map,
+                                                               float* __restrict__ rgb_out, float* __restrict__ alpha_out,
+                                                               float* __restrict__ depth_out,
                                                                int B, int S, float eps, FitTargets fit, FitRecords rec) {
     __shared__ float4 s_part[4];
     __shared__ int s_col_lo_inv[32], s_col_hi1[32];
@@ -332,6 +334,12 @@ __global__ void __launch_bounds__(256) k_render_lit_fit_records(const float* __r
 #pragma unroll
             for (int k = 0; k < 3; k++) rgb_blended[3 * p + k] = v[k];
             alpha_map[p] = alpha;
+            if (rgb_out) {                                    // the images as well (CHW, flipped: rasterize.py:305-317)
+#pragma unroll
+                for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * S + yo) * S + xi] = v[k];
+            }
+            if (alpha_out) alpha_out[o] = alpha;
+            if (depth_out) depth_out[o] = depth;
             const float m = tg[5], d = alpha - tg[4];
 #pragma unroll
             for (int k = 0; k < 3; k++) t_rgb += fabsf(v[k] - tg[k]) * m;      // same terms as k_fit_loss_reduce

@@ -788,7 +788,8 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
                        fit->grad_depth_map};
         LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
-               weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, batch_size, image_size, eps, ft, rec);
+               weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out, depth_out,
+               batch_size, image_size, eps, ft, rec);
         if (!fit->defer_finish)
             LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
                    (int)(tiles.x * tiles.y * tiles.z), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);

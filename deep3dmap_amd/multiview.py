@@ -81,6 +81,8 @@ class MultiViewFit:
         self.renderer.defer_plan_join = True        # _forward_backward below runs backward right behind forward
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
+        self.keep_images = False        # True: the fused objective's pass also writes this step's images to self.images
+        self.images = None              # (rgb, depth, alpha)
         self.targets = None
         self.mask_sum = None            # [1] device scalar: sum of the mask over ALL ranks' views
         self._mask_sum_local = None
@@ -124,8 +126,11 @@ class MultiViewFit:
         r = self.renderer
         if self.objective_in_renderer and r._on_the_fly() and not r.anti_aliasing:
             rgb_t, depth_t, alpha_t = self.targets
+            if self.keep_images and self.images is None:        # persistent buffers (a captured step writes in place)
+                self.images = tuple(torch.empty_like(t) for t in (rgb_t, depth_t, alpha_t))
             return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
-                                     (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum))
+                                     (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum),
+                                     images_out=self.images if self.keep_images else None)
         return self.loss(*self.render())
 
     def _forward_backward(self):

@@ -325,6 +325,12 @@ class _RasterizeLit(torch.autograd.Function):
                 raise ValueError("the fused fit objective needs rgb, alpha and depth without anti-aliasing")
             rgb_t, depth_t, alpha_t, mask = (f32c(t) for t in fit[:4])
             mask_sum = f32c(fit[4]).reshape(1) if len(fit) > 4 and fit[4] is not None else None
+            if len(fit) > 5 and fit[5] is not None:
+                # the images as a by-product of the same pass (caller's buffers, not differentiable outputs)
+                rgb, depth, alpha = fit[5]
+                for t, shape in ((rgb, (B, 3, S, S)), (depth, (B, S, S)), (alpha, (B, S, S))):
+                    if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                        raise ValueError("images_out must be contiguous float32 (rgb [B,3,S,S], depth [B,S,S], alpha [B,S,S])")
             if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
                 raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
             if mask_sum is None and (G > 1 or need_grad):
@@ -564,7 +570,7 @@ def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back
 
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
                       near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
-                      view_groups=1, defer_plan_join=False):
+                      view_groups=1, defer_plan_join=False, images_out=None):
     """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
@@ -574,8 +580,11 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
     ALL ranks' views when these views are one shard of a camera-sharded fit, so that values and gradients add up): the sums are taken where the images are produced and the gradient is written straight into the
     internal-resolution maps, so the images and their gradients never exist in memory.  Same value and gradients as
     core.losses.multiview_fit_loss(*rasterize_lit(...), ...)."""
+    fit = tuple(targets)
+    if images_out is not None:          # (rgb, depth, alpha) buffers the same pass fills with the images render() returns
+        fit = (fit + (None,))[:5] + (tuple(images_out),)
     return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
-                               far, eps, background_color, True, True, True, tuple(targets), view_groups, defer_plan_join)
+                               far, eps, background_color, True, True, True, fit, view_groups, defer_plan_join)
 
 
 def rasterize_rgbad(

@@ -147,15 +147,17 @@ class Renderer(nn.Module):
                          self.rasterizer_eps, self.background_color)
 
     def render_fit_loss(self, vertices, faces, textures, targets, K=None, R=None, t=None, dist_coeffs=None,
-                        orig_size=None):
+                        orig_size=None, images_out=None):
         """The multi-view fit objective of render()'s images against `targets` = (rgb, depth, alpha, mask), evaluated
-        inside the rendering node (rasterize_lit_fit); needs lighting_on_the_fly and no anti-aliasing."""
+        inside the rendering node (rasterize_lit_fit); needs lighting_on_the_fly and no anti-aliasing.  `images_out`
+        = (rgb [B,3,S,S], depth [B,S,S], alpha [B,S,S]) buffers: the same pass also writes the images render() would
+        return (for display / logging; gradients flow through the returned objective only)."""
         if not self._on_the_fly() or self.anti_aliasing:
             raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch) and anti_aliasing=False")
         sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                 view_groups=self.view_groups, defer_plan_join=self.defer_plan_join)
+                                 view_groups=self.view_groups, defer_plan_join=self.defer_plan_join, images_out=images_out)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():

@@ -628,3 +628,22 @@ def test_losses_refuse_gradients_they_do_not_compute():
         silhouette_loss(a[:, 0], b[:, 0])
     photometric_loss(a, b.detach(), conf_sigma=sig.detach()).backward()
     assert a.grad is not None
+
+
+def test_fit_objective_can_leave_the_images_behind():
+    """render_fit_loss(images_out=...): the pass that evaluates the objective also writes the images render() returns
+    (bit for bit), and value and gradients of the objective do not change."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(18)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=64)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    loss0, gv0, gt0 = (t.clone() for t in fit.step())
+    fit.keep_images = True
+    loss1, gv1, gt1 = fit.step()
+    assert float(loss0) == float(loss1) and _rel_max(gv1, gv0) < 1e-5 and _rel_max(gt1, gt0) < 1e-5
+    with torch.no_grad():
+        rgb, depth, alpha = fit.render()
+    for got, ref in zip(fit.images, (rgb, depth, alpha)):
+        assert torch.equal(got, ref)

@@ -20,6 +20,7 @@ timeout 600 python bench.py > $O/${R}_bench_final.json 2> $O/bench.err
 tail -c 400 $O/${R}_bench_final.json
 timeout 300 python bench.py --no-cpu-baseline --materialise-images > $O/${R}_bench_materialise_images.json 2>> $O/bench.err
 cut -c1-160 $O/${R}_bench_materialise_images.json
+timeout 300 python bench.py --no-cpu-baseline --fit-with-images > $O/${R}_bench_fit_with_images.json 2>> $O/bench.err
 D3M_SERIAL_BRANCHES=1 timeout 300 python bench.py --no-cpu-baseline > $O/${R}_bench_serial_branches.json 2>> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --no-cpu-baseline --steps 30 > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_final.csv
