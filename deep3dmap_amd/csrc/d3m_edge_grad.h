@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(256) k_mark_visible_bytes(const int32_t* __res
 __device__ __forceinline__ unsigned visible_nibble(const unsigned char* __restrict__ marks, long i0, long n) {
     if (i0 >= n) return 0u;
     const unsigned m = *(const unsigned*)(marks + i0);          // 0 or 1 per byte
-    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 15u;
+    const unsigned valid = n - i0 >= 4 ? 15u : (1u << (int)(n - i0)) - 1u;      // (bytes past the last face are not the marks')
+    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & valid;
 }
 
 __global__ void __launch_bounds__(256) k_count_visible(const unsigned char* __restrict__ bits, int* __restrict__ vis_block, long n) {
@@ -749,7 +750,7 @@ constexpr int EG_LINE_THREADS = EG_LINE_WAVES * 64;
 constexpr int EG_CHUNK = EG_LINE_THREADS / 2;  // crossings set up at a time: one thread per (crossing, outward | inward)
 constexpr int EG_QUEUE = EG_LINE_THREADS;      // long segments queued in LDS before they are walked (one sort key per thread)
 constexpr size_t EG_LINE_STATIC_LDS = (size_t)EG_QUEUE * (EG_ITEM_DW * 4 + 2) + 1024;   // queue + order + counters
-static_assert((EG_CHUNK & (EG_CHUNK - 1)) == 0, "threads are split into an outward and an inward half by a mask");
+static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole waves the inward ones");
 #ifndef D3M_EG_LINE_MINWAVES
 #define D3M_EG_LINE_MINWAVES 1
 #endif
@@ -836,7 +837,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
         int fn;
         long slot;
     };
-    const int my_x = (int)threadIdx.x & (EG_CHUNK - 1), my_which = (int)threadIdx.x >= EG_CHUNK ? 1 : 0;
+    const int my_which = (int)threadIdx.x >= EG_CHUNK ? 1 : 0, my_x = (int)threadIdx.x - my_which * EG_CHUNK;
     auto set_up = [&](int ci) {
         Setup u;
         u.has = false;
