@@ -65,6 +65,8 @@ constexpr int BIN_THREADS_SMALL = 256;            // ... when 1024 per workgroup
 constexpr int TA_BITS = BIN_THREADS >= 1024 ? 11 : BIN_THREADS >= 512 ? 10 : 9;
 constexpr int TA_SLOTS = 1 << TA_BITS;   // a workgroup touches far fewer distinct tiles
 constexpr int TA_PROBES = 12;
+// the part of the table a launch uses: two slots per lane (a 256-lane workgroup sweeps 512 slots, not 2048)
+__device__ __forceinline__ int ta_bits() { return blockDim.x >= 1024 ? TA_BITS : blockDim.x >= 512 ? TA_BITS - 1 : TA_BITS - 2; }
 struct TileAgg {
     int key[TA_SLOTS];                   // tile id + 1, 0 = empty
     int cnt[TA_SLOTS];
@@ -72,14 +74,15 @@ struct TileAgg {
 };
 
 __device__ __forceinline__ void ta_clear(TileAgg& t) {
-    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x) { t.key[k] = 0; t.cnt[k] = 0; }
+    for (int k = threadIdx.x; k < (1 << ta_bits()); k += blockDim.x) { t.key[k] = 0; t.cnt[k] = 0; }
     __syncthreads();
 }
 
 // slot of `tile` (inserted if new) and this pair's rank among the workgroup's pairs of that tile; -1: table too full
 __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
-    unsigned h = ((unsigned)tile * 2654435761u) >> (32 - TA_BITS);
-    for (int p = 0; p < TA_PROBES; p++, h = (h + 1) & (TA_SLOTS - 1)) {
+    const int bits = ta_bits();
+    unsigned h = ((unsigned)tile * 2654435761u) >> (32 - bits);
+    for (int p = 0; p < TA_PROBES; p++, h = (h + 1) & ((1u << bits) - 1)) {
         int k = t.key[h];
         if (k == 0) k = atomicCAS(&t.key[h], 0, tile + 1);
         if (k == 0 || k == tile + 1) {
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
+    for (int k = threadIdx.x; k < (1 << ta_bits()); k += blockDim.x)
         if (agg.key[k]) atomicAdd(&bb.tile_count[agg.key[k] - 1], agg.cnt[k]);
 }
 
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < TA_SLOTS; k += blockDim.x)
+    for (int k = threadIdx.x; k < (1 << ta_bits()); k += blockDim.x)
         if (agg.key[k]) {
             const int tile = agg.key[k] - 1;
             agg.base[k] = bb.tile_offset[tile] + atomicAdd(&bb.tile_cursor[tile], agg.cnt[k]);
