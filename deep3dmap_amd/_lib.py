@@ -82,6 +82,7 @@ _SIGNATURES = {
                                        _P, _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_output_epilogue_backward_records": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_photometric_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_sum_squared_error": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "d3m_smooth_loss_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),

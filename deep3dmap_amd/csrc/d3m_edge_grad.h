@@ -1161,11 +1161,21 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
 
 // Per-pixel walk records and the lines' non-zero extents, one pass over the five maps: a 32x32 tile per workgroup
 // (the column extents are merged per tile in LDS: one atomic per column and tile).
+// The gradients can also come straight from the OUTPUT images' gradients (ImageGrads: CHW, flipped, 2x2-pooled with
+// anti-aliasing -- rasterize.py:305-326 undone on the fly, d3m_output_epilogue_backward_records): the adjoint of the
+// output epilogue then has no pass and no [B,S,S,3] / [B,S,S] gradient maps of its own; the depth gradient, which the
+// edge gradient does not read, is written out as the map its readers take.
+struct ImageGrads {
+    const float *g_rgb_out, *g_alpha_out, *g_depth_out;   // [B,3,s,s], [B,s,s], [B,s,s] or NULL
+    float* g_depth_map;                                   // [B,S,S] out (with g_depth_out)
+    int s, aa, on;
+};
 __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ fi, const float* __restrict__ alpha,
                                                   const float* __restrict__ galpha, const float* __restrict__ rgb,
                                                   const float* __restrict__ grgb, float4* __restrict__ grad_row,
                                                   float2* __restrict__ dot_row, int* __restrict__ nz_lo_inv,
-                                                  int* __restrict__ nz_hi1, int S, GradScale gs) {
+                                                  int* __restrict__ nz_hi1, int S, GradScale gs,
+                                                  ImageGrads img = ImageGrads{nullptr, nullptr, nullptr, nullptr, 0, 0, 0}) {
     __shared__ int s_col_lo_inv[32], s_col_hi1[32];
     if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
@@ -1182,8 +1192,21 @@ __global__ void __launch_bounds__(256) k_pack_maps(const int32_t* __restrict__ f
             const size_t i = plane + (size_t)y * S + x;
             float4 g = make_float4(0, 0, 0, 0);
             float dot = 0;
-            if (alpha) { g.x = galpha[i] * s_alpha; dot += alpha[i] * g.x; }
-            if (rgb) {
+            if (img.on) {       // output pixel of internal pixel (y, x): flipped, pooled 2x2 with anti-aliasing
+                const int yo = img.aa ? (S - 1 - y) / 2 : S - 1 - y, xo = img.aa ? x / 2 : x;
+                const float sc = img.aa ? 0.25f : 1.0f;
+                const size_t o = ((size_t)b * img.s + yo) * img.s + xo;
+                if (alpha && img.g_alpha_out) { g.x = img.g_alpha_out[o] * sc; dot += alpha[i] * g.x; }
+                if (rgb && img.g_rgb_out) {
+                    const size_t plane_o = (size_t)img.s * img.s, o0 = ((size_t)b * 3 * img.s + yo) * img.s + xo;
+                    g.y = img.g_rgb_out[o0] * sc; g.z = img.g_rgb_out[o0 + plane_o] * sc; g.w = img.g_rgb_out[o0 + 2 * plane_o] * sc;
+                    dot += rgb[3 * i] * g.y;
+                    dot += rgb[3 * i + 1] * g.z;
+                    dot += rgb[3 * i + 2] * g.w;
+                }
+                if (img.g_depth_map) img.g_depth_map[i] = img.g_depth_out[o] * sc;
+            } else if (alpha) { g.x = galpha[i] * s_alpha; dot += alpha[i] * g.x; }
+            if (!img.on && rgb) {
                 g.y = grgb[3 * i] * s_rgb; g.z = grgb[3 * i + 1] * s_rgb; g.w = grgb[3 * i + 2] * s_rgb;
                 dot += rgb[3 * i] * g.y;
                 dot += rgb[3 * i + 1] * g.z;

@@ -308,7 +308,7 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const d3m_vertex_target* vertex_target, void* visibility, void* edge_plan,
                                       size_t edge_plan_size, const d3m_fit_targets* unscaled, d3m_stream_t stream) {
     if (edge_plan && !visibility) return D3M_ERR_INVALID;      // a plan indexes the list of its visibility blob
-    if (unscaled && !unscaled->scratch) return D3M_ERR_INVALID;
+    if (unscaled && !unscaled->scratch && !unscaled->edge_grad) return D3M_ERR_INVALID;    // (records without a scratch: final)
     if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -846,7 +846,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         return D3M_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int B = batch_size, S = image_size;
-    if (unscaled && !unscaled->scratch) return D3M_ERR_INVALID;
+    if (unscaled && !unscaled->scratch && !unscaled->edge_grad) return D3M_ERR_INVALID;    // (records without a scratch: final)
     const GradScale gs = to_grad_scale(unscaled, S);
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
     const size_t view_elems = (size_t)num_tri * ts3 * 3;
@@ -946,6 +946,32 @@ D3M_EXPORT int d3m_output_epilogue_backward(const float* grad_rgb_out, const flo
     LAUNCH("k_output_epilogue_backward", k_output_epilogue_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream,
                        grad_rgb_out, grad_alpha_out, grad_depth_out, grad_rgb_map, grad_alpha_map, grad_depth_map,
                        batch_size, image_size, anti_aliasing ? 1 : 0);
+    return check_launch();
+}
+
+// The same adjoint with the rgb / alpha gradients leaving as the edge gradient's per-pixel records (no gradient maps:
+// d3m_backward_pixel_map / d3m_backward_textures_lit take the records through `unscaled`, scratch NULL = final).
+D3M_EXPORT int d3m_output_epilogue_backward_records(const float* grad_rgb_out, const float* grad_alpha_out,
+                                                    const float* grad_depth_out, const int32_t* face_index_map,
+                                                    const float* rgb_map, const float* alpha_map, void* edge_grad,
+                                                    void* edge_dot, int* edge_nz_lo_inv, int* edge_nz_hi1,
+                                                    float* grad_depth_map, int batch_size, int image_size,
+                                                    int anti_aliasing, d3m_stream_t stream) {
+    if (batch_size <= 0 || image_size <= 0 || !face_index_map || !edge_grad || !edge_dot || !edge_nz_lo_inv || !edge_nz_hi1)
+        return D3M_ERR_INVALID;
+    if ((grad_rgb_out && !rgb_map) || (grad_alpha_out && !alpha_map) || (grad_depth_map && !grad_depth_out)) return D3M_ERR_INVALID;
+    if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = image_size, B = batch_size;
+    const size_t nz_bytes = (size_t)B * 2 * S * 4;
+    HIP_TRY(zero_async(edge_nz_lo_inv, nz_bytes, st));
+    HIP_TRY(zero_async(edge_nz_hi1, nz_bytes, st));
+    const ImageGrads img{grad_rgb_out, grad_alpha_out, grad_depth_out, grad_depth_map, anti_aliasing ? S / 2 : S,
+                         anti_aliasing ? 1 : 0, 1};
+    LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, face_index_map,
+           grad_alpha_out ? alpha_map : (const float*)nullptr, (const float*)nullptr,
+           grad_rgb_out ? rgb_map : (const float*)nullptr, (const float*)nullptr, (float4*)edge_grad, (float2*)edge_dot,
+           edge_nz_lo_inv, edge_nz_hi1, S, GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, img);
     return check_launch();
 }
 

@@ -449,14 +449,21 @@ class _RasterizeLit(torch.autograd.Function):
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
         grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
         grad_loss = scratch = mask_sum = None
+        records = None
         if ctx.fit is None:
-            g_rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
-            g_alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if ra else None
+            # the adjoint of the output epilogue (un-pool, un-flip, CHW -> HWC) writes the rgb / alpha gradients straight
+            # as the edge gradient's per-pixel records (what d3m_backward_pixel_map would pack from gradient maps: one
+            # pass over the pixels instead of two, no [B,S,S,3] / [B,S,S] gradient maps); the depth gradient as a map
+            g_rgb_map = g_alpha_map = None
             g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
-            _lib.check(L.d3m_output_epilogue_backward(
+            records = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),
+                       torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),
+                       torch.empty(2, B, 2, S, dtype=torch.int32, device=dev))
+            _lib.check(L.d3m_output_epilogue_backward_records(
                 _lib.ptr(f32c(g_rgb)), _lib.ptr(f32c(g_alpha) if ra else None), _lib.ptr(f32c(g_depth) if rd else None),
-                _lib.ptr(g_rgb_map), _lib.ptr(g_alpha_map), _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()),
-                "d3m_output_epilogue_backward")
+                _lib.ptr(m["face_index_map"]), _lib.ptr(m["rgb_map"]), _lib.ptr(m["alpha_map"] if ra else None),
+                _lib.ptr(records[0]), _lib.ptr(records[1]), _lib.ptr(records[2][0]), _lib.ptr(records[2][1]),
+                _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward_records")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
             scratch, g_depth_map = ctx.fit[4], ctx.fit[6][3]
             g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (ctx.fit[6][:3])
@@ -504,6 +511,10 @@ class _RasterizeLit(torch.autograd.Function):
             unscaled = None
             if ctx.fit is not None:
                 unscaled = _RasterizeLit._fit_struct(ctx.fit, k, lo, hi, grad_loss)
+            elif records is not None:           # final records: no scratch, no scalars to apply
+                unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
+                                              _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
+                                              _lib.ptr(records[2][0, lo:hi]), _lib.ptr(records[2][1, lo:hi]), 0)
             if gathered:
                 with torch.cuda.stream(auxs[k]):
                     ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)

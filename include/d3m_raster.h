@@ -399,6 +399,15 @@ int d3m_output_epilogue_backward(const float* grad_rgb_out, const float* grad_al
                                  const float* grad_depth_out, float* grad_rgb_map, float* grad_alpha_map,
                                  float* grad_depth_map, int batch_size, int image_size, int anti_aliasing,
                                  d3m_stream_t stream);
+/* The same adjoint, with the rgb / alpha gradients leaving as the per-pixel records the edge gradient walks over
+ * (edge_grad [B,S,S] float4, edge_dot [B,S,S] float2, the lines' non-zero extents edge_nz_* [B,2,S] i32: see
+ * d3m_fit_targets) instead of gradient maps; the depth gradient still leaves as a map.  d3m_backward_pixel_map and
+ * d3m_backward_textures_lit take the records through `unscaled` with scratch = grad_loss = mask_sum = NULL (final). */
+int d3m_output_epilogue_backward_records(const float* grad_rgb_out, const float* grad_alpha_out,
+                                         const float* grad_depth_out, const int32_t* face_index_map,
+                                         const float* rgb_map, const float* alpha_map, void* edge_grad, void* edge_dot,
+                                         int* edge_nz_lo_inv, int* edge_nz_hi1, float* grad_depth_map, int batch_size,
+                                         int image_size, int anti_aliasing, d3m_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * C. Losses on the path (deep3dmap/core/utils/utils.py:82-114; examples/example2.py:43-47).
