@@ -883,6 +883,13 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
         p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
         return p.x + p.y;
     };
+    // the same sum in BOTH halves of a pair (one packed add of the pair with itself swapped)
+    auto diff_of2 = [](const float4 g, const float2 d, const v2f nref_ar, const v2f nref_gb) {
+        v2f p = {d.x, d.x};
+        p = __builtin_elementwise_fma(v2f{g.x, g.y}, nref_ar, p);
+        p = __builtin_elementwise_fma(v2f{g.z, g.w}, nref_gb, p);
+        return p + __builtin_shufflevector(p, p, 1, 0);
+    };
     // both quotients of a pixel from ONE v_rcp_f32 (a quarter-rate instruction): 1/a = b * 1/(a*b).  Two more roundings
     // (~1.5 ulp); |a*b| stays far inside the float range for distances of at most S pixels and |u| >= eps*S/2^k
 #ifdef D3M_EG_TWO_RCP
@@ -893,6 +900,23 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
         return v2f{r, r} * v2f{den.y, den.x};
     };
 #endif
+    // acc += d2 * r in the lanes of `keep` only, as an EXEC-masked instruction: two scalar instructions around one
+    // vector instruction, where the compiler's select form costs two more vector instructions per visit (-5 % kernel)
+    // and its branch form a taken branch.  Never by multiplying with 0: a lane outside its segment may sit exactly on
+    // den == 0 (1/0 = inf, 0 * inf = NaN).
+    auto fma_where = [](v2f& acc, const v2f d2, const v2f r, const unsigned long long keep) {
+#ifdef D3M_EG_SELECT_FMA
+        if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(d2, r, acc);
+#else
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %[sv], %[kp]\n\t"
+                     "v_pk_fma_f32 %[a], %[d], %[rr], %[a]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "+v"(acc), [sv] "=&s"(saved)
+                     : [kp] "s"(keep), [d] "v"(d2), [rr] "v"(r)
+                     : "scc");
+#endif
+    };
     const int row = lane / EG_ROW, rl = lane % EG_ROW;
     // The queue of long segments (EG_QUEUE items in LDS) is filled by as many set-up passes as it takes -- a line of the
     // headline mesh has ~380 crossings, i.e. two passes, of which ~240 segments are long -- and walked when the next
@@ -950,30 +974,25 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                     const float4* pg_to = s_grd + to;
                     v2f den = u + t;                                // advances by exact steps of EG_ROW as well
                     if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
-#pragma unroll 2
                         for (int k = 0; k < n_iter; k++) {
-                            const float diff = diff_of(*pg, *pd, nref_ar, nref_gb);
+                            const v2f d2 = diff_of2(*pg, *pd, nref_ar, nref_gb);
                             const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                            __builtin_amdgcn_ballot_w64(!(diff <= 0));
-                            const v2f r = rcp2(den);
-                            // under the lane mask, not by multiplying with 0: a lane outside its segment may sit exactly on
-                            // den == 0 (1/0 = inf, 0 * inf = NaN)
-                            if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                                                            __builtin_amdgcn_ballot_w64(!(d2.x <= 0));
+                            fma_where(acc, d2, rcp2(den), keep);
                             pg += EG_ROW;
                             pd += EG_ROW;
                             den += (float)EG_ROW;
                         }
                     } else {
-#pragma unroll 2
                         for (int k = 0; k < n_iter; k++) {
                             const float4 g = *pg;
                             const float2 d = *pd;
-                            const float diff = diff_of(g, d, nref_ar, nref_gb);
+                            const v2f d2 = diff_of2(g, d, nref_ar, nref_gb);
                             const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                            __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
+                                                            __builtin_amdgcn_ballot_w64(!(d2.x <= 0)) &
                                                             (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
                             const v2f r = rcp2(den);
-                            if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
+                            fma_where(acc, d2, r, keep);
                             pg += EG_ROW;
                             pd += EG_ROW;
                             den += (float)EG_ROW;
