@@ -3,29 +3,35 @@
 //
 // The reference runs one thread per face; for every integer crossing d0 of every edge, on both axes,
 // that thread walks the image from the edge out to the image BORDER (KCU:354-414) and inward to the
-// opposite edge (KCU:417-495): 1.35 M walks of ~250 pixels for 8 views of the 100k-triangle mesh at 512^2.
+// opposite edge (KCU:417-495): 1.4 M crossings per 8 views of the 100k-triangle mesh at 512^2, walks of ~250 pixels.
 //
 // LINE-MAJOR formulation.  A walk only ever moves along ONE image line (a row for axis 1, a column for
 // axis 0), and a line is shared by hundreds of walks.  So:
-//   0. visibility     faces that own no pixel cannot contribute: flags + compacted list (shared with the gathered
-//                     texture / depth pass through d3m_visibility);
+//   0. visibility     faces that own no pixel cannot contribute: one mark per face (left by the forward's tile pass, or
+//                     by k_mark_visible_bytes from a face_index_map), then flags + compacted list, shared with the
+//                     gathered texture / depth pass through d3m_visibility;
 //  THE PLAN (geometry only: faces + face_index_map; d3m_edge_plan can build it right after the forward pass)
-//   1. k_edge_count   a workgroup publishes the crossing ranges of its 42 faces x 6 (edge, axis) lanes in LDS and
-//                     its threads take ONE crossing each per round: crossings per workgroup and per line;
+//   1. k_edge_count_window   a workgroup iteration takes 42 visible faces x 6 (edge, axis) lanes; a lane crosses the
+//                     consecutive lines d0_from..d0_to, so it adds +1 / -1 at the ends of its range in an LDS array
+//                     indexed by the line, a running sum turns the touched window into counts, and every counted
+//                     line costs the workgroup one global atomic (k_edge_count: the by-key form, for S > 2048);
 //   2. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
-//   3. k_edge_scatter same flattening: one 32-byte record per crossing, written in LINE order;
+//   3. k_edge_scatter the lanes' crossings flattened over the threads (one crossing each per round): the geometry of a
+//                     crossing's two walks, computed once, as one 32-byte record written in LINE order; a crossing
+//                     whose walks cannot contribute gets none;
 //  THE GRADIENT (needs the gradient maps)
-//   4. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- packed in both
-//                     orientations (rows, columns), plus each line's non-zero-gradient extent;
-//   5. k_edge_lines   one workgroup per (view, axis, line): the line's per-pixel records staged in LDS once; a thread
-//                     per (crossing, outward | inward) sets the segment up against them (owner test, clip to the
-//                     extent), walks it if short, queues it in LDS if long; the queued segments are ordered by length
-//                     and walked sixteen per wave (four lanes each) with the factored distance.  The walks never
-//                     touch global memory;
-//      k_edge_overflow  crossings that got no record (workspace smaller than the scene needs) are walked from global
-//                     memory by one thread each; leaves at once otherwise;
-//   6. k_edge_gather  six lanes per visible face add their crossings' slots in order; stored to grad_faces or
-//                     accumulated into the vertex gradient (VertexTarget).
+//   4. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- plus each line's
+//                     non-zero-gradient extent, from gradient maps or from the output images' gradients; the fused fit
+//                     objective's epilogue writes the same records itself (d3m_lit.h) and this pass disappears;
+//   5. k_edge_lines   one workgroup per (view, axis, line), lines in XCD-contiguous order: the line's per-pixel records
+//                     and values staged in LDS once; a thread per (crossing, outward | inward) turns the crossing's
+//                     record into a segment clipped to the extent, walks it if short, queues it in LDS if long; the
+//                     queued segments are ordered by length and walked sixteen per wave (four lanes each) with the
+//                     factored distance.  The walks never touch global memory;
+//      k_edge_overflow  crossings that got no record because the workspace is smaller than the scene needs are walked
+//                     from global memory by one thread each; leaves at once otherwise;
+//   6. k_edge_gather  six lanes per visible face fetch their crossings' results (xpos) and add them in order; stored to
+//                     grad_faces or accumulated into the vertex gradient (VertexTarget).
 // Deterministic up to the final vertex atomics.  The reference OVERWRITES the 9 entries of every front-facing face
 // (KCU:501-502) and leaves culled ones alone (KCU:270); with the caller's zero-initialised grad_faces
 // (rasterize.py:111, a precondition of the C ABI) writing only the faces that own a pixel is the same thing: every
