@@ -511,13 +511,16 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const size_t base = (size_t)bn * S * S;
     // the depth gradient (KCU:543-592) rides along when asked for: same pixels, same weights, same depth
     float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
+    // 1 / z of the three vertices, once per face: the quotients below (KCU:222, :575, :582) become products -- one more
+    // rounding each, in a gradient held to 1e-3; the forward pass keeps the reference's divisions
+    const float rz[3] = {1.0f / fc[2], 1.0f / fc[5], 1.0f / fc[8]};
     if (grad_depth_map) {
         float finv[9];
         face_inverse(fc, S, finv);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
 #pragma unroll
-            for (int l2 = 0; l2 < 3; l2++) dtmp[k] += -finv[3 * l2 + k] / fc[3 * l2 + 2];     // KCU:582
+            for (int l2 = 0; l2 < 3; l2++) dtmp[k] += -finv[3 * l2 + k] * rz[l2];             // KCU:582
         }
     }
     // what the epilogue needs, requested now: this lane's texel (sub) of the face's cube and the face's light
@@ -556,12 +559,13 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
                 const float z_k = fc[3 * k + 2];
                 dacc[3 * k + 0] += -g * dtmp[0] * weight[k] * depth2 * (float)S / 2.0f;      // KCU:588
                 dacc[3 * k + 1] += -g * dtmp[1] * weight[k] * depth2 * (float)S / 2.0f;
-                dacc[3 * k + 2] += g * weight[k] * depth2 / (z_k * z_k);                    // KCU:575
+                dacc[3 * k + 2] += g * weight[k] * depth2 * (rz[k] * rz[k]);                // KCU:575
             }
         }
-        int fl[3];
+        int fl[3] = {0, 0, 0};                    // ts = 2: the position is clamped below 1 (KCU:222-223)
         float fr[3];
-        sample_setup(fc, weight, depth, 2, eps, fl, fr);
+#pragma unroll
+        for (int k = 0; k < 3; k++) fr[k] = fminf(fmaxf(weight[k] * (depth * rz[k]), 0.0f), 1.0f - eps);
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
             float w;
