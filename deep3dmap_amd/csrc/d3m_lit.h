@@ -515,12 +515,17 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     // rounding each, in a gradient held to 1e-3; the forward pass keeps the reference's divisions
     const float rz[3] = {1.0f / fc[2], 1.0f / fc[5], 1.0f / fc[8]};
     if (grad_depth_map) {
-        float finv[9];
-        face_inverse(fc, S, finv);
+        // the x and y columns of the face inverse (face_inverse(): KCU:24-67) over their common denominator
+        float px[3], py[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int n = 0; n < 3; n++) { px[n] = to_pixel(fc[3 * n], S); py[n] = to_pixel(fc[3 * n + 1], S); }
+        const float rden = 1.0f / (px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
+        const float ix[3] = {(py[1] - py[2]) * rden, (py[2] - py[0]) * rden, (py[0] - py[1]) * rden};
+        const float iy[3] = {(px[2] - px[1]) * rden, (px[0] - px[2]) * rden, (px[1] - px[0]) * rden};
 #pragma unroll
-            for (int l2 = 0; l2 < 3; l2++) dtmp[k] += -finv[3 * l2 + k] * rz[l2];             // KCU:582
+        for (int l2 = 0; l2 < 3; l2++) {                                                     // KCU:582
+            dtmp[0] += -ix[l2] * rz[l2];
+            dtmp[1] += -iy[l2] * rz[l2];
         }
     }
     // what the epilogue needs, requested now: this lane's texel (sub) of the face's cube and the face's light
