@@ -123,13 +123,23 @@ struct XGeom {
                                 // XG_IDLE: alive, but neither walk can contribute (no record is written)
 };
 
+// The three quotients of KCU:317 / :427-429 that do not depend on the crossing: the slopes of the lane's edge and of
+// the two other edges along the line axis.  One correctly rounded division each per (face, edge, axis) LANE instead of
+// two per crossing; the crossing's expressions then multiply the same rounded quotients the reference forms first.
+struct EdgeSlopes {
+    float s01, s02, s12;
+};
+__device__ __forceinline__ EdgeSlopes edge_slopes(float p00, float p01, float p10, float p11, float p20, float p21) {
+    return EdgeSlopes{(p11 - p01) / (p10 - p00), (p21 - p01) / (p20 - p00), (p11 - p21) / (p10 - p20)};
+}
+
 template <class Owner>
-__device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p10, float p11, float p20, float p21, int axis,
-                                                   int fn, int is, int d0, Owner&& owner) {
+__device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p10, float p11, float p20, float p21,
+                                                   const EdgeSlopes sl, int axis, int fn, int is, int d0, Owner&& owner) {
     XGeom g;
     const int direction = (axis == 0) ? ((p00 < p10) ? -1 : 1) : ((p00 < p10) ? 1 : -1);   // KCU:297-308
     const float fd0 = (float)d0;
-    g.d1_cross = (p11 - p01) / (p10 - p00) * (fd0 - p00) + p01;                           // KCU:317
+    g.d1_cross = sl.s01 * (fd0 - p00) + p01;                                              // KCU:317
     g.d1_in = (0 < direction) ? f2i(floorf(g.d1_cross)) : f2i(ceilf(g.d1_cross));
     const int d1_out = (int)((unsigned)g.d1_in + (unsigned)direction);
     g.bits = (0 < direction) ? XG_DIRPOS : 0u;
@@ -137,13 +147,14 @@ __device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p
     g.in_from = g.in_to = 0;
     if (g.d1_in < 0 || is <= g.d1_in || d1_out < 0 || is <= d1_out) { g.d1_in = 0; return g; }   // KCU:325-328
     g.bits |= XG_ALIVE | (p10 != fd0 ? XG_F0 : 0u) | (p00 != fd0 ? XG_F1 : 0u);
-    g.q0 = (p10 - p00) / (p10 - fd0);       // KCU:404 / :409: first factor of `dist`
-    g.q1 = (p10 - p00) / (fd0 - p00);
+    // KCU:404 / :409: first factor of `dist` -- by v_rcp_f32, like every quotient of the walk that uses it
+    g.q0 = (p10 - p00) * __builtin_amdgcn_rcpf(p10 - fd0);
+    g.q1 = (p10 - p00) * __builtin_amdgcn_rcpf(fd0 - p00);
     if (owner(d0, g.d1_in) == fn) g.bits |= XG_OWNER;                                       // KCU:354
     // inward: in-pixel .. opposite edge (KCU:417-431)
     float d0_cross2;
-    if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = (p21 - p01) / (p20 - p00) * (fd0 - p00) + p01;
-    else                               d0_cross2 = (p11 - p21) / (p10 - p20) * (fd0 - p20) + p21;
+    if ((fd0 - p00) * (fd0 - p20) < 0) d0_cross2 = sl.s02 * (fd0 - p00) + p01;
+    else                               d0_cross2 = sl.s12 * (fd0 - p20) + p21;
     const int d1_limit = (0 < direction) ? f2i(ceilf(d0_cross2)) : f2i(floorf(d0_cross2));
     g.in_from = max(min(g.d1_in, d1_limit), 0);
     g.in_to = min(max(g.d1_in, d1_limit), is - 1);
@@ -650,6 +661,7 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __restrict__ face_index_map, int is, EdgePlan w) {
     __shared__ LaneTable t;
+    __shared__ float s_slope[3][256];
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const XcdOrder xo(n_blocks);
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
@@ -659,6 +671,12 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
         const long cbase = w.lane_block[blk];               // scanned: first crossing of this workgroup
+        {   // the lane's slopes, once (see EdgeSlopes)
+            const int l = threadIdx.x;
+            const EdgeSlopes sl = edge_slopes(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l]);
+            s_slope[0][l] = sl.s01; s_slope[1][l] = sl.s02; s_slope[2][l] = sl.s12;
+        }
+        __syncthreads();
         for (int c0 = 0; c0 < total; c0 += 256) {
             const int c = c0 + threadIdx.x;
             const bool active = c < total;
@@ -676,7 +694,8 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
             if (active && plan_complete(w)) {
                 const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, d0 = t.d0_from[l] + (c - t.pre[l]);
                 const int32_t* view = face_index_map + (size_t)bn * is * is;
-                g = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, t.fn[l], is, d0,
+                g = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l],
+                                      EdgeSlopes{s_slope[0][l], s_slope[1][l], s_slope[2][l]}, axis, t.fn[l], is, d0,
                                       [&](int e0, int e1) { return view[axis ? (size_t)e0 * is + e1 : (size_t)e1 * is + e0]; });
                 wants = (g.bits & XG_ALIVE) && !(g.bits & XG_IDLE);
                 if (!wants) w.xpos[cbase + c] = -1;
@@ -720,7 +739,9 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
             const int bn = t.bn_axis[l] >> 1, axis = t.bn_axis[l] & 1, fn = t.fn[l];
             const size_t line = ((size_t)bn * 2 + axis) * is + d0;
             const size_t base = (size_t)bn * is * is;
-            const XGeom xg = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l], axis, fn, is, d0,
+            const XGeom xg = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l],
+                                               edge_slopes(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l]),
+                                               axis, fn, is, d0,
                                                [&](int e0, int e1) { return __float_as_int(a.dot[a.pixel(axis, base, e0, e1)].y); });
 #pragma unroll
             for (int which = 0; which < 2; which++) {
