@@ -420,8 +420,9 @@ __global__ void __launch_bounds__(256) k_grid_warp(GridWarp g, float* __restrict
     out[2 * i + 1] = v / (float)(g.H - 1) * 2.0f - 1.0f;
 }
 
-// adjoint (no crop): one workgroup per batch entry; grad_depth per pixel, grad_rot [B,3,3] and grad_trans [B,3] by a
-// workgroup reduction over the H*W pixels.
+// adjoint (no crop): gridDim.y workgroups per batch entry, each a strided share of the pixels; grad_depth per pixel,
+// grad_rot [B,3,3] and grad_trans [B,3] by a workgroup reduction (added with atomics into zeroed arrays when a batch
+// entry has more than one workgroup: one workgroup per entry left 240 of the 256 CUs idle for a batch of 16).
 __global__ void __launch_bounds__(256) k_grid_warp_backward(GridWarp g, const float* __restrict__ g_out,
                                                            float* __restrict__ g_depth, float* __restrict__ g_rot,
                                                            float* __restrict__ g_trans) {
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(256) k_grid_warp_backward(GridWarp g, const fl
     const float* t = g.trans + (size_t)b * 3;
     const float* K = g.K ? cam_ptr(g.K, g.K_b, b, 9) : nullptr;
     float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int pix = threadIdx.x; pix < H * W; pix += 256) {
+    for (int pix = blockIdx.y * 256 + threadIdx.x; pix < H * W; pix += 256 * gridDim.y) {
         float ray[3], p[3];
         gw_ray(iK, (float)(pix % W), (float)(pix / W), ray);
         const float d = g.depth[base + pix];
@@ -470,8 +471,8 @@ __global__ void __launch_bounds__(256) k_grid_warp_backward(GridWarp g, const fl
     for (int k = 0; k < 12; k++) {
         const float v = block_sum_256(acc[k], s_part);
         if (threadIdx.x == 0) {
-            if (k < 9) { if (g_rot) g_rot[b * 9 + k] = v; }
-            else if (g_trans) g_trans[b * 3 + (k - 9)] = v;
+            float* dst = k < 9 ? (g_rot ? g_rot + b * 9 + k : nullptr) : (g_trans ? g_trans + b * 3 + (k - 9) : nullptr);
+            if (dst) { if (gridDim.y > 1) atomicAdd(dst, v); else *dst = v; }
         }
     }
 }

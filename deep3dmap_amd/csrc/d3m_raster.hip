@@ -601,7 +601,15 @@ D3M_EXPORT int d3m_grid_warp_backward(const float* depth, const float* inv_K, in
                               height, width, g))
         return rc;
     if (!grad_out) return D3M_ERR_INVALID;
-    LAUNCH("k_grid_warp_backward", k_grid_warp_backward, dim3(batch_size), dim3(256), (hipStream_t)stream, g, grad_out,
+    // enough workgroups to occupy the chip: up to 16 per batch entry, each with at least 512 pixels
+    const long px = (long)height * width;
+    int split = (int)std::min<long>(16, std::max<long>(1, px / 512));
+    while (split > 1 && (long)batch_size * split > 2048) split /= 2;
+    if (split > 1) {
+        if (grad_rot) HIP_TRY(zero_async(grad_rot, (size_t)batch_size * 9 * 4, (hipStream_t)stream));
+        if (grad_trans) HIP_TRY(zero_async(grad_trans, (size_t)batch_size * 3 * 4, (hipStream_t)stream));
+    }
+    LAUNCH("k_grid_warp_backward", k_grid_warp_backward, dim3(batch_size, split), dim3(256), (hipStream_t)stream, g, grad_out,
            grad_depth, grad_rot, grad_trans);
     return check_launch();
 }
