@@ -184,55 +184,63 @@ __global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
 // ---- pass 3: scatter face ids into the per-tile lists ------------------------------------------
 // PAIRED (fill_back): one lane per (face f, face F/2 + f) pair -- normally exactly one of the two has a rectangle, so
 // every lane has work; should both have one (zero-area faces), the second goes straight to the global cursors.
-template <bool PAIRED>
+// FPT face (pairs) per thread: the table then aggregates FPT x the faces, and the cursors' returning atomics -- one per
+// distinct tile and workgroup, what bounds this pass on dense meshes (a workgroup's consecutive sub-pixel faces are a
+// thin strip through hundreds of tiles) -- are shared by FPT x as many pairs.  (Reading a rectangle is cheap; the count
+// pass, which loads and tests the faces, was slower with more than one face per thread.)
+template <bool PAIRED, int FPT>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
     __shared__ TileAgg agg;
     ta_clear(agg);
     const int Fl = PAIRED ? bb.F / 2 : bb.F;
     constexpr int TA_LOCAL = 4;
-    int packed[TA_LOCAL];
-    const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
-    if (lane_i < (long)bb.B * Fl) {
-        b = (int)(lane_i / Fl);
-        const int f0 = (int)(lane_i % Fl);
-        uint2 r = bb.rect[(size_t)b * bb.F + f0];
-        f = f0;
-        if (PAIRED) {
-            const uint2 r1 = bb.rect[(size_t)b * bb.F + f0 + Fl];
-            if (r.x == RECT_NONE) { r = r1; f = f0 + Fl; }
-            else if (r1.x != RECT_NONE) {             // both copies listed: the second one the plain way
-                const int ax0 = r1.x & 0xFFFF, ay0 = r1.x >> 16, aw = (int)(r1.y & 0xFFFF) - ax0 + 1;
-                const int an = aw * ((int)(r1.y >> 16) - ay0 + 1);
-                for (int s2 = 0; s2 < (an > bb.kcap ? 0 : an); s2++) {
-                    const int tile = b * bb.T + (ay0 + s2 / aw) * bb.tiles_x + ax0 + s2 % aw;
-                    const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
-                    bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f0 + Fl;
+    int packed[FPT][TA_LOCAL], face_of[FPT];
+#pragma unroll
+    for (int it = 0; it < FPT; it++) {
+        const long lane_i = ((long)blockIdx.x * FPT + it) * blockDim.x + threadIdx.x;
+        int tx0 = 0, ty0 = 0, w = 0, nt = 0, b = 0, f = 0;
+        if (lane_i < (long)bb.B * Fl) {
+            b = (int)(lane_i / Fl);
+            const int f0 = (int)(lane_i % Fl);
+            uint2 r = bb.rect[(size_t)b * bb.F + f0];
+            f = f0;
+            if (PAIRED) {
+                const uint2 r1 = bb.rect[(size_t)b * bb.F + f0 + Fl];
+                if (r.x == RECT_NONE) { r = r1; f = f0 + Fl; }
+                else if (r1.x != RECT_NONE) {             // both copies listed: the second one the plain way
+                    const int ax0 = r1.x & 0xFFFF, ay0 = r1.x >> 16, aw = (int)(r1.y & 0xFFFF) - ax0 + 1;
+                    const int an = aw * ((int)(r1.y >> 16) - ay0 + 1);
+                    for (int s2 = 0; s2 < (an > bb.kcap ? 0 : an); s2++) {
+                        const int tile = b * bb.T + (ay0 + s2 / aw) * bb.tiles_x + ax0 + s2 % aw;
+                        const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
+                        bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f0 + Fl;
+                    }
                 }
             }
+            if (r.x != RECT_NONE) {
+                tx0 = r.x & 0xFFFF; ty0 = r.x >> 16;
+                const int tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
+                w = tx1 - tx0 + 1;
+                nt = w * (ty1 - ty0 + 1);
+                if (nt > bb.kcap) nt = 0;                 // lives in big_list
+            }
         }
-        if (r.x != RECT_NONE) {
-            tx0 = r.x & 0xFFFF; ty0 = r.x >> 16;
-            const int tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-            w = tx1 - tx0 + 1;
-            nt = w * (ty1 - ty0 + 1);
-            if (nt > bb.kcap) nt = 0;                 // lives in big_list
-        }
-    }
-    // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a
-    // full table go straight to the global cursor), one cursor atomic per distinct tile, then the scatter
+        // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a
+        // full table go straight to the global cursor), one cursor atomic per distinct tile, then the scatter
+        face_of[it] = f;
 #pragma unroll
-    for (int s = 0; s < TA_LOCAL; s++) packed[s] = -1;
-    for (int s = 0; s < nt; s++) {
-        const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
-        int rank = 0, slot = -1;
-        if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
-        if (slot >= 0) {
+        for (int s = 0; s < TA_LOCAL; s++) packed[it][s] = -1;
+        for (int s = 0; s < nt; s++) {
+            const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
+            int rank = 0, slot = -1;
+            if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
+            if (slot >= 0) {
 #pragma unroll
-            for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[q] = (slot << 16) | rank;
-        } else {
-            const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
-            bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
+                for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[it][q] = (slot << 16) | rank;
+            } else {
+                const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
+                bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
+            }
         }
     }
     __syncthreads();
@@ -243,8 +251,11 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
         }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < TA_LOCAL; s++)
-        if (packed[s] >= 0) bb.pairs[(size_t)agg.base[packed[s] >> 16] + (packed[s] & 0xFFFF)] = f;
+    for (int it = 0; it < FPT; it++) {
+#pragma unroll
+        for (int s = 0; s < TA_LOCAL; s++)
+            if (packed[it][s] >= 0) bb.pairs[(size_t)agg.base[packed[it][s] >> 16] + (packed[it][s] & 0xFFFF)] = face_of[it];
+    }
 }
 
 // ---- pass 4: one wave64 per 8x8 tile ---------------------------------------------------------------

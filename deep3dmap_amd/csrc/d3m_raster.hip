@@ -154,6 +154,18 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
 // binning workgroup: 1024 lanes (fewest global atomics on the tile counters) once that still fills the chip
 static inline unsigned bin_threads(long lanes) { return lanes >= 1024l * 1024 ? BIN_THREADS : BIN_THREADS_SMALL; }
 
+// the list-filling pass: more face (pairs) per thread once the launch stays large (see k_bin_fill)
+template <bool PAIRED>
+static inline void launch_bin_fill(const BinBuffers& bb, long lanes, hipStream_t st) {
+    const unsigned th = bin_threads(lanes);
+    if (lanes >= 4l * 1024 * 1024)
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 4>), dim3(blocks_for(lanes, th * 4)), dim3(th), st, bb);
+    else if (lanes >= 2l * 1024 * 1024)
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 2>), dim3(blocks_for(lanes, th * 2)), dim3(th), st, bb);
+    else
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 1>), dim3(blocks_for(lanes, th)), dim3(th), st, bb);
+}
+
 // grid of the per-pixel backward kernels (they stride): `sparse` = only the pixels of a few large faces have work, and
 // normally there are none
 static inline unsigned px_grid(long n, bool sparse) {
@@ -173,7 +185,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, fs, bb, faces_inv,
            (float*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, bb);
+    launch_bin_fill<false>(bb, nf, st);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     if (n_tiles <= RASTER_SMALL_GRID)
@@ -202,8 +214,8 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
-    if (ifs.fill_back) LAUNCH("k_bin_fill", k_bin_fill<true>, dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, bb);
-    else LAUNCH("k_bin_fill", k_bin_fill<false>, dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, bb);
+    if (ifs.fill_back) launch_bin_fill<true>(bb, nf / 2, st);
+    else launch_bin_fill<false>(bb, nf, st);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};
