@@ -1531,7 +1531,8 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
-    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 2048u)), dim3(256), st, fs, a, w, lane_partial);
+    // (normally leaves at once: a small grid keeps that cheap; with an undersized workspace its workgroups stride)
+    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 512u)), dim3(256), st, fs, a, w, lane_partial);
     LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }

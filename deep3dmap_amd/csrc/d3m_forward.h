@@ -162,20 +162,22 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
 }
 
 // ---- pass 2: give every tile a slice of `pairs` (one atomic per 256 tiles; order is irrelevant) ---
-__global__ void __launch_bounds__(256) k_bin_alloc(BinBuffers bb) {
-    __shared__ int s_wave[4];
+// 1024 tiles per workgroup: the workgroups' returning atomics all hit ONE address and serialise there (~15 ns each)
+constexpr int BIN_ALLOC_THREADS = 1024;
+__global__ void __launch_bounds__(BIN_ALLOC_THREADS) k_bin_alloc(BinBuffers bb) {
+    __shared__ int s_wave[BIN_ALLOC_THREADS / 64];
     __shared__ int s_base;
     const int n = bb.B * bb.T;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * BIN_ALLOC_THREADS + threadIdx.x;
     const int c = i < n ? bb.tile_count[i] : 0;
     const int incl = wave_inclusive_scan(c);
     const int lane = lane_id(), wv = threadIdx.x >> 6;
     if (lane == 63) s_wave[wv] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3];
-        s_base = atomicAdd(bb.alloc_cursor, t0 + t1 + t2 + t3);
-        s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
+        int run = 0;
+        for (int k = 0; k < BIN_ALLOC_THREADS / 64; k++) { const int tk = s_wave[k]; s_wave[k] = run; run += tk; }
+        s_base = atomicAdd(bb.alloc_cursor, run);
     }
     __syncthreads();
     if (i < n) bb.tile_offset[i] = s_base + s_wave[wv] + incl - c;

@@ -184,7 +184,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     const long nf = (long)B * F;
     LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, fs, bb, faces_inv,
            (float*)nullptr);
-    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, BIN_ALLOC_THREADS)), dim3(BIN_ALLOC_THREADS), st, bb);
     launch_bin_fill<false>(bb, nf, st);
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
@@ -213,7 +213,7 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     else
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks);
-    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, 256)), dim3(256), st, bb);
+    LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, BIN_ALLOC_THREADS)), dim3(BIN_ALLOC_THREADS), st, bb);
     if (ifs.fill_back) launch_bin_fill<true>(bb, nf / 2, st);
     else launch_bin_fill<false>(bb, nf, st);
     const int n_tiles = B * bb.T;
