@@ -533,6 +533,19 @@ class _RasterizeLit(torch.autograd.Function):
                                        True, ra,
                                        vertex_target=target, visibility=vis[k], unscaled=unscaled,
                                        edge_plan=m["edge_plan"][k])
+        def light_to_vertices(grad_light):
+            # the light gradient -> world-space vertices through the face normals
+            _lib.check(L.d3m_face_light_backward(
+                _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
+                _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
+                Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
+
+        light_done = False
+        if gathered and need_vert and G == 1:
+            # one pipeline: straight behind the gathered pass on its branch, beside the line walk, not behind the join
+            with torch.cuda.stream(auxs[0]):
+                light_to_vertices(gl_g[0] if light_shared else grad_light)
+            light_done = True
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
@@ -542,14 +555,10 @@ class _RasterizeLit(torch.autograd.Function):
             # shared textures / light: the groups' sums add up (a group's pass already summed over its views)
             if tex_shared:
                 grad_textures = gt_g[0] if G == 1 else torch.stack(gt_g).sum(0)
-            if need_vert:
+            if need_vert and not light_done:
                 if light_shared:
                     grad_light = gl_g[0] if G == 1 else torch.stack(gl_g).sum(0)
-                # the light gradient -> world-space vertices through the face normals
-                _lib.check(L.d3m_face_light_backward(
-                    _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
-                    _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
-                    Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
+                light_to_vertices(grad_light)
             if not need_tex:
                 grad_textures = None
         elif rd:                            # textures and lighting need no gradient: the depth term on its own
