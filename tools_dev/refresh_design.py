@@ -23,7 +23,7 @@ for k, label in rows:
     tab += f"| {label} | {avg(k):.0f} | {sk.get(k, 0) * 1000:.0f} | {bench.kernel_bytes(k, V, F, S, ts) * 32 / 1e6:.0f} | {pmget(k) / 1e6:.0f} |\n"
 oc = sum(float(r['TotalDurationNs']) for r in st if not any(k in r['Name'] for k, _ in rows) and 'k_render_lit_epilogue' not in r['Name']) / 49 / 1e3
 os_ = sum(v for k, v in sk.items() if k not in dict(rows)) * 1000
-tab += f"| everything else (~35 launches: visibility list, scans, cameras, light, fills, view sum) | ≈ {oc:.0f} | ≈ {os_:.0f} | | |\n"
+tab += f"| everything else (26 launches: visibility list, scans, cameras, light, fills, view sum) | ≈ {oc:.0f} | ≈ {os_:.0f} | | |\n"
 a, b = s.index('| kernel | µs in the step (rocprofv3 avg, branches concurrent)'), s.index('**Step: ')
 s = s[:a] + tab + '\n' + s[b:]
 s = re.sub(r'\*\*Step: [0-9.]+ ms = [0-9]+ Mpix/s\*\* in the committed line', f"**Step: {fin['ms_per_step']:.2f} ms = {fin['value']:.0f} Mpix/s** in the committed line", s)
