@@ -29,6 +29,25 @@ class D3MFitTargets(ctypes.Structure):
                 ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P), ("defer_finish", _I)]
 
 
+class D3MG2SBlock(ctypes.Structure):
+    """d3m_g2s_block (include/d3m_raster.h, section D), field for field."""
+    _fields_ = ([("batch_size", _I), ("height", _I), ("width", _I), ("image_size", _I), ("anti_aliasing", _I), ("flip", _I),
+                 ("inv_K", _P), ("inv_K_batch", _I), ("K", _P), ("K_batch", _I),
+                 ("rot_center_depth", _F), ("depth_min", _F), ("depth_max", _F), ("near", _F), ("far", _F),
+                 ("camera", ctypes.POINTER(D3MCamera))] +
+                [(n, _P) for n in ("depth", "albedo", "light_a", "light_b", "light_d", "rot", "trans", "target", "extra_mask",
+                                   "normal", "diffuse_shading", "texture", "recon_depth", "recon_im", "recon_im_mask",
+                                   "losses")] +
+                [("lam_smooth", _F), ("with_smooth", _I)] +
+                [(n, _P) for n in ("screen_vertices", "faces", "face_index_map", "weight_map", "depth_map", "scratch",
+                                   "workspace")] +
+                [("workspace_bytes", _SZ)] +
+                [(n, _P) for n in ("grad_recon_im", "grad_l1", "grad_l1_flip", "grad_smooth", "grad_total",
+                                   "grad_texture", "grad_vertices", "grad_depth_map", "grad_normal", "grad_depth_mesh",
+                                   "grad_depth", "grad_albedo", "grad_light_a", "grad_light_b", "grad_light_d", "grad_rot",
+                                   "grad_trans")])
+
+
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
 
 _SIGNATURES = {
@@ -89,6 +108,9 @@ _SIGNATURES = {
     "d3m_smooth_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_g2s_scratch_floats": (_SZ, [_I, _I, _I, _I]),
+    "d3m_g2s_forward": (_I, [ctypes.POINTER(D3MG2SBlock), _P]),
+    "d3m_g2s_backward": (_I, [ctypes.POINTER(D3MG2SBlock), _P]),
     "d3m_mesh_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "d3m_mesh_render_colors": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "d3m_mesh_render_texture": (_I, [_P] * 8 + [_I] * 10 + [_P, _SZ, _P]),

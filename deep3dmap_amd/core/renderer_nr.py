@@ -205,6 +205,21 @@ class NrRenderer():
     def get_normal_from_depth(self, depth):
         return _DepthNormals.apply(depth, self.inv_K.to(depth.device))
 
+    def reconstruct(self, depth, albedo, light_a, light_b, light_d, input_im=None, flip=False, extra_mask=None,
+                    with_smooth=True, lam_smooth=None):
+        """The renderer block of the gan2shape step (models/frameworks/gan2shape.py:463-497) as one autograd node on fused
+        HIP passes (core/gan2shape_block.py): shading and texture from (depth, albedo, light), recon_depth by warping the
+        depth's mesh with the current view (set_transform_matrices), recon_im by looking the texture up through the
+        inverse warp, the border mask, the masked-L1 terms against `input_im` [b,3,h,w] and the two smooth losses.
+        depth [B,h,w], albedo [B,3,h,w], light_a / light_b [B,1], light_d [B,3]; with `flip`, B = 2b and entries
+        (i, i + b) are an image and its mirror (gan2shape.py:431,449,479-481).  Returns a namespace with normal,
+        diffuse_shading, texture, recon_depth, recon_im, recon_im_mask, loss_l1_im, loss_l1_im_flip, loss_smooth and --
+        given lam_smooth -- loss_total = loss_l1_im (+ loss_l1_im_flip) + lam_smooth * loss_smooth.  Gradients reach
+        depth, albedo, the light terms and the view (through rot_mat / trans_xyz) from recon_im and the losses."""
+        from .gan2shape_block import reconstruct
+        return reconstruct(self, depth, albedo, light_a, light_b, light_d, input_im, flip, extra_mask, with_smooth,
+                           lam_smooth)
+
     # ---- view synthesis (CR:141-277): one frame loop for the three public sweeps ----------------------------------------
     def _frame_mesh(self, images, depth, rigid, crop=None):
         """render the depth's grid mesh, moved by `rigid`, textured with each image of `images` (CR:196-198)."""

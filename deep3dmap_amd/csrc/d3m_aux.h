@@ -377,6 +377,21 @@ __device__ __forceinline__ void gw_ray(const float* iK, float x, float y, float*
     for (int k = 0; k < 3; k++) ray[k] = x * iK[3 * k] + y * iK[3 * k + 1] + iK[3 * k + 2];        // renderer_nr.py:79
 }
 
+// Q = R (p - c) + c + t about c = (0, 0, center_z) (rotate_pts + translate_pts, renderer_nr.py:64-72); p is shifted in place
+__device__ __forceinline__ void gw_rigid(float* p, const float* R, const float* t, float center_z, float* q) {
+    p[2] -= center_z;                                                                         // renderer_nr.py:66
+    q[0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];                                    // :67-68, :71
+    q[1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
+    q[2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + center_z + t[2];
+}
+// grid_3d_to_2d (renderer_nr.py:82-88) of one point: normalised image coordinates of an s_w x s_h image
+__device__ __forceinline__ void gw_project(const float* q, const float* K, int W, int H, float* uv) {
+    const float xn = q[0] / q[2], yn = q[1] / q[2];                                           // :84
+    const float u = xn * K[0] + yn * K[1] + K[2], v = xn * K[3] + yn * K[4] + K[5];           // :85
+    uv[0] = u / (float)(W - 1) * 2.0f - 1.0f;                                                 // :86-87
+    uv[1] = v / (float)(H - 1) * 2.0f - 1.0f;
+}
+
 __global__ void __launch_bounds__(256) k_grid_warp(GridWarp g, float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)g.B * g.H * g.W) return;
@@ -402,22 +417,18 @@ __global__ void __launch_bounds__(256) k_grid_warp(GridWarp g, float* __restrict
         p[1] = r1[1] * dview[ry * g.W + xi];
         p[2] = r2[2] * dview[ry * g.W + cx];
     }
-    p[2] -= g.center_z;                                                                       // renderer_nr.py:66
     const float* R = g.rot + (size_t)b * 9;
     const float* t = g.trans + (size_t)b * 3;
     float q[3];
-    q[0] = p[0] * R[0] + p[1] * R[1] + p[2] * R[2] + t[0];                                    // :67-68, :71
-    q[1] = p[0] * R[3] + p[1] * R[4] + p[2] * R[5] + t[1];
-    q[2] = p[0] * R[6] + p[1] * R[7] + p[2] * R[8] + g.center_z + t[2];
+    gw_rigid(p, R, t, g.center_z, q);
     if (!g.K) {
         out[3 * i + 0] = q[0]; out[3 * i + 1] = q[1]; out[3 * i + 2] = q[2];
         return;
     }
-    const float* K = cam_ptr(g.K, g.K_b, b, 9);
-    const float xn = q[0] / q[2], yn = q[1] / q[2];                                           // :84
-    const float u = xn * K[0] + yn * K[1] + K[2], v = xn * K[3] + yn * K[4] + K[5];           // :85
-    out[2 * i + 0] = u / (float)(g.W - 1) * 2.0f - 1.0f;                                      // :86-87
-    out[2 * i + 1] = v / (float)(g.H - 1) * 2.0f - 1.0f;
+    float uv[2];
+    gw_project(q, cam_ptr(g.K, g.K_b, b, 9), g.W, g.H, uv);
+    out[2 * i + 0] = uv[0];
+    out[2 * i + 1] = uv[1];
 }
 
 // adjoint (no crop): gridDim.y workgroups per batch entry, each a strided share of the pixels; grad_depth per pixel,
@@ -904,15 +915,10 @@ __global__ void __launch_bounds__(256) k_smooth_finish(const float* __restrict__
     if (threadIdx.x == 0) *loss = ((acc[0] / n_xx + acc[1] / n_xy) + acc[2] / n_xy) + acc[3] / n_yy;
 }
 
-// grad_pred[b,y,x] = grad_loss * sum over the (up to 14) second differences that contain the pixel of
-// sign(difference) * coefficient / count -- gathered, one lane per pixel
-__global__ void __launch_bounds__(256) k_smooth_grad(const float* __restrict__ pred, const float* __restrict__ grad_loss,
-                                                    float* __restrict__ grad_pred, int B, int H, int W, float n_xx,
-                                                    float n_xy, float n_yy) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)B * H * W) return;
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    const float* r0 = pred + (i - x);                        // row y
+// d(sum of the four mean-abs second differences) / d pred[y, x]: the (up to 14) differences that contain the pixel,
+// sign(difference) * coefficient / count; r0 = row y of the map
+__device__ __forceinline__ float sm_grad_at(const float* __restrict__ r0, int x, int y, int H, int W, float n_xx, float n_xy,
+                                            float n_yy) {
     float gxx = 0, gxy = 0, gyy = 0;
     // dxx terms starting at x, x-1, x-2 (coefficients +1, -2, +1)
     if (x + 2 < W) gxx += sm_sign(sm_dxx(r0, x));
@@ -928,7 +934,18 @@ __global__ void __launch_bounds__(256) k_smooth_grad(const float* __restrict__ p
     if (y + 1 < H && x >= 1) gxy -= mixed(r0, r0 + W, x - 1);                  // p01
     if (y >= 1 && x + 1 < W) gxy -= mixed(r0 - W, r0, x);                      // p10
     if (y >= 1 && x >= 1) gxy += mixed(r0 - W, r0, x - 1);                     // p11
-    grad_pred[i] = (*grad_loss) * (gxx / n_xx + gxy / n_xy + gyy / n_yy);
+    return gxx / n_xx + gxy / n_xy + gyy / n_yy;
+}
+
+// grad_pred[b,y,x] = grad_loss * sum over the (up to 14) second differences that contain the pixel of
+// sign(difference) * coefficient / count -- gathered, one lane per pixel
+__global__ void __launch_bounds__(256) k_smooth_grad(const float* __restrict__ pred, const float* __restrict__ grad_loss,
+                                                    float* __restrict__ grad_pred, int B, int H, int W, float n_xx,
+                                                    float n_xy, float n_yy) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    grad_pred[i] = (*grad_loss) * sm_grad_at(pred + (i - x), x, y, H, W, n_xx, n_xy, n_yy);
 }
 
 // ---- the multi-view fit objective in three launches ------------------------------------------------------------

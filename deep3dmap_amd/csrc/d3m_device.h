@@ -108,6 +108,24 @@ struct DenseFaces {
     }
 };
 
+// Index triple of input triangle fl of view b: from tri [tri_batch,Ft,3], or -- tri == NULL, grid_w > 0 -- from the
+// implicit topology of a depth map's grid mesh (deep3dmap/core/renderer/utils.py:74-78: grid_w vertices per row, cell
+// (y, x) carries (tl, bl, tr) in the first half of the list and (tr, bl, br) in the second), so that the adapter needs no
+// index tensor at all.
+__device__ __forceinline__ void tri_ids(const int32_t* tri, int tri_batch, int Ft, int grid_w, int b, int fl, int* ids) {
+    if (tri) {
+        const int32_t* t = tri + ((size_t)(tri_batch > 1 ? b : 0) * Ft + fl) * 3;
+        ids[0] = t[0]; ids[1] = t[1]; ids[2] = t[2];
+        return;
+    }
+    const int cells = Ft >> 1, second = fl >= cells, cell = second ? fl - cells : fl;
+    const int y = cell / (grid_w - 1), x = cell - y * (grid_w - 1);
+    const int tl = y * grid_w + x, bl = tl + grid_w;
+    ids[0] = second ? tl + 1 : tl;
+    ids[1] = bl;
+    ids[2] = second ? bl + 1 : tl + 1;
+}
+
 // Indexed: projected vertices [B,V,3] + index triples [Bt,Ft,3]; the fill_back copy (face Ft+f =
 // face f with vertex order reversed, renderer.py:86) is generated on the fly.
 struct IndexedFaces {
@@ -115,14 +133,15 @@ struct IndexedFaces {
     const int32_t* tri;
     int V, Ft, tri_batch, fill_back;
     int vert_batch;   // 1: one vertex array shared by every view (stride 0), otherwise one per view
+    int grid_w = 0;   // tri == NULL: implicit grid topology with this many vertices per row (tri_ids)
     __host__ __device__ __forceinline__ int num_faces() const { return fill_back ? 2 * Ft : Ft; }
     __device__ __forceinline__ void vertex_ids(int b, int f, int* ids) const {
         const bool back = f >= Ft;
-        const int32_t* t = tri + ((size_t)(tri_batch > 1 ? b : 0) * Ft + (back ? f - Ft : f)) * 3;
-        const int i0 = t[0], i1 = t[1], i2 = t[2];
-        ids[0] = back ? i2 : i0;
-        ids[1] = i1;
-        ids[2] = back ? i0 : i2;
+        int t[3];
+        tri_ids(tri, tri_batch, Ft, grid_w, b, back ? f - Ft : f, t);
+        ids[0] = back ? t[2] : t[0];
+        ids[1] = t[1];
+        ids[2] = back ? t[0] : t[2];
     }
     __device__ __forceinline__ void load(int b, int f, float* out) const {
         int ids[3];
@@ -144,10 +163,13 @@ struct VertexTarget {
     float* gv;             // [B, V, 3]
     const int32_t* tri;    // [tri_batch, Ft, 3]
     int V, Ft, tri_batch;
+    int grid_w = 0;        // tri == NULL: implicit grid topology (tri_ids)
     __device__ __forceinline__ float* vertex(int b, int f, int n) const {      // vertex n of (virtual) face f
         const bool back = f >= Ft;
-        const int32_t* t = tri + ((size_t)(tri_batch > 1 ? b : 0) * Ft + (back ? f - Ft : f)) * 3;
-        return gv + ((size_t)b * V + t[back ? 2 - n : n]) * 3;
+        int t[3];
+        tri_ids(tri, tri_batch, Ft, grid_w, b, back ? f - Ft : f, t);
+        const int m = back ? 2 - n : n;
+        return gv + ((size_t)b * V + (m == 0 ? t[0] : (m == 1 ? t[1] : t[2]))) * 3;
     }
 };
 

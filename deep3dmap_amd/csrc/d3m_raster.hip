@@ -17,6 +17,7 @@
 #include "d3m_face_major.h"
 #include "d3m_forward.h"
 #include "d3m_lit.h"
+#include "d3m_g2s.h"
 
 using namespace d3m;
 
@@ -198,14 +199,14 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
 // The same with the faces of an indexed mesh: the first pass reads them through the indices and leaves the dense
 // copy (front-facing faces only) that the tile pass and every later operator use.
 static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, float near, float far, RasterOut out, void* ws,
-                            size_t ws_bytes, hipStream_t st) {
+                            size_t ws_bytes, hipStream_t st, bool counters_cleared = false) {
     // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
     if (rc) return rc;
-    HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
+    if (!counters_cleared) HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
     if (ifs.fill_back)      // one lane per index triple, both copies
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
@@ -1058,6 +1059,119 @@ D3M_EXPORT int d3m_smooth_loss_backward(const float* pred, const float* grad_los
     const long n = (long)batch_size * height * width;
     LAUNCH("k_smooth_grad", k_smooth_grad, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, pred, grad_loss, grad_pred,
            batch_size, height, width, n_xx, n_xy, n_yy);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// D. the gan2shape renderer block (d3m_g2s.h)
+// ---------------------------------------------------------------------------------------------------
+static inline int g2s_split(long pixels, int cap) {
+    const long b = (pixels + 255) / 256;
+    return (int)(b < 1 ? 1 : (b < cap ? b : cap));
+}
+struct G2SLayout { int split_s, split_m, split_f, off_sample, off_smooth, off_front, off_sback, total; };
+static G2SLayout g2s_layout(int B, int H, int W, int s) {
+    G2SLayout L;
+    L.split_s = g2s_split((long)s * s, 32);
+    L.split_f = g2s_split((long)H * W, 32);
+    L.split_m = g2s_split((long)B * H * W, 256);
+    int o = G2S_TOTALS;
+    L.off_sample = o; o += 4 * B * L.split_s;
+    L.off_smooth = o; o += 2 * 4 * L.split_m;
+    L.off_front = o;  o += G2S_FRONT_SUMS * B * L.split_f;
+    L.off_sback = o;  o += G2S_SAMPLE_SUMS * B * L.split_s;
+    L.total = o;
+    return L;
+}
+D3M_EXPORT size_t d3m_g2s_scratch_floats(int batch_size, int height, int width, int image_size) {
+    if (batch_size <= 0 || height <= 0 || width <= 0 || image_size <= 0) return 0;
+    return (size_t)g2s_layout(batch_size, height, width, image_size).total;
+}
+
+static int to_g2s(const d3m_g2s_block* h, G2S& g) {
+    if (!h) return D3M_ERR_INVALID;
+    const int B = h->batch_size, H = h->height, W = h->width, s = h->image_size;
+    if (B <= 0 || H < 3 || W < 3 || s < 2 || (long)B * H * W > 0x3FFFFFFFL || (long)B * s * s > 0x3FFFFFFFL) return D3M_ERR_INVALID;
+    if (h->flip && (B & 1)) return D3M_ERR_INVALID;
+    if (!h->inv_K || !h->K || !h->depth || !h->albedo || !h->light_a || !h->light_b || !h->light_d || !h->rot || !h->trans ||
+        !h->diffuse_shading || !h->texture || !h->recon_im || !h->losses || !h->screen_vertices || !h->faces ||
+        !h->face_index_map || !h->weight_map || !h->depth_map || !h->scratch)
+        return D3M_ERR_INVALID;
+    if ((h->inv_K_batch != 1 && h->inv_K_batch != B) || (h->K_batch != 1 && h->K_batch != B)) return D3M_ERR_INVALID;
+    memset(&g, 0, sizeof(g));
+    if (int rc = to_cam(h->camera, B, g.cam)) return rc;
+    const G2SLayout L = g2s_layout(B, H, W, s);
+    g.B = B; g.H = H; g.W = W; g.s = s; g.aa = h->anti_aliasing ? 1 : 0; g.S = g.aa ? 2 * s : s;
+    g.flip = h->flip ? 1 : 0; g.Bh = g.flip ? B / 2 : B;
+    g.inv_K = h->inv_K; g.invK_b = h->inv_K_batch; g.K = h->K; g.K_b = h->K_batch;
+    g.center_z = h->rot_center_depth; g.depth_lo = h->depth_min; g.depth_hi = h->depth_max;
+    g.depth = h->depth; g.albedo = h->albedo; g.light_a = h->light_a; g.light_b = h->light_b; g.light_d = h->light_d;
+    g.rot = h->rot; g.trans = h->trans; g.target = h->target; g.extra_mask = h->extra_mask;
+    g.normal = h->normal; g.diffuse = h->diffuse_shading; g.texture = h->texture; g.screen_vertices = h->screen_vertices;
+    g.depth_map = h->depth_map; g.recon_depth = h->recon_depth; g.recon_im = h->recon_im; g.recon_mask = h->recon_im_mask;
+    g.losses = h->losses; g.scratch = h->scratch;
+    g.off_sample = L.off_sample; g.off_smooth = L.off_smooth; g.off_front = L.off_front; g.off_sback = L.off_sback;
+    g.split_s = L.split_s; g.split_m = L.split_m; g.split_f = L.split_f;
+    g.lam_smooth = h->lam_smooth; g.with_smooth = h->with_smooth ? 1 : 0;
+    g.grad_recon_im = h->grad_recon_im; g.g_l1 = h->grad_l1; g.g_l1_flip = h->grad_l1_flip; g.g_smooth = h->grad_smooth;
+    g.g_total = h->grad_total;
+    g.grad_texture = h->grad_texture; g.grad_vertices = h->grad_vertices; g.grad_depth_map = h->grad_depth_map;
+    g.grad_normal = h->grad_normal; g.grad_depth_mesh = h->grad_depth_mesh;
+    g.grad_depth = h->grad_depth; g.grad_albedo = h->grad_albedo; g.grad_light_a = h->grad_light_a;
+    g.grad_light_b = h->grad_light_b; g.grad_light_d = h->grad_light_d; g.grad_rot = h->grad_rot; g.grad_trans = h->grad_trans;
+    return D3M_OK;
+}
+
+D3M_EXPORT int d3m_g2s_forward(const d3m_g2s_block* block, d3m_stream_t stream) {
+    G2S g;
+    if (int rc = to_g2s(block, g)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1), Fp = 2 * Ft;
+    float n_xx = 1, n_xy = 1, n_yy = 1;
+    if (g.with_smooth) if (int rc = smooth_dims(B, g.H, g.W, n_xx, n_xy, n_yy)) return rc;
+    BinBuffers bb;
+    if (int rc = make_bins(bb, B, Fp, g.S, block->workspace, block->workspace_bytes)) return rc;
+    // the first pass also clears the tile counters of the binning passes and the accumulators of the backward pass
+    ZeroRanges z;
+    const size_t zero_words[3] = {fwd_layout(B, Fp, g.S).zero_bytes / 4, g.grad_texture ? (size_t)B * 3 * HW : 0,
+                                  g.grad_vertices ? (size_t)B * HW * 3 : 0};
+    uint32_t* const zero_ptr[3] = {(uint32_t*)block->workspace, (uint32_t*)g.grad_texture, (uint32_t*)g.grad_vertices};
+    for (int k = 0; k < 3; k++) {
+        if (zero_words[k] > 0xFFFFFFFFul) return D3M_ERR_INVALID;
+        z.p[k] = zero_ptr[k]; z.n[k] = (unsigned)zero_words[k];
+    }
+    LAUNCH("k_g2s_front", k_g2s_front, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g, z);
+    if (g.with_smooth) LAUNCH("k_g2s_smooth", k_g2s_smooth, dim3(g.split_m, 2), dim3(256), st, g);
+    IndexedFaces ifs{g.screen_vertices, nullptr, HW, Ft, 1, 1, B, g.W};
+    RasterOut out{block->face_index_map, block->weight_map, block->depth_map, nullptr, nullptr};
+    if (int rc = run_forward_mesh(ifs, block->faces, B, g.S, block->near, block->far, out, block->workspace,
+                                  block->workspace_bytes, st, true))
+        return rc;
+    LAUNCH("k_g2s_sample", k_g2s_sample, dim3(g.split_s, g.Bh), dim3(256), st, g);
+    LAUNCH("k_g2s_finish", k_g2s_finish, dim3(1), dim3(256), st, g, n_xx, n_xy, n_yy);
+    return check_launch();
+}
+
+D3M_EXPORT int d3m_g2s_backward(const d3m_g2s_block* block, d3m_stream_t stream) {
+    G2S g;
+    if (int rc = to_g2s(block, g)) return rc;
+    if (!g.grad_texture || !g.grad_vertices || !g.grad_depth_map || !g.grad_normal || !g.grad_depth_mesh || !g.grad_depth ||
+        !g.grad_albedo || !g.recon_mask)
+        return D3M_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1), Fp = 2 * Ft;
+    float n_xx = 1, n_xy = 1, n_yy = 1;
+    if (g.with_smooth) if (int rc = smooth_dims(B, g.H, g.W, n_xx, n_xy, n_yy)) return rc;
+    LAUNCH("k_g2s_sample_backward", k_g2s_sample_backward, dim3(g.split_s, B), dim3(256), st, g);
+    // K6 (KCU:543-592) per covered pixel, straight onto the vertices of the implicit grid (the faces are a few pixels each)
+    DenseFaces fs{block->faces, Fp};
+    VertexTarget vt{g.grad_vertices, nullptr, HW, Ft, 1, g.W};
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid((long)B * g.S * g.S, false)), dim3(256), st, fs,
+           (const float*)block->depth_map, (const int32_t*)block->face_index_map, (const float*)nullptr,
+           (const float*)block->weight_map, (const float*)g.grad_depth_map, (float*)nullptr, B, g.S, (const int*)nullptr, vt);
+    LAUNCH("k_g2s_front_backward", k_g2s_front_backward, dim3(g.split_f, B), dim3(256), st, g, n_xx, n_xy, n_yy);
+    LAUNCH("k_g2s_depth_backward", k_g2s_depth_backward, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g, n_xx, n_xy, n_yy);
+    LAUNCH("k_g2s_finish_backward", k_g2s_finish_backward, dim3(B), dim3(64), st, g);
     return check_launch();
 }
 

@@ -83,3 +83,27 @@ def random_textures(n_faces, texture_size=2, seed=1):
 
 def perturb(vertices, sigma=0.02, seed=2):
     return (vertices + np.random.default_rng(seed).normal(0, sigma, vertices.shape)).astype(np.float32)
+
+
+def gan2shape_inputs(b, hw=64, seed=0, flip=False):
+    """The tensors the gan2shape step hands to its renderer block (models/frameworks/gan2shape.py:418-460; SURVEY.md 8d,
+    config C3): depth [B,hw,hw] = 1 + 0.1 tanh(low-passed noise) with the reference's border clamp (:428-430), albedo
+    [B,3,hw,hw] and light [B,4] in (-1, 1), view vectors [B,6] ~ U(-1,1) x (0.5, 1.0, 0.3 rad; 0.1, 0.1, 0.02): the range :440-443 gives a
+    tanh-bounded view head with configs/gan2shape/celeba.py's 60 degrees / 0.1, input image [b,3,hw,hw]; with `flip` the mirrored copies are appended (:431,449)."""
+    rng = np.random.default_rng(seed)
+    noise = np.pad(rng.standard_normal((b, hw, hw)), ((0, 0), (2, 2), (2, 2)))
+    depth = 1.0 + 0.1 * np.tanh(sum(noise[:, i:i + hw, j:j + hw] for i in range(5) for j in range(5)) / 25.0)
+    border = np.zeros((b, hw, hw))
+    border[:, :, :2] = 1.02
+    border[:, :, -2:] = 1.02
+    depth = depth * (1 - border) + border * 1.04              # border_depth = 0.7 max + 0.3 min (gan2shape.py:58)
+    albedo = np.tanh(rng.standard_normal((b, 3, hw, hw)))
+    light = np.tanh(0.5 * rng.standard_normal((b, 4)))
+    view = rng.uniform(-1, 1, (b, 6)) * np.array([0.5, 1.0, 0.3, 0.1, 0.1, 0.02])
+    input_im = np.tanh(rng.standard_normal((b, 3, hw, hw)))
+    if flip:
+        depth = np.concatenate([depth, depth[:, :, ::-1]], 0)
+        albedo = np.concatenate([albedo, albedo[:, :, :, ::-1]], 0)
+        light, view = np.tile(light, (2, 1)), np.tile(view, (2, 1))
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return f(depth), f(albedo), f(light), f(view), f(input_im)

@@ -447,6 +447,73 @@ int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float
                           const float* grad_loss, float* grad_rgb, float* grad_depth, float* grad_alpha, int batch_size,
                           int height, int width, d3m_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * D. The renderer block of the gan2shape training step as fused passes (deep3dmap/models/frameworks/gan2shape.py:463-497
+ *    through NrRenderer, deep3dmap/core/renderer/renderer_nr.py:74-139):
+ *
+ *      normal          = get_normal_from_depth(depth)                                           renderer_nr.py:127-139
+ *      diffuse_shading = clamp((normal . light_d), min=0);  shading = light_a + light_b * diffuse_shading
+ *      texture         = (albedo / 2 + 0.5) * shading * 2 - 1                                   gan2shape.py:463-466
+ *      recon_depth     = warp_canon_depth(depth)    the depth map's grid mesh (implicit topology, fill_back) moved by
+ *                        (rot, trans), projected by `camera`, rasterized in depth mode, clamped  renderer_nr.py:116-125
+ *      recon_im_mask   = (recon_depth < depth_max) [* the other half's with `flip`] [* extra_mask]   gan2shape.py:476-482
+ *      recon_im        = clamp(grid_sample(texture, get_inv_warped_2d_grid(recon_depth)), -1, 1)  gan2shape.py:475,483
+ *      losses[0]       = photometric_loss(recon_im[:b], target, mask[:b])    (b = batch_size, or half of it with flip)
+ *      losses[1]       = photometric_loss(recon_im[b:], target, mask[b:])    (flip only, else 0)    gan2shape.py:486,489
+ *      losses[2]       = smooth_loss(depth) + smooth_loss(diffuse_shading)   (with_smooth)          gan2shape.py:493-494
+ *      losses[3]       = losses[0] + losses[1] + lam_smooth * losses[2]
+ *
+ *    d3m_g2s_forward: 8 launches; d3m_g2s_backward: 5 (gradients for depth, albedo, light_a, light_b, light_d, rot,
+ *    trans from the gradients of recon_im and of the four loss values).  All pointers device memory unless marked. */
+typedef struct d3m_g2s_block {
+    int batch_size, height, width;       /* canonical maps: depth [B,H,W], albedo [B,3,H,W] */
+    int image_size, anti_aliasing;       /* output images [B,.,s,s]; the mesh is rasterized at 2s with anti-aliasing */
+    int flip;                            /* entries (b, b + B/2) are an image and its mirror: shared mask product */
+    const float* inv_K; int inv_K_batch; /* NrRenderer.inv_K / K, [1|B,3,3] */
+    const float* K; int K_batch;
+    float rot_center_depth;
+    float depth_min, depth_max;          /* recon_depth is clamped to [depth_min, depth_max] (= min_depth - margin,
+                                          * max_depth + margin of renderer_nr.py:122-124) */
+    float near, far;                     /* of the depth rasterization (the rasterizer's defaults, NR/renderer.py:149) */
+    const d3m_camera* camera;            /* HOST: the mesh renderer's camera (renderer_nr.py:47-54) */
+    /* inputs */
+    const float *depth, *albedo;
+    const float *light_a, *light_b;      /* [B] */
+    const float* light_d;                /* [B,3] */
+    const float *rot, *trans;            /* [B,3,3], [B,3]: set_transform_matrices */
+    const float* target;                 /* [b,3,s,s] input_im, or NULL (no photometric terms) */
+    const float* extra_mask;             /* [B,s,s] multiplied into recon_im_mask (gan2shape.py:672), or NULL */
+    /* forward outputs (normal, recon_depth, recon_im_mask may be NULL) */
+    float* normal;                       /* [B,H,W,3] */
+    float* diffuse_shading;              /* [B,H,W] */
+    float* texture;                      /* [B,3,H,W] */
+    float* recon_depth;                  /* [B,s,s] */
+    float* recon_im;                     /* [B,3,s,s] */
+    float* recon_im_mask;                /* [B,s,s]; required when a backward pass follows */
+    float* losses;                       /* [4] */
+    float lam_smooth; int with_smooth;
+    /* kept from forward to backward (caller-allocated, no initialisation) */
+    float* screen_vertices;              /* [B,H*W,3] */
+    float* faces;                        /* [B, 4 (H-1)(W-1), 3, 3] */
+    int32_t* face_index_map;             /* [B,S,S], S = image_size * (anti_aliasing ? 2 : 1) */
+    float *weight_map, *depth_map;       /* [B,S,S,3], [B,S,S] */
+    float* scratch;                      /* d3m_g2s_scratch_floats() */
+    void* workspace; size_t workspace_bytes;   /* d3m_forward_workspace_bytes(B, 4 (H-1)(W-1), S) */
+    /* backward inputs: gradient of recon_im [B,3,s,s] and of the four loss values (device scalars); NULL = zero */
+    const float *grad_recon_im, *grad_l1, *grad_l1_flip, *grad_smooth, *grad_total;
+    /* backward scratch; grad_texture and grad_vertices are cleared by d3m_g2s_forward when it is handed them */
+    float* grad_texture;                 /* [B,3,H,W] */
+    float* grad_vertices;                /* [B,H*W,3] */
+    float* grad_depth_map;               /* [B,S,S] */
+    float* grad_normal;                  /* [B,H,W,3] */
+    float* grad_depth_mesh;              /* [B,H,W] */
+    /* backward outputs (WRITTEN; rot / trans / light may be NULL) */
+    float *grad_depth, *grad_albedo, *grad_light_a, *grad_light_b, *grad_light_d, *grad_rot, *grad_trans;
+} d3m_g2s_block;
+size_t d3m_g2s_scratch_floats(int batch_size, int height, int width, int image_size);
+int d3m_g2s_forward(const d3m_g2s_block* block, d3m_stream_t stream);
+int d3m_g2s_backward(const d3m_g2s_block* block, d3m_stream_t stream);
+
 /* ---- texture assets ----------------------------------------------------------------------------------------- */
 /* Replaces load_textures_cuda (NR/cuda/load_textures_cuda.cpp:6-37, kernel load_textures_cuda_kernel.cu:23-114):
  * fills textures [F, ts, ts, ts, 3] of every face with is_update[f] != 0 by sampling image [H, W, 3] at

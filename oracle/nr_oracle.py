@@ -871,3 +871,35 @@ class NrRenderer:
         if mask is not None:
             return warped, self._mesh_frame(mask, grid_3d, b, h, w)
         return warped
+
+
+def gan2shape_block(renderer, depth, albedo, light_a, light_b, light_d, input_im, flip=False, extra_mask=None,
+                    lam_smooth=0.01):
+    """deep3dmap/models/frameworks/gan2shape.py:463-497 (forward_step1's renderer block; :672 for `extra_mask`) on the
+    oracle's NrRenderer, statement for statement.  `renderer.rot_mat` / `trans_xyz` are the current view.  Returns a dict."""
+    r = renderer
+    b = input_im.shape[0]
+    normal = r.get_normal_from_depth(depth)                                                              # :463
+    diffuse_shading = (normal * light_d.view(-1, 1, 1, 3)).sum(3).clamp(min=0).unsqueeze(1)              # :464
+    shading = light_a.view(-1, 1, 1, 1) + light_b.view(-1, 1, 1, 1) * diffuse_shading                    # :465
+    texture = (albedo / 2 + 0.5) * shading * 2 - 1                                                       # :466
+    recon_depth = r.warp_canon_depth(depth)                                                              # :468
+    grid_2d_from_canon = r.get_inv_warped_2d_grid(recon_depth)                                           # :475
+    margin = (r.max_depth - r.min_depth) / 2
+    recon_im_mask = (recon_depth < r.max_depth + margin).float()                                         # :477
+    if flip:
+        recon_im_mask = recon_im_mask[:b] * recon_im_mask[b:]                                            # :479-481
+        recon_im_mask = recon_im_mask.repeat(2, 1, 1)
+    recon_im_mask = recon_im_mask.unsqueeze(1).detach()
+    if extra_mask is not None:
+        recon_im_mask = recon_im_mask * extra_mask                                                       # :672
+    recon_im = F.grid_sample(texture, grid_2d_from_canon, mode="bilinear").clamp(min=-1, max=1)          # :483
+    loss_l1_im = photometric_loss(recon_im[:b], input_im, mask=recon_im_mask[:b])                        # :486
+    loss_l1_im_flip = photometric_loss(recon_im[b:], input_im, mask=recon_im_mask[b:]) if flip else None  # :489
+    loss_smooth = smooth_loss(depth) + smooth_loss(diffuse_shading)                                      # :493-494
+    loss_total = loss_l1_im + lam_smooth * loss_smooth                                                   # :495 (no perceptual term)
+    if flip:
+        loss_total = loss_total + loss_l1_im_flip                                                        # :496-497
+    return dict(normal=normal, diffuse_shading=diffuse_shading, texture=texture, recon_depth=recon_depth,
+                recon_im=recon_im, recon_im_mask=recon_im_mask, loss_l1_im=loss_l1_im, loss_l1_im_flip=loss_l1_im_flip,
+                loss_smooth=loss_smooth, loss_total=loss_total)

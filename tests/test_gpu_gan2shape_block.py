@@ -1,0 +1,169 @@
+"""GPU tests of the fused gan2shape renderer block (NrRenderer.reconstruct, csrc/d3m_g2s.h) against the oracle's
+statement-for-statement restatement of deep3dmap/models/frameworks/gan2shape.py:463-497 (oracle.nr_oracle.gan2shape_block),
+at the batch sizes the reference trains with: 16, and 32 = 16 images + their mirrors (flip3)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CFG = dict(min_depth=0.9, max_depth=1.1, rot_center_depth=1.0, fov=10, tex_cube_size=2)
+LAM_SMOOTH = 0.01
+
+
+def _inputs(b, hw, seed, flip):
+    """the tensors gan2shape.py:418-460 hands to the block: depth (border clamped, mirrored copies appended with flip),
+    albedo, the three light terms, the view vector and the input image"""
+    rng = np.random.default_rng(seed)
+    t = lambda *shape: torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    depth = 1.0 + 0.08 * torch.tanh(torch.nn.functional.avg_pool2d(t(b, 1, hw, hw), 5, 1, 2)[:, 0])
+    border = torch.nn.functional.pad(torch.zeros(b, hw, hw - 4), (2, 2), value=1.02)           # gan2shape.py:428-430
+    depth = depth * (1 - border) + border * 1.08
+    albedo = torch.tanh(t(b, 3, hw, hw))
+    light = torch.tanh(t(b, 4) * 0.5)
+    view = torch.from_numpy(rng.uniform(-1, 1, (b, 6)).astype(np.float32)) * torch.tensor([0.3, 0.5, 0.2, 0.05, 0.05, 0.02])
+    input_im = torch.tanh(t(b, 3, hw, hw))
+    if flip:
+        depth = torch.cat([depth, depth.flip(2)], 0)                                            # :431-432
+        albedo = torch.cat([albedo, albedo.flip(3)], 0)                                         # :449-450
+        light, view = light.repeat(2, 1), view.repeat(2, 1)                                     # :439, 456
+    return depth, albedo, light, view, input_im
+
+
+def _light_terms(light):
+    """gan2shape.py:457-461"""
+    light_a, light_b = light[:, :1] / 2 + 0.5, light[:, 1:2] / 2 + 0.5
+    light_d = torch.cat([light[:, 2:], torch.ones(light.size(0), 1, device=light.device)], 1)
+    return light_a, light_b, light_d / ((light_d ** 2).sum(1, keepdim=True)) ** 0.5
+
+
+def _run(module, renderer, dev, inputs, rot0, trans0, flip, extra_mask, w_im):
+    depth, albedo, light, _, input_im = inputs
+    leaves = [x.clone().to(dev).requires_grad_(True) for x in (depth, albedo, light, rot0, trans0)]
+    d, a, l, rot, trans = leaves
+    renderer.rot_mat, renderer.trans_xyz = rot, trans
+    la, lb, ld = _light_terms(l)
+    xm = extra_mask.to(dev) if extra_mask is not None else None
+    if module == "oracle":
+        from oracle import nr_oracle as O
+        out = O.gan2shape_block(renderer, d, a, la, lb, ld, input_im.to(dev), flip=flip, extra_mask=xm, lam_smooth=LAM_SMOOTH)
+    else:
+        out = vars(renderer.reconstruct(d, a, la, lb, ld, input_im.to(dev), flip=flip, extra_mask=xm, lam_smooth=LAM_SMOOTH))
+    # the step's objective plus a stand-in for the perceptual term's gradient on recon_im (gan2shape.py:487)
+    objective = out["loss_total"] + (out["recon_im"] * w_im.to(dev)).mean()
+    objective.backward()
+    vals = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in out.items()}
+    return vals, [x.grad.detach().cpu() for x in leaves]
+
+
+@pytest.mark.parametrize("b,flip,hw,masked", [(16, False, 64, False), (16, True, 64, True), (3, False, 24, True), (2, True, 17, False)])
+def test_block_values_and_gradients_against_oracle(b, flip, hw, masked):
+    from deep3dmap_amd.core import NrRenderer
+    from oracle import nr_oracle as O
+    rg, ro = NrRenderer(dict(CFG), hw), O.NrRenderer(dict(CFG), hw)
+    inputs = _inputs(b, hw, 11 + b + hw, flip)
+    B = inputs[0].shape[0]
+    # both sides start from the same (R, t): a last-bit difference between the host's and the device's sin / cos moves
+    # a vertex by an ulp, which can flip the coverage of an edge pixel
+    rot0, trans0 = O.get_transform_matrices(inputs[3])
+    extra = (torch.rand(B, 1, hw, hw, generator=torch.Generator().manual_seed(5)) > 0.2).float() if masked else None
+    w_im = torch.randn(B, 3, hw, hw, generator=torch.Generator().manual_seed(6))
+    ref, g_ref = _run("oracle", ro, "cpu", inputs, rot0, trans0, flip, extra, w_im)
+    got, g_got = _run("product", rg, "cuda", inputs, rot0, trans0, flip, extra, w_im)
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-20))
+    err = {k: rel(got[k], ref[k]) for k in ("normal", "diffuse_shading", "texture", "recon_depth")}
+    err["mask_mismatches"] = int((got["recon_im_mask"] != ref["recon_im_mask"]).sum())
+    # recon_im: the sampling position is an image coordinate computed in f32 with a focal length of ~5.7 image widths
+    # (fov 10), so an ulp of the moved point is ~1e-4 of a texel, times the texture's slope
+    err["recon_im"] = float((got["recon_im"] - ref["recon_im"]).abs().max())
+    for k in ("loss_l1_im", "loss_smooth", "loss_total") + (("loss_l1_im_flip",) if flip else ()):
+        err[k] = abs(float(got[k]) - float(ref[k])) / abs(float(ref[k]))
+    for name, a, r in zip(("depth", "albedo", "light", "rot", "trans"), g_got, g_ref):
+        assert a.shape == r.shape
+        err["grad_" + name] = rel(a, r)
+    tol = dict(normal=1e-5, diffuse_shading=1e-5, texture=1e-5, recon_depth=1e-5, mask_mismatches=0, recon_im=5e-4,
+               loss_l1_im=2e-5, loss_l1_im_flip=2e-5, loss_smooth=2e-5, loss_total=2e-5,
+               # gradients: 1e-3 of the gradient's scale (north_star)
+               grad_depth=1e-3, grad_albedo=1e-3, grad_light=1e-3, grad_rot=1e-3, grad_trans=1e-3)
+    bad = {k: v for k, v in err.items() if not v <= tol[k]}
+    assert not bad, (bad, err)
+    assert got["loss_l1_im_flip"] is None or flip
+
+
+def test_block_view_gradient_and_pieces():
+    """through set_transform_matrices(view): the view vector's gradient; and the block's outputs equal NrRenderer's own
+    step-by-step methods (the drop-in surface) on the same inputs"""
+    from deep3dmap_amd.core import NrRenderer, photometric_loss, smooth_loss
+    from oracle import nr_oracle as O
+    hw, b = 32, 4
+    rg, ro = NrRenderer(dict(CFG), hw), O.NrRenderer(dict(CFG), hw)
+    depth, albedo, light, view, input_im = _inputs(b, hw, 3, False)
+    d, a, l, v = (x.clone().cuda().requires_grad_(True) for x in (depth, albedo, light, view))
+    rg.set_transform_matrices(v)
+    out = rg.reconstruct(d, a, *_light_terms(l), input_im.cuda(), lam_smooth=LAM_SMOOTH)
+    out.loss_total.backward()
+    # the oracle from the device's (R, t), chained to the view by autograd of the reference formulas
+    rot0, trans0 = rg.rot_mat.detach().cpu(), rg.trans_xyz.detach().cpu()
+    w_im = torch.zeros(b, 3, hw, hw)
+    _, (gd, ga, gl, g_rot, g_trans) = _run("oracle", ro, "cpu", (depth, albedo, light, view, input_im), rot0, trans0, False,
+                                           None, w_im)
+    vc = view.clone().requires_grad_(True)
+    rot_c, trans_c = O.get_transform_matrices(vc)
+    ((rot_c * g_rot).sum() + (trans_c * g_trans).sum()).backward()
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    assert rel(v.grad.cpu(), vc.grad) < 1e-3 and rel(d.grad.cpu(), gd) < 1e-3 and rel(a.grad.cpu(), ga) < 1e-3
+    assert rel(l.grad.cpu(), gl) < 1e-3
+    # the same quantities through the step-by-step surface
+    with torch.no_grad():
+        assert torch.equal(rg.get_normal_from_depth(d), out.normal)
+        recon_depth = rg.warp_canon_depth(d)
+        assert torch.equal(recon_depth, out.recon_depth)
+        la, lb, ld = _light_terms(l)
+        diffuse = (out.normal * ld.view(-1, 1, 1, 3)).sum(3).clamp(min=0).unsqueeze(1)
+        assert torch.allclose(diffuse, out.diffuse_shading, atol=1e-6)
+        margin = (rg.max_depth - rg.min_depth) / 2
+        mask = (recon_depth < rg.max_depth + margin).float().unsqueeze(1)
+        assert torch.equal(mask, out.recon_im_mask)
+        grid = rg.get_inv_warped_2d_grid(recon_depth)
+        recon_im = torch.nn.functional.grid_sample(out.texture, grid, mode='bilinear').clamp(min=-1, max=1)
+        assert float((recon_im - out.recon_im).abs().max()) < 5e-4
+        l1 = photometric_loss(recon_im, input_im.cuda(), mask=mask)
+        assert abs(float(l1) - float(out.loss_l1_im)) < 1e-5 * float(l1)
+        sm = smooth_loss(d) + smooth_loss(out.diffuse_shading)
+        assert abs(float(sm) - float(out.loss_smooth)) < 1e-5 * float(sm)
+
+
+def test_block_in_a_captured_step_launches_only_library_kernels():
+    """the step bench.py --workload gan2shape times: view -> reconstruct -> backward, replayed from a HIP graph, equals the
+    eager step"""
+    from deep3dmap_amd.core import NrRenderer
+    from deep3dmap_amd.graph import CapturedStep
+    hw, b = 32, 4
+    r = NrRenderer(dict(CFG), hw)
+    depth, albedo, light, view, input_im = _inputs(b, hw, 9, False)
+    d, a, l, v = (x.clone().cuda().requires_grad_(True) for x in (depth, albedo, light, view))
+    la, lb, ld = (x.detach().requires_grad_(True) for x in _light_terms(l))
+    im = input_im.cuda()
+    one = torch.ones((), device="cuda")
+    leaves = (d, a, la, lb, ld, v)
+
+    def step():
+        for x in leaves:
+            x.grad = None
+        r.set_transform_matrices(v)
+        out = r.reconstruct(d, a, la, lb, ld, im, lam_smooth=LAM_SMOOTH)
+        torch.autograd.backward([out.loss_total], [one])
+        return out.loss_total.detach()
+
+    runner = CapturedStep(step)
+    loss_eager = float(runner())
+    grads_eager = [x.grad.clone() for x in leaves]
+    runner.capture()
+    for _ in range(3):
+        loss = runner()
+    assert abs(float(loss) - loss_eager) <= 1e-6 * abs(loss_eager)
+    for x, g0 in zip(leaves, grads_eager):
+        assert float((x.grad - g0).abs().max()) <= 1e-3 * float(g0.abs().max()) + 1e-12
+    runner.release()
+    assert math.isfinite(loss_eager)
