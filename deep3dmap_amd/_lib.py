@@ -34,18 +34,16 @@ class D3MG2SBlock(ctypes.Structure):
     _fields_ = ([("batch_size", _I), ("height", _I), ("width", _I), ("image_size", _I), ("anti_aliasing", _I), ("flip", _I),
                  ("inv_K", _P), ("inv_K_batch", _I), ("K", _P), ("K_batch", _I),
                  ("rot_center_depth", _F), ("depth_min", _F), ("depth_max", _F), ("near", _F), ("far", _F),
-                 ("camera", ctypes.POINTER(D3MCamera))] +
-                [(n, _P) for n in ("depth", "albedo", "light_a", "light_b", "light_d", "rot", "trans", "target", "extra_mask",
+                 ("camera", ctypes.POINTER(D3MCamera)), ("view", _P), ("view_components", _I)] +
+                [(n, _P) for n in ("rot", "trans", "depth", "albedo", "light_a", "light_b", "light_d", "target", "extra_mask",
                                    "normal", "diffuse_shading", "texture", "recon_depth", "recon_im", "recon_im_mask",
                                    "losses")] +
                 [("lam_smooth", _F), ("with_smooth", _I)] +
-                [(n, _P) for n in ("screen_vertices", "faces", "face_index_map", "weight_map", "depth_map", "scratch",
-                                   "workspace")] +
-                [("workspace_bytes", _SZ)] +
-                [(n, _P) for n in ("grad_recon_im", "grad_l1", "grad_l1_flip", "grad_smooth", "grad_total",
-                                   "grad_texture", "grad_vertices", "grad_depth_map", "grad_normal", "grad_depth_mesh",
+                [(n, _P) for n in ("screen_vertices", "zbuffer", "scratch",
+                                   "grad_recon_im", "grad_l1", "grad_l1_flip", "grad_smooth", "grad_total",
+                                   "grad_texture", "grad_tri", "grad_depth_map", "grad_normal", "grad_depth_mesh",
                                    "grad_depth", "grad_albedo", "grad_light_a", "grad_light_b", "grad_light_d", "grad_rot",
-                                   "grad_trans")])
+                                   "grad_trans", "grad_view")])
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
@@ -108,6 +106,9 @@ _SIGNATURES = {
     "d3m_smooth_loss_backward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_forward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_fit_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "d3m_warp_resample": (_I, [_P, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "d3m_warp_resample_partials": (_I, [_I, _I]),
+    "d3m_warp_resample_backward": (_I, [_P, _P, _I, _P, _I, _P, _P, _F, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "d3m_g2s_scratch_floats": (_SZ, [_I, _I, _I, _I]),
     "d3m_g2s_forward": (_I, [ctypes.POINTER(D3MG2SBlock), _P]),
     "d3m_g2s_backward": (_I, [ctypes.POINTER(D3MG2SBlock), _P]),

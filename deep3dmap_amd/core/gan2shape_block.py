@@ -1,5 +1,5 @@
 """The renderer block of the gan2shape training step (deep3dmap/models/frameworks/gan2shape.py:463-497, "G2S") as ONE
-autograd node on the fused HIP passes of csrc/d3m_g2s.h (d3m_g2s_forward: 8 launches, d3m_g2s_backward: 5) instead of
+autograd node on the fused HIP passes of csrc/d3m_g2s.h (d3m_g2s_forward: 4 launches, d3m_g2s_backward: 5) instead of
 the ~300 eager kernels the reference spends on it per step:
 
     normal          = renderer.get_normal_from_depth(depth)                                          G2S:463
@@ -20,7 +20,6 @@ import torch
 
 from .. import _lib
 from ..neural_renderer import cameras
-from ..neural_renderer import rasterize_ops as ops
 from ..neural_renderer._util import f32c
 from ..neural_renderer.rasterize import DEFAULT_FAR, DEFAULT_NEAR
 
@@ -33,7 +32,7 @@ def _batch(t, B, tail):
 
 class _ReconBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, depth, albedo, light_a, light_b, light_d, rot, trans, target, extra_mask, cfg):
+    def forward(ctx, depth, albedo, light_a, light_b, light_d, view, rot, trans, target, extra_mask, cfg):
         L = _lib.lib()
         ctx.set_materialize_grads(False)
         d, alb = f32c(depth), f32c(albedo)
@@ -42,8 +41,14 @@ class _ReconBlock(torch.autograd.Function):
         _lib.require_device(d, alb, names=["depth", "albedo"])
         if tuple(alb.shape) != (B, 3, H, W):
             raise ValueError("albedo must be [B,3,H,W] for depth [B,H,W]")
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         la, lb, ld = _batch(light_a, B, ()), _batch(light_b, B, ()), _batch(light_d, B, (3,))
-        R, t = _batch(rot, B, (3, 3)), _batch(trans, B, (3,))
+        if view is not None:        # the block turns the view vectors into (R, t) itself (and back, in backward)
+            vw = _batch(view, B, (view.shape[-1],))
+            R, t = e(B, 3, 3), e(B, 3)
+        else:
+            vw = None
+            R, t = _batch(rot, B, (3, 3)), _batch(trans, B, (3,))
         s, aa, flip = int(cfg["image_size"]), bool(cfg["anti_aliasing"]), bool(cfg["flip"])
         S = 2 * s if aa else s
         if flip and B % 2:
@@ -56,16 +61,12 @@ class _ReconBlock(torch.autograd.Function):
         if extra_mask is not None:
             xm = f32c(extra_mask).reshape(-1, s, s)
             xm = xm if xm.shape[0] == B else xm.expand(B, s, s).contiguous()
-        need_grad = any(ctx.needs_input_grad[:7])
-        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        Fp = 4 * (H - 1) * (W - 1)
+        need_grad = any(ctx.needs_input_grad[:8])
         out = SimpleNamespace(normal=e(B, H, W, 3), diffuse=e(B, H, W), texture=e(B, 3, H, W), recon_depth=e(B, s, s),
                               recon_im=e(B, 3, s, s), mask=e(B, s, s), losses=e(4))
-        keep = SimpleNamespace(sv=e(B, H * W, 3), faces=e(B, Fp, 3, 3),
-                               fim=torch.empty((B, S, S), dtype=torch.int32, device=dev), wm=e(B, S, S, 3), dm=e(B, S, S),
+        keep = SimpleNamespace(sv=e(B, H * W, 3), zbuf=torch.empty((B, S, S), dtype=torch.int64, device=dev),
                                scratch=e(int(L.d3m_g2s_scratch_floats(B, H, W, s))),
-                               g_tex=e(B, 3, H, W) if need_grad else None, g_vert=e(B, H * W, 3) if need_grad else None)
-        ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
+                               g_tex=e(B, 3, H, W) if need_grad else None)
         cam, cam_keep = cameras._camera_struct(cfg["camera"], dev)
         blk = _lib.D3MG2SBlock()
         blk.batch_size, blk.height, blk.width, blk.image_size = B, H, W, s
@@ -75,46 +76,47 @@ class _ReconBlock(torch.autograd.Function):
         blk.rot_center_depth, blk.depth_min, blk.depth_max = cfg["rot_center_depth"], cfg["depth_min"], cfg["depth_max"]
         blk.near, blk.far = cfg["near"], cfg["far"]
         blk.camera = ctypes.pointer(cam)
-        for name, tensor in (("depth", d), ("albedo", alb), ("light_a", la), ("light_b", lb), ("light_d", ld), ("rot", R),
-                             ("trans", t), ("target", tgt), ("extra_mask", xm), ("normal", out.normal),
+        blk.view_components = vw.shape[1] if vw is not None else 0
+        for name, tensor in (("view", vw), ("rot", R), ("trans", t), ("depth", d), ("albedo", alb), ("light_a", la),
+                             ("light_b", lb), ("light_d", ld), ("target", tgt), ("extra_mask", xm), ("normal", out.normal),
                              ("diffuse_shading", out.diffuse), ("texture", out.texture), ("recon_depth", out.recon_depth),
                              ("recon_im", out.recon_im), ("recon_im_mask", out.mask), ("losses", out.losses),
-                             ("screen_vertices", keep.sv), ("faces", keep.faces), ("face_index_map", keep.fim),
-                             ("weight_map", keep.wm), ("depth_map", keep.dm), ("scratch", keep.scratch), ("workspace", ws),
-                             ("grad_texture", keep.g_tex), ("grad_vertices", keep.g_vert)):
+                             ("screen_vertices", keep.sv), ("zbuffer", keep.zbuf), ("scratch", keep.scratch),
+                             ("grad_texture", keep.g_tex)):
             setattr(blk, name, tensor.data_ptr() if tensor is not None else None)
-        blk.workspace_bytes = ws.numel()
         lam = cfg.get("lam_smooth")
         blk.with_smooth, blk.lam_smooth = int(bool(cfg["with_smooth"])), float(lam) if lam is not None else 0.0
         _lib.check(L.d3m_g2s_forward(ctypes.byref(blk), _lib.stream_ptr()), "d3m_g2s_forward")
         ctx.blk, ctx.cam = blk, cam                 # the filled struct is reused by backward (pointers stay valid below)
-        ctx.alive = (d, alb, la, lb, ld, R, t, tgt, xm, out, keep, iK, K, cam_keep, ws)
-        ctx.shapes = (tuple(light_a.shape), tuple(light_b.shape), tuple(light_d.shape), tuple(rot.shape), tuple(trans.shape))
-        ctx.mark_non_differentiable(out.normal, out.diffuse, out.texture, out.recon_depth, out.mask)
+        ctx.alive = (d, alb, la, lb, ld, vw, R, t, tgt, xm, out, keep, iK, K, cam_keep)
+        ctx.shapes = tuple(tuple(x.shape) if x is not None else None for x in (light_a, light_b, light_d, view, rot, trans))
+        ctx.mark_non_differentiable(out.normal, out.diffuse, out.texture, out.recon_depth, out.mask, R, t)
         return (out.recon_im, out.losses[0], out.losses[1], out.losses[2], out.losses[3], out.normal, out.diffuse,
-                out.texture, out.recon_depth, out.mask)
+                out.texture, out.recon_depth, out.mask, R, t)
 
     @staticmethod
     def backward(ctx, g_im, g_l1, g_l1f, g_sm, g_total, *_unused):
         L = _lib.lib()
         blk = ctx.blk
-        d, alb, la, lb, ld, R, t, tgt, xm, out, keep, iK, K, cam_keep, ws = ctx.alive
+        d, alb, la, lb, ld, vw, R, t, tgt, xm, out, keep, iK, K, cam_keep = ctx.alive
         if keep.g_tex is None:
             raise RuntimeError("reconstruct(): backward needs inputs that required grad when forward ran")
         B, H, W = d.shape
         dev = d.device
-        S = keep.dm.shape[1]
+        S = keep.zbuf.shape[1]
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grads_in = [f32c(g) if g is not None else None for g in (g_im, g_l1, g_l1f, g_sm, g_total)]
         for name, g in zip(("grad_recon_im", "grad_l1", "grad_l1_flip", "grad_smooth", "grad_total"), grads_in):
             setattr(blk, name, g.data_ptr() if g is not None else None)
-        bufs = dict(grad_depth_map=e(B, S, S), grad_normal=e(B, H, W, 3), grad_depth_mesh=e(B, H, W), grad_depth=e(B, H, W),
-                    grad_albedo=e(B, 3, H, W), grad_light_a=e(B), grad_light_b=e(B), grad_light_d=e(B, 3),
-                    grad_rot=e(B, 3, 3), grad_trans=e(B, 3))
+        bufs = dict(grad_tri=e(B, 2 * (H - 1) * (W - 1), 3, 3), grad_depth_map=e(B, S, S), grad_normal=e(B, H, W, 3),
+                    grad_depth_mesh=e(B, H, W), grad_depth=e(B, H, W), grad_albedo=e(B, 3, H, W), grad_light_a=e(B),
+                    grad_light_b=e(B), grad_light_d=e(B, 3), grad_rot=e(B, 3, 3), grad_trans=e(B, 3))
+        if vw is not None:
+            bufs["grad_view"] = e(*vw.shape)
         for name, tensor in bufs.items():
             setattr(blk, name, tensor.data_ptr())
         _lib.check(L.d3m_g2s_backward(ctypes.byref(blk), _lib.stream_ptr()), "d3m_g2s_backward")
-        sh_a, sh_b, sh_d, sh_R, sh_t = ctx.shapes
+        sh_a, sh_b, sh_d, sh_v, sh_R, sh_t = ctx.shapes
 
         def back(g, shape, per):           # undo _batch(): sum a broadcast batch, restore the caller's shape
             n = 1
@@ -127,8 +129,9 @@ class _ReconBlock(torch.autograd.Function):
                 back(bufs["grad_light_a"], sh_a, ()) if need[2] else None,
                 back(bufs["grad_light_b"], sh_b, ()) if need[3] else None,
                 back(bufs["grad_light_d"], sh_d, (3,)) if need[4] else None,
-                back(bufs["grad_rot"], sh_R, (3, 3)) if need[5] else None,
-                back(bufs["grad_trans"], sh_t, (3,)) if need[6] else None, None, None, None)
+                back(bufs["grad_view"], sh_v, (sh_v[-1],)) if (need[5] and vw is not None) else None,
+                back(bufs["grad_rot"], sh_R, (3, 3)) if (need[6] and vw is None) else None,
+                back(bufs["grad_trans"], sh_t, (3,)) if (need[7] and vw is None) else None, None, None, None)
 
 
 def reconstruct(renderer, depth, albedo, light_a, light_b, light_d, input_im=None, flip=False, extra_mask=None,
@@ -148,8 +151,14 @@ def reconstruct(renderer, depth, albedo, light_a, light_b, light_d, input_im=Non
                depth_min=float(renderer.min_depth - margin), depth_max=float(renderer.max_depth + margin),
                # render_depth rasterizes with the rasterizer's defaults, not the renderer's near / far (NR/renderer.py:149)
                near=float(DEFAULT_NEAR), far=float(DEFAULT_FAR), with_smooth=with_smooth, lam_smooth=lam_smooth)
-    (recon_im, l1, l1f, sm, total, normal, diffuse, texture, recon_depth, mask) = _ReconBlock.apply(
-        depth, albedo, light_a, light_b, light_d, renderer.rot_mat, renderer.trans_xyz, input_im, extra_mask, cfg)
+    # a view set through set_transform_matrices(view) and not looked at since goes into the block as it is: (R, t) are
+    # then computed by the block's first pass, and the view's gradient by its last
+    view = renderer._pending_view()
+    rot, trans = (None, None) if view is not None else (renderer.rot_mat, renderer.trans_xyz)
+    (recon_im, l1, l1f, sm, total, normal, diffuse, texture, recon_depth, mask, R, t) = _ReconBlock.apply(
+        depth, albedo, light_a, light_b, light_d, view, rot, trans, input_im, extra_mask, cfg)
+    if view is not None:
+        renderer._resolve_view(view, R, t)
     return SimpleNamespace(normal=normal, diffuse_shading=diffuse[:, None], texture=texture, recon_depth=recon_depth,
                            recon_im=recon_im, recon_im_mask=mask[:, None], loss_l1_im=l1,
                            loss_l1_im_flip=l1f if flip else None, loss_smooth=sm if with_smooth else None,

@@ -11,7 +11,6 @@ import ctypes
 import math
 
 import torch
-import torch.nn as nn
 
 from .. import _lib
 from .. import neural_renderer as nr
@@ -109,6 +108,57 @@ class _DepthNormals(torch.autograd.Function):
         return gd, None
 
 
+class _WarpResample(torch.autograd.Function):
+    """d3m_warp_resample: the frames of CR:180-184 -- the sampling grid of a target-view depth map under a rigid motion
+    and the lookups F.grid_sample(im, grid, 'bilinear') [and F.grid_sample(mask, grid, 'nearest')] -- in one pass; the
+    adjoint reaches the image, the depth map and the motion (A, t)."""
+
+    @staticmethod
+    def forward(ctx, depth, im, mask, inv_K, K, A, t, center_z):
+        d, src = f32c(depth), f32c(im)
+        B, h, w = d.shape
+        _, C, H, W = src.shape
+        iK, Kc = f32c(inv_K), f32c(K)
+        A_b, t_b = f32c(A.expand(B, 3, 3)), f32c(t.reshape(-1, 3).expand(B, 3))
+        msk = f32c(mask) if mask is not None else None
+        out = torch.empty(B, C, h, w, dtype=torch.float32, device=d.device)
+        out_m = torch.empty(B, msk.shape[1], h, w, dtype=torch.float32, device=d.device) if msk is not None else None
+        _lib.check(_lib.lib().d3m_warp_resample(
+            _lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(Kc), Kc.shape[0], _lib.ptr(A_b), _lib.ptr(t_b), float(center_z),
+            _lib.ptr(src), C, _lib.ptr(msk), msk.shape[1] if msk is not None else 0, _lib.ptr(out), _lib.ptr(out_m), B, h, w,
+            H, W, _lib.stream_ptr()), "d3m_warp_resample")
+        ctx.save_for_backward(d, src, iK, Kc, A_b, t_b)
+        ctx.center_z, ctx.shapes = float(center_z), (tuple(A.shape), tuple(t.shape))
+        if out_m is None:
+            return out
+        ctx.mark_non_differentiable(out_m)             # mode='nearest' has no gradient (nor does torch's)
+        return out, out_m
+
+    @staticmethod
+    def backward(ctx, g, _g_mask=None):
+        d, src, iK, Kc, A_b, t_b = ctx.saved_tensors
+        B, h, w = d.shape
+        _, C, H, W = src.shape
+        L = _lib.lib()
+        need = ctx.needs_input_grad
+        g_src = torch.zeros_like(src) if need[1] else None
+        g_d = torch.empty_like(d) if need[0] else None
+        parts = torch.empty(B, int(L.d3m_warp_resample_partials(h, w)), 12, dtype=torch.float32, device=d.device)
+        _lib.check(L.d3m_warp_resample_backward(
+            _lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(Kc), Kc.shape[0], _lib.ptr(A_b), _lib.ptr(t_b), ctx.center_z,
+            _lib.ptr(src), C, _lib.ptr(f32c(g)), _lib.ptr(g_src), _lib.ptr(g_d), _lib.ptr(parts), B, h, w, H, W,
+            _lib.stream_ptr()), "d3m_warp_resample_backward")
+        gA = gt = None
+        if need[5] or need[6]:
+            sums = parts.sum(1)
+            A_shape, t_shape = ctx.shapes
+            gA = sums[:, :9].reshape(B, 3, 3)
+            gA = gA.sum(0, keepdim=True) if A_shape[0] != B else gA
+            gt = sums[:, 9:]
+            gt = (gt.sum(0, keepdim=True) if t_shape[0] != B else gt).reshape(t_shape)
+        return g_d, g_src, None, None, None, gA if need[5] else None, gt if need[6] else None, None
+
+
 class NrRenderer():
     def __init__(self, cfgs, image_size):
         self.device = cfgs.get('device', 'cpu')
@@ -120,6 +170,7 @@ class NrRenderer():
         self.tex_cube_size = cfgs.get('tex_cube_size', 2)
         self.renderer_min_depth = cfgs.get('renderer_min_depth', 0.1)
         self.renderer_max_depth = cfgs.get('renderer_max_depth', 10.)
+        self._view = self._rot_mat = self._trans_xyz = None
 
         # camera intrinsics: d * K^-1 (u, v, 1)^T = (x, y, z)^T  (CR:24-46)
         R = torch.eye(3, dtype=torch.float32)[None].cuda()
@@ -148,7 +199,48 @@ class NrRenderer():
             self.inv_K = torch.inverse(self.K[0].cpu()).unsqueeze(0).to(self.K.device)
 
     def set_transform_matrices(self, view):
-        self.rot_mat, self.trans_xyz = get_transform_matrices(view)
+        """CR:61-62.  A view on the GPU is kept as it is until rot_mat / trans_xyz are looked at (one fused launch then):
+        reconstruct() feeds it to its first pass instead, which computes (R, t) among other things."""
+        if torch.is_tensor(view) and view.is_cuda and view.dim() == 2 and view.size(1) in (3, 5, 6):
+            self._view, self._rot_mat, self._trans_xyz = view, None, None
+        else:
+            self._view = None
+            self._rot_mat, self._trans_xyz = get_transform_matrices(view)
+
+    def _materialise_view(self):
+        if self._rot_mat is None and getattr(self, "_view", None) is not None:
+            self._rot_mat, self._trans_xyz = get_transform_matrices(self._view)
+            self._view = None
+
+    def _pending_view(self):
+        """the view vectors of set_transform_matrices() if nothing has asked for (R, t) since, else None"""
+        return getattr(self, "_view", None)
+
+    def _resolve_view(self, view, R, t):
+        """reconstruct() has computed the pending view's (R, t) (detached values: the view's gradient went through the
+        block); later readers of rot_mat / trans_xyz get the differentiable form on demand"""
+        if self._pending_view() is view and not view.requires_grad:
+            self._rot_mat, self._trans_xyz, self._view = R, t[:, None, :], None
+
+    @property
+    def rot_mat(self):
+        self._materialise_view()
+        return self._rot_mat
+
+    @rot_mat.setter
+    def rot_mat(self, value):
+        self._materialise_view()
+        self._rot_mat = value
+
+    @property
+    def trans_xyz(self):
+        self._materialise_view()
+        return self._trans_xyz
+
+    @trans_xyz.setter
+    def trans_xyz(self, value):
+        self._materialise_view()
+        self._trans_xyz = value
 
     # ---- the one pass everything below goes through ---------------------------------------------------------------
     def _warp(self, depth, rigid, project=False, crop=None):
@@ -232,9 +324,10 @@ class NrRenderer():
     def _frame_resample(self, im, depth, view, mask=None):
         """the grid_sample form (CR:180-184): warp the depth to `view`, look every target pixel up in the source image."""
         self.set_transform_matrices(view)
-        grid = self.get_inv_warped_2d_grid(self.warp_canon_depth(depth))
-        out = nn.functional.grid_sample(im, grid, mode='bilinear')
-        return out if mask is None else (out, nn.functional.grid_sample(mask, grid, mode='nearest'))
+        back = self._current().inverse()                     # get_inv_warped_2d_grid's motion (CR:102-107)
+        dev = im.device
+        return _WarpResample.apply(self.warp_canon_depth(depth), im, mask, self.inv_K.to(dev), self.K.to(dev),
+                                   back.A.to(dev), back.t.to(dev), self.rot_center_depth)
 
     def _sweep(self, im, depth, euler_angles, v_before, v_after, grid_sample, crop=None):
         dev = im.device

@@ -1069,17 +1069,16 @@ static inline int g2s_split(long pixels, int cap) {
     const long b = (pixels + 255) / 256;
     return (int)(b < 1 ? 1 : (b < cap ? b : cap));
 }
-struct G2SLayout { int split_s, split_m, split_f, off_sample, off_smooth, off_front, off_sback, total; };
+struct G2SLayout { int split_s, split_f, off_sample, off_front, off_sback, total; };
 static G2SLayout g2s_layout(int B, int H, int W, int s) {
     G2SLayout L;
-    L.split_s = g2s_split((long)s * s, 32);
+    const long px = (long)s * s > (long)H * W ? (long)s * s : (long)H * W;     // the sample pass also sweeps the canonical maps
+    L.split_s = g2s_split(px, 32);
     L.split_f = g2s_split((long)H * W, 32);
-    L.split_m = g2s_split((long)B * H * W, 256);
     int o = G2S_TOTALS;
-    L.off_sample = o; o += 4 * B * L.split_s;
-    L.off_smooth = o; o += 2 * 4 * L.split_m;
+    L.off_sample = o; o += G2S_SAMPLE_PART * B * L.split_s;
     L.off_front = o;  o += G2S_FRONT_SUMS * B * L.split_f;
-    L.off_sback = o;  o += G2S_SAMPLE_SUMS * B * L.split_s;
+    L.off_sback = o;  o += G2S_SBACK_SUMS * B * L.split_s;
     L.total = o;
     return L;
 }
@@ -1091,12 +1090,13 @@ D3M_EXPORT size_t d3m_g2s_scratch_floats(int batch_size, int height, int width, 
 static int to_g2s(const d3m_g2s_block* h, G2S& g) {
     if (!h) return D3M_ERR_INVALID;
     const int B = h->batch_size, H = h->height, W = h->width, s = h->image_size;
-    if (B <= 0 || H < 3 || W < 3 || s < 2 || (long)B * H * W > 0x3FFFFFFFL || (long)B * s * s > 0x3FFFFFFFL) return D3M_ERR_INVALID;
+    if (B <= 0 || H < 3 || W < 3 || s < 2 || (long)B * H * W > 0x3FFFFFFFL || (long)B * s * s > 0x0FFFFFFFL) return D3M_ERR_INVALID;
     if (h->flip && (B & 1)) return D3M_ERR_INVALID;
     if (!h->inv_K || !h->K || !h->depth || !h->albedo || !h->light_a || !h->light_b || !h->light_d || !h->rot || !h->trans ||
-        !h->diffuse_shading || !h->texture || !h->recon_im || !h->losses || !h->screen_vertices || !h->faces ||
-        !h->face_index_map || !h->weight_map || !h->depth_map || !h->scratch)
+        !h->diffuse_shading || !h->texture || !h->recon_im || !h->recon_im_mask || !h->losses || !h->screen_vertices ||
+        !h->zbuffer || !h->scratch)
         return D3M_ERR_INVALID;
+    if (h->view && h->view_components != 3 && h->view_components != 5 && h->view_components != 6) return D3M_ERR_INVALID;
     if ((h->inv_K_batch != 1 && h->inv_K_batch != B) || (h->K_batch != 1 && h->K_batch != B)) return D3M_ERR_INVALID;
     memset(&g, 0, sizeof(g));
     if (int rc = to_cam(h->camera, B, g.cam)) return rc;
@@ -1104,74 +1104,101 @@ static int to_g2s(const d3m_g2s_block* h, G2S& g) {
     g.B = B; g.H = H; g.W = W; g.s = s; g.aa = h->anti_aliasing ? 1 : 0; g.S = g.aa ? 2 * s : s;
     g.flip = h->flip ? 1 : 0; g.Bh = g.flip ? B / 2 : B;
     g.inv_K = h->inv_K; g.invK_b = h->inv_K_batch; g.K = h->K; g.K_b = h->K_batch;
-    g.center_z = h->rot_center_depth; g.depth_lo = h->depth_min; g.depth_hi = h->depth_max;
+    g.center_z = h->rot_center_depth; g.depth_lo = h->depth_min; g.depth_hi = h->depth_max; g.near = h->near; g.far = h->far;
+    g.view = h->view; g.view_n = h->view_components; g.rot = h->rot; g.trans = h->trans;
     g.depth = h->depth; g.albedo = h->albedo; g.light_a = h->light_a; g.light_b = h->light_b; g.light_d = h->light_d;
-    g.rot = h->rot; g.trans = h->trans; g.target = h->target; g.extra_mask = h->extra_mask;
+    g.target = h->target; g.extra_mask = h->extra_mask;
     g.normal = h->normal; g.diffuse = h->diffuse_shading; g.texture = h->texture; g.screen_vertices = h->screen_vertices;
-    g.depth_map = h->depth_map; g.recon_depth = h->recon_depth; g.recon_im = h->recon_im; g.recon_mask = h->recon_im_mask;
-    g.losses = h->losses; g.scratch = h->scratch;
-    g.off_sample = L.off_sample; g.off_smooth = L.off_smooth; g.off_front = L.off_front; g.off_sback = L.off_sback;
-    g.split_s = L.split_s; g.split_m = L.split_m; g.split_f = L.split_f;
+    g.zbuf = (unsigned long long*)h->zbuffer; g.recon_depth = h->recon_depth; g.recon_im = h->recon_im;
+    g.recon_mask = h->recon_im_mask; g.losses = h->losses; g.scratch = h->scratch;
+    g.off_sample = L.off_sample; g.off_front = L.off_front; g.off_sback = L.off_sback;
+    g.split_s = L.split_s; g.split_f = L.split_f;
     g.lam_smooth = h->lam_smooth; g.with_smooth = h->with_smooth ? 1 : 0;
+    g.n_xx = g.n_xy = g.n_yy = 1.0f;
+    if (g.with_smooth) if (int rc = smooth_dims(B, H, W, g.n_xx, g.n_xy, g.n_yy)) return rc;
     g.grad_recon_im = h->grad_recon_im; g.g_l1 = h->grad_l1; g.g_l1_flip = h->grad_l1_flip; g.g_smooth = h->grad_smooth;
     g.g_total = h->grad_total;
-    g.grad_texture = h->grad_texture; g.grad_vertices = h->grad_vertices; g.grad_depth_map = h->grad_depth_map;
+    g.grad_texture = h->grad_texture; g.grad_tri = h->grad_tri; g.grad_depth_map = h->grad_depth_map;
     g.grad_normal = h->grad_normal; g.grad_depth_mesh = h->grad_depth_mesh;
     g.grad_depth = h->grad_depth; g.grad_albedo = h->grad_albedo; g.grad_light_a = h->grad_light_a;
     g.grad_light_b = h->grad_light_b; g.grad_light_d = h->grad_light_d; g.grad_rot = h->grad_rot; g.grad_trans = h->grad_trans;
+    g.grad_view = h->grad_view;
     return D3M_OK;
+}
+
+static int to_warp_resample(WarpResample& g, const float* depth, const float* inv_K, int inv_K_batch, const float* K, int K_batch,
+                            const float* rot, const float* trans, float center_z, const float* src, int C, int B, int h, int w,
+                            int H, int W) {
+    if (!depth || !inv_K || !K || !rot || !trans || !src || B <= 0 || h < 2 || w < 2 || H <= 0 || W <= 0 || C <= 0 ||
+        (long)B * h * w > 0x3FFFFFFFL)
+        return D3M_ERR_INVALID;
+    if ((inv_K_batch != 1 && inv_K_batch != B) || (K_batch != 1 && K_batch != B)) return D3M_ERR_INVALID;
+    memset(&g, 0, sizeof(g));
+    g.B = B; g.h = h; g.w = w; g.C = C; g.H = H; g.W = W; g.depth = depth; g.inv_K = inv_K; g.invK_b = inv_K_batch;
+    g.K = K; g.K_b = K_batch; g.rot = rot; g.trans = trans; g.center_z = center_z; g.src = src;
+    return D3M_OK;
+}
+D3M_EXPORT int d3m_warp_resample(const float* depth, const float* inv_K, int inv_K_batch, const float* K, int K_batch,
+                                 const float* rot, const float* trans, float rot_center_depth, const float* src, int channels,
+                                 const float* src_nearest, int channels_nearest, float* out, float* out_nearest,
+                                 int batch_size, int height, int width, int src_height, int src_width, d3m_stream_t stream) {
+    WarpResample g;
+    if (int rc = to_warp_resample(g, depth, inv_K, inv_K_batch, K, K_batch, rot, trans, rot_center_depth, src, channels,
+                                  batch_size, height, width, src_height, src_width))
+        return rc;
+    if (!out || (src_nearest && (!out_nearest || channels_nearest <= 0))) return D3M_ERR_INVALID;
+    g.src_nearest = src_nearest; g.Cn = channels_nearest; g.out = out; g.out_nearest = out_nearest;
+    LAUNCH("k_warp_resample", k_warp_resample, dim3(blocks_for((long)batch_size * height * width, 256)), dim3(256),
+           (hipStream_t)stream, g);
+    return check_launch();
+}
+D3M_EXPORT int d3m_warp_resample_partials(int height, int width) {
+    return height > 0 && width > 0 ? g2s_split((long)height * width, 32) : 0;
+}
+D3M_EXPORT int d3m_warp_resample_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* K, int K_batch,
+                                          const float* rot, const float* trans, float rot_center_depth, const float* src,
+                                          int channels, const float* grad_out, float* grad_src, float* grad_depth,
+                                          float* partials, int batch_size, int height, int width, int src_height,
+                                          int src_width, d3m_stream_t stream) {
+    WarpResample g;
+    if (int rc = to_warp_resample(g, depth, inv_K, inv_K_batch, K, K_batch, rot, trans, rot_center_depth, src, channels,
+                                  batch_size, height, width, src_height, src_width))
+        return rc;
+    if (!grad_out || !partials) return D3M_ERR_INVALID;
+    g.grad_out = grad_out; g.grad_src = grad_src; g.grad_depth = grad_depth; g.partials = partials;
+    LAUNCH("k_warp_resample_backward", k_warp_resample_backward, dim3(d3m_warp_resample_partials(height, width), batch_size),
+           dim3(256), (hipStream_t)stream, g);
+    return check_launch();
 }
 
 D3M_EXPORT int d3m_g2s_forward(const d3m_g2s_block* block, d3m_stream_t stream) {
     G2S g;
     if (int rc = to_g2s(block, g)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1), Fp = 2 * Ft;
-    float n_xx = 1, n_xy = 1, n_yy = 1;
-    if (g.with_smooth) if (int rc = smooth_dims(B, g.H, g.W, n_xx, n_xy, n_yy)) return rc;
-    BinBuffers bb;
-    if (int rc = make_bins(bb, B, Fp, g.S, block->workspace, block->workspace_bytes)) return rc;
-    // the first pass also clears the tile counters of the binning passes and the accumulators of the backward pass
+    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1);
+    // the first pass also clears the z-buffer and (for the backward pass) the texture-gradient accumulator
     ZeroRanges z;
-    const size_t zero_words[3] = {fwd_layout(B, Fp, g.S).zero_bytes / 4, g.grad_texture ? (size_t)B * 3 * HW : 0,
-                                  g.grad_vertices ? (size_t)B * HW * 3 : 0};
-    uint32_t* const zero_ptr[3] = {(uint32_t*)block->workspace, (uint32_t*)g.grad_texture, (uint32_t*)g.grad_vertices};
-    for (int k = 0; k < 3; k++) {
-        if (zero_words[k] > 0xFFFFFFFFul) return D3M_ERR_INVALID;
-        z.p[k] = zero_ptr[k]; z.n[k] = (unsigned)zero_words[k];
-    }
+    z.p[0] = (uint32_t*)g.zbuf;         z.n[0] = (unsigned)((size_t)B * g.S * g.S * 2);
+    z.p[1] = (uint32_t*)g.grad_texture; z.n[1] = g.grad_texture ? (unsigned)((size_t)B * 3 * HW) : 0u;
     LAUNCH("k_g2s_front", k_g2s_front, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g, z);
-    if (g.with_smooth) LAUNCH("k_g2s_smooth", k_g2s_smooth, dim3(g.split_m, 2), dim3(256), st, g);
-    IndexedFaces ifs{g.screen_vertices, nullptr, HW, Ft, 1, 1, B, g.W};
-    RasterOut out{block->face_index_map, block->weight_map, block->depth_map, nullptr, nullptr};
-    if (int rc = run_forward_mesh(ifs, block->faces, B, g.S, block->near, block->far, out, block->workspace,
-                                  block->workspace_bytes, st, true))
-        return rc;
+    LAUNCH("k_g2s_raster", k_g2s_raster, dim3(blocks_for((long)B * Ft, 4 * G2S_PW)), dim3(256), st, g);
     LAUNCH("k_g2s_sample", k_g2s_sample, dim3(g.split_s, g.Bh), dim3(256), st, g);
-    LAUNCH("k_g2s_finish", k_g2s_finish, dim3(1), dim3(256), st, g, n_xx, n_xy, n_yy);
+    LAUNCH("k_g2s_finish", k_g2s_finish, dim3(1), dim3(256), st, g);
     return check_launch();
 }
 
 D3M_EXPORT int d3m_g2s_backward(const d3m_g2s_block* block, d3m_stream_t stream) {
     G2S g;
     if (int rc = to_g2s(block, g)) return rc;
-    if (!g.grad_texture || !g.grad_vertices || !g.grad_depth_map || !g.grad_normal || !g.grad_depth_mesh || !g.grad_depth ||
-        !g.grad_albedo || !g.recon_mask)
+    if (!g.grad_texture || !g.grad_tri || !g.grad_depth_map || !g.grad_normal || !g.grad_depth_mesh || !g.grad_depth)
         return D3M_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1), Fp = 2 * Ft;
-    float n_xx = 1, n_xy = 1, n_yy = 1;
-    if (g.with_smooth) if (int rc = smooth_dims(B, g.H, g.W, n_xx, n_xy, n_yy)) return rc;
+    const int B = g.B, HW = g.H * g.W, Ft = 2 * (g.H - 1) * (g.W - 1);
     LAUNCH("k_g2s_sample_backward", k_g2s_sample_backward, dim3(g.split_s, B), dim3(256), st, g);
-    // K6 (KCU:543-592) per covered pixel, straight onto the vertices of the implicit grid (the faces are a few pixels each)
-    DenseFaces fs{block->faces, Fp};
-    VertexTarget vt{g.grad_vertices, nullptr, HW, Ft, 1, g.W};
-    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid((long)B * g.S * g.S, false)), dim3(256), st, fs,
-           (const float*)block->depth_map, (const int32_t*)block->face_index_map, (const float*)nullptr,
-           (const float*)block->weight_map, (const float*)g.grad_depth_map, (float*)nullptr, B, g.S, (const int*)nullptr, vt);
-    LAUNCH("k_g2s_front_backward", k_g2s_front_backward, dim3(g.split_f, B), dim3(256), st, g, n_xx, n_xy, n_yy);
-    LAUNCH("k_g2s_depth_backward", k_g2s_depth_backward, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g, n_xx, n_xy, n_yy);
-    LAUNCH("k_g2s_finish_backward", k_g2s_finish_backward, dim3(B), dim3(64), st, g);
+    LAUNCH("k_g2s_depth_faces", k_g2s_depth_faces, dim3(blocks_for((long)B * Ft, 4 * G2S_PW)), dim3(256), st, g);
+    LAUNCH("k_g2s_front_backward", k_g2s_front_backward, dim3(g.split_f, B), dim3(256), st, g);
+    LAUNCH("k_g2s_depth_backward", k_g2s_depth_backward, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g);
+    LAUNCH("k_g2s_finish_backward", k_g2s_finish_backward, dim3(B), dim3(256), st, g);
     return check_launch();
 }
 

@@ -448,9 +448,10 @@ int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float
                           int height, int width, d3m_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * D. The renderer block of the gan2shape training step as fused passes (deep3dmap/models/frameworks/gan2shape.py:463-497
- *    through NrRenderer, deep3dmap/core/renderer/renderer_nr.py:74-139):
+ * D. The renderer block of the gan2shape training step as fused passes (deep3dmap/models/frameworks/gan2shape.py:444,
+ *    463-497 through NrRenderer, deep3dmap/core/renderer/renderer_nr.py:61-139):
  *
+ *      rot, trans      = get_transform_matrices(view)   (when `view` is given; else rot / trans are inputs)   utils.py:54-71
  *      normal          = get_normal_from_depth(depth)                                           renderer_nr.py:127-139
  *      diffuse_shading = clamp((normal . light_d), min=0);  shading = light_a + light_b * diffuse_shading
  *      texture         = (albedo / 2 + 0.5) * shading * 2 - 1                                   gan2shape.py:463-466
@@ -463,8 +464,10 @@ int d3m_fit_loss_backward(const float* rgb, const float* rgb_target, const float
  *      losses[2]       = smooth_loss(depth) + smooth_loss(diffuse_shading)   (with_smooth)          gan2shape.py:493-494
  *      losses[3]       = losses[0] + losses[1] + lam_smooth * losses[2]
  *
- *    d3m_g2s_forward: 8 launches; d3m_g2s_backward: 5 (gradients for depth, albedo, light_a, light_b, light_d, rot,
- *    trans from the gradients of recon_im and of the four loss values).  All pointers device memory unless marked. */
+ *    d3m_g2s_forward: 4 launches; d3m_g2s_backward: 5 (gradients for depth, albedo, light_a, light_b, light_d and the
+ *    view -- as rot / trans and, with `view`, the view vector -- from the gradients of recon_im and of the four loss
+ *    values).  The mesh is rasterized by bidding (depth, face) into a 64-bit z-buffer (its triangles are a few pixels
+ *    each): same coverage, depth and tie rule as d3m_forward_face_index_map.  Device pointers unless marked. */
 typedef struct d3m_g2s_block {
     int batch_size, height, width;       /* canonical maps: depth [B,H,W], albedo [B,3,H,W] */
     int image_size, anti_aliasing;       /* output images [B,.,s,s]; the mesh is rasterized at 2s with anti-aliasing */
@@ -477,42 +480,58 @@ typedef struct d3m_g2s_block {
     float near, far;                     /* of the depth rasterization (the rasterizer's defaults, NR/renderer.py:149) */
     const d3m_camera* camera;            /* HOST: the mesh renderer's camera (renderer_nr.py:47-54) */
     /* inputs */
+    const float* view; int view_components;   /* [B, 3|5|6] view vectors, or NULL */
+    float *rot, *trans;                  /* [B,3,3], [B,3]: inputs when view == NULL, else written (set_transform_matrices) */
     const float *depth, *albedo;
     const float *light_a, *light_b;      /* [B] */
     const float* light_d;                /* [B,3] */
-    const float *rot, *trans;            /* [B,3,3], [B,3]: set_transform_matrices */
     const float* target;                 /* [b,3,s,s] input_im, or NULL (no photometric terms) */
     const float* extra_mask;             /* [B,s,s] multiplied into recon_im_mask (gan2shape.py:672), or NULL */
-    /* forward outputs (normal, recon_depth, recon_im_mask may be NULL) */
+    /* forward outputs (normal, recon_depth may be NULL) */
     float* normal;                       /* [B,H,W,3] */
     float* diffuse_shading;              /* [B,H,W] */
     float* texture;                      /* [B,3,H,W] */
     float* recon_depth;                  /* [B,s,s] */
     float* recon_im;                     /* [B,3,s,s] */
-    float* recon_im_mask;                /* [B,s,s]; required when a backward pass follows */
+    float* recon_im_mask;                /* [B,s,s] */
     float* losses;                       /* [4] */
     float lam_smooth; int with_smooth;
     /* kept from forward to backward (caller-allocated, no initialisation) */
     float* screen_vertices;              /* [B,H*W,3] */
-    float* faces;                        /* [B, 4 (H-1)(W-1), 3, 3] */
-    int32_t* face_index_map;             /* [B,S,S], S = image_size * (anti_aliasing ? 2 : 1) */
-    float *weight_map, *depth_map;       /* [B,S,S,3], [B,S,S] */
+    uint64_t* zbuffer;                   /* [B,S,S], S = image_size * (anti_aliasing ? 2 : 1) */
     float* scratch;                      /* d3m_g2s_scratch_floats() */
-    void* workspace; size_t workspace_bytes;   /* d3m_forward_workspace_bytes(B, 4 (H-1)(W-1), S) */
     /* backward inputs: gradient of recon_im [B,3,s,s] and of the four loss values (device scalars); NULL = zero */
     const float *grad_recon_im, *grad_l1, *grad_l1_flip, *grad_smooth, *grad_total;
-    /* backward scratch; grad_texture and grad_vertices are cleared by d3m_g2s_forward when it is handed them */
+    /* backward scratch; grad_texture must already be handed to d3m_g2s_forward, which clears it */
     float* grad_texture;                 /* [B,3,H,W] */
-    float* grad_vertices;                /* [B,H*W,3] */
+    float* grad_tri;                     /* [B, 2 (H-1)(W-1), 3, 3] */
     float* grad_depth_map;               /* [B,S,S] */
     float* grad_normal;                  /* [B,H,W,3] */
     float* grad_depth_mesh;              /* [B,H,W] */
-    /* backward outputs (WRITTEN; rot / trans / light may be NULL) */
-    float *grad_depth, *grad_albedo, *grad_light_a, *grad_light_b, *grad_light_d, *grad_rot, *grad_trans;
+    /* backward outputs (WRITTEN; any of light / rot / trans / view may be NULL) */
+    float *grad_depth, *grad_albedo, *grad_light_a, *grad_light_b, *grad_light_d, *grad_rot, *grad_trans, *grad_view;
 } d3m_g2s_block;
 size_t d3m_g2s_scratch_floats(int batch_size, int height, int width, int image_size);
 int d3m_g2s_forward(const d3m_g2s_block* block, d3m_stream_t stream);
 int d3m_g2s_backward(const d3m_g2s_block* block, d3m_stream_t stream);
+
+/* NrRenderer's grid_sample frames (renderer_nr.py:180-184, 219-222, 263-267) in one pass:
+ *   grid = ((K (Q / Q.z)).xy / (w-1, h-1)) * 2 - 1,  Q = rot_b (depth * inv_K (x, y, 1) - c) + c + trans_b        (as d3m_grid_warp)
+ *   out [B,C,h,w] = F.grid_sample(src [B,C,H,W], grid, mode='bilinear');  out_nearest [B,Cn,h,w] = F.grid_sample(src_nearest,
+ *   grid, mode='nearest') (src_nearest may be NULL) -- zeros padding, align_corners = False.  depth [B,h,w] is the target
+ *   view's depth (recon_depth), (rot, trans) [B,3,3] / [B,3] the composed rigid motion (the inverse view for the frames).
+ * The adjoint ADDS into grad_src [B,C,H,W] (float atomics; caller zeroes; may be NULL) and WRITES grad_depth [B,h,w] (may be
+ * NULL) and, per workgroup, the partial sums of the gradient of (rot, trans): partials [B, d3m_warp_resample_partials(h, w), 12]
+ * (9 + 3; the caller adds them up). */
+int d3m_warp_resample(const float* depth, const float* inv_K, int inv_K_batch, const float* K, int K_batch, const float* rot,
+                      const float* trans, float rot_center_depth, const float* src, int channels, const float* src_nearest,
+                      int channels_nearest, float* out, float* out_nearest, int batch_size, int height, int width,
+                      int src_height, int src_width, d3m_stream_t stream);
+int d3m_warp_resample_partials(int height, int width);
+int d3m_warp_resample_backward(const float* depth, const float* inv_K, int inv_K_batch, const float* K, int K_batch,
+                               const float* rot, const float* trans, float rot_center_depth, const float* src, int channels,
+                               const float* grad_out, float* grad_src, float* grad_depth, float* partials, int batch_size,
+                               int height, int width, int src_height, int src_width, d3m_stream_t stream);
 
 /* ---- texture assets ----------------------------------------------------------------------------------------- */
 /* Replaces load_textures_cuda (NR/cuda/load_textures_cuda.cpp:6-37, kernel load_textures_cuda_kernel.cu:23-114):

@@ -203,3 +203,44 @@ def test_gan2shape_step_batch16_against_oracle():
     rel_max = lambda a, b_: float((a - b_).abs().max() / b_.abs().max())
     assert rel_max(w1, w0) < 1e-5 and abs(l1 - l0) < 1e-5 * abs(l0)
     assert rel_max(g1, g0) < 1e-3 and rel_max(r1, r0) < 1e-3 and rel_max(t1, t0) < 1e-3
+
+
+def _same_view_on_both_sides(rg, ro):
+    """set_transform_matrices on the HIP renderer from the ORACLE's (R, t) (host trigonometry): the two then move
+    bit-identical vertices, rasterize the same coverage, and images can be held to float noise instead of a fraction of
+    flipped edge pixels"""
+    from oracle import nr_oracle as O
+
+    def set_view(view):
+        rot, trans = O.get_transform_matrices(view.detach().cpu())
+        rg.rot_mat, rg.trans_xyz = rot.cuda(), trans.cuda()
+    rg.set_transform_matrices = set_view
+
+
+def test_grid_sample_frames_values_and_gradients_on_the_hip_resampler():
+    """render_given_view(grid_sample=True) (CR:258-267): warp_canon_depth -> inverse-warped grid -> bilinear / nearest
+    lookups, the last three as ONE HIP pass (d3m_warp_resample) instead of torch's grid_sample: values and the gradients
+    wrt the image and the depth map against the oracle (torch-CPU grid_sample)."""
+    hw, b = 32, 3
+    rg, ro = _pair(hw)
+    _same_view_on_both_sides(rg, ro)
+    depth, im, view = _scene(b, hw, 8)
+    mask = (torch.rand(b, 2, hw, hw, generator=torch.Generator().manual_seed(1)) > 0.3).float()
+    w = torch.randn(b, 3, hw, hw, generator=torch.Generator().manual_seed(2))
+    outs = []
+    for r, dev in ((ro, "cpu"), (rg, "cuda")):
+        d = depth.clone().to(dev).requires_grad_(True)
+        i = im.clone().to(dev).requires_grad_(True)
+        out, out_m = r.render_given_view(i, d, view.to(dev), mask=mask.to(dev), grid_sample=True)
+        (out * w.to(dev)).sum().backward()
+        outs.append((out.detach().cpu(), out_m.detach().cpu(), i.grad.cpu(), d.grad.cpu()))
+    (o0, m0, gi0, gd0), (o1, m1, gi1, gd1) = outs
+    # the sampling position is an f32 image coordinate with a focal length of ~5.7 image widths: ~1e-4 texel of noise
+    assert float((o1 - o0).abs().max()) < 5e-4
+    assert float((m1 != m0).float().mean()) < 2e-3          # 'nearest' flips where that noise crosses a texel boundary
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    assert rel(gi1, gi0) < 1e-3 and rel(gd1, gd0) < 2e-3
+    # no torch grid_sample on the product's path
+    import inspect
+    from deep3dmap_amd.core import renderer_nr
+    assert "functional.grid_sample" not in inspect.getsource(renderer_nr)
