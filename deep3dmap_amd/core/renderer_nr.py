@@ -317,9 +317,19 @@ class NrRenderer():
         """render the depth's grid mesh, moved by `rigid`, textured with each image of `images` (CR:196-198)."""
         b, _, h, w = images[0].shape
         vertices = self._warp(depth, rigid, crop=crop)
-        faces = get_face_idx(b, h, w, depth.device)
-        return [self.renderer.render_rgb(vertices, faces, get_textures_from_im(im, tx_size=self.tex_cube_size))
-                .clamp(min=-1., max=1.) for im in images]
+        r = self.renderer
+        # frames that need no gradient (the usual case: visualisation) are rendered from the image itself: implicit grid
+        # topology, texture cubes evaluated in the sampler -- no get_face_idx / get_textures_from_im arrays
+        direct = (self.tex_cube_size == 2 and r.fill_back and r._on_the_fly() and
+                  not (torch.is_grad_enabled() and (vertices.requires_grad or any(im.requires_grad for im in images))))
+        out = []
+        for im in images:
+            if direct and im.shape[1] == 3:
+                out.append(r.render_rgb_image_grid(vertices, im).clamp(min=-1., max=1.))
+            else:
+                out.append(r.render_rgb(vertices, get_face_idx(b, h, w, depth.device),
+                                        get_textures_from_im(im, tx_size=self.tex_cube_size)).clamp(min=-1., max=1.))
+        return out
 
     def _frame_resample(self, im, depth, view, mask=None):
         """the grid_sample form (CR:180-184): warp the depth to `view`, look every target pixel up in the source image."""

@@ -16,6 +16,10 @@ struct LitTextures {
     const float* textures;   // [Bx, F, ts^3, 3]
     const float* light;      // [Bm, F', 3]
     int F, Fp, ts, tex_batch, light_batch, fill_back;
+    // textures == NULL: the 2x2x2 cubes of a grid mesh's faces are evaluated from an image [B,3,im_H,im_W] where they are
+    // sampled (get_textures_from_im, CR/utils.py:81-107: the products and sums of k_textures_from_im, so the same bits)
+    const float* im;
+    int im_H, im_W;
 };
 
 // texel `isc` of virtual face f' of view b -> offset into `textures`, or -1 when outside the virtual array
@@ -122,12 +126,27 @@ __device__ __forceinline__ void sample_pixel_lit(const float* __restrict__ faces
         // the face's light is loaded once; same products and the same corner order as the general loop below
         const bool back = fi >= lt.F;
         const int fo = back ? fi - lt.F : fi;
-        const float4* cube = (const float4*)(lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24);
         float tex[24];
+        if (lt.im) {
+            const int cells = lt.F >> 1, second = fo >= cells, cell = second ? fo - cells : fo;
+            const int cy = cell / (lt.im_W - 1), cx = cell - cy * (lt.im_W - 1);
+            int v[3];
+            tfi_vertices(second, cy, cx, lt.im_W, v);
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const float4 v = cube[q];
-            tex[4 * q] = v.x; tex[4 * q + 1] = v.y; tex[4 * q + 2] = v.z; tex[4 * q + 3] = v.w;
+            for (int c = 0; c < 3; c++) {
+                const float* ch = lt.im + ((size_t)bn * 3 + c) * lt.im_H * lt.im_W;
+                const float c0 = ch[v[0]], c1 = ch[v[1]], c2 = ch[v[2]];
+#pragma unroll
+                for (int idx = 0; idx < 8; idx++)
+                    tex[idx * 3 + c] = (TFI_CUBE[idx][0] * c0 + TFI_CUBE[idx][1] * c1) + TFI_CUBE[idx][2] * c2;
+            }
+        } else {
+            const float4* cube = (const float4*)(lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24);
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const float4 v = cube[q];
+                tex[4 * q] = v.x; tex[4 * q + 1] = v.y; tex[4 * q + 2] = v.z; tex[4 * q + 3] = v.w;
+            }
         }
         const float* li = lt.light + 3 * ((size_t)(lt.light_batch > 1 ? bn : 0) * lt.Fp + fi);
         const float l0 = li[0], l1 = li[1], l2 = li[2];

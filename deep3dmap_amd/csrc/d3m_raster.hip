@@ -241,12 +241,27 @@ D3M_EXPORT int d3m_visibility(const int32_t* face_index_map, void* visibility, s
     return check_launch();
 }
 
+// Index triples of an entry point: tri [tri_batch,Ft,3] with tri_batch = 1 or B -- or tri == NULL and tri_batch = -W:
+// the implicit topology of a depth map's grid mesh with W vertices per row (d3m_device.h tri_ids), V = H*W vertices
+// and Ft = 2 (H-1)(W-1) triangles.  Returns false when the combination is invalid; grid_w = 0 for explicit indices.
+static bool tri_source_ok(const int32_t* tri, int tri_batch, int B, int num_vertices, int num_tri, int& grid_w) {
+    grid_w = 0;
+    if (tri) return tri_batch == 1 || tri_batch == B;
+    if (tri_batch >= -1) return false;
+    grid_w = -tri_batch;
+    if (num_vertices % grid_w) return false;
+    const int grid_h = num_vertices / grid_w;
+    return grid_h >= 2 && num_tri == 2 * (grid_h - 1) * (grid_w - 1);
+}
+
 static int to_vertex_target(const d3m_vertex_target* h, int num_faces, VertexTarget& vt) {
     vt = VertexTarget{nullptr, nullptr, 0, 0, 1};
     if (!h) return D3M_OK;
-    if (!h->grad_vertices || !h->tri || h->num_vertices <= 0 || h->num_tri <= 0) return D3M_ERR_INVALID;
+    if (!h->grad_vertices || h->num_vertices <= 0 || h->num_tri <= 0) return D3M_ERR_INVALID;
     if ((h->fill_back ? 2 : 1) * h->num_tri != num_faces) return D3M_ERR_INVALID;
-    vt = VertexTarget{h->grad_vertices, h->tri, h->num_vertices, h->num_tri, h->tri_batch};
+    int grid_w;
+    if (!h->tri && !tri_source_ok(nullptr, h->tri_batch, 1, h->num_vertices, h->num_tri, grid_w)) return D3M_ERR_INVALID;
+    vt = VertexTarget{h->grad_vertices, h->tri, h->num_vertices, h->num_tri, h->tri ? h->tri_batch : 1, h->tri ? 0 : -h->tri_batch};
     return D3M_OK;
 }
 
@@ -273,11 +288,12 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
                                                int image_size, float near, float far, void* workspace,
                                                size_t workspace_bytes, void* visibility, size_t visibility_size,
                                                d3m_stream_t stream) {
-    if (!vertices || !tri || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
+    if (!vertices || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
         num_vertices <= 0 || num_tri <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
-    if (tri_batch != 1 && tri_batch != batch_size) return D3M_ERR_INVALID;
-    IndexedFaces ifs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, batch_size};
+    int grid_w;
+    if (!tri_source_ok(tri, tri_batch, batch_size, num_vertices, num_tri, grid_w)) return D3M_ERR_INVALID;
+    IndexedFaces ifs{vertices, tri, num_vertices, num_tri, tri ? tri_batch : 1, fill_back ? 1 : 0, batch_size, grid_w};
     RasterOut out{face_index_map, weight_map, depth_map, face_inv_map, nullptr};
     if (visibility) {       // the first step of d3m_visibility rides along: finish it with d3m_visibility(NULL, ...)
         const long nf = (long)batch_size * ifs.num_faces();
@@ -711,10 +727,12 @@ D3M_EXPORT int d3m_face_light(const float* vertices, int vertices_batch, const i
                               float intensity_ambient, float intensity_directional, const float* color_ambient,
                               const float* color_directional, const float* direction, int light_batch, int num_vertices,
                               int num_tri, int fill_back, d3m_stream_t stream) {
-    if (!vertices || !tri || !light || !color_ambient || !color_directional || !direction || light_batch <= 0 ||
+    if (!vertices || !light || !color_ambient || !color_directional || !direction || light_batch <= 0 ||
         num_vertices <= 0 || num_tri <= 0)
         return D3M_ERR_INVALID;
-    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, vertices_batch};
+    int grid_w;
+    if (!tri_source_ok(tri, tri_batch, tri_batch, num_vertices, num_tri, grid_w)) return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri ? tri_batch : 1, fill_back ? 1 : 0, vertices_batch, grid_w};
     const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
     const long n = (long)light_batch * fs.num_faces();
     LAUNCH("k_face_light", k_face_light, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, lp, light, light_batch);
@@ -726,10 +744,12 @@ D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch
                                        float intensity_directional, const float* color_ambient,
                                        const float* color_directional, const float* direction, int light_batch,
                                        int num_vertices, int num_tri, int fill_back, d3m_stream_t stream) {
-    if (!vertices || !tri || !grad_light || !grad_vertices || !color_ambient || !color_directional || !direction ||
+    if (!vertices || !grad_light || !grad_vertices || !color_ambient || !color_directional || !direction ||
         light_batch <= 0 || num_vertices <= 0 || num_tri <= 0)
         return D3M_ERR_INVALID;
-    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri_batch, fill_back ? 1 : 0, vertices_batch};
+    int grid_w;
+    if (!tri_source_ok(tri, tri_batch, tri_batch, num_vertices, num_tri, grid_w)) return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, tri ? tri_batch : 1, fill_back ? 1 : 0, vertices_batch, grid_w};
     const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
     const long n = (long)light_batch * fs.num_faces();
     LAUNCH("k_face_light_backward", k_face_light_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, fs, lp,
@@ -740,9 +760,19 @@ D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch
 static int make_lit(LitTextures& lt, const float* textures, int textures_batch, const float* light, int light_batch,
                     int num_tri, int texture_size, int fill_back, int B) {
     if (!textures || !light || num_tri <= 0 || texture_size <= 0) return D3M_ERR_INVALID;
-    if ((textures_batch != 1 && textures_batch != B) || (light_batch != 1 && light_batch != B)) return D3M_ERR_INVALID;
+    if (light_batch != 1 && light_batch != B) return D3M_ERR_INVALID;
     lt.textures = textures; lt.light = light; lt.F = num_tri; lt.Fp = fill_back ? 2 * num_tri : num_tri;
     lt.ts = texture_size; lt.tex_batch = textures_batch; lt.light_batch = light_batch; lt.fill_back = fill_back ? 1 : 0;
+    lt.im = nullptr; lt.im_W = lt.im_H = 0;
+    if (textures_batch < -1) {
+        // the textures of a depth map's grid mesh taken from an image [B,3,H,W] on the fly (get_textures_from_im,
+        // deep3dmap/core/renderer/utils.py:97-107, tx_size 2): `textures` is the image, W = -textures_batch
+        const int W = -textures_batch;
+        if (texture_size != 2 || W < 2 || num_tri % (2 * (W - 1))) return D3M_ERR_INVALID;
+        lt.im = textures; lt.textures = nullptr; lt.im_W = W; lt.im_H = num_tri / (2 * (W - 1)) + 1; lt.tex_batch = B;
+        return D3M_OK;
+    }
+    if (textures_batch != 1 && textures_batch != B) return D3M_ERR_INVALID;
     return D3M_OK;
 }
 
@@ -863,6 +893,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     LitTextures lt;
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
     if (rc) return rc;
+    if (lt.im) return D3M_ERR_INVALID;      // image-sourced textures are a forward-only form (the cube array is this pass's output)
     if (!workspace || workspace_bytes < d3m_backward_textures_lit_workspace_bytes(batch_size, num_tri, fill_back, texture_size))
         return D3M_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;

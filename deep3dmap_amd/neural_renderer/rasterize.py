@@ -588,6 +588,50 @@ def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
 
 
+def rasterize_lit_image_grid(screen_vertices, vertices, grid_hw, image, light_cfg, image_size=DEFAULT_IMAGE_SIZE,
+                             anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
+                             background_color=DEFAULT_BACKGROUND_COLOR):
+    """rgb [B,3,s,s] of a depth map's grid mesh textured by an image -- what NrRenderer's view-synthesis frames render
+    (deep3dmap/core/renderer/renderer_nr.py:196-198: get_face_idx + get_textures_from_im(tx_size=2) + render_rgb with
+    fill_back) -- with NEITHER array: the triangles are the implicit topology of the (h, w) grid (`grid_hw`), their texture
+    cubes are evaluated from `image` [B,3,h,w] inside the sampler.  Same pixels as rasterize_lit() on the materialised
+    arrays.  Forward only (visualisation frames): with gradients, the cube array is backward's intermediate anyway and the
+    caller takes the materialised route."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (screen_vertices, vertices, image)):
+        raise RuntimeError("rasterize_lit_image_grid is a forward-only path")
+    L = _lib.lib()
+    sv, vertices, im = f32c(screen_vertices), f32c(vertices), f32c(image)
+    h, w = grid_hw
+    B, V, dev = sv.shape[0], sv.shape[1], sv.device
+    if V != h * w or tuple(im.shape) != (B, 3, h, w) or vertices.shape[1] != V:
+        raise ValueError("vertices must be [B,h*w,3] and the image [B,3,h,w]")
+    Ft = 2 * (h - 1) * (w - 1)
+    Fp = 2 * Ft
+    S = int(image_size) * 2 if anti_aliasing else int(image_size)
+    s_out = int(image_size)
+    ia, idr, ca, cd, direction = light_cfg
+    light = torch.empty(vertices.shape[0], Fp, 3, dtype=torch.float32, device=dev)
+    _lib.check(L.d3m_face_light(_lib.ptr(vertices), vertices.shape[0], None, -w, _lib.ptr(light), float(ia), float(idr),
+                                _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), vertices.shape[0], V, Ft, 1,
+                                _lib.stream_ptr()), "d3m_face_light")
+    faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
+    fim = torch.empty((B, S, S), dtype=torch.int32, device=dev)
+    wm = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+    dm = torch.empty((B, S, S), dtype=torch.float32, device=dev)
+    ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
+    _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), None, -w, V, Ft, 1, _lib.ptr(faces), _lib.ptr(fim), _lib.ptr(wm),
+                                                 _lib.ptr(dm), None, B, S, float(near), float(far), _lib.ptr(ws), ws.numel(),
+                                                 None, 0, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+    background = _background_tensor(background_color, dev)
+    rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+    rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
+    _lib.check(L.d3m_render_lit_epilogue(
+        _lib.ptr(faces), _lib.ptr(im), -w, _lib.ptr(light), light.shape[0], _lib.ptr(fim), _lib.ptr(wm), _lib.ptr(dm),
+        _lib.ptr(background), background.shape[0], _lib.ptr(rgb_map), None, _lib.ptr(rgb), None, None, B, Ft, 1, S, 2,
+        float(eps), int(bool(anti_aliasing)), None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
+    return rgb
+
+
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
                       near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
                       view_groups=1, defer_plan_join=False, images_out=None):

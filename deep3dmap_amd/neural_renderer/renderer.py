@@ -9,8 +9,8 @@ import torch
 import torch.nn as nn
 
 from . import cameras, mesh_ops
-from .rasterize import (rasterize, rasterize_depth, rasterize_lit, rasterize_lit_fit, rasterize_rgbad,
-                        rasterize_silhouettes)
+from .rasterize import (rasterize, rasterize_depth, rasterize_lit, rasterize_lit_fit, rasterize_lit_image_grid,
+                        rasterize_rgbad, rasterize_silhouettes)
 
 
 class Renderer(nn.Module):
@@ -145,6 +145,17 @@ class Renderer(nn.Module):
         textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
                          self.rasterizer_eps, self.background_color)
+
+    def render_rgb_image_grid(self, vertices, image, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        """render_rgb of the grid mesh of a depth map (vertices [B,h*w,3], one per pixel, row-major) textured by `image`
+        [B,3,h,w] with tx_size-2 cubes -- render_rgb(vertices, get_face_idx(b,h,w), get_textures_from_im(image, 2)) of
+        deep3dmap's NrRenderer (renderer_nr.py:196-198) without the index and texture arrays (rasterize_lit_image_grid).
+        Forward only; needs fill_back and one light for the batch."""
+        if not (self._on_the_fly() and self.fill_back):
+            raise ValueError("render_rgb_image_grid needs fill_back and lighting_on_the_fly (one light for the batch)")
+        sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+        return rasterize_lit_image_grid(sv, vertices, tuple(image.shape[2:]), image, self._light_cfg(), self.image_size,
+                                        self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color)
 
     def render_fit_loss(self, vertices, faces, textures, targets, K=None, R=None, t=None, dist_coeffs=None,
                         orig_size=None, images_out=None):

@@ -88,7 +88,11 @@ int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, i
                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                     int image_size, float near, float far, void* workspace, size_t workspace_bytes,
                                     void* visibility, size_t visibility_size, d3m_stream_t stream);
-/* `visibility` (NULL, or a blob of d3m_visibility_bytes(B, num_faces)): the tile pass then also leaves the first step
+/* tri == NULL with tri_batch = -W (here, in d3m_face_light(_backward) and in d3m_vertex_target): the IMPLICIT topology of
+ * a depth map's grid mesh with W vertices per row (deep3dmap/core/renderer/utils.py:74-78: num_vertices = H*W, num_tri =
+ * 2 (H-1)(W-1), cell (y, x) carries (tl, bl, tr) in the first half of the list and (tr, bl, br) in the second) -- NrRenderer's
+ * meshes need no index tensor.
+ * `visibility` (NULL, or a blob of d3m_visibility_bytes(B, num_faces)): the tile pass then also leaves the first step
  * of d3m_visibility -- which faces own a pixel -- in the blob, and d3m_visibility(NULL, blob, ...) finishes it without a
  * pass over face_index_map. */
 
@@ -310,7 +314,10 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
                                      int light_batch, const int32_t* face_index_map, const float* weight_map,
                                      const float* depth_map, float* rgb_map, int batch_size, int num_tri,
                                      int fill_back, int image_size, int texture_size, float eps, d3m_stream_t stream);
-/* d3m_forward_texture_sampling_lit followed by d3m_output_epilogue in one pass, without the intermediate
+/* (forward sampling entry points only) textures_batch = -W, W >= 2: `textures` is an IMAGE [B,3,H,W] and the 2x2x2 cubes of
+ * the grid mesh's faces (num_tri = 2 (H-1)(W-1), texture_size 2) are evaluated from it where they are sampled --
+ * get_textures_from_im (deep3dmap/core/renderer/utils.py:81-107) without its [B,F,2,2,2,3] array; same bits.
+ * d3m_forward_texture_sampling_lit followed by d3m_output_epilogue in one pass, without the intermediate
  * rgb_map: writes the blended internal-resolution rgb_blended [B,S,S,3] (covered ? sampled : background) and
  * alpha_map [B,S,S] (NULL to skip) that the backward pass reads, and the output images rgb_out [B,3,s,s],
  * alpha_out / depth_out [B,s,s] (NULL to skip; s = S/2 when anti_aliasing), flipped as rasterize.py:305-326.

@@ -244,3 +244,26 @@ def test_grid_sample_frames_values_and_gradients_on_the_hip_resampler():
     import inspect
     from deep3dmap_amd.core import renderer_nr
     assert "functional.grid_sample" not in inspect.getsource(renderer_nr)
+
+
+def test_image_grid_frames_equal_the_materialised_arrays_bit_for_bit():
+    """render_rgb_image_grid (implicit topology, texture cubes evaluated from the image in the sampler) against
+    render_rgb(vertices, get_face_idx, get_textures_from_im(im, 2)) -- CR:196-198 -- on the same vertices: same bits."""
+    from deep3dmap_amd.core.renderer_nr import Rigid
+    from deep3dmap_amd.core.renderer_utils import get_face_idx, get_textures_from_im
+    for hw, b in ((24, 2), (33, 3)):
+        rg, _ = _pair(hw)
+        depth, im, view = _scene(b, hw, 12)
+        with torch.no_grad():
+            vertices = rg._warp(depth.cuda(), Rigid.of_view(view.cuda()))
+            direct = rg.renderer.render_rgb_image_grid(vertices, im.cuda())
+            ref = rg.renderer.render_rgb(vertices, get_face_idx(b, hw, hw, "cuda"), get_textures_from_im(im.cuda(), tx_size=2))
+        assert direct.shape == ref.shape == (b, 3, hw, hw)
+        assert torch.equal(direct, ref)
+        assert float((direct - 1.0).abs().max()) > 0.1          # not an all-background image
+    # with gradients wanted the frames take the materialised route and differentiate
+    rg, _ = _pair(16)
+    depth, im, view = _scene(1, 16, 13)
+    i = im.cuda().requires_grad_(True)
+    rg.render_given_view(i, depth.cuda(), view.cuda(), grid_sample=False).sum().backward()
+    assert i.grad is not None and float(i.grad.abs().sum()) > 0
