@@ -85,8 +85,8 @@ _SIGNATURES = {
     "d3m_depth_normals_backward": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P]),
     "d3m_textures_from_im": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "d3m_textures_from_im_backward": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "d3m_uv_unwrap": (_I, [_P] * 11 + [_I] * 7 + [_P]),
-    "d3m_uv_unwrap_backward": (_I, [_P] * 12 + [_I] * 7 + [_P]),
+    "d3m_uv_unwrap": (_I, [_P] * 11 + [_I] * 8 + [_P]),
+    "d3m_uv_unwrap_backward": (_I, [_P] * 12 + [_I] * 8 + [_P]),
     "d3m_face_light": (_I, [_P, _I, _P, _I, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_face_light_backward": (_I, [_P, _I, _P, _I, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "d3m_forward_texture_sampling_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -9,6 +9,7 @@ composition), normals are one pass (d3m_depth_normals), image -> face textures o
 view sweeps of render_yaw / render_view / render_given_view share one frame loop."""
 import ctypes
 import math
+import warnings
 
 import torch
 
@@ -60,8 +61,6 @@ class _GridWarp(torch.autograd.Function):
         _lib.check(_lib.lib().d3m_grid_warp(_lib.ptr(d), _lib.ptr(iK), iK.shape[0], _lib.ptr(A_b), _lib.ptr(t_b),
                                             float(center_z), _lib.ptr(Kc), Kc.shape[0] if Kc is not None else 1, crop_c,
                                             _lib.ptr(out), B, H, W, _lib.stream_ptr()), "d3m_grid_warp")
-        if crop is not None and any(ctx.needs_input_grad[:4]):
-            raise NotImplementedError("crop_mesh is a visualisation option (CR:145-158): no gradient through it")
         ctx.save_for_backward(d, iK, A_b, t_b, Kc)
         ctx.center_z = float(center_z)
         ctx.shapes = (tuple(A.shape), tuple(t.shape))
@@ -246,8 +245,16 @@ class NrRenderer():
     def _warp(self, depth, rigid, project=False, crop=None):
         """depth [b,h,w] -> rigidly moved back-projection: points [b,h*w,3], or (project) the sampling grid [b,h,w,2]."""
         dev = depth.device
-        return _GridWarp.apply(depth, self.inv_K.to(dev), rigid.A.to(dev), rigid.t.to(dev), self.rot_center_depth,
-                               self.K.to(dev) if project else None, crop)
+        A, t = rigid.A.to(dev), rigid.t.to(dev)
+        if crop is not None and torch.is_grad_enabled() and any(x.requires_grad for x in (depth, A, t)):
+            # crop_mesh (CR:145-158) is a visualisation option: the reference's in-place border copies are differentiable,
+            # this pass has no adjoint for them -- the frame is rendered, without a graph, and says so (it does not raise:
+            # visualisation code that forgot torch.no_grad() keeps working)
+            warnings.warn("render_yaw(crop_mesh=...): no gradient flows through a cropped mesh; inputs detached",
+                          RuntimeWarning, stacklevel=3)
+            depth, A, t = depth.detach(), A.detach(), t.detach()
+        return _GridWarp.apply(depth, self.inv_K.to(dev), A, t, self.rot_center_depth, self.K.to(dev) if project else None,
+                               crop)
 
     def _current(self):
         return Rigid(self.rot_mat, self.trans_xyz)

@@ -17,9 +17,15 @@ tests are analytic (tests/test_gpu_pt3d.py).
 3. the mesh template_uvs3d / kept triangles seen by an orthographic camera from (0, 0, 2.7) (NDC x, y = world x, y),
    rasterized hard with both windings (pytorch3d does not cull): d3m_forward_face_index_map on the fill_back faces;
 4. per covered pixel (d3m_uv_unwrap): bilinear lookup of imgs at the barycentric mix of face_project (TexturesUV:
-   align_corners, border padding, v measured upwards), times the diffuse term max(0, n . l) of the light at (0, 0, 10)
-   (ambient and specular are 0), background 0.  The alpha channel is the hard coverage (pytorch3d's softmax blend gives a
-   sigmoid of the distance to the face's edges; the caller reads rgb only, imgs2mesh.py:121-122).
+   align_corners, border padding, v measured upwards), shaded by pytorch3d's Phong model, background 0.  WHICH light:
+   the reference builds PointLights at (0, 0, 10) with ambient 0 / diffuse 1 / specular 0 and matching Materials
+   (renderer_pt3d.py:42-43) but never hands them to SoftPhongShader(device, cameras, blend_params) or to renderer(mesh)
+   (:87-93), so pytorch3d 0.6.1 shades with its DEFAULTS: PointLights at (0, 1, 0), ambient 0.5, diffuse 0.3, specular
+   0.2; Materials 1 / 1 / 1, shininess 64 -- colour = (0.5 + 0.3 relu(n.l)) texel + 0.2 relu(v.r)^64 [n.l > 0], view
+   vector towards the camera at (0, 0, 2.7).  That is what runs, so that is what is reproduced (the class attributes
+   below hold the values; set them to the reference's unused ones for the light its author meant).  The alpha channel is
+   the hard coverage (pytorch3d's softmax blend gives a sigmoid of the distance to the face's edges; the caller reads
+   rgb only, imgs2mesh.py:121-122).
 """
 import ctypes
 
@@ -61,10 +67,10 @@ class _UvUnwrap(torch.autograd.Function):
         B, C, H, W = im.shape
         out_img = torch.empty(B, T, T, 4, dtype=torch.float32, device=im.device)
         out_mask = torch.empty(B, T, T, 4, dtype=torch.float32, device=im.device)
-        lt = (ctypes.c_float * 3)(*light)
+        lt = (ctypes.c_float * 10)(*light)
         _lib.check(_lib.lib().d3m_uv_unwrap(_lib.ptr(fi), _lib.ptr(wm), _lib.ptr(tri), _lib.ptr(verts), _lib.ptr(vnormals),
                                             _lib.ptr(uv), _lib.ptr(im), _lib.ptr(used), lt, _lib.ptr(out_img),
-                                            _lib.ptr(out_mask), B, T, tri.shape[0], verts.shape[0], C, H, W,
+                                            _lib.ptr(out_mask), B, fi.shape[0], T, tri.shape[0], verts.shape[0], C, H, W,
                                             _lib.stream_ptr()), "d3m_uv_unwrap")
         ctx.save_for_backward(im, uv, fi, wm, tri, verts, vnormals, used)
         ctx.light, ctx.T = tuple(light), T
@@ -77,41 +83,51 @@ class _UvUnwrap(torch.autograd.Function):
         B, C, H, W = im.shape
         g_im = torch.zeros_like(im) if ctx.needs_input_grad[0] else None
         g_uv = torch.zeros_like(uv) if ctx.needs_input_grad[1] else None
-        lt = (ctypes.c_float * 3)(*ctx.light)
+        lt = (ctypes.c_float * 10)(*ctx.light)
         _lib.check(_lib.lib().d3m_uv_unwrap_backward(
             _lib.ptr(fi), _lib.ptr(wm), _lib.ptr(tri), _lib.ptr(verts), _lib.ptr(vnormals), _lib.ptr(uv), _lib.ptr(im),
-            _lib.ptr(used), lt, _lib.ptr(f32c(g_img)), _lib.ptr(g_im), _lib.ptr(g_uv), B, ctx.T, tri.shape[0],
+            _lib.ptr(used), lt, _lib.ptr(f32c(g_img)), _lib.ptr(g_im), _lib.ptr(g_uv), B, fi.shape[0], ctx.T, tri.shape[0],
             verts.shape[0], C, H, W, _lib.stream_ptr()), "d3m_uv_unwrap_backward")
         return (g_im, g_uv) + (None,) * 8
 
 
 class Pt3dRenderer():
     CAMERA_DISTANCE = 2.7                    # look_at_view_transform(2.7, 0, 0), renderer_pt3d.py:78
-    LIGHT_LOCATION = (0.0, 0.0, 10.0)        # PointLights(location=[[0, 0, 10]]), renderer_pt3d.py:42
+    # what SoftPhongShader falls back to when it is given no lights / materials (pytorch3d 0.6.1 PointLights / Materials
+    # defaults; the reference's own PointLights((0,0,10), 0/1/0) and Materials are constructed but never used)
+    LIGHT_LOCATION = (0.0, 1.0, 0.0)
+    LIGHT_AMBIENT, LIGHT_DIFFUSE, LIGHT_SPECULAR, SHININESS = 0.5, 0.3, 0.2, 64.0
 
     def __init__(self, device, texture_size, lookview):
         self.device = device
         self.texture_size = texture_size
         self.lookview = lookview.view(1, 3).to(torch.float32)
-        self._coverage = {}                  # the UV layout is a constant of the model: its raster is computed once
+        self._coverage = None                # the UV layout is a constant of the model: its raster is computed once
+
+    def _light(self):
+        """d3m_uv_unwrap's light block: location, camera centre, ambient, diffuse, specular, shininess"""
+        return tuple(self.LIGHT_LOCATION) + (0.0, 0.0, self.CAMERA_DISTANCE, self.LIGHT_AMBIENT, self.LIGHT_DIFFUSE,
+                                             self.LIGHT_SPECULAR, self.SHININESS)
 
     def _uv_coverage(self, template_uvs3d, triangles):
         """face_index_map / weight_map [1,T,T(,3)] of the template in UV space (orthographic: NDC xy = world xy,
-        depth = camera distance - z), both windings; cached per (vertices, triangles) storage."""
-        key = (template_uvs3d.data_ptr(), triangles.data_ptr(), template_uvs3d._version, triangles._version)
-        hit = self._coverage.get(key)
-        if hit is None:
-            T = self.texture_size
-            v = f32c(template_uvs3d)
-            screen = torch.stack((v[:, 0], v[:, 1], self.CAMERA_DISTANCE - v[:, 2]), 1)[None]
-            faces = gather_faces(screen, triangles.to(torch.int32)[None], True)
-            fi = torch.empty(1, T, T, dtype=torch.int32, device=v.device)
-            wm = torch.empty(1, T, T, 3, dtype=torch.float32, device=v.device)
-            dm = torch.empty(1, T, T, dtype=torch.float32, device=v.device)
-            dummy = torch.zeros(1, dtype=torch.float32, device=v.device)
-            ops.forward_face_index_map(faces, fi, wm, dm, dummy, dummy, T, 1e-4, 100.0, False, True, False)
-            hit = (fi, wm, vertex_normals(v, triangles))
-            self._coverage = {key: hit}
+        depth = camera distance - z), both windings; cached while the SAME tensors (kept alive here, compared by identity
+        and version) are passed again."""
+        c = self._coverage
+        if (c is not None and c[0] is template_uvs3d and c[1] is triangles and
+                c[2] == (template_uvs3d._version, triangles._version)):
+            return c[3]
+        T = self.texture_size
+        v = f32c(template_uvs3d)
+        screen = torch.stack((v[:, 0], v[:, 1], self.CAMERA_DISTANCE - v[:, 2]), 1)[None]
+        faces = gather_faces(screen, triangles.to(torch.int32)[None], True)
+        fi = torch.empty(1, T, T, dtype=torch.int32, device=v.device)
+        wm = torch.empty(1, T, T, 3, dtype=torch.float32, device=v.device)
+        dm = torch.empty(1, T, T, dtype=torch.float32, device=v.device)
+        dummy = torch.zeros(1, dtype=torch.float32, device=v.device)
+        ops.forward_face_index_map(faces, fi, wm, dm, dummy, dummy, T, 1e-4, 100.0, False, True, False)
+        hit = (fi, wm, vertex_normals(v, triangles))
+        self._coverage = (template_uvs3d, triangles, (template_uvs3d._version, triangles._version), hit)
         return hit
 
     def sample(self, normals, angles, triangles, imgs, template_uvs3d, face_project):
@@ -125,11 +141,9 @@ class Pt3dRenderer():
         used = invisible.any(dim=1).to(torch.int32)
         # 3. coverage of the UV layout, shared by the batch
         fi, wm, vnormals = self._uv_coverage(template_uvs3d, triangles)
-        fi_b = fi.expand(batchsize, T, T).contiguous()
-        wm_b = wm.expand(batchsize, T, T, 3).contiguous()
-        # 4. texture lookup + diffuse shading
-        return _UvUnwrap.apply(imgs, face_project, fi_b, wm_b, triangles.to(torch.int32).contiguous(), f32c(template_uvs3d),
-                               vnormals, used, self.LIGHT_LOCATION, T)
+        # 4. texture lookup + Phong shading (the one coverage map is shared by the batch)
+        return _UvUnwrap.apply(imgs, face_project, fi, wm, triangles.to(torch.int32).contiguous(), f32c(template_uvs3d),
+                               vnormals, used, self._light(), T)
 
     # ---- BASELINE.json config 1 ("pt3d_demos: icosphere, 2 views @64x64, silhouette fit"): demo plumbing ------------
     def silhouettes(self, vertices, faces, azimuths, elevation=0.0, image_size=None):

@@ -684,22 +684,24 @@ D3M_EXPORT int d3m_textures_from_im_backward(const float* grad_textures, float* 
 // ---- Pt3dRenderer.sample's per-pixel pass (d3m_uv.h) ------------------------------------------------------------------
 static int to_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
                         const float* vnormals, const float* uvs, const float* imgs, const int32_t* used, const float* light,
-                        int B, int T, int F, int V, int C, int H, int W, UvUnwrap& a) {
+                        int B, int cov_B, int T, int F, int V, int C, int H, int W, UvUnwrap& a) {
     if (!face_index_map || !weight_map || !tri || !verts || !vnormals || !uvs || !imgs || !used || !light || B <= 0 ||
-        T <= 0 || F <= 0 || V <= 0 || C <= 0 || C > 3 || H <= 0 || W <= 0)
+        T <= 0 || F <= 0 || V <= 0 || C <= 0 || C > 3 || H <= 0 || W <= 0 || (cov_B != 1 && cov_B != B))
         return D3M_ERR_INVALID;
+    // light: location (3), camera centre (3), ambient, diffuse, specular, shininess
     a = UvUnwrap{face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, {light[0], light[1], light[2]},
-                 B, T, F, V, C, H, W};
+                 {light[3], light[4], light[5]}, light[6], light[7], light[8], light[9], B, T, F, V, C, H, W, cov_B};
     return D3M_OK;
 }
 
 D3M_EXPORT int d3m_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
                              const float* vnormals, const float* uvs, const float* imgs, const int32_t* used,
-                             const float* light, float* out_img, float* out_mask, int batch_size, int texture_size,
-                             int num_tri, int num_vertices, int channels, int height, int width, d3m_stream_t stream) {
+                             const float* light, float* out_img, float* out_mask, int batch_size, int coverage_batch,
+                             int texture_size, int num_tri, int num_vertices, int channels, int height, int width,
+                             d3m_stream_t stream) {
     UvUnwrap a;
     if (int rc = to_uv_unwrap(face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, light, batch_size,
-                              texture_size, num_tri, num_vertices, channels, height, width, a))
+                              coverage_batch, texture_size, num_tri, num_vertices, channels, height, width, a))
         return rc;
     if (!out_img || !out_mask) return D3M_ERR_INVALID;
     LAUNCH("k_uv_unwrap", k_uv_unwrap, dim3(blocks_for((long)batch_size * texture_size * texture_size, 256)), dim3(256),
@@ -710,11 +712,11 @@ D3M_EXPORT int d3m_uv_unwrap(const int32_t* face_index_map, const float* weight_
 D3M_EXPORT int d3m_uv_unwrap_backward(const int32_t* face_index_map, const float* weight_map, const int32_t* tri,
                                       const float* verts, const float* vnormals, const float* uvs, const float* imgs,
                                       const int32_t* used, const float* light, const float* grad_img, float* grad_imgs,
-                                      float* grad_uvs, int batch_size, int texture_size, int num_tri, int num_vertices,
-                                      int channels, int height, int width, d3m_stream_t stream) {
+                                      float* grad_uvs, int batch_size, int coverage_batch, int texture_size, int num_tri,
+                                      int num_vertices, int channels, int height, int width, d3m_stream_t stream) {
     UvUnwrap a;
     if (int rc = to_uv_unwrap(face_index_map, weight_map, tri, verts, vnormals, uvs, imgs, used, light, batch_size,
-                              texture_size, num_tri, num_vertices, channels, height, width, a))
+                              coverage_batch, texture_size, num_tri, num_vertices, channels, height, width, a))
         return rc;
     if (!grad_img) return D3M_ERR_INVALID;
     LAUNCH("k_uv_unwrap_backward", k_uv_unwrap_backward, dim3(blocks_for((long)batch_size * texture_size * texture_size, 256)),
@@ -794,7 +796,11 @@ D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float*
 
 D3M_EXPORT size_t d3m_render_fit_scratch_floats(int batch_size, int image_size) {
     if (batch_size <= 0 || image_size <= 0) return 0;
-    return 8 + 4 * (size_t)blocks_for((long)batch_size * image_size * image_size, 256);      // totals | partials
+    // totals | partials: one float4 per 256-pixel workgroup of the plain epilogue, or per 32x32 tile and view of the
+    // records form (k_render_lit_fit_records) -- more of them than pixels / 256 when the image is smaller than a tile
+    const size_t per_pixels = blocks_for((long)batch_size * image_size * image_size, 256);
+    const size_t tiles = (size_t)batch_size * ((image_size + 31) / 32) * ((image_size + 31) / 32);
+    return 8 + 4 * (per_pixels > tiles ? per_pixels : tiles);
 }
 
 static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {

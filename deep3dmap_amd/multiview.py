@@ -78,7 +78,6 @@ class MultiViewFit:
                                     fill_back=True)
         self.renderer.eye = self.eyes
         self.renderer.view_groups = view_groups     # concurrent pipelines over this rank's views (rasterize.py)
-        self.renderer.defer_plan_join = True        # _forward_backward below runs backward right behind forward
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
         self.keep_images = False        # True: the fused objective's pass also writes this step's images to self.images
@@ -136,8 +135,15 @@ class MultiViewFit:
     def _forward_backward(self):
         self.vertices.grad = None
         self.textures.grad = None
-        loss = self.fit_loss()
-        loss.backward()
+        # backward runs right behind forward, on the same stream and inside the same capture: only HERE may the forward
+        # leave its side branch (visibility list, edge plan, the loss's last reduction step) open for backward to join.
+        # A bare fit_loss() (logging, evaluation) joins everything before it returns.
+        self.renderer.defer_plan_join = True
+        try:
+            loss = self.fit_loss()
+            loss.backward()
+        finally:
+            self.renderer.defer_plan_join = False
         # pack [loss | grad_v | grad_t] into the persistent buffer the collective runs on (part of the captured step)
         parts = [loss.detach().reshape(1), self.vertices.grad.reshape(-1)]
         if self.textures.requires_grad:

@@ -277,21 +277,25 @@ int d3m_textures_from_im_backward(const float* grad_textures, float* grad_im, in
 
 /* Pt3dRenderer.sample's per-pixel pass (deep3dmap/core/renderer/renderer_pt3d.py:75-97; the reference runs it through
  * pytorch3d 0.6.1's TexturesUV + SoftPhongShader): for the template mesh rasterized in UV space -- face_index_map /
- * weight_map [B,T,T(,3)] of d3m_forward_face_index_map on its fill_back faces -- every covered pixel samples
+ * weight_map [coverage_batch = 1|B, T,T(,3)] of d3m_forward_face_index_map on its fill_back faces -- every covered pixel samples
  * imgs [B,C<=3,H,W] bilinearly (align_corners, border padding, v up) at the barycentric mix of its face's per-vertex
- * image coordinates uvs [B,V,2] and multiplies by the diffuse term of a point light at `light` against the interpolated
- * vertex normals vnormals [V,3] at the interpolated position verts [V,3].  out_img / out_mask [B,T,T,4] (row 0 = top):
- * rgb = texel * diffuse / diffuse, alpha = coverage; zeros where nothing covers or used[b] == 0.
+ * image coordinates uvs [B,V,2] and shades it with pytorch3d's Phong model against the interpolated vertex normals
+ * vnormals [V,3] at the interpolated position verts [V,3]:
+ *     colour = (ambient + diffuse * relu(n.l)) * texel + specular * relu(v.r)^shininess [n.l > 0]
+ * `light` = HOST array of 10 floats: light location (3), camera centre (3), ambient, diffuse, specular, shininess (the
+ * products light colour x material colour; the reference's shader is built without lights / materials, so pytorch3d's
+ * defaults apply: (0,1,0), (0,0,2.7), 0.5, 0.3, 0.2, 64).  out_img / out_mask [B,T,T,4] (row 0 = top): rgb = the colour
+ * above / the same with texel = 1, alpha = coverage; zeros where nothing covers or used[b] == 0.
  * The adjoint ADDS into grad_imgs [B,C,H,W] and grad_uvs [B,V,2] (either may be NULL; caller zeroes). */
 int d3m_uv_unwrap(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
                   const float* vnormals, const float* uvs, const float* imgs, const int32_t* used, const float* light,
-                  float* out_img, float* out_mask, int batch_size, int texture_size, int num_tri, int num_vertices,
-                  int channels, int height, int width, d3m_stream_t stream);
+                  float* out_img, float* out_mask, int batch_size, int coverage_batch, int texture_size, int num_tri,
+                  int num_vertices, int channels, int height, int width, d3m_stream_t stream);
 int d3m_uv_unwrap_backward(const int32_t* face_index_map, const float* weight_map, const int32_t* tri, const float* verts,
                            const float* vnormals, const float* uvs, const float* imgs, const int32_t* used,
                            const float* light, const float* grad_img, float* grad_imgs, float* grad_uvs, int batch_size,
-                           int texture_size, int num_tri, int num_vertices, int channels, int height, int width,
-                           d3m_stream_t stream);
+                           int coverage_batch, int texture_size, int num_tri, int num_vertices, int channels, int height,
+                           int width, d3m_stream_t stream);
 
 /* --- lighting and fill_back applied on the fly (instead of renderer.py:155-167,203-215 materialising
  * cat(textures, textures.permute(0,1,4,3,2,5)) * light per view) ---------------------------------------

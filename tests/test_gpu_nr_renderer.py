@@ -173,10 +173,14 @@ def test_render_yaw_and_render_view():
 
 
 def test_crop_mesh_has_no_gradient_and_says_so():
-    rg, _ = _pair(16)
+    """render_yaw(crop_mesh=...) with grad-enabled inputs renders (as the reference does) and warns that the cropped mesh
+    carries no gradient -- it does not raise"""
+    rg, ro = _pair(16)
     depth, im, _ = _scene(1, 16, 5)
-    with pytest.raises(NotImplementedError):
-        rg.render_yaw(im.cuda(), depth.cuda().requires_grad_(True), nsample=1, crop_mesh=(1, 1, 1, 1))
+    with pytest.warns(RuntimeWarning, match="crop_mesh"):
+        out = rg.render_yaw(im.cuda(), depth.cuda().requires_grad_(True), nsample=1, crop_mesh=(1, 1, 1, 1))
+    assert out.shape == (1, 1, 3, 16, 16) and not out.requires_grad
+    _images_close(out, ro.render_yaw(im, depth, nsample=1, crop_mesh=(1, 1, 1, 1)))
 
 
 def test_gan2shape_step_batch16_against_oracle():
