@@ -343,6 +343,8 @@ def main():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the second timed pass (the same step through Renderer.render + multiview_fit_loss)")
     ap.add_argument("--materialise-images", action="store_true",
                     help="render() the output images and evaluate the objective on them (multiview_fit_loss) instead of "
                          "inside the rendering node")
@@ -444,6 +446,37 @@ def main():
     ktimes = _lib.collect_kernel_times()
     _lib.kernel_timing(False)
 
+    # The same step through the reference's own surface (not part of `value`): Renderer.render() materialises the output
+    # images, multiview_fit_loss is evaluated on them, their gradients come back through the epilogue's adjoint.
+    dropin = None
+    if not args.materialise_images and not args.no_dropin:
+        fit2 = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
+                            world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=False,
+                            view_groups=args.view_groups)
+        fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
+        loss2, gv2, _ = fit2.step()
+        rel2 = float(torch.linalg.norm(gv2 - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
+        assert rel2 < 1e-3 and abs(float(loss2) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)), (rel2, loss2, loss_eager)
+        if graph_on:
+            fit2.capture_graph()
+        for _ in range(args.warmup):
+            fit2.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fit2.step()
+        barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el2], device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el2 = float(tmax.item())
+        fit2.release_graph()
+        dropin = {"api": "Renderer.render + multiview_fit_loss + backward",
+                  "value": round(n_views * args.image_size ** 2 / (el2 / args.steps) / 1e6, 2), "unit": "Mpix/s",
+                  "ms_per_step": round(el2 / args.steps * 1e3, 4)}
+        del fit2
+
     if rank == 0:
         V, F, S, ts = v.shape[0], tri.shape[0], args.image_size, args.texture_size
         ms_per_step = elapsed / args.steps * 1e3
@@ -495,6 +528,7 @@ def main():
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "roofline": roof,
+            "dropin": dropin,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mesh_n, S, ts)
