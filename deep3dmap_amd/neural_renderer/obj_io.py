@@ -1,10 +1,14 @@
-"""Wavefront OBJ I/O, texture assets and the `Mesh` holder of the neural_renderer package surface
-(NR/load_obj.py:13-164, NR/save_obj.py:10-82, NR/mesh.py:6-43).
+"""Wavefront OBJ / MTL assets of the neural_renderer package surface: `load_obj`, `save_obj`, `load_textures`,
+`create_texture_image`, `Mesh` (the on-disk formats and call signatures of NR/load_obj.py, NR/save_obj.py, NR/mesh.py).
 
-The two texture kernels (uv image -> per-face texture cubes, texture cubes -> atlas image) run in the HIP library
-(`d3m_load_textures`, `d3m_create_texture_image`); text parsing and the PNG/JPEG codec (Pillow, where the reference
-used scikit-image) stay on the host, as in the reference."""
+Organisation (not the reference's): an .obj file is tokenised ONCE into a `_ObjScene` (positions, texture coordinates,
+triangle corners as (position, texcoord) index pairs, one material id per triangle) that every loader reads; an .mtl
+file into one record per material.  Writers format whole arrays (numpy) instead of looping over rows.  The two texture
+kernels -- uv image -> per-face texture cubes, texture cubes -> atlas image -- are entry points of the HIP library
+(`d3m_load_textures`, `d3m_create_texture_image`); the atlas's corner table is built on the device.  The image codec is
+Pillow (the reference used scikit-image)."""
 import os
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -13,21 +17,92 @@ import torch.nn as nn
 from .. import _lib
 
 texture_wrapping_dict = {'REPEAT': 0, 'MIRRORED_REPEAT': 1, 'CLAMP_TO_EDGE': 2, 'CLAMP_TO_BORDER': 3}
+ATLAS_EPS = 1e-5            # the reference's create_texture_image eps
 
 
-def _imread(path):
+# ---- files --------------------------------------------------------------------------------------------------------
+def _read_image(path):
+    """[H,W,3] float32 in 0..1, row 0 = BOTTOM of the picture (texture space), alpha dropped, grey replicated."""
     from PIL import Image
     with Image.open(path) as im:
-        if im.mode not in ('L', 'RGB', 'RGBA'):
-            im = im.convert('RGBA' if 'A' in im.getbands() else 'RGB')
-        return np.asarray(im)
+        rgb = np.asarray(im.convert('RGB'), dtype=np.float32) / 255.0
+    return np.ascontiguousarray(rgb[::-1])
 
 
-def _imsave(path, image):
+def _write_image(path, image):
     from PIL import Image
     if image.dtype != np.uint8:
         image = np.clip(np.rint(np.nan_to_num(image) * 255.0), 0, 255).astype(np.uint8)
     Image.fromarray(image).save(path)
+
+
+class _ObjScene:
+    """One pass over an .obj file.  positions [V,3] f32, texcoords [T,2] f32, tri_pos / tri_tex [F,3] zero-based int32
+    (tri_tex is -1 where a corner has no texture coordinate), tri_material [F] index into `materials` (-1: none),
+    mtllib: the file named by the last `mtllib` statement."""
+
+    def __init__(self, path):
+        pos, tex, corners_p, corners_t, tri_mat = [], [], [], [], []
+        self.materials, self.mtllib = [], None
+        current = -1
+        with open(path) as fh:
+            for line in fh:
+                key, _, rest = line.strip().partition(' ')
+                if key == 'v':
+                    pos.append(rest.split()[:3])
+                elif key == 'vt':
+                    tex.append(rest.split()[:2])
+                elif key == 'f':
+                    p, t = self._corners(rest.split())
+                    for k in range(1, len(p) - 1):                     # a polygon as a fan around its first corner
+                        corners_p.append((p[0], p[k], p[k + 1]))
+                        corners_t.append((t[0], t[k], t[k + 1]))
+                        tri_mat.append(current)
+                elif key == 'usemtl':
+                    name = rest.split()[0]
+                    if name not in self.materials:
+                        self.materials.append(name)
+                    current = self.materials.index(name)
+                elif key == 'mtllib':
+                    self.mtllib = rest.split()[0]
+        self.positions = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
+        self.texcoords = np.asarray(tex, dtype=np.float32).reshape(-1, 2)
+        self.tri_pos = np.asarray(corners_p, dtype=np.int32).reshape(-1, 3) - 1
+        self.tri_tex = np.asarray(corners_t, dtype=np.int32).reshape(-1, 3) - 1
+        self.tri_material = np.asarray(tri_mat, dtype=np.int32)
+
+    @staticmethod
+    def _corners(tokens):
+        """'7', '7/3', '7/3/2', '7//2' -> position indices, texcoord indices (0 where absent), one-based as in the file"""
+        p, t = [], []
+        for tok in tokens:
+            fields = tok.split('/')
+            p.append(int(fields[0]))
+            t.append(int(fields[1]) if len(fields) > 1 and fields[1] else 0)
+        return p, t
+
+
+def _read_materials(path):
+    """.mtl -> OrderedDict name -> {'Kd': [3] float array or None, 'map_Kd': file name or None}"""
+    mats, cur = OrderedDict(), None
+    with open(path) as fh:
+        for line in fh:
+            key, _, rest = line.strip().partition(' ')
+            if key == 'newmtl':
+                cur = mats.setdefault(rest.split()[0], {'Kd': None, 'map_Kd': None})
+            elif cur is not None and key == 'Kd':
+                cur['Kd'] = np.asarray(rest.split()[:3], dtype=np.float64)
+            elif cur is not None and key == 'map_Kd':
+                cur['map_Kd'] = rest.split()[0]
+    return mats
+
+
+def load_mtl(filename_mtl):
+    """(colors {material: Kd [3]}, texture_filenames {material: map_Kd file}) of an .mtl file -- the pair NR/load_obj.py's
+    helper of the same name returns."""
+    mats = _read_materials(filename_mtl)
+    return ({k: m['Kd'] for k, m in mats.items() if m['Kd'] is not None},
+            {k: m['map_Kd'] for k, m in mats.items() if m['map_Kd'] is not None})
 
 
 def _device():
@@ -36,236 +111,163 @@ def _device():
     return torch.device("cuda")
 
 
-def load_mtl(filename_mtl):
-    '''
-    load color (Kd) and filename of textures from *.mtl  (NR/load_obj.py:13-30)
-    '''
-    texture_filenames = {}
-    colors = {}
-    material_name = ''
-    with open(filename_mtl) as f:
-        for line in f:
-            parts = line.split()
-            if not parts:
-                continue
-            if parts[0] == 'newmtl':
-                material_name = parts[1]
-            if parts[0] == 'map_Kd':
-                texture_filenames[material_name] = parts[1]
-            if parts[0] == 'Kd':
-                colors[material_name] = np.array(list(map(float, parts[1:4])))
-    return colors, texture_filenames
-
-
+# ---- uv image -> texture cubes ------------------------------------------------------------------------------------
 def load_textures_from_image(image, faces, textures, is_update, texture_wrapping=0, use_bilinear=True):
-    """The reference's `load_textures_cuda.load_textures` (NR/cuda/load_textures_cuda.cpp:19-37): image [H,W,3],
+    """The reference extension's `load_textures_cuda.load_textures` (NR/cuda/load_textures_cuda.cpp:19-37): image [H,W,3],
     faces [F,3,2] uv corners, textures [F,ts,ts,ts,3] (updated in place and returned), is_update [F] int32."""
     _lib.require_device(image, faces, textures, is_update, names=("image", "faces", "textures", "is_update"))
-    if image.dtype != torch.float32 or faces.dtype != torch.float32 or textures.dtype != torch.float32:
+    if any(t.dtype != torch.float32 for t in (image, faces, textures)):
         raise TypeError("image, faces and textures must be float32")
     if is_update.dtype != torch.int32:
         raise TypeError("is_update must be int32")
+    F = faces.shape[0]
     if image.dim() != 3 or image.shape[2] != 3:
         raise ValueError("image must be [H, W, 3]")
     if faces.dim() != 3 or tuple(faces.shape[1:]) != (3, 2):
         raise ValueError("faces must be [num_faces, 3, 2]")
-    if textures.dim() != 5 or textures.shape[0] != faces.shape[0] or is_update.shape[0] != faces.shape[0]:
+    if textures.dim() != 5 or textures.shape[0] != F or is_update.shape[0] != F:
         raise ValueError("textures must be [num_faces, ts, ts, ts, 3] and is_update [num_faces]")
     _lib.check(_lib.lib().d3m_load_textures(
-        _lib.ptr(image), _lib.ptr(is_update), _lib.ptr(faces), _lib.ptr(textures), faces.shape[0], textures.shape[1],
-        image.shape[0], image.shape[1], int(texture_wrapping), int(bool(use_bilinear)), _lib.stream_ptr()),
-        "d3m_load_textures")
+        _lib.ptr(image), _lib.ptr(is_update), _lib.ptr(faces), _lib.ptr(textures), F, textures.shape[1], image.shape[0],
+        image.shape[1], int(texture_wrapping), int(bool(use_bilinear)), _lib.stream_ptr()), "d3m_load_textures")
+    return textures
+
+
+def _textures_of_scene(scene, obj_dir, filename_mtl, texture_size, texture_wrapping, use_bilinear):
+    dev = _device()
+    F = scene.tri_tex.shape[0]
+    # a corner without a texture coordinate indexes "vt 0" in the reference (one-based 0 -> -1 -> the LAST coordinate)
+    face_uv = torch.from_numpy(scene.texcoords[scene.tri_tex]).to(dev)                   # [F,3,2]
+    textures = torch.full((F, texture_size, texture_size, texture_size, 3), 0.5, dtype=torch.float32, device=dev)
+    mats = _read_materials(filename_mtl)
+    names = np.asarray(scene.materials, dtype=object)
+    of_tri = np.where(scene.tri_material >= 0, scene.tri_material, len(scene.materials))
+    tri_name = np.append(names, '')[of_tri] if F else np.zeros(0, dtype=object)         # '' before any usemtl
+    for name, m in mats.items():                          # constant colours first ...
+        if m['Kd'] is not None:
+            sel = torch.from_numpy(tri_name == name).to(dev)
+            textures[sel] = torch.as_tensor(m['Kd'], dtype=torch.float32, device=dev)
+    for name, m in mats.items():                          # ... then every image over the faces of its material
+        if m['map_Kd'] is not None:
+            image = torch.from_numpy(_read_image(os.path.join(obj_dir, m['map_Kd']))).to(dev)
+            update = torch.from_numpy((tri_name == name).astype(np.int32)).to(dev)
+            load_textures_from_image(image, face_uv, textures, update, texture_wrapping_dict[texture_wrapping], use_bilinear)
     return textures
 
 
 def load_textures(filename_obj, filename_mtl, texture_size, texture_wrapping='REPEAT', use_bilinear=True):
-    """Per-face texture cubes [F, ts, ts, ts, 3] of an .obj with `vt` coordinates and an .mtl
-    (NR/load_obj.py:33-98): Kd colours first, then every map_Kd image sampled onto the faces of its material."""
-    with open(filename_obj) as f:
-        lines = f.readlines()
-    vertices = []
-    for line in lines:
-        parts = line.split()
-        if parts and parts[0] == 'vt':
-            vertices.append([float(v) for v in parts[1:3]])
-    vertices = np.vstack(vertices).astype(np.float32)
+    """Per-face texture cubes [F, ts, ts, ts, 3] of an .obj with `vt` coordinates and an .mtl: 0.5 grey, Kd colours per
+    material, then every map_Kd image sampled onto the faces of its material (what NR/load_obj.py:33-98 produces)."""
+    return _textures_of_scene(_ObjScene(filename_obj), os.path.dirname(filename_obj), filename_mtl, texture_size,
+                              texture_wrapping, use_bilinear)
 
-    def vt_index(token):
-        return int(token.split('/')[1]) if ('/' in token and '//' not in token) else 0
 
-    faces, material_names, material_name = [], [], ''
-    for line in lines:
-        parts = line.split()
-        if not parts:
-            continue
-        if parts[0] == 'f':
-            vs = parts[1:]
-            for i in range(len(vs) - 2):
-                faces.append((vt_index(vs[0]), vt_index(vs[i + 1]), vt_index(vs[i + 2])))
-                material_names.append(material_name)
-        if parts[0] == 'usemtl':
-            material_name = parts[1]
-    dev = _device()
-    faces = np.vstack(faces).astype(np.int32) - 1
-    faces = torch.from_numpy(vertices[faces]).to(dev)
-
-    colors, texture_filenames = load_mtl(filename_mtl)
-    textures = torch.full((faces.shape[0], texture_size, texture_size, texture_size, 3), 0.5, dtype=torch.float32,
-                          device=dev)
-    material_names = np.array(material_names)
-    for material_name, color in colors.items():
-        sel = torch.from_numpy(material_names == material_name).to(dev)
-        textures[sel] = torch.from_numpy(color.astype(np.float32)).to(dev)
-
-    for material_name, filename_texture in texture_filenames.items():
-        filename_texture = os.path.join(os.path.dirname(filename_obj), filename_texture)
-        image = _imread(filename_texture).astype(np.float32) / 255.
-        if image.ndim == 2:                                   # grey image
-            image = np.stack((image,) * 3, -1)
-        if image.shape[2] == 4:                               # alpha ignored
-            image = image[:, :, :3]
-        image = torch.from_numpy(image[::-1, :, :].copy()).to(dev)
-        is_update = torch.from_numpy((material_names == material_name).astype(np.int32)).to(dev)
-        textures = load_textures_from_image(image, faces, textures, is_update,
-                                            texture_wrapping_dict[texture_wrapping], use_bilinear)
-    return textures
+def _fit_unit_cube(vertices):
+    """shift the bounding box's corner to the origin, scale the longest side to 2, centre (load_obj.py:155-159)"""
+    shifted = vertices - vertices.amin(0, keepdim=True)
+    scaled = shifted * (2.0 / shifted.abs().max())
+    return scaled - scaled.amax(0, keepdim=True) / 2
 
 
 def load_obj(filename_obj, normalization=True, texture_size=4, load_texture=False, texture_wrapping='REPEAT',
              use_bilinear=True):
     """
-    Load a Wavefront .obj file: vertices (`v x y z`) and faces (`f a b c ...`, polygons are fanned into
-    triangles, `a/b/c` index triplets use the vertex index).  Returns (vertices [V,3] f32, faces [F,3] i32)
-    on the GPU; `normalization` rescales into the cube [-1, 1]^3 the way load_obj.py:155-159 does.
+    Load a Wavefront .obj file: vertices (`v x y z`) and faces (`f a b c ...`, polygons are fanned into triangles,
+    `a/b/c` corners use the position index).  Returns (vertices [V,3] f32, faces [F,3] i32) on the GPU and, with
+    `load_texture`, the per-face texture cubes [F,ts,ts,ts,3] of its `mtllib`; `normalization` rescales the vertices
+    into the cube [-1, 1]^3.
     """
-    vertices, faces = [], []
-    with open(filename_obj) as f:
-        lines = f.readlines()
-    for line in lines:
-        parts = line.split()
-        if not parts:
-            continue
-        if parts[0] == 'v':
-            vertices.append([float(v) for v in parts[1:4]])
-        elif parts[0] == 'f':
-            vs = [int(p.split('/')[0]) for p in parts[1:]]
-            for i in range(len(vs) - 2):
-                faces.append((vs[0], vs[i + 1], vs[i + 2]))
+    scene = _ObjScene(filename_obj)
     dev = _device()
-    vertices = torch.from_numpy(np.asarray(vertices, dtype=np.float32).reshape(-1, 3)).to(dev)
-    faces = torch.from_numpy(np.asarray(faces, dtype=np.int32).reshape(-1, 3)).to(dev) - 1
+    vertices = torch.from_numpy(scene.positions).to(dev)
+    faces = torch.from_numpy(scene.tri_pos).to(dev)
     textures = None
     if load_texture:
-        for line in lines:
-            if line.startswith('mtllib'):
-                filename_mtl = os.path.join(os.path.dirname(filename_obj), line.split()[1])
-                textures = load_textures(filename_obj, filename_mtl, texture_size, texture_wrapping=texture_wrapping,
-                                         use_bilinear=use_bilinear)
-        if textures is None:
+        if scene.mtllib is None:
             raise Exception('Failed to load textures.')
+        obj_dir = os.path.dirname(filename_obj)
+        textures = _textures_of_scene(scene, obj_dir, os.path.join(obj_dir, scene.mtllib), texture_size, texture_wrapping,
+                                      use_bilinear)
     if normalization:
-        vertices = vertices - vertices.min(0)[0][None, :]
-        vertices = vertices / torch.abs(vertices).max()
-        vertices = vertices * 2
-        vertices = vertices - vertices.max(0)[0][None, :] / 2
-    if load_texture:
-        return vertices, faces, textures
-    return vertices, faces
+        vertices = _fit_unit_cube(vertices)
+    return (vertices, faces, textures) if load_texture else (vertices, faces)
+
+
+# ---- texture cubes -> atlas image -----------------------------------------------------------------------------------
+def _atlas_layout(num_faces, tile, device):
+    """tiles per row / column of the square-ish atlas and the tile-space corners [F,3,2] (x, y) of every face's triangle:
+    (left, top), (left, bottom), (right, bottom) of its tile, in pixels"""
+    per_row = int((num_faces - 1.) ** 0.5) + 1
+    rows = int((num_faces - 1.) / per_row) + 1
+    f = torch.arange(num_faces, device=device)
+    left, top = ((f % per_row) * tile).float(), (torch.div(f, per_row, rounding_mode='floor') * tile).float()
+    right, bottom = left + (tile - 1), top + (tile - 1)
+    corners = torch.stack((torch.stack((left, top), -1), torch.stack((left, bottom), -1), torch.stack((right, bottom), -1)), 1)
+    return per_row, rows, corners.contiguous()
 
 
 def create_texture_image(textures, texture_size_out=16):
-    """Texture atlas of per-face texture cubes (NR/save_obj.py:10-38): returns (image [tile_h*tso, tile_w*tso, 3]
-    numpy, rows flipped for image files; per-face uv corners [F, 3, 2] numpy in [0, 1])."""
+    """Texture atlas of per-face texture cubes: returns (image [rows*tso, per_row*tso, 3] numpy with the rows flipped for
+    image files, per-face uv corners [F,3,2] numpy in [0,1]) -- the pair NR/save_obj.py:10-38 returns."""
     textures = textures.detach().float().contiguous()
     _lib.require_device(textures, names=("textures",))
-    num_faces, texture_size_in = textures.shape[:2]
-    tile_width = int((num_faces - 1.) ** 0.5) + 1
-    tile_height = int((num_faces - 1.) / tile_width) + 1
-    tso = texture_size_out
-    dev = textures.device
-    image = torch.empty(tile_height * tso, tile_width * tso, 3, dtype=torch.float32, device=dev)
-    # tile-space triangle corners [:, :, XY]; a few floats per face, laid out on the host
-    face_nums = np.arange(num_faces)
-    column, row = face_nums % tile_width, face_nums // tile_width
-    vertices = np.zeros((num_faces, 3, 2), dtype=np.float32)
-    vertices[:, 0, 0] = column * tso
-    vertices[:, 0, 1] = row * tso
-    vertices[:, 1, 0] = column * tso
-    vertices[:, 1, 1] = (row + 1) * tso - 1
-    vertices[:, 2, 0] = (column + 1) * tso - 1
-    vertices[:, 2, 1] = (row + 1) * tso - 1
-    vertices_dev = torch.from_numpy(vertices).to(dev)
+    F, ts_in = textures.shape[:2]
+    per_row, rows, corners = _atlas_layout(F, texture_size_out, textures.device)
+    image = torch.empty(rows * texture_size_out, per_row * texture_size_out, 3, dtype=torch.float32, device=textures.device)
     _lib.check(_lib.lib().d3m_create_texture_image(
-        _lib.ptr(vertices_dev), _lib.ptr(textures), _lib.ptr(image), num_faces, texture_size_in, image.shape[0],
-        image.shape[1], tile_width, 1e-5, _lib.stream_ptr()), "d3m_create_texture_image")
-    vertices[:, :, 0] /= (image.shape[1] - 1)
-    vertices[:, :, 1] /= (image.shape[0] - 1)
-    image = image.cpu().numpy()[::-1, ::1]
-    return image, vertices
+        _lib.ptr(corners), _lib.ptr(textures), _lib.ptr(image), F, ts_in, image.shape[0], image.shape[1], per_row,
+        ATLAS_EPS, _lib.stream_ptr()), "d3m_create_texture_image")
+    extent = np.array([image.shape[1] - 1, image.shape[0] - 1], dtype=np.float32)
+    return image.flip(0).cpu().numpy(), corners.cpu().numpy() / extent
+
+
+# ---- writer -------------------------------------------------------------------------------------------------------
+def _rows(fmt, array):
+    """every row of a 2-D array through one format string, newline-terminated"""
+    return ''.join(fmt % tuple(r) for r in array.tolist())
 
 
 def save_obj(filename, vertices, faces, textures=None):
     """Write vertices [V,3] and faces [F,3] as a Wavefront .obj; with `textures` [F,ts,ts,ts,3] also a .png texture
-    atlas, per-face `vt` coordinates and a .mtl next to it (NR/save_obj.py:41-82)."""
-    assert vertices.ndimension() == 2
-    assert faces.ndimension() == 2
-    if textures is not None:
-        filename_mtl = filename[:-4] + '.mtl'
-        filename_texture = filename[:-4] + '.png'
-        material_name = 'material_1'
-        texture_image, vertices_textures = create_texture_image(textures)
-        _imsave(filename_texture, texture_image)
-    v = vertices.detach().cpu().numpy()
-    fa = faces.detach().cpu().numpy()
-    with open(filename, 'w') as f:
-        f.write('# %s\n#\n\n' % os.path.basename(filename))
-        if textures is not None:
-            f.write('mtllib %s\n\n' % os.path.basename(filename_mtl))
-        for vertex in v:
-            f.write('v %.8f %.8f %.8f\n' % (vertex[0], vertex[1], vertex[2]))
-        f.write('\n')
-        if textures is not None:
-            for vertex in vertices_textures.reshape((-1, 2)):
-                f.write('vt %.8f %.8f\n' % (vertex[0], vertex[1]))
-            f.write('\n')
-            f.write('usemtl %s\n' % material_name)
-            for i, face in enumerate(fa):
-                f.write('f %d/%d %d/%d %d/%d\n' % (face[0] + 1, 3 * i + 1, face[1] + 1, 3 * i + 2, face[2] + 1,
-                                                   3 * i + 3))
-            f.write('\n')
-        else:
-            for face in fa:
-                f.write('f %d %d %d\n' % (face[0] + 1, face[1] + 1, face[2] + 1))
-    if textures is not None:
-        with open(filename_mtl, 'w') as f:
-            f.write('newmtl %s\n' % material_name)
-            f.write('map_Kd %s\n' % os.path.basename(filename_texture))
+    atlas, per-corner `vt` coordinates and a .mtl next to it (the files NR/save_obj.py:41-82 writes)."""
+    if vertices.ndimension() != 2 or faces.ndimension() != 2:
+        raise AssertionError("vertices must be [V,3] and faces [F,3]")
+    stem = os.path.splitext(filename)[0]
+    v = vertices.detach().cpu().numpy().astype(np.float64)
+    tri = faces.detach().cpu().numpy().astype(np.int64) + 1
+    chunks = ['# %s\n#\n\n' % os.path.basename(filename)]
+    if textures is None:
+        chunks += [_rows('v %.8f %.8f %.8f\n', v), '\n', _rows('f %d %d %d\n', tri)]
+    else:
+        atlas, uv = create_texture_image(textures)
+        _write_image(stem + '.png', atlas)
+        material = 'material_1'
+        with open(stem + '.mtl', 'w') as fh:
+            fh.write('newmtl %s\nmap_Kd %s\n' % (material, os.path.basename(stem + '.png')))
+        vt = 3 * np.arange(tri.shape[0], dtype=np.int64)[:, None] + np.array([1, 2, 3])     # corner k of face i: vt 3i + k
+        corners = np.stack((tri, vt), -1).reshape(tri.shape[0], 6)                           # v/vt v/vt v/vt
+        chunks += ['mtllib %s\n\n' % os.path.basename(stem + '.mtl'), _rows('v %.8f %.8f %.8f\n', v), '\n',
+                   _rows('vt %.8f %.8f\n', uv.reshape(-1, 2).astype(np.float64)), '\n', 'usemtl %s\n' % material,
+                   _rows('f %d/%d %d/%d %d/%d\n', corners), '\n']
+    with open(filename, 'w') as fh:
+        fh.write(''.join(chunks))
 
 
-class Mesh(object):
-    '''
-    A simple holder of a triangle mesh with a learnable texture (NR/mesh.py:6-43).
-    '''
+# ---- mesh holder ------------------------------------------------------------------------------------------------------
+class Mesh(nn.Module):
+    """A triangle mesh with a learnable texture (the holder of NR/mesh.py): vertices [V,3], faces [F,3], textures
+    [F,ts,ts,ts,3] -- given, or a small random nn.Parameter."""
+
     def __init__(self, vertices, faces, textures=None, texture_size=4):
-        self.vertices = vertices
-        self.faces = faces
-        self.num_vertices = self.vertices.shape[0]
-        self.num_faces = self.faces.shape[0]
+        super().__init__()
+        self.vertices, self.faces = vertices, faces
+        self.num_vertices, self.num_faces = vertices.shape[0], faces.shape[0]
         if textures is None:
-            shape = (self.num_faces, texture_size, texture_size, texture_size, 3)
-            self.textures = nn.Parameter(0.05 * torch.randn(*shape))
-            self.texture_size = texture_size
-        else:
-            self.textures = textures
-            self.texture_size = textures.shape[1]
+            textures = nn.Parameter(0.05 * torch.randn(self.num_faces, texture_size, texture_size, texture_size, 3))
+        self.textures = textures
+        self.texture_size = textures.shape[1]
 
     @classmethod
     def fromobj(cls, filename_obj, normalization=True, load_texture=False, texture_size=4):
-        if load_texture:
-            vertices, faces, textures = load_obj(filename_obj, normalization=normalization,
-                                                 texture_size=texture_size, load_texture=True)
-        else:
-            vertices, faces = load_obj(filename_obj, normalization=normalization, texture_size=texture_size,
-                                       load_texture=False)
-            textures = None
-        return cls(vertices, faces, textures, texture_size)
+        loaded = load_obj(filename_obj, normalization=normalization, texture_size=texture_size, load_texture=load_texture)
+        return cls(loaded[0], loaded[1], loaded[2] if load_texture else None, texture_size)
