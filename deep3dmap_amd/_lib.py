@@ -73,6 +73,7 @@ _SIGNATURES = {
     "d3m_camera_basis": (_I, [_P, _I, _P, _I, _P, _I, _I, _P, _I, _P]),
     "d3m_camera_forward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _I, _I, _P]),
     "d3m_camera_backward": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _P, _I, _I, _P]),
+    "d3m_camera_backward_add": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _P, _I, _I, _P]),
     "d3m_gather_faces": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "d3m_scatter_face_grads": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "d3m_lighting_forward": (_I, [_P, _P, _P, _F, _F, _P, _P, _P, _L, _I, _P]),

@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(256) k_camera_forward(const float* __restrict_
 // chip idle, and each lane's 32 views were a chain of dependent loads).
 __global__ void __launch_bounds__(256) k_camera_backward(const float* __restrict__ vertices, int vb, Cam c,
                                                         const float* __restrict__ grad_out,
-                                                        float* __restrict__ grad_vertices, int B, int V) {
+                                                        float* __restrict__ grad_vertices, int B, int V,
+                                                        bool accumulate = false) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool shared = vb <= 1;
     const long i = shared ? t >> 3 : t;
@@ -194,10 +195,10 @@ __global__ void __launch_bounds__(256) k_camera_backward(const float* __restrict
             acc[k] += dpp_f32<0x141>(acc[k]);     // row_half_mirror: the other quad of the 8
         }
     }
-    if (on && sub == 0) {
-        grad_vertices[i * 3 + 0] = acc[0];
-        grad_vertices[i * 3 + 1] = acc[1];
-        grad_vertices[i * 3 + 2] = acc[2];
+    if (on && sub == 0) {      // (one writer per entry: a plain read-modify-write when accumulating)
+        grad_vertices[i * 3 + 0] = accumulate ? grad_vertices[i * 3 + 0] + acc[0] : acc[0];
+        grad_vertices[i * 3 + 1] = accumulate ? grad_vertices[i * 3 + 1] + acc[1] : acc[1];
+        grad_vertices[i * 3 + 2] = accumulate ? grad_vertices[i * 3 + 2] + acc[2] : acc[2];
     }
 }
 

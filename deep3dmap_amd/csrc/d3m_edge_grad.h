@@ -399,6 +399,53 @@ __global__ void __launch_bounds__(256) k_compact_visible(const unsigned char* __
         if (v[k]) list[pos++] = (int)(i0 + k);             // ascending face order: neighbours stay neighbours
 }
 
+// The same list and flags in ONE launch (count -> scan -> compact were three, 57 us of launches and one-workgroup scans on
+// the plan's critical path): a workgroup takes 8192 faces, counts its visible ones, and reserves its stretch of the list
+// with ONE returning atomic on the list's length (the per-1024-faces cursor tried earlier needed 6272 of them).  The list is ascending inside a
+// chunk and the chunks land in arrival order: neighbouring faces stay neighbours, which is all its readers rely on.
+// (8192 faces per workgroup = 784 atomics: 42 us in the step, beside the sampling pass; 32768 per workgroup = 196
+// atomics: 51 us -- the pass is bound by its 26 MB of flag stores and by what runs beside it, not by the cursor.)
+// *count must be zero on entry (cleared with the marks).
+#ifndef D3M_EG_COMPACT1_NIBBLES
+#define D3M_EG_COMPACT1_NIBBLES 2
+#endif
+constexpr int EG_COMPACT1_NIB = D3M_EG_COMPACT1_NIBBLES;            // 4-face groups per thread
+constexpr int EG_COMPACT1_FACES = 1024 * 4 * EG_COMPACT1_NIB;       // faces per workgroup (8192)
+__global__ void __launch_bounds__(1024) k_compact_visible_atomic(const unsigned char* __restrict__ bits, int* __restrict__ flags,
+                                                                int* __restrict__ list, int* __restrict__ count, long n) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    const long i0 = (long)blockIdx.x * EG_COMPACT1_FACES + threadIdx.x * (4 * EG_COMPACT1_NIB);
+    unsigned nib[EG_COMPACT1_NIB];
+    int c = 0;
+#pragma unroll
+    for (int h = 0; h < EG_COMPACT1_NIB; h++) {
+        nib[h] = visible_nibble(bits, i0 + 4 * h, n);
+        c += __popc(nib[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < EG_COMPACT1_NIB; h++)
+        if (i0 + 4 * h < n)
+            *(int4*)(flags + i0 + 4 * h) = make_int4((int)(nib[h] & 1u), (int)((nib[h] >> 1) & 1u), (int)((nib[h] >> 2) & 1u),
+                                                     (int)((nib[h] >> 3) & 1u));
+    const int incl = wave_inclusive_scan(c);
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int k = 0; k < 16; k++) { const int t = s_wave[k]; s_wave[k] = total; total += t; }
+        s_base = total ? atomicAdd(count, total) : 0;
+    }
+    __syncthreads();
+    int pos = s_base + s_wave[wv] + incl - c;
+#pragma unroll
+    for (int h = 0; h < EG_COMPACT1_NIB; h++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((nib[h] >> k) & 1u) list[pos++] = (int)(i0 + 4 * h + k);
+}
+
 // Six lanes per visible face, one per (edge, axis) pair; 42 faces per 256-thread workgroup.
 constexpr int EG_FACES_PER_BLOCK = 42;
 
@@ -1315,18 +1362,16 @@ inline VisibilityView visibility_view(void* blob, long nf) {
 
 inline hipError_t run_visibility(const int32_t* face_index_map, const VisibilityView& v, int B, int F, int S, hipStream_t st) {
     const long nf = (long)B * F;
-    if (face_index_map) {       // NULL: the marks were left by the forward pass (d3m_forward_face_index_map_mesh)
-        hipError_t e = zero_async(v.marks, eg_align((size_t)nf + 4), st);
+    if (face_index_map) {       // NULL: the marks were left (and the count cleared) by d3m_forward_face_index_map_mesh
+        hipError_t e = zero_async(v.count, 256 + eg_align((size_t)nf + 4), st);      // count | marks are adjacent
         if (e != hipSuccess) return e;
         const long px_blocks = ((long)B * S * S + 255) / 256;
         LAUNCH("k_mark_visible", k_mark_visible_bytes, dim3((unsigned)std::min(px_blocks, 4096l)), dim3(256), st,
                face_index_map, v.marks, B, F, S);
     }
-    const int n_chunks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
-    LAUNCH("k_count_visible", k_count_visible, dim3(n_chunks), dim3(256), st, (const unsigned char*)v.marks, v.vis_block, nf);
-    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, v.vis_block, n_chunks, (const int*)nullptr, 1, v.count);
-    LAUNCH("k_compact_visible", k_compact_visible, dim3(n_chunks), dim3(256), st, (const unsigned char*)v.marks, v.flags, v.list,
-           (const int*)v.vis_block, nf);
+    const int n_chunks = (int)((nf + EG_COMPACT1_FACES - 1) / EG_COMPACT1_FACES);
+    LAUNCH("k_compact_visible", k_compact_visible_atomic, dim3(n_chunks), dim3(1024), st, (const unsigned char*)v.marks, v.flags,
+           v.list, v.count, nf);
     return hipGetLastError();
 }
 

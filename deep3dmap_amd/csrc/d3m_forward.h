@@ -103,8 +103,10 @@ __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
 template <class FS, bool PAIRED>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
                                                   float* __restrict__ faces_dense_out,
-                                                  unsigned char* __restrict__ marks = nullptr) {
+                                                  unsigned char* __restrict__ marks = nullptr,
+                                                  int* __restrict__ marks_count = nullptr) {
     __shared__ TileAgg agg;
+    if (marks_count && blockIdx.x == 0 && threadIdx.x == 0) *marks_count = 0;
     ta_clear(agg);
     const int F = bb.F, Fl = PAIRED ? F / 2 : F;          // faces per view: all / handled by one lane each
     const long lane_i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,6 +281,7 @@ struct RasterOut {
     float* depth_map;
     float* face_inv_map;   // NULL unless the caller wants the reference's [B,S,S,3,3] map
     unsigned char* marks;  // NULL, or [B*F] zeroed by k_bin_count: marks[b*F + f] = 1 for every face that owns a pixel
+    int* marks_count = nullptr;   // with marks: the visibility list's length, cleared by k_bin_count for the compaction pass
 };
 
 // W waves per tile: W = 1 when there are enough tiles to fill the chip; W = 4 for small rasters (a few thousand

@@ -210,10 +210,10 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     const long nf = (long)B * F;
     if (ifs.fill_back)      // one lane per index triple, both copies
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
-               (float*)nullptr, faces_out, out.marks);
+               (float*)nullptr, faces_out, out.marks, out.marks_count);
     else
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
-               (float*)nullptr, faces_out, out.marks);
+               (float*)nullptr, faces_out, out.marks, out.marks_count);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, BIN_ALLOC_THREADS)), dim3(BIN_ALLOC_THREADS), st, bb);
     if (ifs.fill_back) launch_bin_fill<true>(bb, nf / 2, st);
     else launch_bin_fill<false>(bb, nf, st);
@@ -299,6 +299,7 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
         const long nf = (long)batch_size * ifs.num_faces();
         if (visibility_size < visibility_bytes(nf)) return D3M_ERR_WORKSPACE;
         out.marks = visibility_view(visibility, nf).marks;
+        out.marks_count = visibility_view(visibility, nf).count;
     }
     return run_forward_mesh(ifs, faces_out, batch_size, image_size, near, far, out, workspace, workspace_bytes,
                             (hipStream_t)stream);
@@ -504,18 +505,29 @@ D3M_EXPORT int d3m_camera_forward(const float* vertices, int vertices_batch, con
     return check_launch();
 }
 
-D3M_EXPORT int d3m_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam,
-                                   const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
-                                   d3m_stream_t stream) {
+static int run_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam, const float* grad_out,
+                               float* grad_vertices, int batch_size, int num_vertices, bool accumulate, hipStream_t st) {
     if (!vertices || !grad_out || !grad_vertices || batch_size <= 0 || num_vertices <= 0) return D3M_ERR_INVALID;
     if (vertices_batch != 1 && vertices_batch != batch_size) return D3M_ERR_INVALID;
     Cam c;
     int rc = to_cam(cam, batch_size, c);
     if (rc) return rc;
     const long n = vertices_batch > 1 ? (long)batch_size * num_vertices : 8l * num_vertices;     // lanes: see the kernel
-    LAUNCH("k_camera_backward", k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), (hipStream_t)stream, vertices,
-                       vertices_batch, c, grad_out, grad_vertices, batch_size, num_vertices);
+    LAUNCH("k_camera_backward", k_camera_backward, dim3(blocks_for(n, 256)), dim3(256), st, vertices, vertices_batch, c,
+           grad_out, grad_vertices, batch_size, num_vertices, accumulate);
     return check_launch();
+}
+D3M_EXPORT int d3m_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam,
+                                   const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
+                                   d3m_stream_t stream) {
+    return run_camera_backward(vertices, vertices_batch, cam, grad_out, grad_vertices, batch_size, num_vertices, false,
+                               (hipStream_t)stream);
+}
+D3M_EXPORT int d3m_camera_backward_add(const float* vertices, int vertices_batch, const d3m_camera* cam,
+                                       const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
+                                       d3m_stream_t stream) {
+    return run_camera_backward(vertices, vertices_batch, cam, grad_out, grad_vertices, batch_size, num_vertices, true,
+                               (hipStream_t)stream);
 }
 
 D3M_EXPORT int d3m_gather_faces(const float* vertices, const int32_t* tri, int tri_batch, float* faces_out,

@@ -88,6 +88,11 @@ class MultiViewFit:
         # the step's results, packed where they are produced (inside the captured step): [loss | grad_v | grad_t]
         n_t = self.textures.numel() if optimise_textures else 0
         self._flat = torch.zeros(1 + self.vertices.numel() + n_t, dtype=torch.float32, device=self.device)
+        # ... by the rendering node itself where it can: the node's backward writes the two gradients, its forward the loss,
+        # straight into these views of the flat buffer (Renderer.grad_sink); _forward_backward packs only what did not
+        nv = self.vertices.numel()
+        self.renderer.grad_sink = (self._flat[1:1 + nv].view(1, *self.vertices.shape),
+                                   self._flat[1 + nv:].view(1, *self.textures.shape) if n_t else None, self._flat[0:1])
         self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
 
     def render(self, vertices=None, textures=None):
@@ -144,11 +149,17 @@ class MultiViewFit:
             loss.backward()
         finally:
             self.renderer.defer_plan_join = False
-        # pack [loss | grad_v | grad_t] into the persistent buffer the collective runs on (part of the captured step)
+        # [loss | grad_v | grad_t] in the persistent buffer the collective runs on: already there when the rendering node
+        # produced them in place (grad_sink); packed here (part of the captured step) otherwise
         parts = [loss.detach().reshape(1), self.vertices.grad.reshape(-1)]
         if self.textures.requires_grad:
             parts.append(self.textures.grad.reshape(-1))
-        torch.cat(parts, out=self._flat)
+        at = 0
+        for part in parts:
+            dst = self._flat[at:at + part.numel()]
+            if part.data_ptr() != dst.data_ptr():
+                dst.copy_(part)
+            at += part.numel()
         return self._flat
 
     def capture_graph(self, warmup=3):

@@ -123,23 +123,33 @@ def _vec_param(x, device):
     return t[None, :].contiguous() if t.dim() == 1 else t
 
 
+def look_at_params(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
+    """The fused camera kernels' parameter block of look_at(vertices, eye, at, up) -- for callers that run
+    d3m_camera_forward / _backward inside a larger node (rasterize._RasterizeLit) -- or None when a camera parameter
+    requires grad (those go through the torch composition in look_at)."""
+    if _learnable(eye, at, up):
+        return None
+    device = vertices.device
+    eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
+    nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
+    return dict(mode=_lib.CAMERA_LOOK_AT, batch=max(vertices.shape[0], nb), rot=_basis(eye_t, at_t, up_t, True, nb, device),
+                eye_or_t=eye_t, perspective=_perspective_angle is not None,
+                width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+
+
 def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
     """"Look at" transformation of vertices (NR/look_at.py:6-62).
     `eye`, `at`, `up`: list / tuple / ndarray / tensor of shape [3] or [batch, 3]."""
     if vertices.ndimension() != 3:
         raise ValueError('vertices Tensor should have 3 dimensions')
-    device = vertices.device
-    eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
-    nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
-    B = max(vertices.shape[0], nb)          # vertices of batch 1 = one mesh seen by every camera
-    if _learnable(eye, at, up):
+    params = look_at_params(vertices, eye, at, up, _perspective_angle)
+    if params is None:
+        device = vertices.device
+        eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
+        B = max(vertices.shape[0], eye_t.shape[0], at_t.shape[0], up_t.shape[0])   # vertices of batch 1 = one mesh seen by every camera
         return _view_torch(vertices.float().expand(B, -1, -1), eye_t.expand(B, 3),
                            _frame_torch(eye_t.expand(B, 3), at_t.expand(B, 3), up_t.expand(B, 3), True),
                            _perspective_angle)
-    rot = _basis(eye_t, at_t, up_t, True, nb, device)
-    params = dict(mode=_lib.CAMERA_LOOK_AT, batch=B, rot=rot, eye_or_t=eye_t,
-                  perspective=_perspective_angle is not None,
-                  width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
     return _CameraFunction.apply(vertices, params)
 
 

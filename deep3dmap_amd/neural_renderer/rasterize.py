@@ -270,11 +270,25 @@ class _RasterizeLit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
                 far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None, view_groups=1,
-                defer_plan_join=False):
+                defer_plan_join=False, camera=None, grad_sink=None):
         L = _lib.lib()
-        sv, vertices, textures = f32c(screen_vertices), f32c(vertices), f32c(textures)
+        vertices, textures = f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
-        dev = sv.device
+        dev = vertices.device
+        cam_keep = None
+        if camera is not None:
+            # THE CAMERA INSIDE THE NODE (`camera` = the parameter block of cameras._camera_struct, screen_vertices None):
+            # the mesh is both projected and lit, i.e. `vertices` would receive two gradients that autograd then adds
+            # with a kernel of its own; here the camera's adjoint is accumulated onto the light's (d3m_camera_backward_add)
+            # and the node returns ONE gradient.  `grad_sink` = (grad_vertices [1,V,3], grad_textures, loss [1]) buffers
+            # of the caller (MultiViewFit's flat all-reduce buffer): the results are produced in place, no packing copy.
+            from . import cameras
+            cam, cam_keep = cameras._camera_struct(camera, dev)
+            sv = torch.empty(camera["batch"], vertices.shape[1], 3, dtype=torch.float32, device=dev)
+            _lib.check(L.d3m_camera_forward(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(sv),
+                                            camera["batch"], vertices.shape[1], _lib.stream_ptr()), "d3m_camera_forward")
+        else:
+            sv = f32c(screen_vertices)
         B = sv.shape[0]
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
         Fp = 2 * Ft if fill_back else Ft
@@ -337,7 +351,7 @@ class _RasterizeLit(torch.autograd.Function):
                 # view groups are shards of the objective and need the normaliser of the whole batch; and with it known
                 # up front the pass below can leave the gradient as the edge gradient's per-pixel records
                 mask_sum = mask.sum().reshape(1)
-            loss_g = torch.empty(G, dtype=torch.float32, device=dev)
+            loss_g = grad_sink[2] if (grad_sink is not None and G == 1) else torch.empty(G, dtype=torch.float32, device=dev)
             scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(hi - lo, S)), dtype=torch.float32, device=dev)
                        for lo, hi in groups]
             # with a backward pass to come, the same pass leaves the objective's gradient behind -- minus the gradient of the
@@ -420,6 +434,7 @@ class _RasterizeLit(torch.autograd.Function):
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
         ctx.fit = fit_state
+        ctx.camera, ctx.cam_keep, ctx.grad_sink = camera, cam_keep, grad_sink
         ctx.save_for_backward(faces, vertices, tri, textures, light)
         if fit is not None:
             return loss_g.sum() if G > 1 else loss_g.reshape(())
@@ -479,10 +494,12 @@ class _RasterizeLit(torch.autograd.Function):
         grad_textures = grad_vertices = grad_light = None
         tex_shared, light_shared = textures.shape[0] == 1, Bl == 1
         gt_g = gl_g = None
+        sink = ctx.grad_sink
         if gathered:
-            grad_vertices = torch.zeros_like(vertices) if need_vert else None
+            if need_vert:
+                grad_vertices = sink[0].zero_() if (sink is not None and ctx.camera is not None) else torch.zeros_like(vertices)
             if tex_shared:
-                gt_g = [torch.empty_like(textures) for _ in groups]
+                gt_g = [sink[1] if (sink is not None and G == 1) else torch.empty_like(textures) for _ in groups]
             else:
                 grad_textures = torch.empty_like(textures)
                 gt_g = [grad_textures[lo:hi] for lo, hi in groups]
@@ -572,7 +589,19 @@ class _RasterizeLit(torch.autograd.Function):
                                    g_depth_map, grad_faces, S)
             _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
                                                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 14
+        if ctx.camera is not None:
+            # the camera's adjoint joins the light's in the same buffer (or writes it, when there is none)
+            from . import cameras
+            cam, _keep = cameras._camera_struct(ctx.camera, dev)
+            if grad_vertices is None:
+                grad_vertices = sink[0] if sink is not None else torch.empty_like(vertices)
+                fn, what = L.d3m_camera_backward, "d3m_camera_backward"
+            else:
+                fn, what = L.d3m_camera_backward_add, "d3m_camera_backward_add"
+            _lib.check(fn(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(grad_sv), _lib.ptr(grad_vertices),
+                          B, V, _lib.stream_ptr()), what)
+            grad_sv = None
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 16
 
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
@@ -634,7 +663,7 @@ def rasterize_lit_image_grid(screen_vertices, vertices, grid_hw, image, light_cf
 
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
                       near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
-                      view_groups=1, defer_plan_join=False, images_out=None):
+                      view_groups=1, defer_plan_join=False, images_out=None, camera=None, grad_sink=None):
     """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
@@ -648,7 +677,8 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
     if images_out is not None:          # (rgb, depth, alpha) buffers the same pass fills with the images render() returns
         fit = (fit + (None,))[:5] + (tuple(images_out),)
     return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
-                               far, eps, background_color, True, True, True, fit, view_groups, defer_plan_join)
+                               far, eps, background_color, True, True, True, fit, view_groups, defer_plan_join, camera,
+                               grad_sink)
 
 
 def rasterize_rgbad(

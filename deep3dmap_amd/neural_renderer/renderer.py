@@ -165,10 +165,16 @@ class Renderer(nn.Module):
         return (for display / logging; gradients flow through the returned objective only)."""
         if not self._on_the_fly() or self.anti_aliasing:
             raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch) and anti_aliasing=False")
-        sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+        # look_at cameras with constant parameters run INSIDE the node (one gradient for the mesh instead of the camera's
+        # plus the light's; results straight into the caller's grad_sink buffers when it has set them)
+        cam = None
+        if self.camera_mode == 'look_at':
+            cam = cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None)
+        sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                 view_groups=self.view_groups, defer_plan_join=self.defer_plan_join, images_out=images_out)
+                                 view_groups=self.view_groups, defer_plan_join=self.defer_plan_join, images_out=images_out,
+                                 camera=cam, grad_sink=getattr(self, "grad_sink", None) if cam is not None else None)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():

@@ -212,6 +212,11 @@ int d3m_camera_forward(const float* vertices, int vertices_batch, const d3m_came
 int d3m_camera_backward(const float* vertices, int vertices_batch, const d3m_camera* cam,
                         const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
                         d3m_stream_t stream);
+/* the same, ADDED to grad_vertices (which then already holds another path's share, e.g. d3m_face_light_backward's: the two
+ * gradients of a mesh that is both projected and lit need no separate sum) */
+int d3m_camera_backward_add(const float* vertices, int vertices_batch, const d3m_camera* cam,
+                            const float* grad_out, float* grad_vertices, int batch_size, int num_vertices,
+                            d3m_stream_t stream);
 
 /* vertices_to_faces (neural_renderer/vertices_to_faces.py:16-22) with the fill_back copy made on the
  * fly (renderer.py:86): faces_out [B,F',3,3], F' = 2F if fill_back else F; face F+f is face f with
