@@ -272,13 +272,25 @@ __global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __rest
             t_m = m;
             const float d = acc_a * inv - tg[4];
             t_sse = d * d;
-            if (fit.g_rgb) {                              // no anti-aliasing here: the output pixel IS internal pixel p
-                const size_t p = ((size_t)b * S + (S - 1 - yo)) * S + xo;
+            if (fit.g_rgb) {
+                // the unscaled gradient wrt the INTERNAL maps: every internal pixel of the output pixel gets `inv` of the
+                // output pixel's gradient (the adjoint of the 2x2 mean).  The readers' scalars (GradScale) are those of the
+                // output images except 1 / pixels of the silhouette term, which they take from the INTERNAL size S^2 =
+                // s^2 / inv: the alpha gradient therefore carries inv * (1 / inv) = 1.
                 auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
+                float gr[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) fit.g_rgb[3 * p + k] = sgn(acc_rgb[k] - tg[k]) * m;
-                fit.g_depth[p] = sgn(acc_d - tg[3]) * m;
-                fit.g_alpha[p] = 2.0f * d;
+                for (int k = 0; k < 3; k++) gr[k] = sgn(acc_rgb[k] * inv - tg[k]) * m * inv;
+                const float gd = sgn(acc_d * inv - tg[3]) * m * inv, ga = 2.0f * d;
+                for (int dy = 0; dy < n; dy++) {
+                    for (int dx = 0; dx < n; dx++) {
+                        const size_t p = ((size_t)b * S + (S - 1 - (yo * n + dy))) * S + xo * n + dx;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) fit.g_rgb[3 * p + k] = gr[k];
+                        fit.g_depth[p] = gd;
+                        fit.g_alpha[p] = ga;
+                    }
+                }
             }
         }
     }

@@ -838,7 +838,8 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         batch_size <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
     if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
-    if (fit && (anti_aliasing || !alpha_map)) return D3M_ERR_INVALID;     // the objective reads the maps as the images
+    if (fit && !alpha_map) return D3M_ERR_INVALID;
+    if (fit && anti_aliasing && fit->edge_grad) return D3M_ERR_INVALID;   // the records form has no pooled variant: gradient maps
     if (background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
     LitTextures lt;
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);

@@ -128,7 +128,7 @@ class MultiViewFit:
         """The objective of the current mesh against the targets, evaluated inside the rendering node when the renderer
         allows it (no images, no image gradients in memory); otherwise render() + loss()."""
         r = self.renderer
-        if self.objective_in_renderer and r._on_the_fly() and not r.anti_aliasing:
+        if self.objective_in_renderer and r._on_the_fly():
             rgb_t, depth_t, alpha_t = self.targets
             if self.keep_images and self.images is None:        # persistent buffers (a captured step writes in place)
                 self.images = tuple(torch.empty_like(t) for t in (rgb_t, depth_t, alpha_t))

@@ -335,18 +335,18 @@ class _RasterizeLit(torch.autograd.Function):
             depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
         else:
             # the fit objective is evaluated where the images are produced: they are never written (rasterize_lit_fit)
-            if anti_aliasing or not (return_alpha and return_depth):
-                raise ValueError("the fused fit objective needs rgb, alpha and depth without anti-aliasing")
+            if not (return_alpha and return_depth):
+                raise ValueError("the fused fit objective needs rgb, alpha and depth")
             rgb_t, depth_t, alpha_t, mask = (f32c(t) for t in fit[:4])
             mask_sum = f32c(fit[4]).reshape(1) if len(fit) > 4 and fit[4] is not None else None
             if len(fit) > 5 and fit[5] is not None:
                 # the images as a by-product of the same pass (caller's buffers, not differentiable outputs)
                 rgb, depth, alpha = fit[5]
-                for t, shape in ((rgb, (B, 3, S, S)), (depth, (B, S, S)), (alpha, (B, S, S))):
+                for t, shape in ((rgb, (B, 3, s_out, s_out)), (depth, (B, s_out, s_out)), (alpha, (B, s_out, s_out))):
                     if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
-                        raise ValueError("images_out must be contiguous float32 (rgb [B,3,S,S], depth [B,S,S], alpha [B,S,S])")
-            if tuple(rgb_t.shape) != (B, 3, S, S) or any(tuple(t.shape) != (B, S, S) for t in (depth_t, alpha_t, mask)):
-                raise ValueError("fit targets must be rgb [B,3,S,S] and depth / alpha / mask [B,S,S]")
+                        raise ValueError("images_out must be contiguous float32 (rgb [B,3,s,s], depth [B,s,s], alpha [B,s,s])")
+            if tuple(rgb_t.shape) != (B, 3, s_out, s_out) or any(tuple(t.shape) != (B, s_out, s_out) for t in (depth_t, alpha_t, mask)):
+                raise ValueError("fit targets must be rgb [B,3,s,s] and depth / alpha / mask [B,s,s] at the output size")
             if mask_sum is None and (G > 1 or need_grad):
                 # view groups are shards of the objective and need the normaliser of the whole batch; and with it known
                 # up front the pass below can leave the gradient as the edge gradient's per-pixel records
@@ -355,16 +355,22 @@ class _RasterizeLit(torch.autograd.Function):
             scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(hi - lo, S)), dtype=torch.float32, device=dev)
                        for lo, hi in groups]
             # with a backward pass to come, the same pass leaves the objective's gradient behind -- minus the gradient of the
-            # loss, only known later -- in the form its readers want: the edge gradient's per-pixel records (what
-            # d3m_backward_pixel_map would otherwise pack from gradient maps: no pixel pass in backward at all), the
-            # lines' non-zero extents, and the depth gradient as a map
+            # loss, only known later -- in the form its readers want.  Without anti-aliasing: the edge gradient's per-pixel
+            # records (what d3m_backward_pixel_map would otherwise pack from gradient maps: no pixel pass in backward at
+            # all), the lines' non-zero extents, and the depth gradient as a map.  With anti-aliasing (an output pixel
+            # is the mean of four internal ones): unscaled gradient MAPS at the internal size, packed by backward.
             g_maps = None
-            if need_grad:
+            if need_grad and not anti_aliasing:
                 g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
                           torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
                           torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev),          # nz_lo_inv | nz_hi1
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
-            fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum)
+            elif need_grad:
+                g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),        # grad_rgb_map
+                          torch.empty(B, S, S, dtype=torch.float32, device=dev),           # grad_alpha_map
+                          None,
+                          torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
+            fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, bool(anti_aliasing))
         cur = torch.cuda.current_stream()
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k) for k in range(G)]
@@ -409,7 +415,8 @@ class _RasterizeLit(torch.autograd.Function):
                     # (which would wait for a free slot behind the plan's kernels) goes to the end of the side branch
                     # (one pipeline only: a second cross-stream edge into a group's side branch makes graph REPLAY
                     #  segfault on ROCm 7.2, like the fork of a fork above)
-                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None, defer_finish=vis is not None and G == 1)
+                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None,
+                                                      defer_finish=vis is not None and G == 1 and not anti_aliasing)
                 # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
                 _lib.check(L.d3m_render_lit_epilogue(
                     _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -418,7 +425,7 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
                     int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
                     ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
-                if fit_c is not None and vis is not None and G == 1:
+                if fit_c is not None and vis is not None and G == 1 and not anti_aliasing:
                     auxs[k].wait_stream(mains[k])
                     with torch.cuda.stream(auxs[k]):
                         _lib.check(L.d3m_fit_finish(ctypes.byref(fit_c), Bg, S, _lib.stream_ptr()), "d3m_fit_finish")
@@ -444,15 +451,18 @@ class _RasterizeLit(torch.autograd.Function):
     @staticmethod
     def _fit_struct(fit_state, k, lo, hi, grad_loss, defer_finish=False):
         """d3m_fit_targets of view group k (views lo..hi): forward's `fit` (grad_loss None) / backward's `unscaled`."""
-        rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum = fit_state
-        eg = ed = nz_lo = nz_hi = gd = None
-        if g_maps is not None:
+        rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, pooled = fit_state
+        eg = ed = nz_lo = nz_hi = gd = g_rgb = g_alpha = None
+        if g_maps is not None and not pooled:       # records (no anti-aliasing)
             eg, ed, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
             nz_lo, nz_hi = g_maps[2][0, lo:hi], g_maps[2][1, lo:hi]
+        elif g_maps is not None:                    # unscaled gradient maps at the internal size (anti-aliasing)
+            g_rgb, g_alpha, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
         return _lib.D3MFitTargets(
             _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
-            _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), None, None, _lib.ptr(gd), _lib.ptr(grad_loss),
-            _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi), int(defer_finish))
+            _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(g_rgb), _lib.ptr(g_alpha), _lib.ptr(gd),
+            _lib.ptr(grad_loss), _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi),
+            int(defer_finish))
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
@@ -481,7 +491,9 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward_records")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
             scratch, g_depth_map = ctx.fit[4], ctx.fit[6][3]
-            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (ctx.fit[6][:3])
+            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (ctx.fit[6][:3]) ...
+            if ctx.fit[8]:                              # ... or, with anti-aliasing, as unscaled maps
+                g_rgb_map, g_alpha_map = ctx.fit[6][0], ctx.fit[6][1]
             grad_loss = f32c(g_rgb).reshape(1)
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over the compacted list of the faces that own a pixel.  The edge gradient (K4: ~8
@@ -663,8 +675,10 @@ def rasterize_lit_image_grid(screen_vertices, vertices, grid_hw, image, light_cf
 
 def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, targets, image_size=DEFAULT_IMAGE_SIZE,
                       near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS, background_color=DEFAULT_BACKGROUND_COLOR,
-                      view_groups=1, defer_plan_join=False, images_out=None, camera=None, grad_sink=None):
-    """The multi-view fit objective of the images rasterize_lit() would return (no anti-aliasing),
+                      view_groups=1, defer_plan_join=False, images_out=None, camera=None, grad_sink=None,
+                      anti_aliasing=False):
+    """The multi-view fit objective of the images rasterize_lit() would return (targets at the output size; with
+    anti_aliasing the objective of the 2x2-pooled images),
 
         photometric_loss(rgb, rgb_t, mask) + sum((alpha - alpha_t)^2) / S^2 + photometric_loss(depth, depth_t, mask),
 
@@ -676,9 +690,9 @@ def rasterize_lit_fit(screen_vertices, vertices, tri, textures, light_cfg, fill_
     fit = tuple(targets)
     if images_out is not None:          # (rgb, depth, alpha) buffers the same pass fills with the images render() returns
         fit = (fit + (None,))[:5] + (tuple(images_out),)
-    return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, False, near,
-                               far, eps, background_color, True, True, True, fit, view_groups, defer_plan_join, camera,
-                               grad_sink)
+    return _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size,
+                               bool(anti_aliasing), near, far, eps, background_color, True, True, True, fit, view_groups,
+                               defer_plan_join, camera, grad_sink)
 
 
 def rasterize_rgbad(

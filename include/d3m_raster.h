@@ -335,7 +335,9 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
  *     photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (s*s) + photometric_loss(depth, ...)
  * (deep3dmap/core/utils/utils.py:105-114 composed as d3m_fit_loss_forward does) evaluated in the same pass, where
  * the images are produced: *fit->loss receives the value, the images themselves need not be written (rgb_out NULL)
- * and are not read again.  No anti-aliasing; alpha_map is required.
+ * and are not read again.  alpha_map is required.  With anti_aliasing the targets are at the output size s = S/2, the
+ * objective is that of the pooled images, and its gradient leaves as grad_*_map only (the records form below is for
+ * anti_aliasing == 0).
  * With fit->grad_*_map set the pass also leaves the objective's gradient wrt the internal-resolution maps
  * (rgb_blended, alpha_map, depth_map) there, WITHOUT the scalar factors that are only known later - sign(rgb - target)
  * * mask, 2 (alpha - target), sign(depth - target) * mask - so that backward needs no pass over the pixels of its

@@ -414,7 +414,7 @@ def test_fused_fit_loss_matches_composed_losses_and_oracle(shape):
 def test_fit_objective_inside_the_rendering_node(ts):
     """Renderer.render_fit_loss (objective summed where the images are produced, gradient written straight into the
     internal maps) against multiview_fit_loss on the rendered images: same value, same vertex / texture gradients,
-    with a non-unit upstream gradient; anti-aliasing is refused."""
+    with a non-unit upstream gradient."""
     nr = _nr()
     from deep3dmap_amd import synthetic
     from deep3dmap_amd.core import multiview_fit_loss
@@ -445,11 +445,63 @@ def test_fit_objective_inside_the_rendering_node(ts):
     # the two paths differ only in the order the four sums are added up (a factor 1/den on every gradient)
     for ga, gb in zip(a[1:], b[1:]):
         assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
-    ra = nr.Renderer(image_size=56, anti_aliasing=True, camera_mode="look_at", fill_back=True)
-    ra.eye = eyes
-    with pytest.raises(ValueError):
-        ra.render_fit_loss(torch.from_numpy(v).float().cuda()[None], tri_d, torch.from_numpy(tex).float().cuda()[None],
-                           (rgb_t, depth_t, alpha_t, alpha_t))
+
+
+@pytest.mark.parametrize("ts,frozen_tex", [(2, False), (1, False), (2, True)])
+def test_fit_objective_inside_the_rendering_node_with_anti_aliasing(ts, frozen_tex):
+    """The same with anti-aliasing (SURVEY C2 is AA-on): the objective of the 2x2-pooled images, evaluated in the pass that
+    pools them; its gradient leaves as unscaled maps at the internal size.  MultiViewFit.fit_loss never changes path
+    behind the caller's back."""
+    nr = _nr()
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core import multiview_fit_loss
+    v, tri = synthetic.grid_mesh(14)
+    tex = synthetic.random_textures(tri.shape[0], ts)
+    eyes = torch.from_numpy(synthetic.camera_ring(3)).float().cuda()
+    r = nr.Renderer(image_size=40, anti_aliasing=True, camera_mode="look_at", fill_back=True)
+    r.eye = eyes
+    tri_d = torch.from_numpy(tri).int().cuda()[None]
+    with torch.no_grad():
+        tv = torch.from_numpy(synthetic.perturb(v, 0.04)).float().cuda()
+        rgb_t, depth_t, alpha_t = r(tv[None], tri_d, torch.from_numpy(tex).float().cuda()[None])
+    assert rgb_t.shape[-1] == 40
+    mask = (alpha_t > 0.5).float()
+
+    def run(inside):
+        vv = torch.from_numpy(v).float().cuda().requires_grad_(True)
+        tt = torch.from_numpy(tex).float().cuda().requires_grad_(not frozen_tex)
+        if inside:
+            loss = r.render_fit_loss(vv[None], tri_d, tt[None], (rgb_t, depth_t, alpha_t, mask))
+        else:
+            rgb, depth, alpha = r(vv[None], tri_d, tt[None])
+            loss = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask)
+        (loss * 0.6).backward()
+        return loss.detach(), vv.grad, tt.grad
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], rtol=2e-6)
+    for ga, gb in zip(a[1:], b[1:]):
+        if gb is None:
+            assert ga is None
+            continue
+        assert float(gb.abs().max()) > 0 and float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
+    # the camera-sharded fit takes the fused path with anti-aliasing too, and a captured step replays it
+    from deep3dmap_amd.multiview import MultiViewFit
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=40, anti_aliasing=True)
+    fit.set_targets_from(synthetic.perturb(v, 0.04))
+    l0, gv0, gt0 = fit.step()
+    l0, gv0, gt0 = float(l0), gv0.clone(), gt0.clone()
+    fit2 = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=40, anti_aliasing=True, objective_in_renderer=False)
+    fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
+    l1, gv1, gt1 = fit2.step()
+    assert abs(l0 - float(l1)) <= 2e-6 * abs(float(l1))
+    assert float((gv0 - gv1).abs().max()) <= 2e-5 * float(gv1.abs().max())
+    assert float((gt0 - gt1).abs().max()) <= 2e-5 * float(gt1.abs().max())
+    fit.capture_graph()
+    for _ in range(3):
+        l2, gv2, _ = fit.step()
+    assert abs(float(l2) - l0) <= 1e-6 * abs(l0) and float((gv2 - gv0).abs().max()) <= 1e-4 * float(gv0.abs().max())
+    fit.release_graph()
 
 
 @pytest.mark.parametrize("n", [3, 5, 6])
