@@ -342,6 +342,8 @@ def main():
     ap.add_argument("--mesh-n", type=int, default=225, help="grid_mesh(n): 225 -> 100,352 triangles")
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
+    ap.add_argument("--anti-aliasing", action="store_true",
+                    help="render at twice the size and pool (SURVEY config C2 is AA-on); the headline configuration is AA-off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the second timed pass (the same step through Renderer.render + multiview_fit_loss)")
@@ -394,7 +396,7 @@ def main():
     v, tri = synthetic.grid_mesh(args.mesh_n)
     tex = synthetic.random_textures(tri.shape[0], args.texture_size)
     eyes = synthetic.camera_ring(n_views)
-    fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
+    fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=args.anti_aliasing, rank=rank,
                        world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images,
                        view_groups=args.view_groups)
     fit.set_targets_from(synthetic.perturb(v))
@@ -450,7 +452,7 @@ def main():
     # images, multiview_fit_loss is evaluated on them, their gradients come back through the epilogue's adjoint.
     dropin = None
     if not args.materialise_images and not args.no_dropin:
-        fit2 = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=False, rank=rank,
+        fit2 = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=args.anti_aliasing, rank=rank,
                             world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=False,
                             view_groups=args.view_groups)
         fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
@@ -482,14 +484,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         pix = n_views * S * S
         value = pix / (elapsed / args.steps) / 1e6
-        a_fwd, a_bwd = algorithmic_bytes(V, F, S, S, ts)
+        Si = 2 * S if args.anti_aliasing else S                       # internal raster size
+        a_fwd, a_bwd = algorithmic_bytes(V, F, Si, S, ts)
         step_bytes = (a_fwd + a_bwd) * args.views_per_gpu
         # dominant kernel = largest summed duration in the instrumented pass
         per_kernel = {k: (c, ms) for k, (c, ms) in ktimes.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         dom_count, dom_ms = per_kernel[dom]
         dom_avg_s = dom_ms / dom_count / 1e3
-        kb = kernel_bytes(dom, V, F, S, ts)
+        kb = kernel_bytes(dom, V, F, Si, ts)
         roof = None
         if kb is not None:
             ach = kb * args.views_per_gpu / dom_avg_s / 1e9
@@ -509,7 +512,8 @@ def main():
                 roof["valu_source"] = valu_src
                 roof["valu_issue_frac"] = round(valu * 4 / (1024 * 2.4e9) / dom_avg_s, 3)
         out = {
-            "metric": "rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512", "value": round(value, 2), "unit": "Mpix/s",
+            "metric": ("rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512" if (args.mesh_n, S) == (225, 512) else
+                       f"rendered Mpix/s fwd+bwd, {F}-tri mesh @{S}x{S}"), "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
@@ -523,7 +527,7 @@ def main():
                        "api": "render+loss" if args.materialise_images else
                               ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"),
                        "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
-                       "texture_size": ts, "fill_back": True, "anti_aliasing": False, "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
+                       "texture_size": ts, "fill_back": True, "anti_aliasing": bool(args.anti_aliasing), "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}"},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},

@@ -1,15 +1,18 @@
 #!/bin/bash
 # on the GPU box: bench lines of BASELINE.json's other configurations and the secondary workloads (one JSON line each)
-R=${R:-r02}
+R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 : > $O/${R}_bench_other_configs.jsonl
 run() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; timeout 600 python bench.py --no-cpu-baseline "$@" 2>> $O/bench.err | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
-run "config 2: 53138-triangle face mesh @256x256, 1 view (grid_mesh(164) = 53138 triangles)" --mesh-n 164 --image-size 256 --views-per-gpu 1
+run "config 2: 53138-triangle face mesh @256x256 with anti-aliasing (S = 512), 1 view (grid_mesh(164) = 53138 triangles)" --mesh-n 164 --image-size 256 --views-per-gpu 1 --anti-aliasing
+run "config 2 without anti-aliasing" --mesh-n 164 --image-size 256 --views-per-gpu 1
 run "config 4 per-GPU shard at 4 GPUs: 8 of the 32 cameras" --views-per-gpu 8
 run "config 5: 1002528-triangle mesh @1024x1024, 8 views" --mesh-n 709 --image-size 1024 --views-per-gpu 8
+run "config 5 per-GPU shard at 8 GPUs: 32 of the 256 cameras" --mesh-n 709 --image-size 1024 --views-per-gpu 32 --steps 10
 run "64 views per GPU" --views-per-gpu 64
-run "config 3: gan2shape step, batch 16" --workload gan2shape
+run "config 3: gan2shape renderer block, batch 16" --workload gan2shape
+run "config 3 with flip3: batch 32" --workload gan2shape --flip
 run "face3d mesh_cython family" --workload mesh_family
 python3 - <<PY
 import json
