@@ -247,7 +247,12 @@ def gan2shape_workload(args):
     dom = max(ktimes, key=lambda k: ktimes[k][1])
     dom_avg_s = ktimes[dom][1] / ktimes[dom][0] / 1e3
     V, F = hw * hw, 2 * (hw - 1) * (hw - 1)
-    dom_bytes = {"k_raster_tiles": 12 * V + 12 * F + 20 * S * S,
+    # algorithmic bytes per batch entry of the passes that can dominate: screen vertices in, z-buffer (8 B / raster
+    # pixel) out; vertices + z-buffer + depth-map gradient in, nine sums per triangle out; ...
+    dom_bytes = {"k_g2s_raster": 12 * V + 8 * S * S,
+                 "k_g2s_depth_faces": 12 * V + 12 * S * S + 36 * F,
+                 "k_g2s_sample_backward": hw * hw * (12 + 12 + 4 + 12) + 12 * S * S + 12 * V,
+                 "k_raster_tiles": 12 * V + 12 * F + 20 * S * S,
                  "k_backward_depth_map": 24 * S * S + 12 * V + 12 * F + 12 * V}.get(dom)
     roof = None
     if dom_bytes is not None:

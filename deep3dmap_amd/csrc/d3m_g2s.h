@@ -273,6 +273,7 @@ struct G2SStage {
     float inv_bw[G2S_PW];
     int pre[WAVE + 1];
     __attribute__((aligned(16))) unsigned char head[G2S_HEADS];
+    uint32_t ring[2 * WAVE];            // candidates that passed the cheap test, waiting for a full wave of them
 };
 
 // lane j < G2S_PW <- pair (wave's first pair + j): returns its candidate count (0: culled / off screen / out of range)
@@ -297,15 +298,24 @@ __device__ __forceinline__ int g2s_stage_pair(const G2S& g, G2SStage& st, long p
     return cnt;
 }
 
-// body(owner lane, pixel x, pixel y) for every candidate of the staged pairs, 64 per step
-template <class F>
-__device__ __forceinline__ void g2s_candidates(G2SStage& st, int cnt, F&& body) {
+// Every candidate of the staged pairs, 64 per step, in two phases: cheap(owner lane, x, y) -> bool on every candidate;
+// the ones that pass wait in a ring until a full wave of them has gathered (and at the end), and costly(owner lane, x, y)
+// then runs on 64 busy lanes instead of on the ~third of a step's candidates that survive (k_raster_tiles' scheme).
+template <class Cheap, class Costly>
+__device__ __forceinline__ void g2s_candidates(G2SStage& st, int cnt, Cheap&& cheap, Costly&& costly) {
     const int lane = lane_id();
     const int incl = wave_inclusive_scan(cnt);
     if (lane == 0) st.pre[0] = 0;
     st.pre[lane + 1] = incl;
     const int total = __shfl(incl, 63, 64);
     int carry = 0;                                  // wave-uniform: mark of the last candidate so far
+    int head = 0, waiting = 0;                      // wave-uniform: the ring
+    auto drain = [&](int n) {
+        if (lane < n) {
+            const uint32_t e = st.ring[(head + lane) & (2 * WAVE - 1)];
+            costly((int)(e & 63u), (int)((e >> 6) & 0x1FFFu), (int)(e >> 19));
+        }
+    };
     for (int w0 = 0; w0 < total; w0 += G2S_HEADS) {
         reinterpret_cast<uint4*>(st.head)[lane] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
@@ -318,15 +328,29 @@ __device__ __forceinline__ void g2s_candidates(G2SStage& st, int cnt, F&& body) 
             uint32_t own = wave_max_scan(c < wend ? (uint32_t)st.head[c - w0] : 0u);
             own = max(own, (uint32_t)carry);
             carry = __builtin_amdgcn_readlane((int)own, 63);
+            bool pass = false;
+            uint32_t ent = 0;
             if (c < wend) {
                 const int lo = (int)own - 1, local = c - st.pre[lo], bw = st.bw[lo];
                 int row = (int)((float)local * st.inv_bw[lo]), col = local - row * bw;       // local / bw, fixed up
                 if (col < 0) { row--; col += bw; } else if (col >= bw) { row++; col -= bw; }
-                body(lo, st.x0[lo] + col, st.y0[lo] + row);
+                const int xi = st.x0[lo] + col, yi = st.y0[lo] + row;
+                pass = cheap(lo, xi, yi);
+                ent = (uint32_t)lo | ((uint32_t)xi << 6) | ((uint32_t)yi << 19);              // S <= 8192
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) st.ring[(head + waiting + mask_rank(m)) & (2 * WAVE - 1)] = ent;
+            waiting += __popcll(m);
+            wave_lds_sync();
+            if (waiting >= WAVE) {
+                drain(WAVE);
+                head = (head + WAVE) & (2 * WAVE - 1);
+                waiting -= WAVE;
             }
         }
         wave_lds_sync();                            // before the marks are cleared again
     }
+    if (waiting > 0) drain(waiting);
 }
 
 // warp_canon_depth's coverage: candidates that pass the reference's tests (KCU:110-139 through d3m_device.h: same
@@ -338,28 +362,31 @@ __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
     const long pair = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * G2S_PW + lane_id();
     bool reversed;
     const int cnt = g2s_stage_pair(g, st, pair, Ft, reversed);
-    g2s_candidates(st, cnt, [&](int lo, int xi, int yi) {
-        float face[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : st.face[k][lo];
-        if (!inside_face(face, pixel_center(xi, S), pixel_center(yi, S))) return;
-        const int fid = st.fid[lo];
+    auto slot_of = [&](int lo, int xi, int yi) {
         const long owner_pair = pair - lane_id() + lo;                 // (the pairs of a wave may straddle two views)
-        unsigned long long* slot = g.zbuf + ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
-        // early z: the interpolated depth cannot fall below the smallest vertex depth by more than a few ulp
-        // (k_raster_tiles), so a triangle whose nearest vertex lies behind the pixel's current winner is skipped
-        const float z0 = st.face[2][lo], z1 = st.face[5][lo], z2 = st.face[8][lo];
-        const float zmin = fminf(z0, fminf(z1, z2));
-        const unsigned long long cur = *slot;
-        if (zmin > 0.0f && (uint32_t)(~ordered_bits(zmin * 0.99999f)) < (uint32_t)(cur >> 32)) return;
-        face[2] = z0; face[5] = z1; face[8] = z2;
-        float finv[9], w[3], zp;
+        return g.zbuf + ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
+    };
+    g2s_candidates(st, cnt,
+        [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
+            float face[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) finv[k] = st.finv[k][lo];
-        if (!weights_depth(face, finv, xi, yi, g.near, g.far, w, zp)) return;
-        const unsigned long long e = g2s_bid(zp, fid);
-        if (e > cur) atomicMax(slot, e);
-    });
+            for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : st.face[k][lo];
+            if (!inside_face(face, pixel_center(xi, S), pixel_center(yi, S))) return false;
+            // early z: the interpolated depth cannot fall below the smallest vertex depth by more than a few ulp
+            // (k_raster_tiles), so a triangle whose nearest vertex lies behind the pixel's current winner is skipped
+            const float zmin = fminf(st.face[2][lo], fminf(st.face[5][lo], st.face[8][lo]));
+            const unsigned long long cur = *slot_of(lo, xi, yi);
+            return !(zmin > 0.0f && (uint32_t)(~ordered_bits(zmin * 0.99999f)) < (uint32_t)(cur >> 32));
+        },
+        [&](int lo, int xi, int yi) {              // costly: barycentrics and depth (seven divisions), the bid
+            float face[9], finv[9], w[3], zp;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
+            if (!weights_depth(face, finv, xi, yi, g.near, g.far, w, zp)) return;
+            const unsigned long long e = g2s_bid(zp, st.fid[lo]);
+            unsigned long long* slot = slot_of(lo, xi, yi);
+            if (e > *slot) atomicMax(slot, e);
+        });
 }
 
 // grid (split_s, Bh): with flip a lane handles its pixel in both halves of the batch, which share the mask product.
@@ -554,29 +581,33 @@ __global__ void __launch_bounds__(256) k_g2s_depth_faces(G2S g) {
 #pragma unroll
         for (int k = 0; k < 9; k++) s_acc[k][lane] = 0.0f;
     }
-    g2s_candidates(st, cnt, [&](int lo, int xi, int yi) {
+    auto pixel_of = [&](int lo, int xi, int yi) {
         const long owner_pair = pair - lane + lo;
-        const size_t p = ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
-        if (g2s_bid_face(g.zbuf[p]) != st.fid[lo]) return;
-        float face[9], finv[9], w[3], zp;
+        return ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
+    };
+    g2s_candidates(st, cnt,
+        [&](int lo, int xi, int yi) { return g2s_bid_face(g.zbuf[pixel_of(lo, xi, yi)]) == st.fid[lo]; },
+        [&](int lo, int xi, int yi) {
+            const size_t p = pixel_of(lo, xi, yi);
+            float face[9], finv[9], w[3], zp;
 #pragma unroll
-        for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
-        weights_depth(face, finv, xi, yi, g.near, g.far, w, zp);
-        float tmp[2] = {0, 0};
+            for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
+            weights_depth(face, finv, xi, yi, g.near, g.far, w, zp);
+            float tmp[2] = {0, 0};
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < 2; k++) {
 #pragma unroll
-            for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / face[3 * l + 2];     // KCU:582
-        }
-        const float gd = g.grad_depth_map[p], depth2 = zp * zp;
+                for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / face[3 * l + 2];     // KCU:582
+            }
+            const float gd = g.grad_depth_map[p], depth2 = zp * zp;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float z_k = face[3 * k + 2];
-            atomicAdd(&s_acc[3 * k + 0][lo], -gd * tmp[0] * w[k] * depth2 * (float)S / 2.0f);          // KCU:588
-            atomicAdd(&s_acc[3 * k + 1][lo], -gd * tmp[1] * w[k] * depth2 * (float)S / 2.0f);
-            atomicAdd(&s_acc[3 * k + 2][lo], gd * w[k] * depth2 / (z_k * z_k));                        // KCU:575
-        }
-    });
+            for (int k = 0; k < 3; k++) {
+                const float z_k = face[3 * k + 2];
+                atomicAdd(&s_acc[3 * k + 0][lo], -gd * tmp[0] * w[k] * depth2 * (float)S / 2.0f);          // KCU:588
+                atomicAdd(&s_acc[3 * k + 1][lo], -gd * tmp[1] * w[k] * depth2 * (float)S / 2.0f);
+                atomicAdd(&s_acc[3 * k + 2][lo], gd * w[k] * depth2 / (z_k * z_k));                        // KCU:575
+            }
+        });
     wave_lds_sync();
     if (lane < G2S_PW && pair < (long)g.B * Ft) {
         float* o = g.grad_tri + (size_t)pair * 9;

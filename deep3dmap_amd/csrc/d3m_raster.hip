@@ -1142,6 +1142,7 @@ static int to_g2s(const d3m_g2s_block* h, G2S& g) {
     const int B = h->batch_size, H = h->height, W = h->width, s = h->image_size;
     if (B <= 0 || H < 3 || W < 3 || s < 2 || (long)B * H * W > 0x3FFFFFFFL || (long)B * s * s > 0x0FFFFFFFL) return D3M_ERR_INVALID;
     if (h->flip && (B & 1)) return D3M_ERR_INVALID;
+    if (s * (h->anti_aliasing ? 2 : 1) > 8192) return D3M_ERR_INVALID;      // the candidate walk packs pixel coordinates in 13 bits
     if (!h->inv_K || !h->K || !h->depth || !h->albedo || !h->light_a || !h->light_b || !h->light_d || !h->rot || !h->trans ||
         !h->diffuse_shading || !h->texture || !h->recon_im || !h->recon_im_mask || !h->losses || !h->screen_vertices ||
         !h->zbuffer || !h->scratch)

@@ -133,25 +133,33 @@ def test_committed_bench_line_and_profiles_are_consistent():
     import json
     sys.path.insert(0, ROOT)
     import bench
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_final.json")))
+    R = "r03"                                           # the round whose artefacts bench.py reads (the newest)
+    line = json.load(open(os.path.join(ROOT, "profiles", f"{R}_bench_final.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "dropin"):
         assert key in line, key
     assert line["unit"] == "Mpix/s" and line["vs_baseline"] is None and line["dtype"] == "f32"
     assert "workload" in line["config"] and "model" not in line["config"]
     roof = line["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
     traffic, traffic_src = bench.measured_traffic(roof["kernel"])
-    assert roof["traffic"] == traffic and roof["traffic_source"] == traffic_src and traffic_src.startswith("profiles/r02_")
+    assert roof["traffic"] == traffic and roof["traffic_source"] == traffic_src and traffic_src.startswith(f"profiles/{R}_")
     valu, valu_src = bench.measured_valu(roof["kernel"])
     assert roof.get("valu_wave_instructions") == valu and roof.get("valu_source") == valu_src
     assert line["cpu_baseline"]["kind"] in ("port", "reference") and line["cpu_baseline"]["cores"] >= 1
-    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_final.csv")))]
-    row = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_kernel_stats_final.csv")))
+    names = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{R}_kernel_stats_final.csv")))]
+    row = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{R}_kernel_stats_final.csv")))
            if roof["kernel"] in r["Name"]]
     assert names and row
     # rocprofv3's average duration of that kernel agrees with the HIP-event average in the bench line
     assert abs(float(row[0]["AverageNs"]) / 1e3 - roof["avg_launch_us"]) < 0.1 * roof["avg_launch_us"]
+    # the drop-in form of the same step rides in the line, and the gan2shape block's line carries its launch count
+    assert line["dropin"]["api"].startswith("Renderer.render") and 0 < line["dropin"]["value"] < line["value"]
+    g2s = json.load(open(os.path.join(ROOT, "profiles", f"{R}_bench_gan2shape.json")))
+    assert g2s["launches_per_step"] <= 20 and g2s["ms_per_step"] <= 0.20 and "roofline" in g2s
+    stats = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{R}_kernel_stats_gan2shape.csv")))]
+    replayed = [n for n in stats if "k_g2s_" in n]
+    assert len(replayed) == 9
 
 
 _WORKER = r"""
