@@ -34,13 +34,35 @@ def _close(a, b, tol=1e-5):
     assert err <= tol, err
 
 
-def _images_close(a, b, frac=0.02, tol=2e-3):
-    """rendered images: equal up to the handful of edge pixels whose coverage flips with the last bits of the projected
-    vertices (torch-CPU vs HIP camera arithmetic)."""
+def _images_close(a, b, frac=0.004, tol=2e-3):
+    """rendered MESH frames: the product composes a frame's rigid motions into ONE (A, t) on [B,3,3] before it moves the
+    points, the oracle moves them step by step as the reference does -- the vertices agree to an ulp or two, and an edge
+    pixel whose centre lies that close to an edge may flip.  Everything else must agree to `tol`; the flipped fraction is
+    bounded (measured: <= 0.2 % of the pixels at 32x32 .. 64x64)."""
     a, b = a.detach().cpu(), b.detach().cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     bad = ((a - b).abs() > tol).float().mean()
     assert float(bad) <= frac, float(bad)
+
+
+def _resampled_close(a, b, tol=5e-4):
+    """grid_sample frames with the SAME (R, t) on both sides (_same_view_on_both_sides): identical vertices, identical
+    coverage, so every pixel must agree -- to the f32 noise of a sampling coordinate scaled by the focal length"""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert float((a - b).abs().max()) <= tol, float((a - b).abs().max())
+
+
+def _same_view_on_both_sides(rg, ro):
+    """set_transform_matrices on the HIP renderer from the ORACLE's (R, t) (host trigonometry): the two then move
+    bit-identical vertices, rasterize the same coverage, and images can be held to float noise instead of a fraction of
+    flipped edge pixels"""
+    from oracle import nr_oracle as O
+
+    def set_view(view):
+        rot, trans = O.get_transform_matrices(view.detach().cpu())
+        rg.rot_mat, rg.trans_xyz = rot.cuda(), trans.cuda()
+    rg.set_transform_matrices = set_view
 
 
 # ---- a18: helpers against the reference's own outputs (golden d3m/*) --------------------------------------------------
@@ -131,16 +153,21 @@ def test_render_given_view_both_branches():
     rg, ro = _pair(hw)
     depth, im, view = _scene(b, hw, 3)
     mask = (torch.rand(b, 1, hw, hw) > 0.3).float()
+    _same_view_on_both_sides(rg, ro)          # (the mesh branch composes its own Rigid from the view: not affected)
     for grid_sample in (True, False):
+        close = _resampled_close if grid_sample else _images_close
         a = ro.render_given_view(im, depth, view, grid_sample=grid_sample)
         g = rg.render_given_view(im.cuda(), depth.cuda(), view.cuda(), grid_sample=grid_sample)
-        _images_close(g, a)
+        close(g, a)
         a_im, a_m = ro.render_given_view(im, depth, view, mask=mask if grid_sample else mask.repeat(1, 3, 1, 1),
                                          grid_sample=grid_sample)
         g_im, g_m = rg.render_given_view(im.cuda(), depth.cuda(), view.cuda(),
                                          mask=(mask if grid_sample else mask.repeat(1, 3, 1, 1)).cuda(), grid_sample=grid_sample)
-        _images_close(g_im, a_im)
-        _images_close(g_m, a_m, frac=0.03)
+        close(g_im, a_im)
+        if grid_sample:     # 'nearest' flips where the coordinate noise crosses a texel boundary
+            assert float((g_m.cpu() != a_m).float().mean()) < 2e-3
+        else:
+            _images_close(g_m, a_m)
 
 
 def test_render_yaw_and_render_view():
@@ -159,17 +186,18 @@ def test_render_yaw_and_render_view():
         g = rg.render_yaw(ig, dg, **{k: (v.cuda() if torch.is_tensor(v) and k != "rotations" else v) for k, v in kw.items()})
         assert g.shape == (b, 2, 3, hw, hw)
         _images_close(g, a)
-    # grid_sample path
+    # grid_sample path, same (R, t) on both sides: every pixel
+    _same_view_on_both_sides(rg, ro)
     a = ro.render_yaw(im, depth, rotations=rot, v_before=view, grid_sample=True)
     g = rg.render_yaw(ig, dg, rotations=rot, v_before=view.cuda(), grid_sample=True)
-    _images_close(g, a)
+    _resampled_close(g, a)
     # default sweep length
     assert rg.render_yaw(ig, dg, nsample=3, maxr=30).shape == (b, 3, 3, hw, hw)
     for grid_sample in (False, True):
         a = ro.render_view(im, depth, v_before=view, maxr=[10, 30], nsample=[2, 3], grid_sample=grid_sample)
         g = rg.render_view(ig, dg, v_before=view.cuda(), maxr=[10, 30], nsample=[2, 3], grid_sample=grid_sample)
         assert g.shape == (b, 5, 3, hw, hw)
-        _images_close(g, a)
+        (_resampled_close if grid_sample else _images_close)(g, a)
 
 
 def test_crop_mesh_has_no_gradient_and_says_so():
@@ -207,18 +235,6 @@ def test_gan2shape_step_batch16_against_oracle():
     rel_max = lambda a, b_: float((a - b_).abs().max() / b_.abs().max())
     assert rel_max(w1, w0) < 1e-5 and abs(l1 - l0) < 1e-5 * abs(l0)
     assert rel_max(g1, g0) < 1e-3 and rel_max(r1, r0) < 1e-3 and rel_max(t1, t0) < 1e-3
-
-
-def _same_view_on_both_sides(rg, ro):
-    """set_transform_matrices on the HIP renderer from the ORACLE's (R, t) (host trigonometry): the two then move
-    bit-identical vertices, rasterize the same coverage, and images can be held to float noise instead of a fraction of
-    flipped edge pixels"""
-    from oracle import nr_oracle as O
-
-    def set_view(view):
-        rot, trans = O.get_transform_matrices(view.detach().cpu())
-        rg.rot_mat, rg.trans_xyz = rot.cuda(), trans.cuda()
-    rg.set_transform_matrices = set_view
 
 
 def test_grid_sample_frames_values_and_gradients_on_the_hip_resampler():
