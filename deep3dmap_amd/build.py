@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libd3m_raster.so")
 # product library; build_library() ignores it.
 LOAD_PATH = os.environ.get("D3M_LIB_PATH", LIB_PATH)
 SOURCES = ["d3m_raster.hip"]
-HEADERS = ["d3m_launch.h", "d3m_device.h", "d3m_forward.h", "d3m_backward.h", "d3m_edge_grad.h", "d3m_face_major.h", "d3m_lit.h", "d3m_aux.h", "d3m_textures.h", "d3m_mesh.h", "d3m_uv.h", "d3m_g2s.h",
+HEADERS = ["d3m_launch.h", "d3m_device.h", "d3m_forward.h", "d3m_backward.h", "d3m_edge_grad.h", "d3m_face_major.h", "d3m_lit.h", "d3m_aux.h", "d3m_textures.h", "d3m_mesh.h", "d3m_uv.h", "d3m_g2s.h", "d3m_bid.h",
            os.path.join("..", "..", "include", "d3m_raster.h")]
 # -ffp-contract=off: every f32 operation rounds once, so coverage decisions are bit-identical to the
 # reference algorithm evaluated without FMA contraction ("Arithmetic contract").

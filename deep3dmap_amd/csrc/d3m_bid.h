@@ -1,0 +1,212 @@
+// d3m_bid.h -- coverage by BIDDING: the rasterizer for meshes whose triangles are a pixel or a few.
+//
+// d3m_forward.h bins faces to 8x8 tiles and gives every tile a wave: three passes of set-up (count, allocate, fill)
+// before the first pixel is tested, and every (face, tile) pair pays for the face's set-up again.  When the triangles
+// are no bigger than a tile's pixels that is most of the work (a 1 M-triangle mesh at 1024^2: 0.62 ms of binning + 1.08 ms
+// of tile pass per 8 views).  Here the faces come to the pixels instead: a wave stages PW triangles (pairs, with
+// fill_back: at most one of a pair's two orientations faces the camera) in LDS -- vertices, pixel-space inverse,
+// bounding box --, numbers the boxes' pixels through, and takes the next 64 (pixel, face) candidates per step whichever
+// face they belong to; the ones that pass the reference's tests (KCU:110-139 through d3m_device.h: same operations, same
+// bits) BID ~((ordered depth bits << 32) | face) for their pixel in a 64-bit z-buffer with atomicMax -- "nearest, lowest
+// index among equals" (KCU:142), independent of order.  A per-pixel pass then turns the winners into the maps.
+#pragma once
+#include "d3m_device.h"
+#include "d3m_forward.h"
+
+namespace d3m {
+
+// z-buffer entries: the bid of (depth zp, face fid) is ~((ordered_bits(zp) << 32) | fid), so that atomicMax keeps the
+// nearest face, the lowest index among equal depths (KCU:142), and 0 means "nothing here"
+__device__ __forceinline__ unsigned long long bid_key(float zp, int fid) {
+    return ~(((unsigned long long)ordered_bits(zp) << 32) | (uint32_t)fid);
+}
+__device__ __forceinline__ float bid_depth(unsigned long long e, float far) {
+    if (e == 0ull) return far;                                  // uncovered pixels keep `far` (NR/rasterize.py:55)
+    const uint32_t u = ~(uint32_t)(e >> 32);
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+__device__ __forceinline__ int bid_face(unsigned long long e) { return e == 0ull ? -1 : (int)~(uint32_t)e; }
+
+constexpr int BID_HEADS = 16 * WAVE;        // candidates per window of owner marks (one uint4 per lane)
+// what lane j < PW stages for its face; the candidate walk's scratch
+template <int PW>
+struct BidStage {
+    float face[9][PW], finv[9][PW];
+    int fid[PW], x0[PW], y0[PW], bw[PW];
+    float inv_bw[PW];
+    int pre[WAVE + 1];
+    __attribute__((aligned(16))) unsigned char head[BID_HEADS];
+    uint32_t ring[2 * WAVE];            // candidates that passed the cheap test, waiting for a full wave of them
+};
+
+// Every candidate of the staged pairs, 64 per step, in two phases: cheap(owner lane, x, y) -> bool on every candidate;
+// the ones that pass wait in a ring until a full wave of them has gathered (and at the end), and costly(owner lane, x, y)
+// then runs on 64 busy lanes instead of on the ~third of a step's candidates that survive (k_raster_tiles' scheme).
+template <int PW, class Cheap, class Costly>
+__device__ __forceinline__ void bid_candidates(BidStage<PW>& st, int cnt, Cheap&& cheap, Costly&& costly) {
+    const int lane = lane_id();
+    const int incl = wave_inclusive_scan(cnt);
+    if (lane == 0) st.pre[0] = 0;
+    st.pre[lane + 1] = incl;
+    const int total = __shfl(incl, 63, 64);
+    int carry = 0;                                  // wave-uniform: mark of the last candidate so far
+    int head = 0, waiting = 0;                      // wave-uniform: the ring
+    auto drain = [&](int n) {
+        if (lane < n) {
+            const uint32_t e = st.ring[(head + lane) & (2 * WAVE - 1)];
+            costly((int)(e & 63u), (int)((e >> 6) & 0x1FFFu), (int)(e >> 19));
+        }
+    };
+    for (int w0 = 0; w0 < total; w0 += BID_HEADS) {
+        reinterpret_cast<uint4*>(st.head)[lane] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        const int start = incl - cnt;
+        if (cnt > 0 && start >= w0 && start < w0 + BID_HEADS) st.head[start - w0] = (unsigned char)(lane + 1);
+        wave_lds_sync();
+        const int wend = min(total, w0 + BID_HEADS);
+        for (int c0 = w0; c0 < wend; c0 += WAVE) {
+            const int c = c0 + lane;
+            uint32_t own = wave_max_scan(c < wend ? (uint32_t)st.head[c - w0] : 0u);
+            own = max(own, (uint32_t)carry);
+            carry = __builtin_amdgcn_readlane((int)own, 63);
+            bool pass = false;
+            uint32_t ent = 0;
+            if (c < wend) {
+                const int lo = (int)own - 1, local = c - st.pre[lo], bw = st.bw[lo];
+                int row = (int)((float)local * st.inv_bw[lo]), col = local - row * bw;       // local / bw, fixed up
+                if (col < 0) { row--; col += bw; } else if (col >= bw) { row++; col -= bw; }
+                const int xi = st.x0[lo] + col, yi = st.y0[lo] + row;
+                pass = cheap(lo, xi, yi);
+                ent = (uint32_t)lo | ((uint32_t)xi << 6) | ((uint32_t)yi << 19);              // S <= 8192
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+            if (pass) st.ring[(head + waiting + mask_rank(m)) & (2 * WAVE - 1)] = ent;
+            waiting += __popcll(m);
+            wave_lds_sync();
+            if (waiting >= WAVE) {
+                drain(WAVE);
+                head = (head + WAVE) & (2 * WAVE - 1);
+                waiting -= WAVE;
+            }
+        }
+        wave_lds_sync();                            // before the marks are cleared again
+    }
+    if (waiting > 0) drain(waiting);
+}
+
+
+// ---- the generic passes: any indexed mesh -----------------------------------------------------------------------------
+// k_bid_faces: lane j < PW of a wave stages face (pair) j of the wave's PW -- read through the indices, oriented, its
+// dense copy left in faces_dense_out for the later passes (as k_bin_count does) -- then the wave walks the candidates.
+// PAIRED (fill_back): lane j handles index triple j in both orientations; at most one faces the camera.
+template <class FS, int PW, bool PAIRED>
+__global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __restrict__ zbuf,
+                                                   float* __restrict__ faces_dense_out, int B, int S, float near, float far,
+                                                   unsigned char* __restrict__ marks, int* __restrict__ marks_count) {
+    __shared__ BidStage<PW> s_stage[4];
+    if (marks_count && blockIdx.x == 0 && threadIdx.x == 0) *marks_count = 0;     // (as k_bin_count: see RasterOut)
+    __shared__ int s_view[4][PW];
+    BidStage<PW>& st = s_stage[threadIdx.x >> 6];
+    int (&view)[PW] = s_view[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int F = fs.num_faces(), Fl = PAIRED ? F / 2 : F;
+    const long unit = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PW + lane;
+    int cnt = 0;
+    if (lane < PW && unit < (long)B * Fl) {
+        const int b = (int)(unit / Fl), f0 = (int)(unit - (long)b * Fl);
+        if (marks) {                                  // "owns a pixel": set by the resolve pass
+            marks[(size_t)b * F + f0] = 0;
+            if (PAIRED) marks[(size_t)b * F + f0 + Fl] = 0;
+        }
+        float v[9], face[9], finv[9];
+        fs.load(b, f0, v);
+        bool rev = false, front = !backside(v);
+        if (!front && PAIRED) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) face[k] = v[(2 - k / 3) * 3 + k % 3];
+            rev = true;
+            front = !backside(face);
+        }
+        if (!rev) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) face[k] = v[k];
+        }
+        if (front) {
+            const int fid = rev ? f0 + Fl : f0;
+            if (faces_dense_out) {
+                float* o = faces_dense_out + ((size_t)b * F + fid) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) o[k] = face[k];
+            }
+            int x0, x1, y0, y1;
+            if (pixel_bbox(face, S, x0, x1, y0, y1)) {
+                face_inverse(face, S, finv);
+#pragma unroll
+                for (int k = 0; k < 9; k++) { st.face[k][lane] = face[k]; st.finv[k][lane] = finv[k]; }
+                const int bw = x1 - x0 + 1;
+                st.fid[lane] = fid; st.x0[lane] = x0; st.y0[lane] = y0; st.bw[lane] = bw;
+                st.inv_bw[lane] = 1.0f / (float)bw;
+                view[lane] = b;
+                cnt = bw * (y1 - y0 + 1);
+            }
+        }
+    }
+    bid_candidates<PW>(st, cnt,
+        [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
+            float face[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : st.face[k][lo];
+            if (!inside_face(face, pixel_center(xi, S), pixel_center(yi, S))) return false;
+            const float zmin = fminf(st.face[2][lo], fminf(st.face[5][lo], st.face[8][lo]));
+            const unsigned long long cur = zbuf[((size_t)view[lo] * S + yi) * S + xi];
+            return !(zmin > 0.0f && (uint32_t)(~ordered_bits(zmin * 0.99999f)) < (uint32_t)(cur >> 32));
+        },
+        [&](int lo, int xi, int yi) {              // costly: barycentrics and depth (seven divisions), the bid
+            float face[9], finv[9], w[3], zp;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
+            if (!weights_depth(face, finv, xi, yi, near, far, w, zp)) return;
+            const unsigned long long e = bid_key(zp, st.fid[lo]);
+            unsigned long long* slot = zbuf + ((size_t)view[lo] * S + yi) * S + xi;
+            if (e > *slot) atomicMax(slot, e);
+        });
+}
+
+// k_bid_resolve: one lane per pixel: the winner's weights and depth recomputed (same arithmetic -> same bits), every
+// pixel of every map written (uncovered: the reference's initial values), the faces that own a pixel marked.
+__global__ void __launch_bounds__(256) k_bid_resolve(DenseFaces fs, const unsigned long long* __restrict__ zbuf, RasterOut out,
+                                                    int B, int S, float near, float far) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < (long)B * S * S;
+    const unsigned long long e = on ? zbuf[i] : 0ull;
+    const int fid = bid_face(e);
+    if (out.marks) {            // a run of pixels of one face along a row speaks up once
+        const int left = __shfl_up(fid, 1, 64);
+        if (fid >= 0 && !(lane_id() > 0 && left == fid)) out.marks[(size_t)(i / ((long)S * S)) * fs.num_faces() + fid] = 1;
+    }
+    if (!on) return;
+    if (fid >= 0) {
+        const int b = (int)(i / ((long)S * S)), pix = (int)(i - (long)b * S * S);
+        float face[9], finv[9], w[3], zp;
+        fs.load(b, fid, face);
+        face_inverse(face, S, finv);
+        weights_depth(face, finv, pix % S, pix / S, near, far, w, zp);
+        out.depth_map[i] = zp;
+        out.face_index_map[i] = fid;
+        out.weight_map[3 * i + 0] = w[0]; out.weight_map[3 * i + 1] = w[1]; out.weight_map[3 * i + 2] = w[2];
+        if (out.face_inv_map) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
+        }
+    } else {
+        out.depth_map[i] = far;
+        out.face_index_map[i] = -1;
+        out.weight_map[3 * i + 0] = 0.0f; out.weight_map[3 * i + 1] = 0.0f; out.weight_map[3 * i + 2] = 0.0f;
+        if (out.face_inv_map) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = 0.0f;
+        }
+    }
+}
+
+}  // namespace d3m

@@ -28,6 +28,7 @@
 // materialised between them, and how many float atomics a pass issues (~37 G/s on this chip in these patterns).
 #pragma once
 #include "d3m_aux.h"
+#include "d3m_bid.h"
 #include "d3m_forward.h"
 
 namespace d3m {
@@ -109,18 +110,6 @@ __device__ __forceinline__ void g2s_inverse_view(const float* R, const float* t,
     }
 }
 
-// z-buffer entries: the bid of (depth zp, face fid) is ~((ordered_bits(zp) << 32) | fid), so that atomicMax keeps the
-// nearest face, the lowest index among equal depths (KCU:142), and 0 means "nothing here"
-__device__ __forceinline__ unsigned long long g2s_bid(float zp, int fid) {
-    return ~(((unsigned long long)ordered_bits(zp) << 32) | (uint32_t)fid);
-}
-__device__ __forceinline__ float g2s_bid_depth(unsigned long long e, float far) {
-    if (e == 0ull) return far;                                  // uncovered pixels keep `far` (NR/rasterize.py:55)
-    const uint32_t u = ~(uint32_t)(e >> 32);
-    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
-}
-__device__ __forceinline__ int g2s_bid_face(unsigned long long e) { return e == 0ull ? -1 : (int)~(uint32_t)e; }
-
 // recon_depth of output pixel (yo, xo): the raster's depth flipped and 2x2-pooled as rasterize_rgbad does
 // (NR/rasterize.py:305-326, same summation order as k_output_epilogue), then clamped (CR:122-124).  `pooled` = before.
 __device__ __forceinline__ float g2s_recon_depth(const G2S& g, int b, int yo, int xo, float& pooled) {
@@ -128,7 +117,7 @@ __device__ __forceinline__ float g2s_recon_depth(const G2S& g, int b, int yo, in
     float acc = 0.0f;
     for (int dy = 0; dy < n; dy++)
         for (int dx = 0; dx < n; dx++)
-            acc += g2s_bid_depth(g.zbuf[((size_t)b * S + (S - 1 - (yo * n + dy))) * S + xo * n + dx], g.far);
+            acc += bid_depth(g.zbuf[((size_t)b * S + (S - 1 - (yo * n + dy))) * S + xo * n + dx], g.far);
     pooled = acc * (g.aa ? 0.25f : 1.0f);
     return fminf(fmaxf(pooled, g.depth_lo), g.depth_hi);
 }
@@ -252,29 +241,17 @@ __global__ void __launch_bounds__(256) k_g2s_front(G2S g, ZeroRanges z) {
     g.screen_vertices[3 * i] = o[0]; g.screen_vertices[3 * i + 1] = o[1]; g.screen_vertices[3 * i + 2] = o[2];
 }
 
-// ---- the (pixel, triangle) candidates of 64 triangle pairs, dealt evenly to the 64 lanes of a wave ---------------------
-// A depth map's mesh seen from the side has a few long slivers among its pixel-sized triangles (bounding boxes of
-// 16 px in the median, 200 at the 99th percentile, > 1000 at the top): lanes that each walk their own triangle's box
-// wait for the longest of the wave.  Instead lane j stages pair j's front-facing triangle in LDS (vertices, pixel-space
-// inverse, box), the boxes' pixels are numbered through (prefix sum), and every step of the walk takes the next 64
-// candidates whichever triangle they belong to -- the owner of a candidate is the running maximum of "first candidate
-// of triangle j" marks, as in k_raster_tiles.
-constexpr int G2S_HEADS = 16 * WAVE;        // candidates per window of owner marks (one uint4 per lane)
+// ---- the mesh's coverage by bidding (d3m_bid.h): G2S_PW triangle pairs of the implicit grid per wave ----------------------
 // Pairs per wave.  A wave's walk is a chain of dependent steps (LDS marks -> owner -> z-buffer entry -> bid), ~0.5 us
-// each, and the pass ends with its slowest wave: 64 pairs per wave left 2 waves per SIMD and tail waves of 100+ steps
-// (0.09 ms for the pass); 16 pairs -- the other lanes only help with the walk -- give 8 waves per SIMD and short chains.
+// each, and the pass ends with its slowest wave: a depth map's mesh seen from 57 degrees has bounding boxes of 16 px in
+// the median, 200 at the 99th percentile, > 1000 at the top.  64 pairs per wave left 2 waves per SIMD and tail waves of
+// 100+ steps (0.09 ms for the pass); 16 pairs -- the other lanes only help with the walk -- give 8 waves per SIMD and
+// short chains (0.05 ms; 4, 8 and 32 pairs: 0.055-0.059).
 #ifndef D3M_G2S_PAIRS_PER_WAVE
 #define D3M_G2S_PAIRS_PER_WAVE 16
 #endif
 constexpr int G2S_PW = D3M_G2S_PAIRS_PER_WAVE;
-struct G2SStage {
-    float face[9][G2S_PW], finv[9][G2S_PW];
-    int fid[G2S_PW], x0[G2S_PW], y0[G2S_PW], bw[G2S_PW];
-    float inv_bw[G2S_PW];
-    int pre[WAVE + 1];
-    __attribute__((aligned(16))) unsigned char head[G2S_HEADS];
-    uint32_t ring[2 * WAVE];            // candidates that passed the cheap test, waiting for a full wave of them
-};
+typedef BidStage<G2S_PW> G2SStage;
 
 // lane j < G2S_PW <- pair (wave's first pair + j): returns its candidate count (0: culled / off screen / out of range)
 __device__ __forceinline__ int g2s_stage_pair(const G2S& g, G2SStage& st, long pair, int Ft, bool& reversed) {
@@ -298,61 +275,6 @@ __device__ __forceinline__ int g2s_stage_pair(const G2S& g, G2SStage& st, long p
     return cnt;
 }
 
-// Every candidate of the staged pairs, 64 per step, in two phases: cheap(owner lane, x, y) -> bool on every candidate;
-// the ones that pass wait in a ring until a full wave of them has gathered (and at the end), and costly(owner lane, x, y)
-// then runs on 64 busy lanes instead of on the ~third of a step's candidates that survive (k_raster_tiles' scheme).
-template <class Cheap, class Costly>
-__device__ __forceinline__ void g2s_candidates(G2SStage& st, int cnt, Cheap&& cheap, Costly&& costly) {
-    const int lane = lane_id();
-    const int incl = wave_inclusive_scan(cnt);
-    if (lane == 0) st.pre[0] = 0;
-    st.pre[lane + 1] = incl;
-    const int total = __shfl(incl, 63, 64);
-    int carry = 0;                                  // wave-uniform: mark of the last candidate so far
-    int head = 0, waiting = 0;                      // wave-uniform: the ring
-    auto drain = [&](int n) {
-        if (lane < n) {
-            const uint32_t e = st.ring[(head + lane) & (2 * WAVE - 1)];
-            costly((int)(e & 63u), (int)((e >> 6) & 0x1FFFu), (int)(e >> 19));
-        }
-    };
-    for (int w0 = 0; w0 < total; w0 += G2S_HEADS) {
-        reinterpret_cast<uint4*>(st.head)[lane] = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-        const int start = incl - cnt;
-        if (cnt > 0 && start >= w0 && start < w0 + G2S_HEADS) st.head[start - w0] = (unsigned char)(lane + 1);
-        wave_lds_sync();
-        const int wend = min(total, w0 + G2S_HEADS);
-        for (int c0 = w0; c0 < wend; c0 += WAVE) {
-            const int c = c0 + lane;
-            uint32_t own = wave_max_scan(c < wend ? (uint32_t)st.head[c - w0] : 0u);
-            own = max(own, (uint32_t)carry);
-            carry = __builtin_amdgcn_readlane((int)own, 63);
-            bool pass = false;
-            uint32_t ent = 0;
-            if (c < wend) {
-                const int lo = (int)own - 1, local = c - st.pre[lo], bw = st.bw[lo];
-                int row = (int)((float)local * st.inv_bw[lo]), col = local - row * bw;       // local / bw, fixed up
-                if (col < 0) { row--; col += bw; } else if (col >= bw) { row++; col -= bw; }
-                const int xi = st.x0[lo] + col, yi = st.y0[lo] + row;
-                pass = cheap(lo, xi, yi);
-                ent = (uint32_t)lo | ((uint32_t)xi << 6) | ((uint32_t)yi << 19);              // S <= 8192
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-            if (pass) st.ring[(head + waiting + mask_rank(m)) & (2 * WAVE - 1)] = ent;
-            waiting += __popcll(m);
-            wave_lds_sync();
-            if (waiting >= WAVE) {
-                drain(WAVE);
-                head = (head + WAVE) & (2 * WAVE - 1);
-                waiting -= WAVE;
-            }
-        }
-        wave_lds_sync();                            // before the marks are cleared again
-    }
-    if (waiting > 0) drain(waiting);
-}
-
 // warp_canon_depth's coverage: candidates that pass the reference's tests (KCU:110-139 through d3m_device.h: same
 // operations, same bits) bid for their pixel.  One wave per G2S_PW triangle pairs, four independent waves per workgroup.
 __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
@@ -366,7 +288,7 @@ __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
         const long owner_pair = pair - lane_id() + lo;                 // (the pairs of a wave may straddle two views)
         return g.zbuf + ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
     };
-    g2s_candidates(st, cnt,
+    bid_candidates(st, cnt,
         [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
             float face[9];
 #pragma unroll
@@ -383,7 +305,7 @@ __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
 #pragma unroll
             for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
             if (!weights_depth(face, finv, xi, yi, g.near, g.far, w, zp)) return;
-            const unsigned long long e = g2s_bid(zp, st.fid[lo]);
+            const unsigned long long e = bid_key(zp, st.fid[lo]);
             unsigned long long* slot = slot_of(lo, xi, yi);
             if (e > *slot) atomicMax(slot, e);
         });
@@ -585,8 +507,8 @@ __global__ void __launch_bounds__(256) k_g2s_depth_faces(G2S g) {
         const long owner_pair = pair - lane + lo;
         return ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
     };
-    g2s_candidates(st, cnt,
-        [&](int lo, int xi, int yi) { return g2s_bid_face(g.zbuf[pixel_of(lo, xi, yi)]) == st.fid[lo]; },
+    bid_candidates(st, cnt,
+        [&](int lo, int xi, int yi) { return bid_face(g.zbuf[pixel_of(lo, xi, yi)]) == st.fid[lo]; },
         [&](int lo, int xi, int yi) {
             const size_t p = pixel_of(lo, xi, yi);
             float face[9], finv[9], w[3], zp;
