@@ -375,15 +375,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # D3M_BENCH_FORCE_DIST=1 (debug, not used by the driver): initialise the process group and run every collective even
+    # with ONE rank -- the RCCL calls of the N > 1 path (communicator with device_id, the step's all-reduce on the flat device
+    # buffer, barriers, the MAX over ranks) execute on a single-GPU box (tests/test_gpu_multirank.py)
+    dist_on = world > 1 or os.environ.get("D3M_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # Debug overrides (not used by the driver): exercise the N>1 code path on a single-GPU box by putting every
     # rank on device 0 and reducing over gloo instead of RCCL.
     if os.environ.get("D3M_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if dist_on:
         backend = os.environ.get("D3M_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -391,8 +398,9 @@ def main():
             dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from deep3dmap_amd import _lib, synthetic
+    from deep3dmap_amd import _lib, synthetic, multiview
     from deep3dmap_amd.multiview import MultiViewFit
+    multiview.COLLECTIVES_WITH_ONE_RANK = dist_on and world == 1
 
     if args.scaling == "strong":
         assert args.total_views % world == 0, "--total-views must split evenly over the GPUs"
@@ -408,7 +416,7 @@ def main():
     fit.keep_images = args.fit_with_images
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -432,7 +440,7 @@ def main():
         loss, gv, gt = fit.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -474,7 +482,7 @@ def main():
             fit2.step()
         barrier()
         el2 = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([el2], device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el2 = float(tmax.item())
@@ -542,7 +550,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mesh_n, S, ts)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,11 +23,16 @@ def shard_views(n_views, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
+COLLECTIVES_WITH_ONE_RANK = False      # debug (bench.py D3M_BENCH_FORCE_DIST): issue the collective even in a group of one
+
+
 def allreduce_sum_(flat, group=None):
     """In-place SUM-all-reduce of one flat device buffer (one collective per step).  Under "nccl" (= RCCL) the buffer
     stays on the device and travels over xGMI; under "gloo" (CPU-test / single-GPU debug configuration only) it is
     staged through the host."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    if dist.get_world_size(group) == 1 and not COLLECTIVES_WITH_ONE_RANK:
         return flat
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         host = flat.cpu()

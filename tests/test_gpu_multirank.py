@@ -98,3 +98,29 @@ def test_bench_two_ranks_through_torch_distributed_run(scaling):
     assert two["metric"] == one["metric"] and two["unit"] == "Mpix/s"
     assert two["value"] == pytest.approx(two["config"]["total_views"] * 512 * 512 / (two["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert 0.01 * one["value"] < two["value"] < 2.5 * one["value"], (one["value"], two["value"])
+
+
+def test_bench_one_rank_through_rccl():
+    """The RCCL calls of bench.py's N > 1 path on this box's one GPU: `torch.distributed.run --nproc-per-node 1` with
+    D3M_BENCH_FORCE_DIST=1 makes the bench create the "nccl" process group (device_id), issue the step's all-reduce on the
+    flat DEVICE buffer behind every graph replay, the barriers and the MAX-reduce of the elapsed time -- with one rank.  No
+    exchange between GPUs is exercised (that needs the driver's 8-GPU node); what is: the library loads, the communicator
+    comes up, the collectives run on the step's buffers in stream order, and the replayed step still reproduces its eager
+    gradients (asserted inside bench.py)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", D3M_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "D3M_BENCH_BACKEND", "D3M_BENCH_SINGLE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+           "--no-cpu-baseline", "--no-dropin"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    log_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(log_dir, exist_ok=True)
+    with open(os.path.join(log_dir, "bench_one_rank_rccl.log"), "w") as f:
+        f.write(f"--- D3M_BENCH_FORCE_DIST=1 {' '.join(cmd[1:])} (exit {p.returncode}) ---\n{p.stdout}\n{p.stderr[-3000:]}\n")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0

@@ -270,3 +270,67 @@ def test_ops_reject_float64_like_the_reference_extension():
     m = torch.zeros(1, 8, 8, 3, device="cuda")
     with pytest.raises(RuntimeError, match="Float"):
         ops.forward_face_index_map(f, fi, m, m[..., 0].contiguous(), m, m, 8, 0.1, 100.0, 0, 1, 1)
+
+
+def test_c_entry_points_reject_bad_arguments_before_any_launch():
+    """Error behaviour of the C ABI (include/d3m_raster.h: "0 on success, one of the D3M_ERR_* codes otherwise"), called
+    raw: every rejected call returns D3M_ERR_INVALID / D3M_ERR_WORKSPACE and leaves the device alone (a following valid
+    call on the same stream succeeds and d3m_last_hip_error() stays 0)."""
+    import ctypes
+    from deep3dmap_amd import _lib
+    L = _lib.lib()
+    INVALID, WORKSPACE = 1, 2
+    dev = "cuda"
+    z = torch.zeros(4096, device=dev)
+    zi = torch.zeros(4096, device=dev, dtype=torch.int32)
+    p, pi, st = _lib.ptr(z), _lib.ptr(zi), _lib.stream_ptr()
+    # the gan2shape block: no struct, a flipped batch of odd size, a raster beyond the candidate walk's 13-bit coordinates,
+    # a missing buffer, a view of an unknown layout
+    assert L.d3m_g2s_forward(None, st) == INVALID and L.d3m_g2s_backward(None, st) == INVALID
+    blk, cam0 = _lib.D3MG2SBlock(), _lib.D3MCamera()          # complete but for the one defect of each case
+    blk.batch_size, blk.height, blk.width, blk.image_size = 3, 8, 8, 8
+    blk.inv_K_batch = blk.K_batch = 1
+    blk.camera = ctypes.pointer(cam0)
+    for name in ("inv_K", "K", "rot", "trans", "depth", "albedo", "light_a", "light_b", "light_d", "normal", "diffuse_shading",
+                 "texture", "recon_depth", "recon_im", "recon_im_mask", "losses", "screen_vertices", "zbuffer", "scratch"):
+        setattr(blk, name, p)
+    blk.flip = 1
+    assert L.d3m_g2s_forward(ctypes.byref(blk), st) == INVALID                # odd batch with flip3
+    blk.flip, blk.image_size = 0, 8193
+    assert L.d3m_g2s_forward(ctypes.byref(blk), st) == INVALID                # S > 8192
+    blk.image_size, blk.zbuffer = 8, None
+    assert L.d3m_g2s_forward(ctypes.byref(blk), st) == INVALID                # a required buffer is missing
+    blk.zbuffer, blk.view, blk.view_components = p, p, 4
+    assert L.d3m_g2s_forward(ctypes.byref(blk), st) == INVALID                # view of 4 components
+    assert L.d3m_g2s_scratch_floats(0, 8, 8, 8) == 0 and L.d3m_g2s_scratch_floats(2, 8, 8, 8) > 0
+    # the view-synthesis resampler
+    assert L.d3m_warp_resample(None, p, 1, p, 1, p, p, 1.0, p, 3, None, 0, p, None, 1, 8, 8, 8, 8, st) == INVALID
+    assert L.d3m_warp_resample(p, p, 2, p, 1, p, p, 1.0, p, 3, None, 0, p, None, 4, 8, 8, 8, 8, st) == INVALID     # inv_K batch 2 of 4
+    assert L.d3m_warp_resample(p, p, 1, p, 1, p, p, 1.0, p, 0, None, 0, p, None, 1, 8, 8, 8, 8, st) == INVALID     # no channels
+    assert L.d3m_warp_resample_partials(0, 8) <= 0 < L.d3m_warp_resample_partials(8, 8)
+    # coverage on an index-free mesh: the row length must divide the vertex count and fix the triangle count
+    args = lambda tri, tb, V, Ft: (p, tri, tb, V, Ft, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, z.numel() * 4, None, 0, st)
+    assert L.d3m_forward_face_index_map_mesh(*args(None, 1, 16, 18)) == INVALID        # neither indices nor a row length
+    assert L.d3m_forward_face_index_map_mesh(*args(None, -5, 16, 18)) == INVALID       # 16 vertices are no rows of 5
+    assert L.d3m_forward_face_index_map_mesh(*args(None, -4, 16, 17)) == INVALID       # a 4x4 grid has 18 triangles
+    assert L.d3m_forward_face_index_map_mesh(*args(pi, 3, 16, 18)) == INVALID          # index batch 3 of 1
+    tiny = (p, None, -4, 16, 18, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, 64, None, 0, st)
+    assert L.d3m_forward_face_index_map_mesh(*tiny) == WORKSPACE
+    # the camera's adjoint onto an existing gradient; the objective's scratch for small rasters (ADVICE round 2)
+    cam = _lib.D3MCamera()
+    assert L.d3m_camera_backward_add(p, 3, ctypes.byref(cam), p, p, 2, 4, st) == INVALID    # 3 meshes for 2 views
+    assert L.d3m_camera_backward_add(p, 1, None, p, p, 2, 4, st) == INVALID
+    for S in (1, 2, 8, 15, 16, 64):
+        assert L.d3m_render_fit_scratch_floats(2, S) >= 8 + 4 * 2
+    assert L.d3m_last_hip_error() == 0
+    # ... and the stream is still usable: a valid call right behind the rejected ones
+    sv = torch.rand(1, 16, 3, device=dev) * 1.6 - 0.8
+    sv[..., 2] = 1.0 + sv[..., 2].abs()
+    faces = torch.empty(1, 36, 3, 3, device=dev)
+    fi = torch.empty(1, 8, 8, dtype=torch.int32, device=dev)
+    wm, dm = torch.empty(1, 8, 8, 3, device=dev), torch.empty(1, 8, 8, device=dev)
+    ws = torch.empty(int(L.d3m_forward_workspace_bytes(1, 36, 8)), dtype=torch.uint8, device=dev)
+    rc = L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), None, -4, 16, 18, 1, _lib.ptr(faces), _lib.ptr(fi), _lib.ptr(wm), _lib.ptr(dm),
+                                           None, 1, 8, 0.1, 100.0, _lib.ptr(ws), ws.numel(), None, 0, st)
+    torch.cuda.synchronize()
+    assert rc == 0 and int((fi >= 0).sum()) > 0 and L.d3m_last_hip_error() == 0
