@@ -858,9 +858,10 @@ static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole wav
 // reading, up to entry 2*S + 16 of the image arrays; what they read is never used (their lanes are masked), it only
 // has to lie inside the workgroup's LDS allocation.  The arrays are therefore laid out pairs | gradients | values |
 // tail: an overrun of the 8-byte pairs ends in the gradients, one of the 16-byte gradients in the values and the
-// tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  Without
-// PAD (large S) the index is clamped.
-template <bool USE_RGB, bool USE_ALPHA, bool PAD>
+// tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  (Up to round 3
+// rasters above 28 KB of line image walked a second, clamped-index form of the loop -- two reciprocals and a select per
+// visit: the same LDS, and on the 1024^2 configuration 1.66 ms where this form takes 1.46.  Removed.)
+template <bool USE_RGB, bool USE_ALPHA>
 __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w,
                                                                                       float2* __restrict__ lane_partial) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
@@ -1042,7 +1043,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                 const int n_iter = (max_len + EG_ROW - 1) / EG_ROW;
                 float t = (float)(from + rl) - d1_cross;            // t = d1 - d1_cross advances by exact steps
                 v2f acc = {0.0f, 0.0f};
-                if (PAD) {
+                {
                     const float4* pg = s_grd + from + rl;
                     const float2* pd = s_df + from + rl;
                     const float4* pg_to = s_grd + to;
@@ -1071,21 +1072,6 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_
                             pd += EG_ROW;
                             den += (float)EG_ROW;
                         }
-                    }
-                } else {
-                    int d1 = from + rl;
-                    for (int k = 0; k < n_iter; k++) {
-                        const int dc = min(d1, is - 1);                       // keep the LDS address inside the line
-                        const float2 d = s_df[dc];
-                        const float diff = diff_of(s_grd[dc], d, nref_ar, nref_gb);
-                        const unsigned long long keep = __builtin_amdgcn_ballot_w64(d1 <= to) &
-                                                        __builtin_amdgcn_ballot_w64(!(diff <= 0)) &
-                                                        (__builtin_amdgcn_ballot_w64(__float_as_int(d.y) == fn) | m_outward);
-                        const v2f den = u + t;
-                        const v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-                        if (__builtin_amdgcn_inverse_ballot_w64(keep)) acc = __builtin_elementwise_fma(v2f{diff, diff}, r, acc);
-                        d1 += EG_ROW;
-                        t += (float)EG_ROW;
                     }
                 }
                 // row sums: quad swaps, then the two mirrors -> every lane of the row holds the segment's sum
@@ -1493,11 +1479,11 @@ struct EdgeRecords {
 };
 
 // the lanes' overflow sums start at zero -- only ever used when the plan is incomplete (leaves at once otherwise)
-// dynamic LDS of k_edge_lines: pairs [S] (8 B, padded to 16), gradients [S] and values [S] (16 B); with PAD the
-// gradients must be readable up to entry 2*S + 16
-inline size_t edge_lines_lds(int S, bool pad) {
+// dynamic LDS of k_edge_lines: pairs [S] (8 B, padded to 16), gradients [S] and values [S] (16 B); the gradients must be
+// readable up to entry 2*S + 16 (PAD)
+inline size_t edge_lines_lds(int S) {
     const size_t pairs = (size_t)(S + (S & 1)) * 8, body = pairs + (size_t)S * 32;
-    return pad ? std::max(body, pairs + (size_t)(2 * S + 16) * 16) : body;
+    return std::max(body, pairs + (size_t)(2 * S + 16) * 16);
 }
 
 template <class FS>
@@ -1506,9 +1492,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
                   size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
     if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
-    const size_t smem_pad = edge_lines_lds(S, true);
-    const bool pad = smem_pad <= 28 * 1024;
-    const size_t smem = pad ? smem_pad : edge_lines_lds(S, false);
+    const size_t smem = edge_lines_lds(S);
     if (smem + EG_LINE_STATIC_LDS > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
     const EdgeLayout L = edge_layout(B, F, S);
     if (!ws || ws_bytes < L.fixed_bytes + (shared_plan ? 0 : edge_plan_min_bytes(B, F, S))) return 2;   // D3M_ERR_WORKSPACE
@@ -1553,25 +1537,19 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
-#define D3M_LINES1(RGB, ALPHA, PADDED)                                                                               \
-    do {                                                                                                             \
-        if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                          \
-            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, PADDED>,                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
-            if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
-        }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, PADDED>), glines, dim3(EG_LINE_THREADS), smem, st, a, w, \
-                    lane_partial);                                                                                   \
-    } while (0)
 #define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
-        if (pad) D3M_LINES1(RGB, ALPHA, true);                                                                       \
-        else D3M_LINES1(RGB, ALPHA, false);                                                                          \
+        if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                 \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)smem);                                                                      \
+            if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
+        }                                                                                                            \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_THREADS), smem, st, a, w,       \
+                    lane_partial);                                                                                   \
     } while (0)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
-#undef D3M_LINES1
 #undef D3M_LINES
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
