@@ -94,15 +94,96 @@ __device__ __forceinline__ void bid_candidates(BidStage<PW>& st, int cnt, Cheap&
     if (waiting > 0) drain(waiting);
 }
 
+// The same walk for SLIVERS.  A box of w x h pixels around a needle-shaped triangle holds few pixels of the triangle
+// (the 1 M-triangle configuration: boxes of 5 x 7 = 38 candidates around 4 px^2 of area), and every candidate costs the
+// owner look-up above.  Here the units that are numbered through are the ROWS of the staged boxes: a lane takes one row of
+// one face, intersects the row's line with the three half-planes of KCU:115-117 -- approximately (v_rcp_f32), then widened by
+// half a pixel on either side and clipped to the box: the exact test below still decides, the span only must not lose a
+// pixel (NaN / horizontal edges drop out of the min / max and leave the box's bounds) -- and walks the span's pixels itself;
+// survivors of cheap() go through the same ring to costly().  ~40 instructions per row once, then the cheap test alone
+// per candidate, and about two candidates per row instead of the box's width.
+template <int PW, class Cheap, class Costly>
+__device__ __forceinline__ void bid_rows(BidStage<PW>& st, int rows, int S, Cheap&& cheap, Costly&& costly) {
+    const int lane = lane_id();
+    const int incl = wave_inclusive_scan(rows);
+    if (lane == 0) st.pre[0] = 0;
+    st.pre[lane + 1] = incl;
+    const int total = __shfl(incl, 63, 64);
+    int carry = 0, head = 0, waiting = 0;           // wave-uniform
+    auto drain = [&](int n) {
+        if (lane < n) {
+            const uint32_t e = st.ring[(head + lane) & (2 * WAVE - 1)];
+            costly((int)(e & 63u), (int)((e >> 6) & 0x1FFFu), (int)(e >> 19));
+        }
+    };
+    const float half = 0.5f * (float)S;
+    for (int w0 = 0; w0 < total; w0 += BID_HEADS) {
+        reinterpret_cast<uint4*>(st.head)[lane] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        const int start = incl - rows;
+        if (rows > 0 && start >= w0 && start < w0 + BID_HEADS) st.head[start - w0] = (unsigned char)(lane + 1);
+        wave_lds_sync();
+        const int wend = min(total, w0 + BID_HEADS);
+        for (int c0 = w0; c0 < wend; c0 += WAVE) {
+            const int c = c0 + lane;
+            uint32_t own = wave_max_scan(c < wend ? (uint32_t)st.head[c - w0] : 0u);
+            own = max(own, (uint32_t)carry);
+            carry = __builtin_amdgcn_readlane((int)own, 63);
+            int lo = 0, xi = 0, xb = -1, yi = 0;
+            if (c < wend) {
+                lo = (int)own - 1;
+                yi = st.y0[lo] + (c - st.pre[lo]);
+                const float yp = pixel_center(yi, S);
+                float x_lo = -3.0e38f, x_hi = 3.0e38f;
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    const int n = (e + 1) % 3;
+                    const float xa = st.face[3 * e][lo], ya = st.face[3 * e + 1][lo];
+                    const float dy = st.face[3 * n + 1][lo] - ya;
+                    const float x = xa + ((yp - ya) * (st.face[3 * n][lo] - xa)) * __builtin_amdgcn_rcpf(dy);
+                    if (dy > 0.0f) x_hi = fminf(x_hi, x);            // (yp - ya)(xb - xa) >= (xp - xa) dy  <=>  xp <= x
+                    else if (dy < 0.0f) x_lo = fmaxf(x_lo, x);       //                                     <=>  xp >= x
+                }
+                // NDC -> pixel index (KCU:47), half a pixel of slack, the box's bounds
+                const float p_lo = fminf(fmaxf(x_lo * half + (half - 0.5f) - 0.5f, -1.0f), 65536.0f);
+                const float p_hi = fminf(fmaxf(x_hi * half + (half - 0.5f) + 0.5f, -1.0f), 65536.0f);
+                xi = max(st.x0[lo], (int)ceilf(p_lo));
+                xb = min(st.x0[lo] + st.bw[lo] - 1, (int)floorf(p_hi));
+            }
+            const int steps = __builtin_amdgcn_readlane((int)wave_max_scan((uint32_t)max(xb - xi + 1, 0)), 63);
+            for (int k = 0; k < steps; k++) {
+                const bool pass = xi <= xb && cheap(lo, xi, yi);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) st.ring[(head + waiting + mask_rank(m)) & (2 * WAVE - 1)] = (uint32_t)lo | ((uint32_t)xi << 6) | ((uint32_t)yi << 19);
+                waiting += __popcll(m);
+                wave_lds_sync();
+                if (waiting >= WAVE) {
+                    drain(WAVE);
+                    head = (head + WAVE) & (2 * WAVE - 1);
+                    waiting -= WAVE;
+                }
+                xi++;
+            }
+        }
+        wave_lds_sync();                            // before the marks are cleared again
+    }
+    if (waiting > 0) drain(waiting);
+}
+
 
 // ---- the generic passes: any indexed mesh -----------------------------------------------------------------------------
 // k_bid_faces: lane j < PW of a wave stages face (pair) j of the wave's PW -- read through the indices, oriented, its
 // dense copy left in faces_dense_out for the later passes (as k_bin_count does) -- then the wave walks the candidates.
 // PAIRED (fill_back): lane j handles index triple j in both orientations; at most one faces the camera.
+// A face whose box holds more than BID_BIG_AREA pixels is not walked here -- PW such faces would keep one wave busy for
+// milliseconds while the chip idles -- but listed (big_list: face index within the batch; big_count zeroed by the caller) for
+// k_bid_big, which gives every 64 rows of such a box a wave of their own.
+constexpr int BID_BIG_AREA = 1024;
 template <class FS, int PW, bool PAIRED>
 __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __restrict__ zbuf,
                                                    float* __restrict__ faces_dense_out, int B, int S, float near, float far,
-                                                   unsigned char* __restrict__ marks, int* __restrict__ marks_count) {
+                                                   unsigned char* __restrict__ marks, int* __restrict__ marks_count,
+                                                   int* __restrict__ big_list, int* __restrict__ big_count) {
     __shared__ BidStage<PW> s_stage[4];
     if (marks_count && blockIdx.x == 0 && threadIdx.x == 0) *marks_count = 0;     // (as k_bin_count: see RasterOut)
     __shared__ int s_view[4][PW];
@@ -139,7 +220,10 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
                 for (int k = 0; k < 9; k++) o[k] = face[k];
             }
             int x0, x1, y0, y1;
-            if (pixel_bbox(face, S, x0, x1, y0, y1)) {
+            const bool boxed = pixel_bbox(face, S, x0, x1, y0, y1);
+            if (boxed && (long)(x1 - x0 + 1) * (y1 - y0 + 1) > BID_BIG_AREA) {
+                big_list[atomicAdd(big_count, 1)] = b * F + fid;
+            } else if (boxed) {
                 face_inverse(face, S, finv);
 #pragma unroll
                 for (int k = 0; k < 9; k++) { st.face[k][lane] = face[k]; st.finv[k][lane] = finv[k]; }
@@ -147,11 +231,11 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
                 st.fid[lane] = fid; st.x0[lane] = x0; st.y0[lane] = y0; st.bw[lane] = bw;
                 st.inv_bw[lane] = 1.0f / (float)bw;
                 view[lane] = b;
-                cnt = bw * (y1 - y0 + 1);
+                cnt = y1 - y0 + 1;                    // rows of the box (bid_rows)
             }
         }
     }
-    bid_candidates<PW>(st, cnt,
+    bid_rows<PW>(st, cnt, S,
         [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
             float face[9];
 #pragma unroll
@@ -170,6 +254,52 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
             unsigned long long* slot = zbuf + ((size_t)view[lo] * S + yi) * S + xi;
             if (e > *slot) atomicMax(slot, e);
         });
+}
+
+// k_bid_big: the listed big faces.  Workgroup (i, j) takes faces i, i + gridDim.x, ... and of each the rows
+// y0 + 256 j .. y0 + 256 j + 255 of its box (and every 256 gridDim.y-th block of rows after them): a lane per row, the
+// row's span as in bid_rows, every pixel of it tested and bid for by the lane itself (inside such a face most pass).
+__global__ void __launch_bounds__(256) k_bid_big(DenseFaces fs, unsigned long long* __restrict__ zbuf, const int* __restrict__ big_list,
+                                                 const int* __restrict__ big_count, int S, float near, float far) {
+    const int n = *big_count, F = fs.num_faces();
+    const float half = 0.5f * (float)S;
+    for (int item = blockIdx.x; item < n; item += gridDim.x) {
+        const int gi = big_list[item], b = gi / F, fid = gi - b * F;
+        float face[9], finv[9];
+        fs.load(b, fid, face);
+        int x0, x1, y0, y1;
+        if (!pixel_bbox(face, S, x0, x1, y0, y1)) continue;
+        face_inverse(face, S, finv);
+        const float zmin = fminf(face[2], fminf(face[5], face[8]));
+        const uint32_t zkey = zmin > 0.0f ? (uint32_t)(~ordered_bits(zmin * 0.99999f)) : 0xFFFFFFFFu;
+        for (int yi = y0 + (int)blockIdx.y * 256 + (int)threadIdx.x; yi <= y1; yi += 256 * (int)gridDim.y) {
+            const float yp = pixel_center(yi, S);
+            float x_lo = -3.0e38f, x_hi = 3.0e38f;
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                const int m = (e + 1) % 3;
+                const float xa = face[3 * e], ya = face[3 * e + 1], dy = face[3 * m + 1] - ya;
+                const float x = xa + ((yp - ya) * (face[3 * m] - xa)) * __builtin_amdgcn_rcpf(dy);
+                if (dy > 0.0f) x_hi = fminf(x_hi, x);
+                else if (dy < 0.0f) x_lo = fmaxf(x_lo, x);
+            }
+            const float p_lo = fminf(fmaxf(x_lo * half + (half - 0.5f) - 0.5f, -1.0f), 65536.0f);
+            const float p_hi = fminf(fmaxf(x_hi * half + (half - 0.5f) + 0.5f, -1.0f), 65536.0f);
+            const int xb = min(x1, (int)floorf(p_hi));
+            unsigned long long* row = zbuf + ((size_t)b * S + yi) * S;
+            float flat[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) flat[k] = (k % 3 == 2) ? 0.0f : face[k];
+            for (int xi = max(x0, (int)ceilf(p_lo)); xi <= xb; xi++) {
+                if (!inside_face(flat, pixel_center(xi, S), yp)) continue;
+                if (zkey < (uint32_t)(row[xi] >> 32)) continue;                 // early z (see k_bid_faces)
+                float w[3], zp;
+                if (!weights_depth(face, finv, xi, yi, near, far, w, zp)) continue;
+                const unsigned long long e = bid_key(zp, fid);
+                if (e > row[xi]) atomicMax(&row[xi], e);
+            }
+        }
+    }
 }
 
 // k_bid_resolve: one lane per pixel: the winner's weights and depth recomputed (same arithmetic -> same bits), every

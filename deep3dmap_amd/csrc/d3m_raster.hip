@@ -120,9 +120,13 @@ static FwdLayout fwd_layout(int B, int F, int S) {
     return L;
 }
 
+// what coverage by bidding keeps in the workspace instead (run_forward_mesh): z-buffer | big-face count | big-face list
+static size_t bid_workspace_bytes(int B, int F, int S) {
+    return align_up((size_t)B * S * S * 8, 256) + 256 + align_up((size_t)B * F * 4, 256);
+}
 D3M_EXPORT size_t d3m_forward_workspace_bytes(int B, int F, int S) {
     if (B <= 0 || F <= 0 || S <= 0) return 0;
-    return fwd_layout(B, F, S).fixed_bytes + (size_t)KCAP_DEFAULT * B * F * 4;
+    return std::max(fwd_layout(B, F, S).fixed_bytes + (size_t)KCAP_DEFAULT * B * F * 4, bid_workspace_bytes(B, F, S));
 }
 D3M_EXPORT size_t d3m_forward_workspace_min_bytes(int B, int F, int S) {
     if (B <= 0 || F <= 0 || S <= 0) return 0;
@@ -205,24 +209,33 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
-    // Coverage by bidding (d3m_bid.h) instead of binning: same maps, bit for bit (the whole parity suite passes on it).
-    // MEASURED, NOT THE DEFAULT: on the 1 M-triangle mesh at 1024^2 it takes 1.55 ms per 8 views against the binned
-    // path's 1.70, and 5.95 against 5.70 ms per 32 views -- D3M_BID=1 selects it for such comparisons.
+    // COVERAGE BY BIDDING (d3m_bid.h) instead of binning -- same maps, bit for bit -- where it is the faster of the two
+    // (DESIGN.md 4.5, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
+    // mesh at 1024^2: 1.02 ms per 8 views against 1.70), and batches of at most 32768 tiles, where the tile pass runs four
+    // waves per tile on a chip it cannot fill (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.48
+    // against 0.44, so the big batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
+    // workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
     {
         static const char* force = getenv("D3M_BID");
-        const bool dense = force && force[0] == '1';
-        const size_t zbytes = (size_t)B * S * S * 8;
-        if (dense && !counters_cleared && S <= 8192 && ws && ws_bytes >= zbytes) {
+        const int tiles_x = (S + TILE - 1) / TILE;
+        const bool wanted = force ? force[0] == '1'
+                                  : ((double)S * S < 1.5 * (double)ifs.Ft || (long)B * tiles_x * tiles_x <= RASTER_SMALL_GRID);
+        const size_t zbytes = align_up((size_t)B * S * S * 8, 256);
+        if (wanted && !counters_cleared && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S)) {
             unsigned long long* zbuf = (unsigned long long*)ws;
-            HIP_TRY(zero_async(zbuf, zbytes, st));
-            constexpr int PW = 64;          // sub-pixel faces: a handful of candidates each, set-up on every lane
+            int* big_count = (int*)((char*)ws + zbytes);
+            int* big_list = (int*)((char*)ws + zbytes + 256);
+            HIP_TRY(zero_async(zbuf, zbytes + 256, st));
+            constexpr int PW = 64;          // a lane per face (pair) for the set-up: the boxes are a few rows each
             const long units = (long)B * (ifs.fill_back ? F / 2 : F);
             if (ifs.fill_back)
                 LAUNCH("k_bid_faces", (k_bid_faces<IndexedFaces, PW, true>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, ifs,
-                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count);
+                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count, big_list, big_count);
             else
                 LAUNCH("k_bid_faces", (k_bid_faces<IndexedFaces, PW, false>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, ifs,
-                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count);
+                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count, big_list, big_count);
+            LAUNCH("k_bid_big", k_bid_big, dim3(128, (unsigned)((S + 255) / 256)), dim3(256), st, DenseFaces{faces_out, F}, zbuf,
+                   (const int*)big_list, (const int*)big_count, S, near, far);
             LAUNCH("k_bid_resolve", k_bid_resolve, dim3(blocks_for((long)B * S * S, 256)), dim3(256), st, DenseFaces{faces_out, F},
                    (const unsigned long long*)zbuf, out, B, S, near, far);
             return check_launch();
