@@ -12,7 +12,10 @@
 
 namespace d3m {
 
-constexpr int FM_MAX_BBOX_AREA = 1024;   // larger faces are left to the per-pixel atomic kernels
+#ifndef D3M_FM_MAX_BBOX_AREA
+#define D3M_FM_MAX_BBOX_AREA 4096
+#endif
+constexpr int FM_MAX_BBOX_AREA = D3M_FM_MAX_BBOX_AREA;   // larger faces are left to the per-pixel atomic kernels
 // Lanes per face.  The bounding-box scan is a chain of dependent loads (owner index, then the pixel's maps): one
 // lane per face serialises ~10-25 of them.  FM_LANES adjacent lanes share a face, take every FM_LANES-th pixel of
 // its box and combine their partial sums with quad shuffles / LDS; the visible faces of a mesh come in long index

@@ -210,7 +210,7 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
     // COVERAGE BY BIDDING (d3m_bid.h) instead of binning -- same maps, bit for bit -- where it is the faster of the two
-    // (DESIGN.md 4.5, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
+    // (DESIGN.md 4.1, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
     // mesh at 1024^2: 1.02 ms per 8 views against 1.70), and batches of at most 32768 tiles, where the tile pass runs four
     // waves per tile on a chip it cannot fill (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.48
     // against 0.44, so the big batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward

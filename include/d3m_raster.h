@@ -54,10 +54,11 @@ int d3m_timing_collect(const char** names, int* counts, float* total_ms, int max
  * A. The five operators of `neural_renderer.cuda.rasterize` (KCPP:193-199), same argument order.
  * ---------------------------------------------------------------------------------------------- */
 
-/* Bytes of scratch d3m_forward_face_index_map needs for (batch_size, num_faces, image_size):
- * per-tile face lists built on the device.  A smaller buffer is accepted down to
- * d3m_forward_workspace_min_bytes(); it only lowers the size above which a face is handled as
- * "large" (scanned by every tile of its view).  Contents need no initialisation. */
+/* Bytes of scratch d3m_forward_face_index_map(_mesh) needs for (batch_size, num_faces, image_size):
+ * per-tile face lists built on the device -- or, for the meshes and batch sizes where d3m_forward_face_index_map_mesh
+ * covers by bidding instead of binning, a 64-bit z-buffer and a list of big faces: the larger of the two.
+ * A smaller buffer is accepted down to d3m_forward_workspace_min_bytes(); it lowers the size above which a face is handled
+ * as "large" (scanned by every tile of its view) and rules the bidding form out.  Contents need no initialisation. */
 size_t d3m_forward_workspace_bytes(int batch_size, int num_faces, int image_size);
 size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_size);
 
