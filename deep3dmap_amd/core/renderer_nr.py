@@ -179,7 +179,7 @@ class NrRenderer():
         K = torch.tensor([[fx, 0., cx], [0., fy, cy], [0., 0., 1.]], dtype=torch.float32)
         # (inverted on the host: a 3x3 inverse is the same few flops anywhere, and the host's LAPACK is the one the CPU
         #  oracle uses -- identical bits in inv_K mean identical back-projected vertices)
-        self.inv_K_origin = torch.inverse(K).unsqueeze(0).cuda()
+        self.inv_K_origin = torch.inverse(K).contiguous().unsqueeze(0).cuda()    # (LAPACK returns column-major strides: contiguous once, not per call)
         self.K_origin = K.unsqueeze(0).cuda()
         self.inv_K = self.inv_K_origin.clone()
         self.K = self.K_origin.clone()
@@ -195,7 +195,7 @@ class NrRenderer():
     def downscale_K(self, downscale):
         if downscale > 1:
             self.K = torch.cat((self.K_origin[:, 0:2] / downscale, self.K_origin[:, 2:]), dim=1)
-            self.inv_K = torch.inverse(self.K[0].cpu()).unsqueeze(0).to(self.K.device)
+            self.inv_K = torch.inverse(self.K[0].cpu()).contiguous().unsqueeze(0).to(self.K.device)
 
     def set_transform_matrices(self, view):
         """CR:61-62.  A view on the GPU is kept as it is until rot_mat / trans_xyz are looked at (one fused launch then):

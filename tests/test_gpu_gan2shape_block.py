@@ -167,3 +167,13 @@ def test_block_in_a_captured_step_launches_only_library_kernels():
         assert float((x.grad - g0).abs().max()) <= 1e-3 * float(g0.abs().max()) + 1e-12
     runner.release()
     assert math.isfinite(loss_eager)
+    # ... and ONLY library kernels: no torch op inside the step launches one (round 3 found a 4 us copy per step -- the
+    # column-major strides torch.inverse leaves on inv_K, made contiguous on every call)
+    from torch.profiler import profile, ProfilerActivity
+    step(); torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    foreign = [k for k in kernels if "k_g2s_" not in k and "Memcpy" not in k and "Memset" not in k]
+    assert len([k for k in kernels if "k_g2s_" in k]) == 9 and not foreign, kernels

@@ -10,6 +10,8 @@ run "config 2 without anti-aliasing" --mesh-n 164 --image-size 256 --views-per-g
 run "config 4 per-GPU shard at 4 GPUs: 8 of the 32 cameras" --views-per-gpu 8
 run "config 5: 1002528-triangle mesh @1024x1024, 8 views" --mesh-n 709 --image-size 1024 --views-per-gpu 8
 run "config 5 per-GPU shard at 8 GPUs: 32 of the 256 cameras" --mesh-n 709 --image-size 1024 --views-per-gpu 32 --steps 10
+run "config 4 per-GPU shard at 2 GPUs: 16 of the 32 cameras" --views-per-gpu 16
+run "config 4 per-GPU shard at 8 GPUs: 4 of the 32 cameras" --views-per-gpu 4
 run "64 views per GPU" --views-per-gpu 64
 run "config 3: gan2shape renderer block, batch 16" --workload gan2shape
 run "config 3 with flip3: batch 32" --workload gan2shape --flip
@@ -20,3 +22,7 @@ for l in open("$O/${R}_bench_other_configs.jsonl"):
     if l.startswith("#"): print(l.strip()); continue
     d=json.loads(l); print("   ", d["value"], d["unit"], d["ms_per_step"], "ms")
 PY
+# config 5 (the bidding form of coverage): kernel stats of the 8-view line
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -o stats -- python3 bench.py --no-cpu-baseline --no-dropin --mesh-n 709 --image-size 1024 --views-per-gpu 8 --steps 20 > $O/c5_stats.log 2>&1
+cp $(find $O/c5_stats -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_config5.csv
+head -8 $O/${R}_kernel_stats_config5.csv | cut -c1-140
