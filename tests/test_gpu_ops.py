@@ -334,3 +334,57 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
                                            None, 1, 8, 0.1, 100.0, _lib.ptr(ws), ws.numel(), None, 0, st)
     torch.cuda.synchronize()
     assert rc == 0 and int((fi >= 0).sum()) > 0 and L.d3m_last_hip_error() == 0
+
+
+@pytest.mark.parametrize("S,V,Ft,size,fill_back", [(64, 300, 500, 0.05, True), (100, 200, 300, 0.3, False), (37, 40, 64, 1.5, True),
+                                                    (256, 30, 24, 2.5, True), (129, 2000, 6000, 0.02, True)])
+def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, size, fill_back):
+    """d3m_forward_face_index_map_mesh -- which covers small batches and dense meshes by BIDDING (csrc/d3m_bid.h: rows of the
+    boxes, a pass of its own for big faces) -- against d3m_forward_face_index_map on the gathered faces (the binned tile pass,
+    itself bit-equal to the oracle's brute force and to the reference's kernel above): the same maps, bit for bit, on needles,
+    sub-pixel and screen-filling triangles, rasters that are no multiple of the tile, a face with a NaN vertex, a
+    zero-area face, and the dense copy / visibility marks both forms leave behind."""
+    import ctypes
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    L = _lib.lib()
+    rng = np.random.default_rng(S * 7919 + V)
+    B = 2
+    verts = np.concatenate([rng.uniform(-1.2, 1.2, (B, V, 2)), rng.uniform(0.3, 4.0, (B, V, 1))], -1).astype(np.float32)
+    # triangles of neighbouring-in-space vertices (size controls their extent), plus a few long needles
+    centre = rng.uniform(-1.1, 1.1, (Ft, 1, 2))
+    d2 = ((verts[0, None, :, :2] - centre) ** 2).sum(-1)                       # [Ft, V]
+    near = np.argsort(d2 + rng.uniform(0, size * size, d2.shape), 1)[:, :3]
+    tri = near.astype(np.int32)
+    tri[::17, 2] = rng.integers(0, V, len(tri[::17]))                            # needles across the image
+    tri[5] = (tri[5, 0], tri[5, 0], tri[5, 1])                                   # zero area
+    verts[1, tri[9, 0], 0] = np.nan                                              # a NaN vertex in the second view
+    sv, tr = _dev(verts), torch.from_numpy(tri[None]).cuda()
+    Fp = 2 * Ft if fill_back else Ft
+    faces = torch.empty(B, Fp, 3, 3, device="cuda")
+    fi = torch.empty(B, S, S, dtype=torch.int32, device="cuda")
+    wm, dm, fim = torch.empty(B, S, S, 3, device="cuda"), torch.empty(B, S, S, device="cuda"), torch.empty(B, S, S, 3, 3, device="cuda")
+    ws = torch.empty(int(L.d3m_forward_workspace_bytes(B, Fp, S)), dtype=torch.uint8, device="cuda")
+    vis = torch.empty(int(L.d3m_visibility_bytes(B, Fp)), dtype=torch.uint8, device="cuda")
+    _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), _lib.ptr(tr), 1, V, Ft, int(fill_back), _lib.ptr(faces), _lib.ptr(fi),
+                                                 _lib.ptr(wm), _lib.ptr(dm), _lib.ptr(fim), B, S, 0.5, 3.5, _lib.ptr(ws), ws.numel(),
+                                                 _lib.ptr(vis), vis.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+    _lib.check(L.d3m_visibility(None, _lib.ptr(vis), vis.numel(), B, Fp, S, _lib.stream_ptr()), "d3m_visibility")
+    # the reference composition: vertices_to_faces (+ the reversed copies), then the operator
+    g = torch.from_numpy(verts)[:, torch.from_numpy(tri).long()]                 # [B,Ft,3,3]
+    dense = torch.cat([g, g.flip(2)], 1) if fill_back else g
+    fd = dense.contiguous().cuda()
+    fi2 = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
+    wm2, dm2, fim2 = torch.zeros(B, S, S, 3, device="cuda"), torch.full((B, S, S), 3.5, device="cuda"), torch.zeros(B, S, S, 3, 3, device="cuda")
+    ops.forward_face_index_map(fd, fi2, wm2, dm2, fim2, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
+    torch.cuda.synchronize()
+    cov = float((fi2 >= 0).float().mean())
+    assert cov > 0.02, cov
+    assert torch.equal(fi, fi2), int((fi != fi2).sum())
+    for a, b in ((wm, wm2), (dm, dm2), (fim, fim2)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+    # the dense copy holds every face that owns a pixel, as gathered; the visibility list names exactly those faces
+    owners = torch.unique((fi2.long() + torch.arange(B, device="cuda")[:, None, None] * Fp)[fi2 >= 0])
+    assert np.array_equal(faces.reshape(-1, 9)[owners].cpu().numpy(), fd.reshape(-1, 9)[owners].cpu().numpy(), equal_nan=True)
+    flags = vis.view(torch.int32)[:B * Fp]                                       # the blob starts with one flag per face
+    assert torch.equal(flags.nonzero().flatten(), owners)
