@@ -183,7 +183,8 @@ template <class FS, int PW, bool PAIRED>
 __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __restrict__ zbuf,
                                                    float* __restrict__ faces_dense_out, int B, int S, float near, float far,
                                                    unsigned char* __restrict__ marks, int* __restrict__ marks_count,
-                                                   int* __restrict__ big_list, int* __restrict__ big_count) {
+                                                   int* __restrict__ big_list, int* __restrict__ big_count,
+                                                   float* __restrict__ faces_inv = nullptr) {
     __shared__ BidStage<PW> s_stage[4];
     if (marks_count && blockIdx.x == 0 && threadIdx.x == 0) *marks_count = 0;     // (as k_bin_count: see RasterOut)
     __shared__ int s_view[4][PW];
@@ -218,6 +219,11 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
                 float* o = faces_dense_out + ((size_t)b * F + fid) * 9;
 #pragma unroll
                 for (int k = 0; k < 9; k++) o[k] = face[k];
+            }
+            if (faces_inv) {                      // the reference's K1 scratch (KCU:24-67), for the callers that pass it
+                face_inverse(face, S, finv);
+#pragma unroll
+                for (int k = 0; k < 9; k++) faces_inv[((size_t)b * F + fid) * 9 + k] = finv[k];
             }
             int x0, x1, y0, y1;
             const bool boxed = pixel_bbox(face, S, x0, x1, y0, y1);

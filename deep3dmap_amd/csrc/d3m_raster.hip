@@ -180,10 +180,46 @@ static inline unsigned px_grid(long n, bool sparse) {
     return (unsigned)(b < cap ? b : cap);
 }
 
+// COVERAGE BY BIDDING (d3m_bid.h) instead of binning -- same maps, bit for bit -- where it is the faster of the two
+// (DESIGN.md 4.1, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
+// mesh at 1024^2: 1.02 ms per 8 views against 1.70), and batches of at most 32768 tiles, where the tile pass runs four
+// waves per tile on a chip it cannot fill (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.48
+// against 0.44, so the big batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
+// workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
+static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
+    static const char* force = getenv("D3M_BID");
+    const int tiles_x = (S + TILE - 1) / TILE;
+    const bool wanted = force ? force[0] == '1'
+                              : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= RASTER_SMALL_GRID);
+    return wanted && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);
+}
+// FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)
+template <class FS, bool PAIRED>
+static int run_bidding(FS fs, float* faces_dense, float* faces_dense_out, float* faces_inv, int B, int F, int S, float near,
+                       float far, RasterOut out, void* ws, hipStream_t st) {
+    const size_t zbytes = align_up((size_t)B * S * S * 8, 256);
+    unsigned long long* zbuf = (unsigned long long*)ws;
+    int* big_count = (int*)((char*)ws + zbytes);
+    int* big_list = (int*)((char*)ws + zbytes + 256);
+    HIP_TRY(zero_async(zbuf, zbytes + 256, st));
+    constexpr int PW = 64;          // a lane per face (pair) for the set-up: the boxes are a few rows each
+    const long units = (long)B * (PAIRED ? F / 2 : F);
+    LAUNCH("k_bid_faces", (k_bid_faces<FS, PW, PAIRED>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, fs, zbuf, faces_dense_out,
+           B, S, near, far, out.marks, out.marks_count, big_list, big_count, faces_inv);
+    LAUNCH("k_bid_big", k_bid_big, dim3(128, (unsigned)((S + 255) / 256)), dim3(256), st, DenseFaces{faces_dense, F}, zbuf,
+           (const int*)big_list, (const int*)big_count, S, near, far);
+    LAUNCH("k_bid_resolve", k_bid_resolve, dim3(blocks_for((long)B * S * S, 256)), dim3(256), st, DenseFaces{faces_dense, F},
+           (const unsigned long long*)zbuf, out, B, S, near, far);
+    return check_launch();
+}
+
 template <class FS>
 static int run_forward(FS fs, int B, int F, int S, float near, float far, RasterOut out, float* faces_inv, void* ws,
                        size_t ws_bytes, hipStream_t st) {
     if (S > 8 * 65535) return D3M_ERR_INVALID;
+    // (dense faces: a caller's fill_back copies are faces of their own here, two per triangle)
+    if (bidding_wanted(B, F / 2, S, ws, ws_bytes, F))
+        return run_bidding<FS, false>(fs, const_cast<float*>(fs.faces), nullptr, faces_inv, B, F, S, near, far, out, ws, st);
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
     if (rc) return rc;
@@ -209,37 +245,9 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
-    // COVERAGE BY BIDDING (d3m_bid.h) instead of binning -- same maps, bit for bit -- where it is the faster of the two
-    // (DESIGN.md 4.1, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
-    // mesh at 1024^2: 1.02 ms per 8 views against 1.70), and batches of at most 32768 tiles, where the tile pass runs four
-    // waves per tile on a chip it cannot fill (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.48
-    // against 0.44, so the big batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
-    // workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
-    {
-        static const char* force = getenv("D3M_BID");
-        const int tiles_x = (S + TILE - 1) / TILE;
-        const bool wanted = force ? force[0] == '1'
-                                  : ((double)S * S < 1.5 * (double)ifs.Ft || (long)B * tiles_x * tiles_x <= RASTER_SMALL_GRID);
-        const size_t zbytes = align_up((size_t)B * S * S * 8, 256);
-        if (wanted && !counters_cleared && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S)) {
-            unsigned long long* zbuf = (unsigned long long*)ws;
-            int* big_count = (int*)((char*)ws + zbytes);
-            int* big_list = (int*)((char*)ws + zbytes + 256);
-            HIP_TRY(zero_async(zbuf, zbytes + 256, st));
-            constexpr int PW = 64;          // a lane per face (pair) for the set-up: the boxes are a few rows each
-            const long units = (long)B * (ifs.fill_back ? F / 2 : F);
-            if (ifs.fill_back)
-                LAUNCH("k_bid_faces", (k_bid_faces<IndexedFaces, PW, true>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, ifs,
-                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count, big_list, big_count);
-            else
-                LAUNCH("k_bid_faces", (k_bid_faces<IndexedFaces, PW, false>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, ifs,
-                       zbuf, faces_out, B, S, near, far, out.marks, out.marks_count, big_list, big_count);
-            LAUNCH("k_bid_big", k_bid_big, dim3(128, (unsigned)((S + 255) / 256)), dim3(256), st, DenseFaces{faces_out, F}, zbuf,
-                   (const int*)big_list, (const int*)big_count, S, near, far);
-            LAUNCH("k_bid_resolve", k_bid_resolve, dim3(blocks_for((long)B * S * S, 256)), dim3(256), st, DenseFaces{faces_out, F},
-                   (const unsigned long long*)zbuf, out, B, S, near, far);
-            return check_launch();
-        }
+    if (!counters_cleared && bidding_wanted(B, ifs.Ft, S, ws, ws_bytes, F)) {
+        if (ifs.fill_back) return run_bidding<IndexedFaces, true>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st);
+        return run_bidding<IndexedFaces, false>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st);
     }
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
