@@ -5,10 +5,12 @@
 // are no bigger than a tile's pixels that is most of the work (a 1 M-triangle mesh at 1024^2: 0.62 ms of binning + 1.08 ms
 // of tile pass per 8 views).  Here the faces come to the pixels instead: a wave stages PW triangles (pairs, with
 // fill_back: at most one of a pair's two orientations faces the camera) in LDS -- vertices, pixel-space inverse,
-// bounding box --, numbers the boxes' pixels through, and takes the next 64 (pixel, face) candidates per step whichever
-// face they belong to; the ones that pass the reference's tests (KCU:110-139 through d3m_device.h: same operations, same
-// bits) BID ~((ordered depth bits << 32) | face) for their pixel in a 64-bit z-buffer with atomicMax -- "nearest, lowest
+// bounding box --, numbers the boxes' ROWS through, and takes the next 64 rows per step whichever face they belong to (a lane
+// walks its row's span: bid_rows below); the pixels that pass the reference's tests (KCU:110-139 through d3m_device.h: same
+// operations, same bits) BID ~((ordered depth bits << 32) | face) in a 64-bit z-buffer with atomicMax -- "nearest, lowest
 // index among equals" (KCU:142), independent of order.  A per-pixel pass then turns the winners into the maps.
+// Also where the tile pass cannot fill the chip (small batches); and the gan2shape block's two walks (d3m_g2s.h) use the
+// same machinery on its implicit grid mesh.
 #pragma once
 #include "d3m_device.h"
 #include "d3m_forward.h"
@@ -33,75 +35,23 @@ template <int PW>
 struct BidStage {
     float face[9][PW], finv[9][PW];
     int fid[PW], x0[PW], y0[PW], bw[PW];
-    float inv_bw[PW];
     int pre[WAVE + 1];
     __attribute__((aligned(16))) unsigned char head[BID_HEADS];
     uint32_t ring[2 * WAVE];            // candidates that passed the cheap test, waiting for a full wave of them
 };
 
-// Every candidate of the staged pairs, 64 per step, in two phases: cheap(owner lane, x, y) -> bool on every candidate;
-// the ones that pass wait in a ring until a full wave of them has gathered (and at the end), and costly(owner lane, x, y)
-// then runs on 64 busy lanes instead of on the ~third of a step's candidates that survive (k_raster_tiles' scheme).
-template <int PW, class Cheap, class Costly>
-__device__ __forceinline__ void bid_candidates(BidStage<PW>& st, int cnt, Cheap&& cheap, Costly&& costly) {
-    const int lane = lane_id();
-    const int incl = wave_inclusive_scan(cnt);
-    if (lane == 0) st.pre[0] = 0;
-    st.pre[lane + 1] = incl;
-    const int total = __shfl(incl, 63, 64);
-    int carry = 0;                                  // wave-uniform: mark of the last candidate so far
-    int head = 0, waiting = 0;                      // wave-uniform: the ring
-    auto drain = [&](int n) {
-        if (lane < n) {
-            const uint32_t e = st.ring[(head + lane) & (2 * WAVE - 1)];
-            costly((int)(e & 63u), (int)((e >> 6) & 0x1FFFu), (int)(e >> 19));
-        }
-    };
-    for (int w0 = 0; w0 < total; w0 += BID_HEADS) {
-        reinterpret_cast<uint4*>(st.head)[lane] = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-        const int start = incl - cnt;
-        if (cnt > 0 && start >= w0 && start < w0 + BID_HEADS) st.head[start - w0] = (unsigned char)(lane + 1);
-        wave_lds_sync();
-        const int wend = min(total, w0 + BID_HEADS);
-        for (int c0 = w0; c0 < wend; c0 += WAVE) {
-            const int c = c0 + lane;
-            uint32_t own = wave_max_scan(c < wend ? (uint32_t)st.head[c - w0] : 0u);
-            own = max(own, (uint32_t)carry);
-            carry = __builtin_amdgcn_readlane((int)own, 63);
-            bool pass = false;
-            uint32_t ent = 0;
-            if (c < wend) {
-                const int lo = (int)own - 1, local = c - st.pre[lo], bw = st.bw[lo];
-                int row = (int)((float)local * st.inv_bw[lo]), col = local - row * bw;       // local / bw, fixed up
-                if (col < 0) { row--; col += bw; } else if (col >= bw) { row++; col -= bw; }
-                const int xi = st.x0[lo] + col, yi = st.y0[lo] + row;
-                pass = cheap(lo, xi, yi);
-                ent = (uint32_t)lo | ((uint32_t)xi << 6) | ((uint32_t)yi << 19);              // S <= 8192
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-            if (pass) st.ring[(head + waiting + mask_rank(m)) & (2 * WAVE - 1)] = ent;
-            waiting += __popcll(m);
-            wave_lds_sync();
-            if (waiting >= WAVE) {
-                drain(WAVE);
-                head = (head + WAVE) & (2 * WAVE - 1);
-                waiting -= WAVE;
-            }
-        }
-        wave_lds_sync();                            // before the marks are cleared again
-    }
-    if (waiting > 0) drain(waiting);
-}
-
-// The same walk for SLIVERS.  A box of w x h pixels around a needle-shaped triangle holds few pixels of the triangle
-// (the 1 M-triangle configuration: boxes of 5 x 7 = 38 candidates around 4 px^2 of area), and every candidate costs the
-// owner look-up above.  Here the units that are numbered through are the ROWS of the staged boxes: a lane takes one row of
-// one face, intersects the row's line with the three half-planes of KCU:115-117 -- approximately (v_rcp_f32), then widened by
-// half a pixel on either side and clipped to the box: the exact test below still decides, the span only must not lose a
-// pixel (NaN / horizontal edges drop out of the min / max and leave the box's bounds) -- and walks the span's pixels itself;
-// survivors of cheap() go through the same ring to costly().  ~40 instructions per row once, then the cheap test alone
-// per candidate, and about two candidates per row instead of the box's width.
+// The walk.  Two phases: cheap(owner lane, x, y) -> bool on every candidate; the ones that pass wait in a ring until a full
+// wave of them has gathered (and at the end), and costly(owner lane, x, y) then runs on 64 busy lanes instead of on the
+// ~third of a step's candidates that survive (k_raster_tiles' scheme).  The units that are numbered through over the 64
+// lanes are the ROWS of the staged boxes, not their pixels: a box of w x h pixels around a needle-shaped triangle holds few
+// pixels of the triangle (the 1 M-triangle configuration: boxes of 5 x 7 = 38 candidates around 4 px^2 of area; the
+// gan2shape meshes seen from 57 degrees: 14 x overdraw), and with the pixels numbered through every one of them paid the
+// owner look-up (the first form of this walk: 1.46 against 0.93 ms on that configuration, 42 against 30 us in
+// k_g2s_raster).  A lane takes one row of one face, intersects the row's line with the three half-planes of KCU:115-117
+// -- approximately (v_rcp_f32), then widened by half a pixel on either side and clipped to the box: the exact test below
+// still decides, the span only must not lose a pixel (NaN / horizontal edges drop out of the min / max and leave the box's
+// bounds) -- and walks the span's pixels itself.  ~40 instructions per row once, then the cheap test alone per candidate,
+// and about two candidates per row instead of the box's width.
 template <int PW, class Cheap, class Costly>
 __device__ __forceinline__ void bid_rows(BidStage<PW>& st, int rows, int S, Cheap&& cheap, Costly&& costly) {
     const int lane = lane_id();
@@ -235,7 +185,6 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
                 for (int k = 0; k < 9; k++) { st.face[k][lane] = face[k]; st.finv[k][lane] = finv[k]; }
                 const int bw = x1 - x0 + 1;
                 st.fid[lane] = fid; st.x0[lane] = x0; st.y0[lane] = y0; st.bw[lane] = bw;
-                st.inv_bw[lane] = 1.0f / (float)bw;
                 view[lane] = b;
                 cnt = y1 - y0 + 1;                    // rows of the box (bid_rows)
             }

@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(256) k_g2s_front(G2S g, ZeroRanges z) {
 constexpr int G2S_PW = D3M_G2S_PAIRS_PER_WAVE;
 typedef BidStage<G2S_PW> G2SStage;
 
-// lane j < G2S_PW <- pair (wave's first pair + j): returns its candidate count (0: culled / off screen / out of range)
+// lane j < G2S_PW <- pair (wave's first pair + j): returns the rows of its box (0: culled / off screen / out of range)
 __device__ __forceinline__ int g2s_stage_pair(const G2S& g, G2SStage& st, long pair, int Ft, bool& reversed) {
     const int lane = lane_id(), S = g.S;
     int cnt = 0;
@@ -268,8 +268,7 @@ __device__ __forceinline__ int g2s_stage_pair(const G2S& g, G2SStage& st, long p
             for (int k = 0; k < 9; k++) { st.face[k][lane] = face[k]; st.finv[k][lane] = finv[k]; }
             const int bw = x1 - x0 + 1;
             st.fid[lane] = fid; st.x0[lane] = x0; st.y0[lane] = y0; st.bw[lane] = bw;
-            st.inv_bw[lane] = 1.0f / (float)bw;
-            cnt = bw * (y1 - y0 + 1);
+            cnt = y1 - y0 + 1;                  // the box's rows (bid_rows)
         }
     }
     return cnt;
@@ -288,7 +287,7 @@ __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
         const long owner_pair = pair - lane_id() + lo;                 // (the pairs of a wave may straddle two views)
         return g.zbuf + ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
     };
-    bid_candidates(st, cnt,
+    bid_rows(st, cnt, S,
         [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
             float face[9];
 #pragma unroll
@@ -507,7 +506,7 @@ __global__ void __launch_bounds__(256) k_g2s_depth_faces(G2S g) {
         const long owner_pair = pair - lane + lo;
         return ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
     };
-    bid_candidates(st, cnt,
+    bid_rows(st, cnt, S,
         [&](int lo, int xi, int yi) { return bid_face(g.zbuf[pixel_of(lo, xi, yi)]) == st.fid[lo]; },
         [&](int lo, int xi, int yi) {
             const size_t p = pixel_of(lo, xi, yi);
