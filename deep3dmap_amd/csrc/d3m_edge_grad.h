@@ -861,8 +861,12 @@ static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole wav
 // tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  (Up to round 3
 // rasters above 28 KB of line image walked a second, clamped-index form of the loop -- two reciprocals and a select per
 // visit: the same LDS, and on the 1024^2 configuration 1.66 ms where this form takes 1.46.  Removed.)
-template <bool USE_RGB, bool USE_ALPHA>
-__global__ void __launch_bounds__(EG_LINE_THREADS, D3M_EG_LINE_MINWAVES) k_edge_lines(EdgeGradArgs a, EdgePlan w,
+// MINW (waves per SIMD the register allocation must allow): 8 = at most 64 VGPRs, i.e. FOUR workgroups per CU where the
+// line's LDS image leaves room for four (S <= ~600: the kernel's phases -- stage, set up, order, walk -- are separated by
+// barriers and overlap only ACROSS workgroups; 0.545 -> 0.513 ms alone on the headline step); larger rasters fit three
+// workgroups at most and keep the 70 registers the compiler wants (1024^2: 1.452 ms against 1.468 with 64).
+template <bool USE_RGB, bool USE_ALPHA, int MINW>
+__global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradArgs a, EdgePlan w,
                                                                                       float2* __restrict__ lane_partial) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
@@ -1537,19 +1541,25 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
-#define D3M_LINES(RGB, ALPHA)                                                                                        \
+#define D3M_LINES1(RGB, ALPHA, MINW)                                                                                 \
     do {                                                                                                             \
         if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                 \
-            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)smem);                                                                      \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, MINW>,                                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_THREADS), smem, st, a, w,       \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, MINW>), glines, dim3(EG_LINE_THREADS), smem, st, a, w, \
                     lane_partial);                                                                                   \
+    } while (0)
+#define D3M_LINES(RGB, ALPHA)                                                                                        \
+    do {                                                                                                             \
+        if (4 * (smem + EG_LINE_STATIC_LDS) <= 160 * 1024) D3M_LINES1(RGB, ALPHA, 8);                                \
+        else D3M_LINES1(RGB, ALPHA, D3M_EG_LINE_MINWAVES);                                                           \
     } while (0)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
+#undef D3M_LINES1
 #undef D3M_LINES
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder

@@ -209,7 +209,10 @@ struct FitTargets {
     float *g_rgb, *g_alpha, *g_depth;
 };
 
-__global__ void __launch_bounds__(256) k_render_lit_epilogue(const float* __restrict__ faces, LitTextures lt,
+#ifndef D3M_EPI_MINWAVES
+#define D3M_EPI_MINWAVES 4
+#endif
+__global__ void __launch_bounds__(256, D3M_EPI_MINWAVES) k_render_lit_epilogue(const float* __restrict__ faces, LitTextures lt,
                                                             const int32_t* __restrict__ face_index_map,
                                                             const float* __restrict__ weight_map,
                                                             const float* __restrict__ depth_map,
@@ -324,7 +327,12 @@ struct FitRecords {
     float* g_depth;        // [B,S,S] sign(depth - target) * mask (the depth gradient stays a map: k_backward_textures_lit)
 };
 
-__global__ void __launch_bounds__(256) k_render_lit_fit_records(const float* __restrict__ faces, LitTextures lt,
+// (4 waves per SIMD: the compiler wants 134 registers, six more than four waves allow; held to 128 the pass -- bound by its
+//  memory round trips, i.e. by how many of them are in flight -- takes 0.198 instead of 0.233 ms alone; 5 waves spill: 0.35)
+#ifndef D3M_FIT_MINWAVES
+#define D3M_FIT_MINWAVES 4
+#endif
+__global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_records(const float* __restrict__ faces, LitTextures lt,
                                                                const int32_t* __restrict__ face_index_map,
                                                                const float* __restrict__ weight_map,
                                                                const float* __restrict__ depth_map,
@@ -661,6 +669,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
 // FM_LANES lanes per face.  Without a list every face of [B,F'] gets its lanes (hidden ones leave at once: ~95 % of
 // a fill_back mesh, i.e. mostly idle waves); with the compacted list of a d3m_visibility only faces that own a pixel
 // do, on a fixed grid that strides over the list.
+// (111 registers, 4 waves per SIMD; held to 5 or 6 waves it spills and loses: 0.26 / 0.34 ms against 0.22)
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs a) {
     const int sub = threadIdx.x % LIT_LANES, slot = threadIdx.x / LIT_LANES;
     if (a.list) {
