@@ -29,11 +29,12 @@ __device__ __forceinline__ float bid_depth(unsigned long long e, float far) {
 }
 __device__ __forceinline__ int bid_face(unsigned long long e) { return e == 0ull ? -1 : (int)~(uint32_t)e; }
 
-constexpr int BID_HEADS = 16 * WAVE;        // candidates per window of owner marks (one uint4 per lane)
-// what lane j < PW stages for its face; the candidate walk's scratch
-template <int PW>
+constexpr int BID_HEADS = 16 * WAVE;        // rows per window of owner marks (one uint4 per lane)
+// what lane j < PW stages for its face; the walk's scratch.  FINV false: the pixel-space inverse is not staged (2.3 KB per
+// wave at PW = 64) but set up again by the survivors' step -- LDS, not registers, bounds k_bid_faces' occupancy
+template <int PW, bool FINV = true>
 struct BidStage {
-    float face[9][PW], finv[9][PW];
+    float face[9][PW], finv[9][FINV ? PW : 1];
     int fid[PW], x0[PW], y0[PW], bw[PW];
     int pre[WAVE + 1];
     __attribute__((aligned(16))) unsigned char head[BID_HEADS];
@@ -52,8 +53,8 @@ struct BidStage {
 // still decides, the span only must not lose a pixel (NaN / horizontal edges drop out of the min / max and leave the box's
 // bounds) -- and walks the span's pixels itself.  ~40 instructions per row once, then the cheap test alone per candidate,
 // and about two candidates per row instead of the box's width.
-template <int PW, class Cheap, class Costly>
-__device__ __forceinline__ void bid_rows(BidStage<PW>& st, int rows, int S, Cheap&& cheap, Costly&& costly) {
+template <int PW, bool FINV, class Cheap, class Costly>
+__device__ __forceinline__ void bid_rows(BidStage<PW, FINV>& st, int rows, int S, Cheap&& cheap, Costly&& costly) {
     const int lane = lane_id();
     const int incl = wave_inclusive_scan(rows);
     if (lane == 0) st.pre[0] = 0;
@@ -135,10 +136,15 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
                                                    unsigned char* __restrict__ marks, int* __restrict__ marks_count,
                                                    int* __restrict__ big_list, int* __restrict__ big_count,
                                                    float* __restrict__ faces_inv = nullptr) {
-    __shared__ BidStage<PW> s_stage[4];
+#ifdef D3M_BID_STAGE_FINV
+    constexpr bool FINV = true;
+#else
+    constexpr bool FINV = false;
+#endif
+    __shared__ BidStage<PW, FINV> s_stage[4];
     if (marks_count && blockIdx.x == 0 && threadIdx.x == 0) *marks_count = 0;     // (as k_bin_count: see RasterOut)
     __shared__ int s_view[4][PW];
-    BidStage<PW>& st = s_stage[threadIdx.x >> 6];
+    BidStage<PW, FINV>& st = s_stage[threadIdx.x >> 6];
     int (&view)[PW] = s_view[threadIdx.x >> 6];
     const int lane = lane_id();
     const int F = fs.num_faces(), Fl = PAIRED ? F / 2 : F;
@@ -182,7 +188,10 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
             } else if (boxed) {
                 face_inverse(face, S, finv);
 #pragma unroll
-                for (int k = 0; k < 9; k++) { st.face[k][lane] = face[k]; st.finv[k][lane] = finv[k]; }
+                for (int k = 0; k < 9; k++) {
+                    st.face[k][lane] = face[k];
+                    if (FINV) st.finv[k][lane] = finv[k];
+                }
                 const int bw = x1 - x0 + 1;
                 st.fid[lane] = fid; st.x0[lane] = x0; st.y0[lane] = y0; st.bw[lane] = bw;
                 view[lane] = b;
@@ -203,7 +212,13 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
         [&](int lo, int xi, int yi) {              // costly: barycentrics and depth (seven divisions), the bid
             float face[9], finv[9], w[3], zp;
 #pragma unroll
-            for (int k = 0; k < 9; k++) { face[k] = st.face[k][lo]; finv[k] = st.finv[k][lo]; }
+            for (int k = 0; k < 9; k++) face[k] = st.face[k][lo];
+            if (FINV) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) finv[k] = st.finv[k][lo];
+            } else {
+                face_inverse(face, S, finv);          // (the same operations as at staging: the same bits)
+            }
             if (!weights_depth(face, finv, xi, yi, near, far, w, zp)) return;
             const unsigned long long e = bid_key(zp, st.fid[lo]);
             unsigned long long* slot = zbuf + ((size_t)view[lo] * S + yi) * S + xi;
