@@ -44,6 +44,10 @@ def kernel_bytes(name, V, F, S, ts):
     grads = P * (4 + 12)               # their gradients
     table = {
         "k_raster_tiles": 12 * V + 12 * F + 20 * P,
+        # coverage by bidding (csrc/d3m_bid.h): the mesh in, the 8-byte z-buffer entry of every pixel written at least
+        # once; then that entry in and the three maps out
+        "k_bid_faces": 12 * V + 12 * F + 8 * P,
+        "k_bid_resolve": 8 * P + 20 * P,
         "k_bin_count": 12 * V + 12 * F,
         "k_bin_fill": 12 * F,
         "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
