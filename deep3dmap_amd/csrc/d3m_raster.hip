@@ -182,15 +182,16 @@ static inline unsigned px_grid(long n, bool sparse) {
 
 // COVERAGE BY BIDDING (d3m_bid.h) instead of binning -- same maps, bit for bit -- where it is the faster of the two
 // (DESIGN.md 4.1, A/B on one box): meshes of (sub-)pixel triangles, fewer than 1.5 raster pixels each (the 1 M-triangle
-// mesh at 1024^2: 1.02 ms per 8 views against 1.70), and batches of at most 32768 tiles, where the tile pass runs four
-// waves per tile on a chip it cannot fill (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.48
-// against 0.44, so the big batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
+// mesh at 1024^2: 0.95 ms per 8 views against 1.70), and batches of at most 65536 tiles, which the tile pass cannot fill
+// the chip with as well (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.47 against 0.45, so the big
+// batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
 // workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
+static const long BID_MAX_TILES = 65536;     // 16 views at 512^2: +1 % there, +1.5 % at 12, -2 % at 24 (A/B, round 3)
 static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
     static const char* force = getenv("D3M_BID");
     const int tiles_x = (S + TILE - 1) / TILE;
     const bool wanted = force ? force[0] == '1'
-                              : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= RASTER_SMALL_GRID);
+                              : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
     return wanted && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);
 }
 // FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)
