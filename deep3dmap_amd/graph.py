@@ -24,11 +24,15 @@ class CapturedStep:
 
     def _enter(self):
         cur = torch.cuda.current_stream()
-        self.stream.wait_stream(cur)          # inputs written by the caller's stream are visible
+        # (a caller that already runs ON the dedicated stream -- `with torch.cuda.stream(step.stream):` around its loop --
+        #  needs no fences: back-to-back replays then follow each other without a cross-stream event in between)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)      # inputs written by the caller's stream are visible
         return cur
 
     def _exit(self, cur, out, eager):
-        cur.wait_stream(self.stream)          # results are visible to the caller's stream
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)      # results are visible to the caller's stream
         # Eager outputs were allocated on the dedicated stream but are consumed on the caller's.  Instead of
         # record_stream() (its deferred-free events are a hazard around graph capture) the last outputs are
         # simply kept alive until the next call, whose entry fence makes their release stream-ordered.

@@ -179,6 +179,12 @@ class MultiViewFit:
         self._runner.release()
 
     @property
+    def stream(self):
+        """The stream every step of this fit runs on (eager, captured or replayed).  A loop of steps wrapped in
+        `with torch.cuda.stream(fit.stream):` runs without the per-step fences against the caller's stream."""
+        return self._runner.stream
+
+    @property
     def graph_captured(self):
         return self._runner.graph is not None
 
