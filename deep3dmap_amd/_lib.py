@@ -56,6 +56,8 @@ _SIGNATURES = {
     "d3m_timing_collect": (_I, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I), ctypes.POINTER(_F), _I]),
     "d3m_forward_workspace_bytes": (_SZ, [_I, _I, _I]),
     "d3m_forward_workspace_min_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_set_coverage_form": (_I, [_I]),
+    "d3m_get_coverage_form": (_I, []),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
     "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ, _P]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
@@ -188,6 +190,25 @@ def require_device(*tensors, names=None):
             raise RuntimeError(f"{n}: expected scalar type Float but found {t.dtype}; "
                                "libd3m_raster is built for float32 (the reference's float64 dispatch, "
                                "rasterize_cuda_kernel.cu:614, is not reachable from its own Python either)")
+
+
+COVERAGE_FORMS = {"auto": -1, "binned": 0, "bidding": 1}
+
+
+class coverage_form:
+    """Context manager: run the forward's coverage in one form ("auto" | "binned" | "bidding", d3m_set_coverage_form)."""
+
+    def __init__(self, form):
+        self.form = COVERAGE_FORMS[form] if isinstance(form, str) else int(form)
+
+    def __enter__(self):
+        self.previous = lib().d3m_get_coverage_form()
+        check(lib().d3m_set_coverage_form(self.form), "d3m_set_coverage_form")
+        return self
+
+    def __exit__(self, *exc):
+        lib().d3m_set_coverage_form(self.previous)
+        return False
 
 
 def kernel_timing(enable):

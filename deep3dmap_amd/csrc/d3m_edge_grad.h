@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradAr
         bool has;
         Segment sg;
         int fn;
-        long slot;
+        uint32_t slot;      // (a plan holds fewer than 2^31 results: edge_plan_view)
     };
     const int my_which = (int)threadIdx.x >= EG_CHUNK ? 1 : 0, my_x = (int)threadIdx.x - my_which * EG_CHUNK;
     auto set_up = [&](int ci) {
@@ -923,9 +923,9 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradAr
         u.fn = 0;
         u.slot = 0;
         if (ci < n_x) {
-            const uint4 r0 = xrec[2 * (size_t)ci], r1 = xrec[2 * (size_t)ci + 1];
+            const uint4 r0 = xrec[2u * (uint32_t)ci], r1 = xrec[2u * (uint32_t)ci + 1u];      // (uniform base + 32-bit offset)
             u.fn = (int)r1.y;
-            u.slot = 2 * ((long)x_first + ci) + my_which;
+            u.slot = 2u * (uint32_t)(x_first + ci) + (uint32_t)my_which;
             u.has = geometry_segment(record_to_geometry(r0, r1), my_which, axis, d0, is, p_lo, p_hi, u.sg);
         }
         return u;
@@ -1084,16 +1084,30 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradAr
                 s0 += dpp_f32<0x4E>(s0);  s1 += dpp_f32<0x4E>(s1);
                 if (EG_ROW >= 8) { s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1); }
                 if (EG_ROW == 16) { s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1); }
-                if (have && rl == 0) {
-                    if (bits & 24u) {                                  // the t == 0 pixel must use -eps (see item format)
-                        const int df = (bits & 8u) ? from : to;
+                // What the loop did not need -- result slot, the item's flags, its reference values for the rare t == 0
+                // correction -- is READ AGAIN from the item here, once per sixteen segments, instead of being carried through
+                // the loop in registers: with them the kernel wants 70 VGPRs, i.e. 24 bytes of scratch per lane in the
+                // 64-register form (four workgroups per CU) -- 335 MB of scratch stores per headline launch (round 3's
+                // WRITE_SIZE 95 -> 353 MB).  The asm statement keeps the compiler from merging the two reads.
+                asm volatile("" ::: "memory");
+                if (base + row < nc && rl == 0) {
+                    const uint4 z0 = q[0];
+                    const uint32_t zbits = z0.x & 63u;
+                    const float zinv0 = __uint_as_float(z0.y), zinv1 = __uint_as_float(q[1].y);
+                    if (zbits & 24u) {                                 // the t == 0 pixel must use -eps (see item format)
+                        const float4 zrv = s_val[q[1].z];
+                        const v2f zref_ar = {USE_ALPHA ? -zrv.x : 0.0f, USE_RGB ? -zrv.y : 0.0f};
+                        const v2f zref_gb = {USE_RGB ? -zrv.z : 0.0f, USE_RGB ? -zrv.w : 0.0f};
+                        const int df = (zbits & 8u) ? (int)(z0.z & 0xFFFF) : (int)(z0.z >> 16);
                         const float2 d = s_df[df];
-                        const float diff = diff_of(s_grd[df], d, nref_ar, nref_gb);
-                        const float dpos = (!(diff <= 0) && (!(bits & 1u) || __float_as_int(d.y) == fn)) ? diff : 0.0f;
-                        if (u.x * inv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.x));
-                        if (u.y * inv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(u.y));
+                        const float diff = diff_of(s_grd[df], d, zref_ar, zref_gb);
+                        const float dpos = (!(diff <= 0) && (!(zbits & 1u) || __float_as_int(d.y) == (int)(z0.x >> 6))) ? diff : 0.0f;
+                        const float zs = (zbits & 32u) ? 1.0f : -1.0f;
+                        const float ux = zs * (a.eps * fabsf(zinv0)), uy = zs * (a.eps * fabsf(zinv1));
+                        if (ux * zinv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(ux));
+                        if (uy * zinv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(uy));
                     }
-                    w.results[(int)q0v.w] = make_float2((bits & 2u) ? inv0 * s0 : 0.0f, (bits & 4u) ? inv1 * s1 : 0.0f);
+                    w.results[z0.w] = make_float2((zbits & 2u) ? zinv0 * s0 : 0.0f, (zbits & 4u) ? zinv1 * s1 : 0.0f);
                 }
             }
 
@@ -1126,7 +1140,7 @@ __global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradAr
                                           ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u) |
                                           (0 < s_t ? 32u : 0u);
                     rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-rq0),
-                                      (uint32_t)q.from | ((uint32_t)q.to << 16), (uint32_t)u.slot);
+                                      (uint32_t)q.from | ((uint32_t)q.to << 16), u.slot);
                     rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(-rq1), (uint32_t)q.ref_pos, 0u);
                     queued = true;
                 } else {                                      // short (or not oriented): this thread walks it, from LDS

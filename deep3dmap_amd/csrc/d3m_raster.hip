@@ -20,6 +20,7 @@
 #include "d3m_g2s.h"
 #include "d3m_bid.h"
 #include <cstdlib>
+#include <atomic>
 
 using namespace d3m;
 
@@ -187,11 +188,32 @@ static inline unsigned px_grid(long n, bool sparse) {
 // batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
 // workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
 static const long BID_MAX_TILES = 65536;     // 16 views at 512^2: +1 % there, +1.5 % at 12, -2 % at 24 (A/B, round 3)
+// which form of coverage the forward takes: -1 chosen per launch (above), 0 binned only, 1 bidding wherever its
+// workspace fits.  Process-wide; D3M_BID=0 / 1 in the environment sets the initial value (measurements), and
+// d3m_set_coverage_form() changes it between launches (the parity tests run every scene in both forms).
+static std::atomic<int> g_coverage_form{-2};        // -2: not yet read from the environment
+static int coverage_form() {
+    int f = g_coverage_form.load(std::memory_order_relaxed);
+    if (f == -2) {
+        const char* e = getenv("D3M_BID");
+        f = e ? (e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1) : -1;
+        int expected = -2;
+        if (!g_coverage_form.compare_exchange_strong(expected, f)) f = expected;
+    }
+    return f;
+}
+D3M_EXPORT int d3m_set_coverage_form(int form) {
+    if (form < -1 || form > 1) return D3M_ERR_INVALID;
+    (void)coverage_form();
+    g_coverage_form.store(form);
+    return D3M_OK;
+}
+D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
 static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
-    static const char* force = getenv("D3M_BID");
+    const int form = coverage_form();
     const int tiles_x = (S + TILE - 1) / TILE;
-    const bool wanted = force ? force[0] == '1'
-                              : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
+    const bool wanted = form >= 0 ? form == 1
+                                  : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
     return wanted && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);
 }
 // FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)

@@ -50,6 +50,7 @@ def _raster_forward(faces, textures, image_size, near, far, eps, background, ret
     ops.forward_face_index_map(faces, m["face_index_map"], m["weight_map"], m["depth_map"], face_inv_map, faces_inv,
                                S, near, far, return_rgb, return_alpha, want_finv)
     m["face_inv_map"] = face_inv_map
+    m["faces_inv"] = faces_inv
     rgb_sampled = None
     if return_rgb:
         rgb_sampled = torch.zeros(B, S, S, 3, dtype=torch.float32, device=dev)

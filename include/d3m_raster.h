@@ -62,6 +62,14 @@ int d3m_timing_collect(const char** names, int* counts, float* total_ms, int max
 size_t d3m_forward_workspace_bytes(int batch_size, int num_faces, int image_size);
 size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_size);
 
+/* Which of the two forms of coverage d3m_forward_face_index_map(_mesh) runs (both replace KCU:70-169 and
+ * produce the same maps bit for bit): -1 = chosen per launch by mesh density and batch size (the default), 0 = per-tile
+ * face lists only (k_bin_* -> k_raster_tiles), 1 = bidding into a 64-bit z-buffer wherever its workspace fits
+ * (k_bid_faces -> k_bid_big -> k_bid_resolve).  Process-wide, read at every launch; the environment variable D3M_BID=0/1
+ * sets the initial value.  Returns D3M_ERR_INVALID for any other value. */
+int d3m_set_coverage_form(int form);
+int d3m_get_coverage_form(void);
+
 /* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
  *   faces          [B,F,3,3] f32 in   NDC x,y in [-1,1] (+y up), z = depth
  *   face_index_map [B,S,S]   i32 out  index of the nearest covering face, -1 where uncovered

@@ -38,3 +38,42 @@ def golden_case(golden, name):
 
 def golden_case_names(golden):
     return sorted({k.split("/")[1] for k in golden.files if k.startswith("kern/")})
+
+
+@pytest.fixture(params=["binned", "bidding"])
+def coverage(request):
+    """Runs the test once per form of the forward's coverage (d3m_set_coverage_form): per-tile face lists
+    (k_bin_* -> k_raster_tiles, the form of big batches: bench.py's 32 views) and bidding into a 64-bit z-buffer
+    (k_bid_*: small batches, dense meshes).  The form is back on "auto" afterwards."""
+    from deep3dmap_amd import _lib
+    with _lib.coverage_form(request.param):
+        yield request.param
+
+
+class kernels_launched:
+    """with kernels_launched() as k: ...  ->  k.names = the library kernels launched inside (d3m_timing_collect)."""
+
+    def __enter__(self):
+        from deep3dmap_amd import _lib
+        _lib.collect_kernel_times()
+        _lib.kernel_timing(True)
+        self.names = set()
+        return self
+
+    def __exit__(self, *exc):
+        from deep3dmap_amd import _lib
+        self.times = _lib.collect_kernel_times()
+        self.names = set(self.times)
+        _lib.kernel_timing(False)
+        return False
+
+
+COVERAGE_KERNELS = {"binned": {"k_bin_count", "k_bin_alloc", "k_bin_fill", "k_raster_tiles"},
+                    "bidding": {"k_bid_faces", "k_bid_big", "k_bid_resolve"}}
+
+
+def assert_coverage_form_ran(names, form):
+    """The kernels of `form` ran and none of the other form's did."""
+    other = "bidding" if form == "binned" else "binned"
+    assert COVERAGE_KERNELS[form] <= set(names), (form, sorted(names))
+    assert not (COVERAGE_KERNELS[other] & set(names)), (form, sorted(names))

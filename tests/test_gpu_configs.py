@@ -224,10 +224,13 @@ def test_full_size_workload_properties():
 
 
 def test_one_wave_per_tile_path_equals_four_waves_per_tile_path():
-    """The tile pass runs one wave per tile when a launch has more than 32768 tiles (the bench.py configuration) and
-    four waves per tile below that (what every other test exercises and the oracle comparisons pin).  Nine views at
-    512x512 (36864 tiles) rendered in one batch must give bit-identical maps to the same views rendered one by one."""
-    from deep3dmap_amd import neural_renderer as nr, synthetic
+    """The per-tile-list form of coverage runs ONE wave per tile when a launch has more than 32768 tiles (bench.py's 32
+    views: k_raster_tiles<..., 1>) and FOUR waves per tile below that.  Nine views at 512x512 (36864 tiles) rendered in
+    one batch with the lists forced (d3m_set_coverage_form(0): "auto" would cover so small a batch by bidding) must give
+    bit-identical maps to the same views rendered one by one (4096 tiles each: four waves per tile), and both to the
+    bidding form of the same batch; which kernels ran is read from the launch record, not inferred."""
+    from conftest import assert_coverage_form_ran, kernels_launched
+    from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
     from deep3dmap_amd.neural_renderer.mesh_ops import gather_faces
     from deep3dmap_amd.neural_renderer.rasterize import _raster_forward
     v, tri = synthetic.grid_mesh(40)
@@ -236,13 +239,22 @@ def test_one_wave_per_tile_path_equals_four_waves_per_tile_path():
     ft = torch.from_numpy(tri).cuda()[None].expand(9, -1, -1).contiguous()
     faces = gather_faces(nr.look_at(vt, eyes, _perspective_angle=30), ft, True)
     tex = torch.rand(9, faces.shape[1], 2, 2, 2, 3, device="cuda")
-    many, _ = _raster_forward(faces, tex, 512, 0.1, 100.0, 1e-3, None, True, True, True, False)
+    with _lib.coverage_form("binned"), kernels_launched() as k:
+        many, _ = _raster_forward(faces, tex, 512, 0.1, 100.0, 1e-3, None, True, True, True, False)
+    assert_coverage_form_ran(k.names, "binned")
     assert float((many["face_index_map"] >= 0).float().mean()) > 0.05
-    for i in range(9):
-        one, _ = _raster_forward(faces[i:i + 1].contiguous(), tex[i:i + 1].contiguous(), 512, 0.1, 100.0, 1e-3, None, True,
-                                 True, True, False)
-        for k in ("face_index_map", "weight_map", "depth_map"):
-            assert torch.equal(many[k][i], one[k][0]), (i, k)
+    with _lib.coverage_form("bidding"), kernels_launched() as k:
+        bid, _ = _raster_forward(faces, tex, 512, 0.1, 100.0, 1e-3, None, True, True, True, False)
+    assert_coverage_form_ran(k.names, "bidding")
+    for key in ("face_index_map", "weight_map", "depth_map"):
+        assert torch.equal(many[key], bid[key]), key
+    with _lib.coverage_form("binned"), kernels_launched() as k:
+        for i in range(9):
+            one, _ = _raster_forward(faces[i:i + 1].contiguous(), tex[i:i + 1].contiguous(), 512, 0.1, 100.0, 1e-3, None, True,
+                                     True, True, False)
+            for key in ("face_index_map", "weight_map", "depth_map"):
+                assert torch.equal(many[key][i], one[key][0]), (i, key)
+    assert_coverage_form_ran(k.names, "binned")
 
 
 def test_full_size_fit_step_fused_objective_equals_materialised_images():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_case
+from conftest import assert_coverage_form_ran, golden_case, kernels_launched
 
 pytestmark = pytest.mark.gpu
 
@@ -50,9 +50,11 @@ def _forward(c):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_forward_ops_match_reference_vectors(golden, name):
+def test_forward_ops_match_reference_vectors(golden, name, coverage):
     c = golden_case(golden, name)
-    m = _forward(c)
+    with kernels_launched() as k:
+        m = _forward(c)
+    assert_coverage_form_ran(k.names, coverage)
     assert np.array_equal(m["face_index_map"].cpu().numpy(), c["face_index_map"])
     assert np.array_equal(m["sampling_index_map"].cpu().numpy(), c["sampling_index_map"])
     for key in ("weight_map", "depth_map", "face_inv_map", "faces_inv", "sampling_weight_map"):
@@ -115,9 +117,9 @@ def test_ops_reject_cpu_and_noncontiguous_tensors():
 
 
 @pytest.mark.parametrize("S,F,size", [(64, 500, 0.05), (100, 300, 0.3), (37, 64, 1.5)])
-def test_forward_equals_oracle_bruteforce_on_random_scenes(S, F, size):
-    """Binned tile raster vs the oracle's brute-force loop: tiny, medium and screen-filling triangles,
-    image sizes that are not multiples of the 8-pixel tile."""
+def test_forward_equals_oracle_bruteforce_on_random_scenes(S, F, size, coverage):
+    """Both forms of coverage (per-tile lists | bidding) vs the oracle's brute-force loop: tiny, medium and
+    screen-filling triangles, image sizes that are not multiples of the 8-pixel tile."""
     from deep3dmap_amd.neural_renderer import rasterize_ops as ops
     from oracle import nr_oracle as O
     rng = np.random.default_rng(S * 1000 + F)
@@ -131,7 +133,9 @@ def test_forward_equals_oracle_bruteforce_on_random_scenes(S, F, size):
     wm = torch.zeros(B, S, S, 3, device="cuda")
     dm = torch.full((B, S, S), 3.5, device="cuda")
     fim = torch.zeros(B, S, S, 3, 3, device="cuda")
-    ops.forward_face_index_map(fd, fi, wm, dm, fim, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
+    with kernels_launched() as k:
+        ops.forward_face_index_map(fd, fi, wm, dm, fim, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
+    assert_coverage_form_ran(k.names, coverage)
     assert np.array_equal(fi.cpu().numpy(), ref["face_index_map"])
     assert np.array_equal(wm.cpu().numpy(), ref["weight_map"])
     assert np.array_equal(dm.cpu().numpy(), ref["depth_map"])
@@ -202,7 +206,7 @@ def test_edge_gradient_on_an_image_wider_than_the_line_window():
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_backward_operators_differential_fuzz(seed):
+def test_backward_operators_differential_fuzz(seed, coverage):
     """Random small scenes through K4 / K5 / K6 against the oracle: triangle sizes from sub-pixel to screen-filling,
     vertices snapped to pixel centres or pixel edges in some scenes (integer crossings -> the t == 0 pixel of inward
     walks, shared-edge ties), duplicated and degenerate faces, faces partly or wholly off screen, and gradient maps
@@ -253,10 +257,12 @@ def test_backward_operators_differential_fuzz(seed):
     scale = float(np.abs(gf_ref[ok]).max()) if ok.any() else 0.0
     assert np.abs(gf.cpu().numpy()[ok] - gf_ref[ok]).max() <= GRAD_RTOL * scale, (B, S, Fn, size, mode, gmode)
     assert _grad_close(gt.cpu().numpy(), gt_ref)
-    # and the forward maps of the same scene, bit for bit
+    # and the forward maps of the same scene, bit for bit, in the form of coverage under test
     fi2 = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
     wm2, dm2 = torch.zeros(B, S, S, 3, device="cuda"), torch.full((B, S, S), 3.5, device="cuda")
-    ops.forward_face_index_map(fd, fi2, wm2, dm2, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), S, 0.5, 3.5, 1, 1, 0)
+    with kernels_launched() as k:
+        ops.forward_face_index_map(fd, fi2, wm2, dm2, torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda"), S, 0.5, 3.5, 1, 1, 0)
+    assert_coverage_form_ran(k.names, coverage)
     assert np.array_equal(fi2.cpu().numpy(), m["face_index_map"]) and np.array_equal(dm2.cpu().numpy(), m["depth_map"])
     assert np.array_equal(wm2.cpu().numpy(), m["weight_map"])
 
@@ -338,12 +344,13 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
 
 @pytest.mark.parametrize("S,V,Ft,size,fill_back", [(64, 300, 500, 0.05, True), (100, 200, 300, 0.3, False), (37, 40, 64, 1.5, True),
                                                     (256, 30, 24, 2.5, True), (129, 2000, 6000, 0.02, True)])
-def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, size, fill_back):
-    """d3m_forward_face_index_map_mesh -- which covers small batches and dense meshes by BIDDING (csrc/d3m_bid.h: rows of the
-    boxes, a pass of its own for big faces) -- against d3m_forward_face_index_map on the gathered faces (the binned tile pass,
-    itself bit-equal to the oracle's brute force and to the reference's kernel above): the same maps, bit for bit, on needles,
-    sub-pixel and screen-filling triangles, rasters that are no multiple of the tile, a face with a NaN vertex, a
-    zero-area face, and the dense copy / visibility marks both forms leave behind."""
+def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, size, fill_back, coverage):
+    """d3m_forward_face_index_map_mesh in one form of coverage (`coverage`: the per-tile lists, or BIDDING -- csrc/d3m_bid.h:
+    rows of the boxes, a pass of its own for big faces) against d3m_forward_face_index_map on the gathered faces in the
+    OTHER form (each bit-equal to the oracle's brute force and to the reference's kernel above): the same maps, bit for
+    bit, on needles, sub-pixel and screen-filling triangles, rasters that are no multiple of the tile, a face with a NaN
+    vertex, a zero-area face, and the dense copy / visibility marks both forms leave behind.  Which form ran on either
+    side is read from the launch record."""
     import ctypes
     from deep3dmap_amd import _lib
     from deep3dmap_amd.neural_renderer import rasterize_ops as ops
@@ -366,9 +373,11 @@ def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, s
     wm, dm, fim = torch.empty(B, S, S, 3, device="cuda"), torch.empty(B, S, S, device="cuda"), torch.empty(B, S, S, 3, 3, device="cuda")
     ws = torch.empty(int(L.d3m_forward_workspace_bytes(B, Fp, S)), dtype=torch.uint8, device="cuda")
     vis = torch.empty(int(L.d3m_visibility_bytes(B, Fp)), dtype=torch.uint8, device="cuda")
-    _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), _lib.ptr(tr), 1, V, Ft, int(fill_back), _lib.ptr(faces), _lib.ptr(fi),
-                                                 _lib.ptr(wm), _lib.ptr(dm), _lib.ptr(fim), B, S, 0.5, 3.5, _lib.ptr(ws), ws.numel(),
-                                                 _lib.ptr(vis), vis.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+    with kernels_launched() as k:
+        _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), _lib.ptr(tr), 1, V, Ft, int(fill_back), _lib.ptr(faces), _lib.ptr(fi),
+                                                     _lib.ptr(wm), _lib.ptr(dm), _lib.ptr(fim), B, S, 0.5, 3.5, _lib.ptr(ws), ws.numel(),
+                                                     _lib.ptr(vis), vis.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+    assert_coverage_form_ran(k.names, coverage)
     _lib.check(L.d3m_visibility(None, _lib.ptr(vis), vis.numel(), B, Fp, S, _lib.stream_ptr()), "d3m_visibility")
     # the reference composition: vertices_to_faces (+ the reversed copies), then the operator
     g = torch.from_numpy(verts)[:, torch.from_numpy(tri).long()]                 # [B,Ft,3,3]
@@ -376,8 +385,10 @@ def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, s
     fd = dense.contiguous().cuda()
     fi2 = torch.full((B, S, S), -1, dtype=torch.int32, device="cuda")
     wm2, dm2, fim2 = torch.zeros(B, S, S, 3, device="cuda"), torch.full((B, S, S), 3.5, device="cuda"), torch.zeros(B, S, S, 3, 3, device="cuda")
-    ops.forward_face_index_map(fd, fi2, wm2, dm2, fim2, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
-    torch.cuda.synchronize()
+    other = "bidding" if coverage == "binned" else "binned"
+    with _lib.coverage_form(other), kernels_launched() as k:
+        ops.forward_face_index_map(fd, fi2, wm2, dm2, fim2, torch.zeros_like(fd), S, 0.5, 3.5, 0, 1, 1)
+    assert_coverage_form_ran(k.names, other)
     cov = float((fi2 >= 0).float().mean())
     assert cov > 0.02, cov
     assert torch.equal(fi, fi2), int((fi != fi2).sum())

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import assert_coverage_form_ran, kernels_launched
 from oracle import nr_oracle as O
 from oracle import nr_ref_hip as RH
 
@@ -93,9 +94,10 @@ def _assert_maps_equal(m, ref, keys=("face_index_map", "weight_map", "depth_map"
 
 
 @pytest.mark.parametrize("seed", range(40))
-def test_product_operators_against_device_reference_fuzz(seed):
+def test_product_operators_against_device_reference_fuzz(seed, coverage):
     """Sub-pixel to screen-filling triangles, vertices snapped to pixel centres / edges, duplicated and degenerate
-    faces, off-screen faces, dense / boxed / single-pixel gradient maps -- product vs the reference's kernels."""
+    faces, off-screen faces, dense / boxed / single-pixel gradient maps -- product vs the reference's kernels, once per
+    form of coverage (`coverage`: per-tile lists | bidding)."""
     rng = np.random.default_rng(5000 + seed)
     B = int(rng.integers(1, 3))
     S = int(rng.choice([16, 24, 33, 48, 64, 100]))
@@ -116,9 +118,12 @@ def test_product_operators_against_device_reference_fuzz(seed):
     fd = torch.from_numpy(faces).cuda()
     td = torch.rand(B, faces.shape[1], ts, ts, ts, 3, device="cuda")
     ref = RH.forward(fd, td, S, 0.5, 3.5, 1e-3, (0.1, 0.2, 0.3))
-    m = _product_forward(fd, td, S, 0.5, 3.5, 1e-3, (0.1, 0.2, 0.3))
+    with kernels_launched() as k:
+        m = _product_forward(fd, td, S, 0.5, 3.5, 1e-3, (0.1, 0.2, 0.3))
+    assert_coverage_form_ran(k.names, coverage)
     _assert_maps_equal(m, ref, ("face_index_map", "weight_map", "depth_map", "rgb_map", "alpha_map", "face_inv_map",
                                 "sampling_index_map", "sampling_weight_map"))
+    assert np.array_equal(m["faces_inv"].cpu().numpy(), ref["faces_inv"].cpu().numpy(), equal_nan=True)     # K1, KCU:24-67
     g_rgb = torch.randn(B, S, S, 3, device="cuda")
     g_alpha = torch.randn(B, S, S, device="cuda")
     g_depth = torch.randn(B, S, S, device="cuda")
@@ -142,8 +147,8 @@ def test_product_operators_against_device_reference_fuzz(seed):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_sliver_faces_against_device_reference(seed):
-    """The binned forward's one theoretical deviation: a (near-)zero-area face selected by brute force at
+def test_sliver_faces_against_device_reference(seed, coverage):
+    """The forward's one theoretical deviation (either form bounds a face's pixels by its dilated box): a (near-)zero-area face selected by brute force at
     a pixel outside its dilated bounding box.  800 slivers per scene -- collinear up to rounding, thin, and exactly
     collinear through pixel centres -- product vs the reference's kernels: counted, and the count must be zero."""
     rng = np.random.default_rng(seed)
@@ -162,7 +167,9 @@ def test_sliver_faces_against_device_reference(seed):
     fd = torch.from_numpy(np.concatenate([faces, faces[:, :, ::-1]], 1).copy()).cuda()
     td = torch.rand(1, fd.shape[1], 2, 2, 2, 3, device="cuda")
     ref = RH.forward(fd, td, S, 0.5, 3.5, 1e-3, (0, 0, 0))
-    m = _product_forward(fd, td, S, 0.5, 3.5, 1e-3, (0, 0, 0))
+    with kernels_launched() as k:
+        m = _product_forward(fd, td, S, 0.5, 3.5, 1e-3, (0, 0, 0))
+    assert_coverage_form_ran(k.names, coverage)
     assert int((m["face_index_map"] != ref["face_index_map"]).sum()) == 0
     _assert_maps_equal(m, ref, ("weight_map", "depth_map", "rgb_map"))
 
@@ -196,17 +203,19 @@ def _record(name, info):
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 
 
-def _full_size_check(faces, S, ts, expect_path, seed, textures_batch=None):
-    """Forward maps EQUAL to the reference's, K4/K5/K6 gradients within 1e-3, on one full-size scene."""
+def _full_size_check(faces, S, ts, form, ran, seed, textures_batch=None):
+    """Forward maps EQUAL to the reference's, K4/K5/K6 gradients within 1e-3, on one full-size scene.
+    form: the coverage form the caller selected ("binned" | "bidding" | "auto"); ran: the form that must have RUN, checked
+    by the names of the launched kernels, not by arithmetic on the tile count."""
     from deep3dmap_amd import _lib
     B, Fp = faces.shape[:2]
-    n_tiles = B * ((S + 7) // 8) ** 2
-    assert (n_tiles > 32768) == (expect_path == "one_wave_per_tile"), n_tiles
     gen = torch.Generator(device="cuda").manual_seed(seed)
     tex = torch.rand(B, Fp, ts, ts, ts, 3, device="cuda", generator=gen)
     near, far, eps, bg = 0.1, 100.0, 1e-3, (0.3, 0.2, 0.1)
     ref = RH.forward(faces, tex, S, near, far, eps, bg)
-    m = _product_forward(faces, tex, S, near, far, eps, bg)
+    with _lib.coverage_form(form), kernels_launched() as k:
+        m = _product_forward(faces, tex, S, near, far, eps, bg)
+    assert_coverage_form_ran(k.names, ran)
     cov = float((ref["face_index_map"] >= 0).float().mean())
     assert 0.2 < cov < 0.95, cov
     mismatched = int((m["face_index_map"] != ref["face_index_map"]).sum())
@@ -220,12 +229,15 @@ def _full_size_check(faces, S, ts, expect_path, seed, textures_batch=None):
     assert torch.isfinite(gf_ref).all() and torch.isfinite(gf).all()
     errs = {"grad_faces": _rel_max(gf, gf_ref), "grad_textures": _rel_max(gt, gt_ref)}
     assert errs["grad_faces"] <= GRAD_RTOL and errs["grad_textures"] <= GRAD_RTOL, errs
+    del gf, gt, gf_ref, gt_ref, g_rgb, g_alpha, g_depth
     # INFORMATIONAL: the default (FMA-contracted) build of the same reference text -- what a stock build of its setup.py
     # computes.  The reference's arithmetic is ill-conditioned on small / sliver triangles (face_inv divides by twice
     # the signed area, KCU:52-61; a 1-pixel triangle's barycentrics amplify one ulp of its vertices by ~1e3), so its own
     # two builds disagree with EACH OTHER: winners flip on edge pixels and barycentrics move by 1e-4..1e-1.  The numbers
     # are recorded (gpurun_out/parity_full_size.json -> profiles/) and only sanity-bounded here; the contract that is
     # asserted is equality with the uncontracted build above, which is stricter than north_star's 1e-4.
+    m = {k_: m[k_] for k_ in ("face_index_map", "depth_map", "weight_map")}
+    del ref
     fma = RH.forward(faces, tex, S, near, far, eps, bg, contract="fma")
     same = (fma["face_index_map"] == m["face_index_map"])
     covered = same & (m["face_index_map"] >= 0)
@@ -237,17 +249,31 @@ def _full_size_check(faces, S, ts, expect_path, seed, textures_batch=None):
              "fma_depth_median": float(d_depth.median()), "fma_weight_median": float(d_w.median()),
              "fma_weight_max": float(d_w.max())}
     assert flipped < 1e-3 and stats["fma_depth_median"] < 1e-5 and stats["fma_depth_over_1e-4_frac"] < 5e-3, stats
-    return {"coverage": cov, "pixels": B * S * S, "faces": Fp, "mismatched_pixels": mismatched, **stats, **errs}
+    return {"coverage": cov, "pixels": B * S * S, "faces": Fp, "mismatched_pixels": mismatched, "coverage_form": ran,
+            "coverage_kernels": sorted(n for n in k.names if n.startswith(("k_bin", "k_bid", "k_raster"))), **stats, **errs}
 
 
-def test_config4_full_size_one_wave_per_tile_path_against_reference():
-    """BASELINE config 4 / the bench.py workload: 100,352 triangles (fill_back: 200,704), 512x512, NINE of the 32
-    cameras in one launch = 36,864 tiles, i.e. the one-wave-per-tile path bench.py runs."""
+def test_config4_nine_views_against_reference(coverage):
+    """BASELINE config 4's mesh: 100,352 triangles (fill_back: 200,704), 512x512, NINE of the 32 cameras in one launch
+    (36,864 tiles), in each form of coverage."""
     from deep3dmap_amd import synthetic
     eyes = synthetic.camera_ring(32)[[0, 3, 7, 11, 14, 18, 22, 26, 29]]
     _, _, _, faces, S = _config_scene(225, eyes, 512, False)
-    info = _full_size_check(faces, S, 2, "one_wave_per_tile", 4)
-    _record("config4_100352tri_512_9views", info)
+    info = _full_size_check(faces, S, 2, coverage, coverage, 4)
+    _record(f"config4_100352tri_512_9views[{coverage}]", info)
+
+
+def test_config4_bench_launch_shape_auto_dispatch_against_reference():
+    """The launch bench.py times: ALL 32 cameras of config 4 in one launch = 131,072 tiles, form of coverage left to the
+    library ("auto") -- which must pick the per-tile lists with ONE wave per tile (k_bin_count -> k_bin_alloc -> k_bin_fill
+    -> k_raster_tiles<..., 1>: more than 65,536 tiles) -- against the reference's kernels (32 x 5e10 pixel-face tests)."""
+    from deep3dmap_amd import _lib, synthetic
+    eyes = synthetic.camera_ring(32)
+    _, _, _, faces, S = _config_scene(225, eyes, 512, False)
+    assert faces.shape[0] * ((S + 7) // 8) ** 2 == 131072
+    assert _lib.lib().d3m_get_coverage_form() == -1
+    info = _full_size_check(faces, S, 2, "auto", "binned", 41)
+    _record("config4_100352tri_512_32views[auto=binned]", info)
 
 
 def test_config4_full_size_against_the_cpu_port():
@@ -263,38 +289,40 @@ def test_config4_full_size_against_the_cpu_port():
         assert np.array_equal(m[k].cpu().numpy(), ref[k]), k
 
 
-def test_config2_full_size_against_reference():
+def test_config2_full_size_against_reference(coverage):
     """BASELINE config 2: ~53k-triangle mesh (grid_mesh(164): 53,138; fill_back 106,276) @256x256 with anti-aliasing
-    (internal raster 512x512), single view."""
+    (internal raster 512x512), single view (4,096 tiles: the per-tile lists run four waves per tile)."""
     from deep3dmap_amd import synthetic
     eyes = synthetic.camera_ring(8)[[1]]
     _, _, _, faces, S = _config_scene(164, eyes, 256, True)
     assert S == 512 and faces.shape[1] == 106276
-    info = _full_size_check(faces, S, 2, "four_waves_per_tile", 2)
-    _record("config2_53138tri_256aa_1view", info)
+    info = _full_size_check(faces, S, 2, coverage, coverage, 2)
+    _record(f"config2_53138tri_256aa_1view[{coverage}]", info)
 
 
-def test_config5_full_size_against_reference():
+def test_config5_full_size_against_reference(coverage):
     """BASELINE config 5: 1,002,528 triangles (fill_back 2,005,056) @1024x1024, one of the 256 cameras (the reference's
     brute force is 2.1e12 pixel-face tests per view)."""
     from deep3dmap_amd import synthetic
     eyes = synthetic.camera_ring(256)[[37]]
     _, _, _, faces, S = _config_scene(709, eyes, 1024, False)
     assert faces.shape[1] == 2005056
-    info = _full_size_check(faces, S, 2, "four_waves_per_tile", 5)
-    _record("config5_1002528tri_1024_1view", info)
+    info = _full_size_check(faces, S, 2, coverage, coverage, 5)
+    _record(f"config5_1002528tri_1024_1view[{coverage}]", info)
 
 
-def test_config4_mesh_path_and_lit_step_against_reference():
+@pytest.mark.parametrize("views,form,ran", [(9, "binned", "binned"), (9, "bidding", "bidding"), (20, "auto", "binned")])
+def test_config4_mesh_path_and_lit_step_against_reference(views, form, ran):
     """The path bench.py actually runs -- coverage straight from the indexed mesh (d3m_forward_face_index_map_mesh),
-    fill_back and lighting on the fly, fused backward into vertex gradients -- on nine full-size views: its maps
+    fill_back and lighting on the fly, fused backward into vertex gradients -- on nine full-size views in each form of
+    coverage, and on twenty (81,920 tiles) with the form left to the library, which must take the per-tile lists: its maps
     against the reference's kernels fed with the materialised faces / lit textures (NR/renderer.py:155-167), and
     d(loss)/d(screen vertices), d(loss)/d(textures) against the reference's K4+K5+K6 gradients pushed through the
     gather's adjoint."""
     from deep3dmap_amd import neural_renderer as nr, synthetic
     from deep3dmap_amd.neural_renderer import mesh_ops
     from deep3dmap_amd.neural_renderer.rasterize import rasterize_lit
-    eyes_np = synthetic.camera_ring(32)[[1, 4, 8, 12, 15, 19, 23, 27, 30]]
+    eyes_np = synthetic.camera_ring(32)[[1, 4, 8, 12, 15, 19, 23, 27, 30]] if views == 9 else synthetic.camera_ring(32)[3:3 + views]
     v, tri, sv, faces, S = _config_scene(225, eyes_np, 512, False)
     B = len(eyes_np)
     tex0 = torch.from_numpy(synthetic.random_textures(tri.shape[0], 2)).cuda()
@@ -309,7 +337,10 @@ def test_config4_mesh_path_and_lit_step_against_reference():
     ref = RH.forward(faces, tex_lit, S, 0.1, 100.0, 1e-3, (0, 0, 0))
     svg = sv.detach().clone().requires_grad_(True)
     texg = tex0[None].clone().requires_grad_(True)
-    out = rasterize_lit(svg, vt, ft, texg, light_cfg, True, 512, False, 0.1, 100.0, 1e-3, (0, 0, 0))
+    from deep3dmap_amd import _lib
+    with _lib.coverage_form(form), kernels_launched() as k:
+        out = rasterize_lit(svg, vt, ft, texg, light_cfg, True, 512, False, 0.1, 100.0, 1e-3, (0, 0, 0))
+    assert_coverage_form_ran(k.names, ran)
     # images: [B,3,s,s] flipped CHW of the internal maps (NR/rasterize.py:305-317)
     assert torch.equal(out["rgb"], ref["rgb_map"].permute(0, 3, 1, 2).flip(2))
     assert torch.equal(out["alpha"], ref["alpha_map"].flip(1))

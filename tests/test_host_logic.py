@@ -39,6 +39,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.d3m_error_string(2) == b"workspace missing or too small"
 
 
+def test_coverage_form_switch_is_host_state():
+    """d3m_set_coverage_form: -1 / 0 / 1 accepted and read back, anything else D3M_ERR_INVALID and no change; the
+    context manager restores the previous form (no launch involved: runs without a GPU)."""
+    from deep3dmap_amd import _lib
+    L = _lib.lib()
+    start = L.d3m_get_coverage_form()
+    assert start in (-1, 0, 1)
+    for form in (0, 1, -1):
+        assert L.d3m_set_coverage_form(form) == 0 and L.d3m_get_coverage_form() == form
+    assert L.d3m_set_coverage_form(2) == 1 and L.d3m_set_coverage_form(-2) == 1 and L.d3m_get_coverage_form() == -1
+    with _lib.coverage_form("binned"):
+        assert L.d3m_get_coverage_form() == 0
+        with _lib.coverage_form("bidding"):
+            assert L.d3m_get_coverage_form() == 1
+        assert L.d3m_get_coverage_form() == 0
+    assert L.d3m_get_coverage_form() == -1
+    L.d3m_set_coverage_form(start)
+
+
 def test_library_is_gfx950_code_object():
     from deep3dmap_amd.build import LIB_PATH
     blob = open(LIB_PATH, "rb").read()
