@@ -34,6 +34,40 @@ def _own_stream(stream):
     return torch.cuda.stream(stream) if os.environ.get("D3M_BENCH_OWN_STREAM", "1") == "1" else contextlib.nullcontext()
 
 
+def library_identity():
+    """(path relative to the repo, first 16 hex digits of the sha256) of the shared library this process timed."""
+    import hashlib
+    from deep3dmap_amd import _lib
+    path = os.path.abspath(_lib.LIB_PATH)
+    sha = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    return (os.path.relpath(path, ROOT) if path.startswith(ROOT) else path), sha
+
+
+def refuse_dev_switches(allow):
+    """A bench line is a claim about the PRODUCT build with its own correctness checks on: the developer switches that
+    swap the library (D3M_LIB_PATH: tuning variants, -DD3M_DEV_SKIP builds whose results are wrong by construction) or
+    disable the asserts (D3M_BENCH_TIMING_EXPERIMENT) are refused unless --allow-dev is passed, and then named in the line."""
+    used = [k for k in ("D3M_LIB_PATH", "D3M_BENCH_TIMING_EXPERIMENT") if os.environ.get(k)]
+    if used and not allow:
+        sys.exit(f"bench.py: {', '.join(used)} set in the environment -- developer switches; pass --allow-dev to time such a "
+                 "build (the line then says so)")
+    return used
+
+
+def timed_repeats(run_steps, barrier, repeats, steps):
+    """`repeats` timed regions of exactly `steps` steps each, every one bracketed by barrier + device synchronisation on
+    both sides; returns the seconds of each region."""
+    out = []
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = run_steps()
+        barrier()
+        out.append(time.perf_counter() - t0)
+    return out, last
+
+
 def algorithmic_bytes(V, F, S, s, ts, alpha=1, depth=1, rgb=1, tex_grad=1):
     """compulsory HBM bytes per view, forward and backward."""
     P, Po = S * S, s * s
@@ -236,12 +270,8 @@ def gan2shape_workload(args):
     with _own_stream(runner.stream):
         for _ in range(args.warmup):
             runner()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = runner()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        regions, loss = timed_repeats(runner, torch.cuda.synchronize, max(1, args.repeats), args.steps)
+        elapsed = float(np.median(regions))
     if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):      # (kernel-timing experiments with deliberately wrong results)
         assert abs(float(loss) - loss_eager) <= 1e-5 * abs(loss_eager), (float(loss), loss_eager)
         for x, g0 in zip(leaves, g_eager):
@@ -278,6 +308,9 @@ def gan2shape_workload(args):
         "metric": f"rendered Mpix/s fwd+bwd, gan2shape renderer block (64x64 depth-to-mesh, batch {B})",
         "value": round(B * hw * hw / step_s / 1e6, 2), "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "repeats": len(regions), "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+        "library": library_identity()[0], "library_sha16": library_identity()[1], "dev_switches": args.dev_switches,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"gan2shape renderer block (gan2shape.py:444,463-497): view [{B},6] -> (R,t); depth [{B},64,64] -> "
                                "normals -> shading -> texture; 7938-tri implicit grid mesh x2 (fill_back) -> recon_depth @64 "
@@ -379,7 +412,13 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="gan2shape workload: batch size")
     ap.add_argument("--flip", action="store_true",
                     help="gan2shape workload: append the mirrored copies (flip3, gan2shape.py:431: 2 x batch entries)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each (barrier-bracketed); value / ms_per_step = their MEDIAN, "
+                         "min and max ride in the line (box-to-box and run-to-run spread is 1-2 %%)")
+    ap.add_argument("--allow-dev", action="store_true",
+                    help="accept D3M_LIB_PATH / D3M_BENCH_TIMING_EXPERIMENT (developer builds and timing experiments)")
     args = ap.parse_args()
+    dev_switches = args.dev_switches = refuse_dev_switches(args.allow_dev)
     if args.workload == "gan2shape":
         return gan2shape_workload(args)
     if args.workload == "mesh_family":
@@ -445,19 +484,19 @@ def main():
             fit.release_graph()
             graph_on = False
             torch.cuda.synchronize()
+    def max_over_ranks(seconds):
+        if not dist_on:
+            return list(seconds)
+        tmax = torch.tensor(seconds, device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return [float(x) for x in tmax.tolist()]
+
     with _own_stream(fit.stream):
         for _ in range(args.warmup):
             fit.step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss, gv, gt = fit.step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        regions, (loss, gv, gt) = timed_repeats(fit.step, barrier, max(1, args.repeats), args.steps)
+    regions = max_over_ranks(regions)                   # every region: the slowest rank's time
+    elapsed = float(np.median(regions))
     if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):
         assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
     # the replayed graph must reproduce the eager step (same inputs every step: no optimiser in the loop)
@@ -491,23 +530,19 @@ def main():
         with _own_stream(fit2.stream):
             for _ in range(args.warmup):
                 fit2.step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fit2.step()
-            barrier()
-            el2 = time.perf_counter() - t0
-        if dist_on:
-            tmax = torch.tensor([el2], device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el2 = float(tmax.item())
+            regions2, _ = timed_repeats(fit2.step, barrier, max(1, args.repeats), args.steps)
+        regions2 = max_over_ranks(regions2)
+        el2 = float(np.median(regions2))
         fit2.release_graph()
         dropin = {"api": "Renderer.render + multiview_fit_loss + backward",
                   "value": round(n_views * args.image_size ** 2 / (el2 / args.steps) / 1e6, 2), "unit": "Mpix/s",
-                  "ms_per_step": round(el2 / args.steps * 1e3, 4)}
+                  "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                  "ms_per_step_min": round(min(regions2) / args.steps * 1e3, 4),
+                  "ms_per_step_max": round(max(regions2) / args.steps * 1e3, 4)}
         del fit2
 
     if rank == 0:
+        lib_path, lib_sha = library_identity()
         V, F, S, ts = v.shape[0], tri.shape[0], args.image_size, args.texture_size
         ms_per_step = elapsed / args.steps * 1e3
         pix = n_views * S * S
@@ -543,6 +578,11 @@ def main():
             "metric": ("rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512" if (args.mesh_n, S) == (225, 512) else
                        f"rendered Mpix/s fwd+bwd, {F}-tri mesh @{S}x{S}"), "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # value / ms_per_step: the MEDIAN of `repeats` barrier-bracketed regions of `steps` steps each
+            "repeats": len(regions), "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+            "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
+            "library": lib_path, "library_sha16": lib_sha, "dev_switches": dev_switches,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
                                    f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "

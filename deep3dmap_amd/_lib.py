@@ -58,6 +58,7 @@ _SIGNATURES = {
     "d3m_forward_workspace_min_bytes": (_SZ, [_I, _I, _I]),
     "d3m_set_coverage_form": (_I, [_I]),
     "d3m_get_coverage_form": (_I, []),
+    "d3m_forward_coverage_form": (_I, [_I, _I, _I]),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
     "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ, _P]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
@@ -98,6 +99,7 @@ _SIGNATURES = {
                                      _P, _P]),
     "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
     "d3m_fit_finish": (_I, [ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
+    "d3m_fit_loss_records": (_I, [_P, _P, _P, _P, ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
                                        _P, _P, _P, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

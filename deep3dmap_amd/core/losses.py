@@ -108,13 +108,68 @@ class _MultiViewFitLoss(torch.autograd.Function):
         return g_rgb, g_depth, g_alpha, None, None, None, None, None
 
 
+class _FitLossOnLitImages(torch.autograd.Function):
+    """multiview_fit_loss on the three images of ONE lit render node (Renderer.render's on-the-fly path, no anti-aliasing):
+    the value in one pass over the images (d3m_fit_loss_records), and in the same pass the objective's gradient as the edge
+    gradient's per-pixel records -- what Renderer.render_fit_loss leaves behind.  backward() hands the render node the
+    scalar gradient through the link and returns zero-stride zero images: the render node's backward recognises them and
+    takes the records route (no gradient images, no d3m_fit_loss_backward, no k_pack_maps).  Same value and gradients as
+    the plain node below."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, alpha, rgb_t, depth_t, alpha_t, mask, mask_sum, lit):
+        from ..neural_renderer.rasterize import LitImagesLink, _RasterizeLit
+        if any(ctx.needs_input_grad[3:8]):
+            raise NotImplementedError("multiview_fit_loss: targets, mask and mask_sum are constants (detach them)")
+        L = _lib.lib()
+        B, _, S, _ = rgb.shape
+        dev = rgb.device
+        rgb_t, depth_t, alpha_t, mask = (f32c(x) for x in (rgb_t, depth_t, alpha_t, mask))
+        mask_sum = f32c(mask_sum).reshape(1) if mask_sum is not None else mask.sum().reshape(1)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(B, S)), dtype=torch.float32, device=dev)]
+        g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
+                  torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
+                  torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev),          # nz_lo_inv | nz_hi1
+                  torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
+        fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps, mask_sum, False)
+        fit_c = _RasterizeLit._fit_struct(fit_state, 0, 0, B, None)
+        import ctypes
+        _lib.check(L.d3m_fit_loss_records(_lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(lit.maps["face_index_map"]),
+                                          ctypes.byref(fit_c), B, S, _lib.stream_ptr()), "d3m_fit_loss_records")
+        link = LitImagesLink(fit_state, (rgb, depth, alpha), torch.zeros(1, dtype=torch.float32, device=dev))
+        lit.linked_fit = link
+        ctx.link = link
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        link = ctx.link
+        link.grad_loss = f32c(g).reshape(1)
+        link.pending = True
+        g_rgb, g_depth, g_alpha = link.dummies()
+        return g_rgb, g_depth, g_alpha, None, None, None, None, None, None
+
+
 def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum=None):
     """photometric_loss(rgb, rgb_target, mask) + silhouette_loss(alpha, alpha_target) / (H*W) +
     photometric_loss(depth, depth_target, mask): the multi-view fit objective as ONE autograd node (a reduction and a
     finish launch forward, one gradient launch backward) instead of three loss nodes and their eager glue.
     rgb [B,3,H,W]; depth, alpha, mask and the targets [B,H,W].  `mask_sum` (device scalar, optional) replaces sum(mask)
     as the normaliser of the two photometric terms: the mask's sum over ALL shards when these views are one rank's share
-    of a camera-sharded objective (deep3dmap_amd/multiview.py)."""
+    of a camera-sharded objective (deep3dmap_amd/multiview.py).
+
+    When rgb, depth and alpha are the three images of one Renderer.render() call (NR/renderer.py:200-246) on the lit path
+    without anti-aliasing, the objective's gradient never exists as images: see _FitLossOnLitImages."""
+    if torch.is_grad_enabled() and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+                                       for x in (rgb, depth, alpha)):
+        from ..neural_renderer.rasterize import lit_images_link
+        lit = lit_images_link(rgb, depth, alpha)
+        B = rgb.shape[0]
+        if lit is not None and rgb.dim() == 4 and rgb.shape[1] == 3 and rgb.shape[2] == rgb.shape[3] and all(
+                tuple(x.shape) == (B,) + tuple(rgb.shape[2:]) for x in (depth, alpha, depth_target, alpha_target, mask)) \
+                and tuple(rgb_target.shape) == tuple(rgb.shape):
+            return _FitLossOnLitImages.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum, lit)
     return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum)
 
 

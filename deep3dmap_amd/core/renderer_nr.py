@@ -199,7 +199,15 @@ class NrRenderer():
 
     def set_transform_matrices(self, view):
         """CR:61-62.  A view on the GPU is kept as it is until rot_mat / trans_xyz are looked at (one fused launch then):
-        reconstruct() feeds it to its first pass instead, which computes (R, t) among other things."""
+        reconstruct() feeds it to its first pass instead, which computes (R, t) among other things.
+
+        ALIASING CONTRACT (differs from the reference, which computes (R, t) here and now): the tensor itself is kept, not
+        a copy, and it is READ when (R, t) are first needed -- by reconstruct(), a render_* method or a look at rot_mat /
+        trans_xyz.  A caller that refills `view` IN PLACE between this call and that read (a preallocated buffer under
+        graph replay) gets the transform of the NEW contents -- which is what a replayed training step wants, and why no
+        snapshot is taken (a clone would be one more launch in the 9-launch block) -- ; pass `view.clone()` to pin the
+        values of the moment.  Assigning rot_mat or trans_xyz first resolves a pending view (the other half of the pair
+        still comes from it)."""
         if torch.is_tensor(view) and view.is_cuda and view.dim() == 2 and view.size(1) in (3, 5, 6):
             self._view, self._rot_mat, self._trans_xyz = view, None, None
         else:

@@ -577,10 +577,13 @@ __device__ __forceinline__ bool plan_complete(const EdgePlan& w) { return w.allo
 // counters directly.  S <= EG_WINDOW_MAX_S (LDS: 16 bytes per line); beyond it the by-key kernels below are used.
 constexpr int EG_WINDOW_MAX_S = 2048;
 struct LineWindow {
-    int* cnt[2];        // [S + 1] per axis: range ends -> counts; all zero between iterations
+    int* lds;           // [2][S + 1] per axis: range ends -> counts; all zero between iterations
+    int stride;         // S + 1
+    // (address arithmetic, not a two-pointer array: indexed by a run-time axis that array lived in scratch memory)
+    __device__ __forceinline__ int* cnt(int axis) const { return lds + axis * stride; }
 };
 __device__ __forceinline__ void window_open(LineWindow& win, int* lds, int is) {
-    win.cnt[0] = lds; win.cnt[1] = lds + (is + 1);
+    win.lds = lds; win.stride = is + 1;
     for (int k = threadIdx.x; k < 2 * (is + 1); k += blockDim.x) lds[k] = 0;
 }
 // the lanes' range ends; returns after the barrier that makes them (and the window bounds) visible.  s_lo / s_hi:
@@ -592,8 +595,8 @@ __device__ __forceinline__ void window_ranges(const LineWindow& win, const LaneT
     const int l = threadIdx.x;
     if (on && n_cross > 0 && (t.bn_axis[l] >> 1) == view) {
         const int axis = t.bn_axis[l] & 1, from = t.d0_from[l], to1 = from + n_cross;    // to + 1 <= is
-        atomicAdd(&win.cnt[axis][from], 1);
-        atomicAdd(&win.cnt[axis][to1], -1);
+        atomicAdd(&win.cnt(axis)[from], 1);
+        atomicAdd(&win.cnt(axis)[to1], -1);
         atomicMin(&s_lo[axis], from);
         atomicMax(&s_hi[axis], to1);
     }
@@ -630,11 +633,11 @@ __global__ void __launch_bounds__(256) k_edge_count_window(FS fs, int is, EdgePl
             int run = 0;
             for (int d0 = s_lo[axis] + lane; d0 - lane <= s_hi[axis]; d0 += 64) {
                 const bool in = d0 <= s_hi[axis];
-                const int v = in ? win.cnt[axis][d0] : 0;
+                const int v = in ? win.cnt(axis)[d0] : 0;
                 const int incl = wave_inclusive_scan(v) + run;
                 run = __builtin_amdgcn_readlane(incl, 63);
                 if (in) {
-                    win.cnt[axis][d0] = 0;
+                    win.cnt(axis)[d0] = 0;
                     if (incl > 0) atomicAdd(&w.line_count[((size_t)view * 2 + axis) * is + d0], incl);
                 }
             }
@@ -825,9 +828,6 @@ constexpr int EG_CHUNK = EG_LINE_THREADS / 2;  // crossings set up at a time: on
 constexpr int EG_QUEUE = EG_LINE_THREADS;      // long segments queued in LDS before they are walked (one sort key per thread)
 constexpr size_t EG_LINE_STATIC_LDS = (size_t)EG_QUEUE * (EG_ITEM_DW * 4 + 2) + 1024;   // queue + order + counters
 static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole waves the inward ones");
-#ifndef D3M_EG_LINE_MINWAVES
-#define D3M_EG_LINE_MINWAVES 1
-#endif
 
 // ---- 5. one workgroup per (view, axis, line): set up the line's crossings, walk their segments ------------------
 // The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a chunk of
@@ -861,13 +861,15 @@ static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole wav
 // tail, and the per-iteration address clamp disappears at the price of 16*16 bytes, not of a second image.  (Up to round 3
 // rasters above 28 KB of line image walked a second, clamped-index form of the loop -- two reciprocals and a select per
 // visit: the same LDS, and on the 1024^2 configuration 1.66 ms where this form takes 1.46.  Removed.)
-// MINW (waves per SIMD the register allocation must allow): 8 = at most 64 VGPRs, i.e. FOUR workgroups per CU where the
-// line's LDS image leaves room for four (S <= ~600: the kernel's phases -- stage, set up, order, walk -- are separated by
-// barriers and overlap only ACROSS workgroups; 0.545 -> 0.513 ms alone on the headline step); larger rasters fit three
-// workgroups at most and keep the 70 registers the compiler wants (1024^2: 1.452 ms against 1.468 with 64).
-template <bool USE_RGB, bool USE_ALPHA, int MINW>
-__global__ void __launch_bounds__(EG_LINE_THREADS, MINW) k_edge_lines(EdgeGradArgs a, EdgePlan w,
-                                                                                      float2* __restrict__ lane_partial) {
+// REGISTERS: at most 64 VGPRs (eight waves per SIMD), i.e. FOUR workgroups per CU where the line's LDS image leaves room
+// for four (S <= ~600): the kernel's phases -- stage, set up, order, walk -- are separated by barriers and overlap only
+// ACROSS workgroups.  Round 3 forced the bound onto a 70-register allocation, and the compiler met it with 24 bytes of
+// scratch per lane (335 MB of spill stores per headline launch); since round 4 the walk re-reads what it needs after its
+// loop from the queue item instead of carrying it, the allocation is 62-64 registers without the bound, and
+// tests/test_host_logic.py fails on any scratch in the library.
+template <bool USE_RGB, bool USE_ALPHA>
+__global__ void __launch_bounds__(EG_LINE_THREADS, 8) k_edge_lines(EdgeGradArgs a, EdgePlan w,
+                                                                                   float2* __restrict__ lane_partial) {
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
         const long n = (long)*w.n_visible * 6;
@@ -1555,25 +1557,19 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
-#define D3M_LINES1(RGB, ALPHA, MINW)                                                                                 \
+#define D3M_LINES(RGB, ALPHA)                                                                                        \
     do {                                                                                                             \
         if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                 \
-            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, MINW>,                                     \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>,                                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, MINW>), glines, dim3(EG_LINE_THREADS), smem, st, a, w, \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_THREADS), smem, st, a, w,       \
                     lane_partial);                                                                                   \
-    } while (0)
-#define D3M_LINES(RGB, ALPHA)                                                                                        \
-    do {                                                                                                             \
-        if (4 * (smem + EG_LINE_STATIC_LDS) <= 160 * 1024) D3M_LINES1(RGB, ALPHA, 8);                                \
-        else D3M_LINES1(RGB, ALPHA, D3M_EG_LINE_MINWAVES);                                                           \
     } while (0)
     if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
     else if (m.use_rgb) D3M_LINES(true, false);
     else D3M_LINES(false, true);
-#undef D3M_LINES1
 #undef D3M_LINES
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder

@@ -601,6 +601,9 @@ __global__ void __launch_bounds__(256) k_g2s_front_backward(G2S g) {
         for (int c = 0; c < 3; c++) {
             const size_t o = ((size_t)b * 3 + c) * HW + pix;
             const float gt = g.grad_texture[o];
+            // the accumulator's one reader hands it back ZEROED: k_g2s_sample_backward ADDS into it, and a second backward
+            // pass over the same forward (retain_graph, torch.autograd.grad per loss term) must not see the first one's sums
+            g.grad_texture[o] = 0.0f;
             if (g.grad_albedo) g.grad_albedo[o] = gt * shading;           // d/d albedo of (albedo/2 + 0.5) * shading * 2 - 1
             g_sh += gt * ((g.albedo[o] / 2.0f + 0.5f) * 2.0f);
         }

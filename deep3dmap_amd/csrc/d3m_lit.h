@@ -432,6 +432,88 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
     }
 }
 
+// The same objective and the same records from FINISHED images: what multiview_fit_loss(*Renderer.render(...)) runs when
+// its three images come straight from one lit render node (core/losses.py).  The images hold the very floats the fused pass
+// above has in registers (rgb_out = the blended colour, alpha_out = covered, depth_out = the depth map; no anti-aliasing:
+// an output pixel is an internal pixel), so partial sums, records, extents and the depth gradient are bit-identical to
+// its own -- and backward takes the records route: no gradient images, no k_fit_loss_grad, no k_pack_maps.  Reads
+// 20 B (images) + 24 B (targets) + 4 B (owner) per pixel, writes 28 B.
+__global__ void __launch_bounds__(256) k_fit_loss_records(const float* __restrict__ rgb_im, const float* __restrict__ depth_im,
+                                                         const float* __restrict__ alpha_im,
+                                                         const int32_t* __restrict__ face_index_map, int B, int S,
+                                                         FitTargets fit, FitRecords rec) {
+    __shared__ float4 s_part[4];
+    __shared__ int s_col_lo_inv[32], s_col_hi1[32];
+    if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
+    __syncthreads();
+    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const float inv_pixels = 1.0f / (float)((long)S * S), inv_3den = 1.0f / (3.0f * *rec.mask_sum);
+    float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
+    auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
+    for (int r = ty; r < 32; r += 8) {
+        const int yi = y0 + r, xi = x0 + tx;                  // internal pixel; row 0 = bottom (rasterize.py:311-317)
+        bool nz = false;
+        if (yi < S && xi < S) {
+            const int yo = S - 1 - yi;                        // output row
+            const size_t p = ((size_t)b * S + yi) * S + xi, o = ((size_t)b * S + yo) * S + xi;
+            float tg[6], v[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                tg[k] = fit.rgb_t[(((size_t)b * 3 + k) * S + yo) * S + xi];
+                v[k] = rgb_im[(((size_t)b * 3 + k) * S + yo) * S + xi];
+            }
+            tg[3] = fit.depth_t[o]; tg[4] = fit.alpha_t[o]; tg[5] = fit.mask[o];
+            const int fi = face_index_map[p];
+            const float depth = depth_im[o], alpha = alpha_im[o];
+            const float m = tg[5], d = alpha - tg[4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) t_rgb += fabsf(v[k] - tg[k]) * m;      // same terms as k_fit_loss_reduce
+            t_d += fabsf(depth - tg[3]) * m;
+            t_m += m;
+            t_sse += d * d;
+            float4 g;
+            g.x = (2.0f * d) * inv_pixels;
+            g.y = (sgn(v[0] - tg[0]) * m) * inv_3den;
+            g.z = (sgn(v[1] - tg[1]) * m) * inv_3den;
+            g.w = (sgn(v[2] - tg[2]) * m) * inv_3den;
+            float dot = alpha * g.x;
+            dot += v[0] * g.y;
+            dot += v[1] * g.z;
+            dot += v[2] * g.w;
+            rec.grad[p] = g;
+            rec.dot[p] = make_float2(dot, __int_as_float(fi));
+            rec.g_depth[p] = sgn(depth - tg[3]) * m;
+            nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
+        }
+        const unsigned long long ball = __ballot(nz);
+        const unsigned half = (threadIdx.x & 32) ? (unsigned)(ball >> 32) : (unsigned)ball;
+        if (half != 0 && tx == 0) {
+            const size_t line = ((size_t)b * 2 + 1) * S + (y0 + r);
+            atomicMax(&rec.nz_lo_inv[line], S - (x0 + (__ffs((int)half) - 1)));
+            atomicMax(&rec.nz_hi1[line], x0 + (32 - __clz((int)half)));
+        }
+        if (nz) {
+            atomicMax(&s_col_lo_inv[tx], S - (y0 + r));
+            atomicMax(&s_col_hi1[tx], y0 + r + 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
+        const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
+        atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
+        atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);
+    }
+    const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float4 t = s_part[0];
+        for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+        reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // totals[0..3] = the four sums over `n` workgroup partials, totals[4] = *loss = the objective (k_fit_loss_finish for
 // the tens of thousands of partials the fused epilogue leaves: 1024 lanes, 16-byte loads)
 __global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restrict__ partials, int n, float pixels,

@@ -209,12 +209,17 @@ D3M_EXPORT int d3m_set_coverage_form(int form) {
     return D3M_OK;
 }
 D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
-static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
+static bool bidding_preferred(int B, long triangles, int S) {
     const int form = coverage_form();
     const int tiles_x = (S + TILE - 1) / TILE;
-    const bool wanted = form >= 0 ? form == 1
-                                  : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
-    return wanted && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);
+    return form >= 0 ? form == 1 : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
+}
+static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
+    return bidding_preferred(B, triangles, S) && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);
+}
+D3M_EXPORT int d3m_forward_coverage_form(int batch_size, int num_triangles, int image_size) {
+    if (batch_size <= 0 || num_triangles <= 0 || image_size <= 0) return -1;
+    return bidding_preferred(batch_size, num_triangles, image_size) && image_size <= 8192 ? 1 : 0;
 }
 // FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)
 template <class FS, bool PAIRED>
@@ -952,6 +957,27 @@ D3M_EXPORT int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int im
     const int tiles = ((image_size + 31) / 32) * ((image_size + 31) / 32) * batch_size;
     LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), (hipStream_t)stream, (const float4*)(fit->scratch + 8),
            tiles, (float)((long)image_size * image_size), fit->mask_sum, fit->scratch, fit->loss);
+    return check_launch();
+}
+
+// The fit objective of FINISHED images that came out of one lit render (no anti-aliasing), with its gradient left as the
+// edge gradient's per-pixel records: see k_fit_loss_records.  fit: targets, mask, mask_sum, scratch
+// (d3m_render_fit_scratch_floats), loss, edge_grad / edge_dot / edge_nz_* (zeroed) / grad_depth_map.
+D3M_EXPORT int d3m_fit_loss_records(const float* rgb, const float* depth, const float* alpha, const int32_t* face_index_map,
+                                    const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream) {
+    if (!rgb || !depth || !alpha || !face_index_map || !fit || batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    if (!fit->edge_grad || !fit->edge_dot || !fit->edge_nz_lo_inv || !fit->edge_nz_hi1 || !fit->mask_sum || !fit->grad_depth_map)
+        return D3M_ERR_INVALID;
+    FitTargets ft;
+    if (int rc = to_fit_targets(fit, ft)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
+    FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
+                   fit->grad_depth_map};
+    LAUNCH("k_fit_loss_records", k_fit_loss_records, tiles, dim3(256), st, rgb, depth, alpha, face_index_map, batch_size,
+           image_size, ft, rec);
+    LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
+           (int)(tiles.x * tiles.y * tiles.z), (float)((long)image_size * image_size), fit->mask_sum, fit->scratch, fit->loss);
     return check_launch();
 }
 

@@ -94,10 +94,11 @@ class MultiViewFit:
         n_t = self.textures.numel() if optimise_textures else 0
         self._flat = torch.zeros(1 + self.vertices.numel() + n_t, dtype=torch.float32, device=self.device)
         # ... by the rendering node itself where it can: the node's backward writes the two gradients, its forward the loss,
-        # straight into these views of the flat buffer (Renderer.grad_sink); _forward_backward packs only what did not
+        # straight into these views of the flat buffer (render_fit_loss(grad_sink=...)); _forward_backward packs only what did not
         nv = self.vertices.numel()
-        self.renderer.grad_sink = (self._flat[1:1 + nv].view(1, *self.vertices.shape),
-                                   self._flat[1 + nv:].view(1, *self.textures.shape) if n_t else None, self._flat[0:1])
+        self._sink = (self._flat[1:1 + nv].view(1, *self.vertices.shape),
+                      self._flat[1 + nv:].view(1, *self.textures.shape) if n_t else None, self._flat[0:1])
+        self._use_sink = False          # only the step's own forward + backward hands the buffers to the node (per call)
         self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
 
     def render(self, vertices=None, textures=None):
@@ -139,7 +140,8 @@ class MultiViewFit:
                 self.images = tuple(torch.empty_like(t) for t in (rgb_t, depth_t, alpha_t))
             return r.render_fit_loss(self.vertices[None], self.triangles[None], self.textures[None],
                                      (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum),
-                                     images_out=self.images if self.keep_images else None)
+                                     images_out=self.images if self.keep_images else None,
+                                     grad_sink=self._sink if self._use_sink else None)
         return self.loss(*self.render())
 
     def _forward_backward(self):
@@ -148,12 +150,16 @@ class MultiViewFit:
         # backward runs right behind forward, on the same stream and inside the same capture: only HERE may the forward
         # leave its side branch (visibility list, edge plan, the loss's last reduction step) open for backward to join.
         # A bare fit_loss() (logging, evaluation) joins everything before it returns.
+        # Only here, too, does the node get the flat buffer's views as its destinations (a bare fit_loss() returns a loss
+        # of its own, not an alias of _flat[0] that the next step's collective overwrites).
         self.renderer.defer_plan_join = True
+        self._use_sink = True
         try:
             loss = self.fit_loss()
             loss.backward()
         finally:
             self.renderer.defer_plan_join = False
+            self._use_sink = False
         # [loss | grad_v | grad_t] in the persistent buffer the collective runs on: already there when the rendering node
         # produced them in place (grad_sink); packed here (part of the captured step) otherwise
         parts = [loss.detach().reshape(1), self.vertices.grad.reshape(-1)]

@@ -224,10 +224,24 @@ def _vec3_host(x):
 _side_streams = {}
 
 
-def _side_stream(device, which=0):
+def _serial_branches(batch, num_tri, image_size):
+    """Whether a lit render node runs its side branches (visibility list + edge plan beside the sampling pass; the
+    gathered texture / depth pass beside the line walk) on the forking stream instead.  Measured: once
+    every kernel of the step fills the chip by itself -- the big batches of ordinary meshes, i.e. exactly the launches
+    whose coverage runs on per-tile lists -- the cross-queue waits of the branches cost more than the tails they fill
+    (32 views of the headline mesh: -1.5 %), while small batches and dense meshes gain 3-6 % from them.
+    D3M_SERIAL_BRANCHES=1 / 0 forces / forbids (measurements)."""
+    env = os.environ.get("D3M_SERIAL_BRANCHES")
+    if env is not None and env != "":
+        return env != "0"
+    return _lib.lib().d3m_forward_coverage_form(int(batch), int(num_tri), int(image_size)) == 0
+
+
+def _side_stream(device, which=0, serial=False):
     """Extra streams per (device, forking stream) for the branches a lit render node runs beside its main line: the
-    visibility list / the gathered texture pass of every view group, and the main line of every group but the first."""
-    if os.environ.get("D3M_SERIAL_BRANCHES"):        # measurement aid: every branch on the forking stream (kernels run alone)
+    visibility list / the gathered texture pass of every view group, and the main line of every group but the first.
+    serial: the forking stream itself (see _serial_branches)."""
+    if serial:
         return torch.cuda.current_stream(device)
     index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     key = (index, torch.cuda.current_stream(device).cuda_stream, which)       # one set per stream that forks
@@ -250,6 +264,77 @@ def _bslice(t, lo, hi):
     if t is None:
         return None
     return t if t.shape[0] == 1 else t[lo:hi]
+
+
+class LitImagesLink:
+    """What a fit objective evaluated on the finished images of ONE lit render node (core.losses.multiview_fit_loss on
+    the outputs of Renderer.render) shares with that node's backward: the objective's gradient as the edge gradient's
+    per-pixel records (`fit_state`, the tuple _RasterizeLit keeps for its own fused objective), the scalar gradient of the
+    loss, and the zero-stride zero images the loss node returns instead of gradient images."""
+
+    def __init__(self, fit_state, images, zero):
+        self.fit_state, self.images, self.zero = fit_state, images, zero
+        self.grad_loss = None
+        self.pending = False            # the loss node's backward ran and the render node's has not consumed it yet
+
+    def dummies(self):
+        rgb, depth, alpha = self.images
+        return self.zero.expand(rgb.shape), self.zero.expand(depth.shape), self.zero.expand(alpha.shape)
+
+    def is_dummy(self, g):
+        return g is not None and g.data_ptr() == self.zero.data_ptr() and all(st == 0 for st in g.stride())
+
+    def add_gradient_images(self, g_rgb, g_alpha, g_depth):
+        """other consumers of the images sent gradients too: the objective's own gradient images after all
+        (d3m_fit_loss_backward), added to what arrived"""
+        rgb, depth, alpha = self.images
+        rgb_t, depth_t, alpha_t, mask, scratch = self.fit_state[:5]
+        B, _, H, W = rgb.shape
+        own = [torch.empty_like(t) for t in (rgb, depth, alpha)]
+        t = (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)
+        _lib.check(_lib.lib().d3m_fit_loss_backward(*[_lib.ptr(x) for x in t], _lib.ptr(scratch[0]), _lib.ptr(self.grad_loss),
+                                                    _lib.ptr(own[0]), _lib.ptr(own[1]), _lib.ptr(own[2]), B, H, W,
+                                                    _lib.stream_ptr()), "d3m_fit_loss_backward")
+        add = lambda g, o: o if (g is None or self.is_dummy(g)) else g + o
+        return add(g_rgb, own[0]), add(g_alpha, own[2]), add(g_depth, own[1])
+
+
+def lit_images_link(rgb, depth, alpha):
+    """The lit render node (its autograd context) whose three output images these are -- rgb, depth and alpha exactly as
+    rasterize_lit() / Renderer.render() returned them, without anti-aliasing, one pipeline, gradients wanted, no objective
+    linked yet -- or None."""
+    fn = rgb.grad_fn
+    if fn is None or fn is not depth.grad_fn or fn is not alpha.grad_fn or not isinstance(fn, _RasterizeLit._backward_cls):
+        return None
+    if (rgb.output_nr, alpha.output_nr, depth.output_nr) != (0, 1, 2):
+        return None
+    cfg = getattr(fn, "cfg", None)
+    if cfg is None or fn.fit is not None or getattr(fn, "linked_fit", None) is not None:
+        return None
+    S, _eps, aa, ra, rd, _fb, _light, _Bl, groups = cfg
+    if aa or not (ra and rd) or len(groups) != 1 or fn.maps.get("visibility") is None:
+        return None
+    return fn
+
+
+def _checked_sink(grad_sink, vertices, textures):
+    """`grad_sink` = (grad_vertices, grad_textures | None, loss [1]): caller-owned buffers the lit node writes its results
+    into in place (MultiViewFit: views of the flat all-reduce buffer).  They are RAW destinations of kernels that write
+    vertices.numel() / textures.numel() floats, so they are used only when they fit this call exactly -- shape, float32,
+    contiguous, same device; anything else (a per-view mesh [B,V,3], another V or F, a sink left over from another fit)
+    gets fresh buffers instead of an out-of-bounds write."""
+    if grad_sink is None:
+        return None
+    gv, gt, loss = grad_sink
+
+    def fits(buf, like):
+        return (torch.is_tensor(buf) and buf.dtype == torch.float32 and buf.is_contiguous() and buf.device == like.device
+                and tuple(buf.shape) == tuple(like.shape))
+    if not fits(gv, vertices) or (gt is not None and not fits(gt, textures)):
+        return None
+    if not (torch.is_tensor(loss) and loss.dtype == torch.float32 and loss.numel() == 1 and loss.device == vertices.device):
+        return None
+    return grad_sink
 
 
 class _RasterizeLit(torch.autograd.Function):
@@ -276,6 +361,7 @@ class _RasterizeLit(torch.autograd.Function):
         vertices, textures = f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
         dev = vertices.device
+        grad_sink = _checked_sink(grad_sink, vertices, textures)
         cam_keep = None
         if camera is not None:
             # THE CAMERA INSIDE THE NODE (`camera` = the parameter block of cameras._camera_struct, screen_vertices None):
@@ -373,8 +459,9 @@ class _RasterizeLit(torch.autograd.Function):
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, bool(anti_aliasing))
         cur = torch.cuda.current_stream()
+        serial = G == 1 and _serial_branches(B, Ft, S)
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
-        auxs = [_side_stream(dev, G + k) for k in range(G)]
+        auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
         # on the same stream and (if captured) in the same capture, may leave that branch open at the end of forward
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
@@ -476,7 +563,18 @@ class _RasterizeLit(torch.autograd.Function):
         grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
         grad_loss = scratch = mask_sum = None
         records = None
-        if ctx.fit is None:
+        # A fit objective evaluated on this node's finished images (core.losses.multiview_fit_loss -> LitImagesLink) has left
+        # its gradient as per-pixel records and sends zero-stride ZERO images back: if those are all that arrived, backward
+        # is the fused objective's (no gradient images exist); if other consumers of the images added theirs, the
+        # objective's gradient images are materialised after all and added.
+        fit, link = ctx.fit, getattr(ctx, "linked_fit", None)
+        if fit is None and link is not None and link.pending:
+            link.pending = False
+            if link.is_dummy(g_rgb) and link.is_dummy(g_alpha) and link.is_dummy(g_depth):
+                fit, g_rgb = link.fit_state, link.grad_loss
+            else:
+                g_rgb, g_alpha, g_depth = link.add_gradient_images(g_rgb, g_alpha, g_depth)
+        if fit is None:
             # the adjoint of the output epilogue (un-pool, un-flip, CHW -> HWC) writes the rgb / alpha gradients straight
             # as the edge gradient's per-pixel records (what d3m_backward_pixel_map would pack from gradient maps: one
             # pass over the pixels instead of two, no [B,S,S,3] / [B,S,S] gradient maps); the depth gradient as a map
@@ -491,10 +589,10 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(records[0]), _lib.ptr(records[1]), _lib.ptr(records[2][0]), _lib.ptr(records[2][1]),
                 _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward_records")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
-            scratch, g_depth_map = ctx.fit[4], ctx.fit[6][3]
-            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (ctx.fit[6][:3]) ...
-            if ctx.fit[8]:                              # ... or, with anti-aliasing, as unscaled maps
-                g_rgb_map, g_alpha_map = ctx.fit[6][0], ctx.fit[6][1]
+            scratch, g_depth_map = fit[4], fit[6][3]
+            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (fit[6][:3]) ...
+            if fit[8]:                                  # ... or, with anti-aliasing, as unscaled maps
+                g_rgb_map, g_alpha_map = fit[6][0], fit[6][1]
             grad_loss = f32c(g_rgb).reshape(1)
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over the compacted list of the faces that own a pixel.  The edge gradient (K4: ~8
@@ -512,7 +610,8 @@ class _RasterizeLit(torch.autograd.Function):
             if need_vert:
                 grad_vertices = sink[0].zero_() if (sink is not None and ctx.camera is not None) else torch.zeros_like(vertices)
             if tex_shared:
-                gt_g = [sink[1] if (sink is not None and G == 1) else torch.empty_like(textures) for _ in groups]
+                gt_g = [sink[1] if (sink is not None and sink[1] is not None and G == 1) else torch.empty_like(textures)
+                        for _ in groups]
             else:
                 grad_textures = torch.empty_like(textures)
                 gt_g = [grad_textures[lo:hi] for lo, hi in groups]
@@ -523,8 +622,9 @@ class _RasterizeLit(torch.autograd.Function):
                     grad_light = torch.empty_like(light)
                     gl_g = [grad_light[lo:hi] for lo, hi in groups]
         cur = torch.cuda.current_stream()
+        serial = G == 1 and _serial_branches(B, Ft, S)
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
-        auxs = [_side_stream(dev, G + k) for k in range(G)]
+        auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         plan_ready = m["plan_ready"]
         for k in range(G):
             if mains[k] is not cur:
@@ -539,8 +639,8 @@ class _RasterizeLit(torch.autograd.Function):
             fi_g, wm_g, dm_g = m["face_index_map"][lo:hi], m["weight_map"][lo:hi], m["depth_map"][lo:hi]
             target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back))
             unscaled = None
-            if ctx.fit is not None:
-                unscaled = _RasterizeLit._fit_struct(ctx.fit, k, lo, hi, grad_loss)
+            if fit is not None:
+                unscaled = _RasterizeLit._fit_struct(fit, k, lo, hi, grad_loss)
             elif records is not None:           # final records: no scratch, no scalars to apply
                 unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
                                               _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
@@ -592,11 +692,11 @@ class _RasterizeLit(torch.autograd.Function):
             if not need_tex:
                 grad_textures = None
         elif rd:                            # textures and lighting need no gradient: the depth term on its own
-            if ctx.fit is not None:
+            if fit is not None:
                 # d3m_backward_depth_map takes final maps: the fused objective left sign(depth - target) * mask, which
                 # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); totals[2] of the scratch holds that
                 # sum (the same in every group: with more than one the normaliser is the batch's mask_sum)
-                g_depth_map = g_depth_map * (grad_loss / ctx.fit[7])          # mask_sum: set whenever gradients are wanted
+                g_depth_map = g_depth_map * (grad_loss / fit[7])              # mask_sum: set whenever gradients are wanted
             grad_faces = torch.zeros_like(faces)
             ops.backward_depth_map(faces, m["depth_map"], m["face_index_map"], m["face_inv_map"], m["weight_map"],
                                    g_depth_map, grad_faces, S)

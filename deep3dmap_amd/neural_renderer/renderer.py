@@ -158,11 +158,14 @@ class Renderer(nn.Module):
                                         self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color)
 
     def render_fit_loss(self, vertices, faces, textures, targets, K=None, R=None, t=None, dist_coeffs=None,
-                        orig_size=None, images_out=None):
+                        orig_size=None, images_out=None, grad_sink=None):
         """The multi-view fit objective of render()'s images against `targets` = (rgb, depth, alpha, mask), evaluated
         inside the rendering node (rasterize_lit_fit); needs lighting_on_the_fly.  `images_out`
         = (rgb [B,3,S,S], depth [B,S,S], alpha [B,S,S]) buffers: the same pass also writes the images render() would
-        return (for display / logging; gradients flow through the returned objective only)."""
+        return (for display / logging; gradients flow through the returned objective only).  `grad_sink` = (grad_vertices
+        like `vertices`, grad_textures like `textures` | None, loss [1]): buffers of the CALLER that the node writes the
+        objective and its two gradients into in place (per call, never remembered; ignored unless they fit this call's
+        tensors exactly and the camera runs inside the node)."""
         if not self._on_the_fly():
             raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch)")
         # look_at cameras with constant parameters run INSIDE the node (one gradient for the mesh instead of the camera's
@@ -174,7 +177,7 @@ class Renderer(nn.Module):
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
                                  view_groups=self.view_groups, defer_plan_join=self.defer_plan_join, images_out=images_out,
-                                 camera=cam, grad_sink=getattr(self, "grad_sink", None) if cam is not None else None,
+                                 camera=cam, grad_sink=grad_sink if cam is not None else None,
                                  anti_aliasing=self.anti_aliasing)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):

@@ -69,6 +69,10 @@ size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_
  * sets the initial value.  Returns D3M_ERR_INVALID for any other value. */
 int d3m_set_coverage_form(int form);
 int d3m_get_coverage_form(void);
+/* The form (0 | 1) a launch of d3m_forward_face_index_map_mesh on `batch_size` views of a mesh of `num_triangles` triangles
+ * (before fill_back) at `image_size` takes with a workspace of d3m_forward_workspace_bytes(); -1 for invalid sizes.  Callers
+ * that shape the work AROUND the coverage pass by its form (the lit render node: side branches or one stream) ask here. */
+int d3m_forward_coverage_form(int batch_size, int num_triangles, int image_size);
 
 /* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
  *   faces          [B,F,3,3] f32 in   NDC x,y in [-1,1] (+y up), z = depth
@@ -147,7 +151,12 @@ int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, co
 /* Which faces own a pixel depends on face_index_map only.  d3m_visibility builds, once per forward result, the
  * flags and the compacted list of those faces in a caller-owned blob of d3m_visibility_bytes(); backward operators
  * that are handed the blob (`visibility`, NULL = each builds its own) skip that work and run over the list.
- * face_index_map NULL: the blob went through d3m_forward_face_index_map_mesh, which left the first step in it. */
+ * face_index_map NULL: the blob went through d3m_forward_face_index_map_mesh, which left the first step in it (the
+ * marks) and cleared the list's counter -- ONE finishing call per forward: the list is appended under that counter, so a
+ * second d3m_visibility(NULL, ...) on the same blob without a new forward would append the list a second time (call with
+ * the face_index_map instead, which clears first).  The list is ascending within chunks of 8192 faces; the chunks land in
+ * arrival order, so the ORDER of the list -- and with it the order of the float atomics of the passes that run over it
+ * -- may differ from run to run (the sums agree to rounding; the flags and the set of listed faces do not vary). */
 size_t d3m_visibility_bytes(int batch_size, int num_faces);
 int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visibility_size, int batch_size,
                    int num_faces, int image_size, d3m_stream_t stream);
@@ -384,6 +393,15 @@ struct d3m_fit_targets {
 };
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
+/* The same objective evaluated on FINISHED images -- rgb [B,3,S,S], depth / alpha [B,S,S], row 0 = top: what
+ * d3m_render_lit_epilogue wrote as rgb_out / depth_out / alpha_out without anti-aliasing -- with its gradient left as the
+ * edge gradient's per-pixel records, exactly as the fused pass leaves them (fit->edge_grad, edge_dot, edge_nz_* zeroed by
+ * the caller, grad_depth_map, mask_sum; *fit->loss is complete on return of the stream).  face_index_map [B,S,S] (row 0 =
+ * bottom) supplies the records' owner.  This is how the reference-shaped composition  loss(*renderer.render(...))
+ * (NR/renderer.py:200-246 + the caller's loss) reaches the records route of d3m_backward_pixel_map /
+ * d3m_backward_textures_lit without gradient images. */
+int d3m_fit_loss_records(const float* rgb, const float* depth, const float* alpha, const int32_t* face_index_map,
+                         const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
 int d3m_render_lit_epilogue(const float* faces, const float* textures, int textures_batch, const float* light,
                             int light_batch, const int32_t* face_index_map, const float* weight_map,
                             const float* depth_map, const float* background, int background_batch,
@@ -529,7 +547,8 @@ typedef struct d3m_g2s_block {
     float* scratch;                      /* d3m_g2s_scratch_floats() */
     /* backward inputs: gradient of recon_im [B,3,s,s] and of the four loss values (device scalars); NULL = zero */
     const float *grad_recon_im, *grad_l1, *grad_l1_flip, *grad_smooth, *grad_total;
-    /* backward scratch; grad_texture must already be handed to d3m_g2s_forward, which clears it */
+    /* backward scratch; grad_texture must already be handed to d3m_g2s_forward, which clears it; d3m_g2s_backward
+     * hands it back zeroed, so any number of backward passes may follow one forward */
     float* grad_texture;                 /* [B,3,H,W] */
     float* grad_tri;                     /* [B, 2 (H-1)(W-1), 3, 3] */
     float* grad_depth_map;               /* [B,S,S] */

@@ -91,6 +91,29 @@ def test_block_values_and_gradients_against_oracle(b, flip, hw, masked):
     assert got["loss_l1_im_flip"] is None or flip
 
 
+def test_block_backward_twice_and_per_loss_term():
+    """One forward, several backward passes (retain_graph; torch.autograd.grad per loss term): k_g2s_sample_backward
+    ADDS into the texture-gradient accumulator, which its reader hands back zeroed -- the second pass must give the first
+    one's gradients, and the terms' gradients must add up to the total's."""
+    from deep3dmap_amd.core import NrRenderer
+    hw, b = 32, 4
+    rg = NrRenderer(dict(CFG), hw)
+    depth, albedo, light, view, input_im = _inputs(b, hw, 9, False)
+    d, a, l = (x.clone().cuda().requires_grad_(True) for x in (depth, albedo, light))
+    rg.set_transform_matrices(view.cuda())
+    out = rg.reconstruct(d, a, *_light_terms(l), input_im.cuda(), lam_smooth=LAM_SMOOTH)
+    first = torch.autograd.grad(out.loss_total, (d, a, l), retain_graph=True)
+    second = torch.autograd.grad(out.loss_total, (d, a, l), retain_graph=True)
+    for x, y in zip(first, second):
+        assert float(x.abs().max()) > 0 and torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(x.abs().max()))
+    # loss_total = loss_l1_im + lam_smooth * loss_smooth (gan2shape.py:495-497)
+    g_l1 = torch.autograd.grad(out.loss_l1_im, (d, a, l), retain_graph=True)
+    g_sm = torch.autograd.grad(out.loss_smooth, (d, a, l), retain_graph=True, allow_unused=True)
+    for tot, x, y in zip(first, g_l1, g_sm):
+        y = torch.zeros_like(x) if y is None else y
+        assert float((tot - (x + LAM_SMOOTH * y)).abs().max()) <= 1e-4 * float(tot.abs().max())
+
+
 def test_block_view_gradient_and_pieces():
     """through set_transform_matrices(view): the view vector's gradient; and the block's outputs equal NrRenderer's own
     step-by-step methods (the drop-in surface) on the same inputs"""

@@ -58,6 +58,27 @@ def test_coverage_form_switch_is_host_state():
     L.d3m_set_coverage_form(start)
 
 
+def test_no_kernel_spills_to_scratch():
+    """`hipcc -Rpass-analysis=kernel-resource-usage` on the product build's flags: NO kernel of the library uses scratch
+    memory (round 3's 64-register form of k_edge_lines spilled 24 B per lane = 335 MB of stores per headline launch, and
+    nobody looked), and the hot kernels keep the occupancy their launch bounds were chosen for."""
+    from deep3dmap_amd.resource_usage import kernel_resource_usage
+    table = kernel_resource_usage()
+    assert len(table) >= 100
+    spilling = {k: (v["scratch"], v["vgpr_spill"], v["sgpr_spill"]) for k, v in table.items()
+                if v["scratch"] or v["vgpr_spill"]}
+    assert not spilling, spilling
+
+    def rows(prefix):
+        got = [v for k, v in table.items() if ("d3m::" + prefix) in k]
+        assert got, prefix
+        return got
+    assert all(r["vgprs"] <= 64 and r["occupancy"] == 8 for r in rows("k_edge_lines<"))
+    assert all(r["vgprs"] <= 128 for r in rows("k_render_lit_fit_records")) and all(r["vgprs"] <= 128 for r in rows("k_backward_textures_lit_faces"))
+    for name in ("k_raster_tiles<", "k_bid_faces<", "k_edge_scatter<", "k_edge_count_window<", "k_edge_gather<", "k_bin_count<"):
+        assert all(r["scratch"] == 0 for r in rows(name))
+
+
 def test_library_is_gfx950_code_object():
     from deep3dmap_amd.build import LIB_PATH
     blob = open(LIB_PATH, "rb").read()
