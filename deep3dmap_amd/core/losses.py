@@ -137,9 +137,11 @@ class _FitLossOnLitImages(torch.autograd.Function):
         import ctypes
         _lib.check(L.d3m_fit_loss_records(_lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(alpha), _lib.ptr(lit.maps["face_index_map"]),
                                           ctypes.byref(fit_c), B, S, _lib.stream_ptr()), "d3m_fit_loss_records")
-        link = LitImagesLink(fit_state, (rgb, depth, alpha), torch.zeros(1, dtype=torch.float32, device=dev))
+        link = LitImagesLink(fit_state, (tuple(rgb.shape), tuple(depth.shape), tuple(alpha.shape)),
+                             torch.zeros(1, dtype=torch.float32, device=dev))
         lit.linked_fit = link
         ctx.link = link
+        ctx.save_for_backward(rgb, depth, alpha)
         return loss.reshape(())
 
     @staticmethod
@@ -147,6 +149,7 @@ class _FitLossOnLitImages(torch.autograd.Function):
         link = ctx.link
         link.grad_loss = f32c(g).reshape(1)
         link.pending = True
+        link.images = ctx.saved_tensors         # lent until the render node's backward has run (see LitImagesLink)
         g_rgb, g_depth, g_alpha = link.dummies()
         return g_rgb, g_depth, g_alpha, None, None, None, None, None, None
 

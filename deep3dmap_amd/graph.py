@@ -9,7 +9,15 @@ replays.  Autograd binds a leaf's AccumulateGrad node to the stream that was cur
 created; if a step is warmed up (or ever run eagerly) on one stream and captured on another, autograd
 inserts a cross-stream wait inside the capture, which either aborts the capture or leaves un-joined work
 in it -- observed here as GPU memory faults on later replays.  `CapturedStep` owns a dedicated stream and
-fences it against the caller's stream on entry and exit."""
+fences it against the caller's stream on entry and exit.
+
+A second rule, found in round 4 as an intermittent `Fatal Python error: Aborted` in the test suite: NO GARBAGE
+COLLECTION DURING CAPTURE.  The step's backward runs on autograd's worker thread; a collection that happens to
+trigger there may finalise unrelated cyclic garbage -- another CapturedStep with its HIP graph and memory pool, side
+streams, events -- and destroying those inside an open capture aborts the process.  capture() collects first and keeps
+the collector off until the capture has ended."""
+import gc
+
 import torch
 
 
@@ -59,9 +67,16 @@ class CapturedStep:
                 self.fn()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime meanwhile
-        with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
-            self._static_out = self.fn()
+        gc.collect()                        # whatever is dead dies NOW, not inside the capture (see the module text)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime meanwhile
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+                self._static_out = self.fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
         self.graph = graph
         cur.wait_stream(self.stream)
         return self

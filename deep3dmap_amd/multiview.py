@@ -7,6 +7,8 @@ f32 buffer [3V (+ F*ts^3*3)] per step -- RCCL over xGMI when the process group's
 The reference has no such path (it only runs a different image per rank); this is the north-star's
 "shard by camera + all-reduce of vertex gradients".
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -99,7 +101,11 @@ class MultiViewFit:
         self._sink = (self._flat[1:1 + nv].view(1, *self.vertices.shape),
                       self._flat[1 + nv:].view(1, *self.textures.shape) if n_t else None, self._flat[0:1])
         self._use_sink = False          # only the step's own forward + backward hands the buffers to the node (per call)
-        self._runner = CapturedStep(self._forward_backward)     # eager or replayed, always on one stream
+        # eager or replayed, always on one stream.  (Through a weak reference: a bound method would make fit -> runner ->
+        # fit a cycle, and a fit with its captured graph, memory pool and streams should die with its last reference, not
+        # whenever the collector next runs -- see graph.py on collections inside a capture.)
+        me = weakref.ref(self)
+        self._runner = CapturedStep(lambda: me()._forward_backward())
 
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices

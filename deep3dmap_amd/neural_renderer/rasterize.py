@@ -272,14 +272,17 @@ class LitImagesLink:
     per-pixel records (`fit_state`, the tuple _RasterizeLit keeps for its own fused objective), the scalar gradient of the
     loss, and the zero-stride zero images the loss node returns instead of gradient images."""
 
-    def __init__(self, fit_state, images, zero):
-        self.fit_state, self.images, self.zero = fit_state, images, zero
+    def __init__(self, fit_state, shapes, zero):
+        self.fit_state, self.shapes, self.zero = fit_state, shapes, zero
         self.grad_loss = None
         self.pending = False            # the loss node's backward ran and the render node's has not consumed it yet
+        # The images themselves are NOT kept here: the render node's context holds this link, and an image holds that
+        # context as its grad_fn -- a reference cycle through the autograd graph.  The loss node (which saved them) lends
+        # them for the time between its backward and the render node's.
+        self.images = None
 
     def dummies(self):
-        rgb, depth, alpha = self.images
-        return self.zero.expand(rgb.shape), self.zero.expand(depth.shape), self.zero.expand(alpha.shape)
+        return tuple(self.zero.expand(s) for s in self.shapes)
 
     def is_dummy(self, g):
         return g is not None and g.data_ptr() == self.zero.data_ptr() and all(st == 0 for st in g.stride())
@@ -574,6 +577,7 @@ class _RasterizeLit(torch.autograd.Function):
                 fit, g_rgb = link.fit_state, link.grad_loss
             else:
                 g_rgb, g_alpha, g_depth = link.add_gradient_images(g_rgb, g_alpha, g_depth)
+            link.images = None
         if fit is None:
             # the adjoint of the output epilogue (un-pool, un-flip, CHW -> HWC) writes the rgb / alpha gradients straight
             # as the edge gradient's per-pixel records (what d3m_backward_pixel_map would pack from gradient maps: one

@@ -699,3 +699,84 @@ def test_fit_objective_can_leave_the_images_behind():
         rgb, depth, alpha = fit.render()
     for got, ref in zip(fit.images, (rgb, depth, alpha)):
         assert torch.equal(got, ref)
+
+
+def test_dropin_render_plus_fit_loss_takes_the_records_route():
+    """The reference-shaped composition -- images = Renderer.render(...) (NR/renderer.py:200-246), then
+    multiview_fit_loss(images, targets) -- under autograd: the loss node finds that its three images are the outputs of
+    one lit render node, evaluates the objective and leaves its gradient as the edge gradient's per-pixel records in ONE
+    pass (k_fit_loss_records), and backward runs without gradient images (no k_fit_loss_grad, no k_pack_maps).  Images
+    bit-equal to render(), loss and gradients equal to Renderer.render_fit_loss (the fused objective) and to the plain
+    loss node on detached copies of the images."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core.losses import _MultiViewFitLoss, multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(20)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(4), image_size=96)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    loss0, gv0, gt0 = (t.clone() for t in fit.step())                # the fused objective (render_fit_loss)
+    rgb_t, depth_t, alpha_t = fit.targets
+    with torch.no_grad():
+        ref_images = fit.render()
+    fit.vertices.grad = fit.textures.grad = None
+    with kernels_launched() as k:
+        rgb, depth, alpha = fit.render()
+        loss = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+        loss.backward()
+    assert "k_fit_loss_records" in k.names and not ({"k_fit_loss_grad", "k_fit_loss_reduce", "k_pack_maps"} & k.names), sorted(k.names)
+    for got, ref in zip((rgb, depth, alpha), ref_images):
+        assert torch.equal(got.detach(), ref)
+    assert abs(float(loss) - float(loss0)) <= 1e-6 * abs(float(loss0))
+    assert _rel_max(fit.vertices.grad, gv0) < 1e-5 and _rel_max(fit.textures.grad, gt0) < 1e-5
+    # a scaled loss (the scalar gradient travels through the link) and a second backward over the same graph
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    loss = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+    (loss * 2.5).backward(retain_graph=True)
+    assert _rel_max(fit.vertices.grad, 2.5 * gv0) < 1e-5 and _rel_max(fit.textures.grad, 2.5 * gt0) < 1e-5
+    fit.vertices.grad = fit.textures.grad = None
+    loss.backward()
+    assert _rel_max(fit.vertices.grad, gv0) < 1e-5 and _rel_max(fit.textures.grad, gt0) < 1e-5
+    # a NEGATIVE gradient of the loss: the edge gradient is not linear in it (a pixel counts iff its diff_grad > 0,
+    # KCU:401/:481), so the comparison is with the plain loss node on gradient images
+    neg = []
+    for linked in (True, False):
+        fit.vertices.grad = fit.textures.grad = None
+        rgb, depth, alpha = fit.render()
+        node = multiview_fit_loss if linked else (lambda *a: _MultiViewFitLoss.apply(*a))
+        (node(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum) * -1.5).backward()
+        neg.append((fit.vertices.grad.clone(), fit.textures.grad.clone()))
+    assert _rel_max(neg[0][0], neg[1][0]) < 1e-5 and _rel_max(neg[0][1], neg[1][1]) < 1e-5
+    assert _rel_max(neg[0][0], -1.5 * gv0) > 1e-2
+    # ANOTHER consumer of the images beside the objective: the objective's gradient images are materialised after all
+    # and added to the other's (same result as the plain loss node + the other term on one graph)
+    w = torch.randn_like(rgb_t)
+    grads = []
+    for linked in (True, False):
+        fit.vertices.grad = fit.textures.grad = None
+        rgb, depth, alpha = fit.render()
+        node = multiview_fit_loss if linked else (lambda *a: _MultiViewFitLoss.apply(*a))
+        total = node(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum) + (rgb * w).mean() + depth.clamp(max=4).mean()
+        total.backward()
+        grads.append((fit.vertices.grad.clone(), fit.textures.grad.clone()))
+    assert _rel_max(grads[0][0], grads[1][0]) < 1e-5 and _rel_max(grads[0][1], grads[1][1]) < 1e-5
+    # the other consumer ALONE, after an objective was linked and never back-propagated: nothing of it may leak in
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+    (rgb * w).mean().backward()
+    only = fit.vertices.grad.clone()
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    (rgb * w).mean().backward()
+    assert _rel_max(only, fit.vertices.grad) < 1e-5
+    # the captured drop-in step (MultiViewFit(objective_in_renderer=False)) replays the same numbers
+    fit2 = MultiViewFit(v, tri, tex, synthetic.camera_ring(4), image_size=96, objective_in_renderer=False)
+    fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
+    fit2.capture_graph()
+    for _ in range(3):
+        loss2, gv2, gt2 = fit2.step()
+    assert abs(float(loss2) - float(loss0)) <= 1e-6 * abs(float(loss0)) and _rel_max(gv2, gv0) < 1e-5 and _rel_max(gt2, gt0) < 1e-5
+    fit2.release_graph()
