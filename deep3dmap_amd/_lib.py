@@ -51,6 +51,7 @@ CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
 _SIGNATURES = {
     "d3m_version": (ctypes.c_char_p, []),
     "d3m_last_hip_error": (_I, []),
+    "d3m_zero_ranges": (_I, [ctypes.POINTER(_P), ctypes.POINTER(_SZ), _I, _P]),
     "d3m_error_string": (ctypes.c_char_p, [_I]),
     "d3m_timing_enable": (None, [_I]),
     "d3m_timing_collect": (_I, [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_I), ctypes.POINTER(_F), _I]),
@@ -211,6 +212,16 @@ class coverage_form:
     def __exit__(self, *exc):
         lib().d3m_set_coverage_form(self.previous)
         return False
+
+
+def zero_(*tensors):
+    """Zero-fill up to six contiguous device tensors with one launch (d3m_zero_ranges); returns them."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if ts:
+        ptrs = (_P * len(ts))(*[t.data_ptr() for t in ts])
+        sizes = (_SZ * len(ts))(*[t.numel() * t.element_size() for t in ts])
+        check(lib().d3m_zero_ranges(ptrs, sizes, len(ts), stream_ptr()), "d3m_zero_ranges")
+    return tensors
 
 
 def kernel_timing(enable):

@@ -49,16 +49,13 @@ __global__ void __launch_bounds__(256) k_backward_textures(const int32_t* __rest
 
 // KCU:543-592: 9 float atomics per covered pixel into its face's gradient.
 template <class FS>
-__global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* __restrict__ depth_map,
-                                                           const int32_t* __restrict__ face_index_map,
-                                                           const float* __restrict__ face_inv_map,
-                                                           const float* __restrict__ weight_map,
-                                                           const float* __restrict__ grad_depth_map,
-                                                           float* __restrict__ grad_faces, int B, int S,
-                                                           const int* __restrict__ only_large, VertexTarget vt,
-                                                           GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0, nullptr},
-                                                           const int* __restrict__ n_large = nullptr) {
-    if (n_large && *n_large == 0) return;          // no face was left to this kernel (uniform exit)
+__device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __restrict__ depth_map,
+                                                          const int32_t* __restrict__ face_index_map,
+                                                          const float* __restrict__ face_inv_map,
+                                                          const float* __restrict__ weight_map,
+                                                          const float* __restrict__ grad_depth_map,
+                                                          float* __restrict__ grad_faces, int B, int S,
+                                                          const int* __restrict__ only_large, VertexTarget vt, GradScale gs) {
     // (a fixed grid striding over the pixels: see k_backward_textures_lit_pixels)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * blockDim.x) {
     const int fn = face_index_map[i];
@@ -95,6 +92,21 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
         atomicAdd(&gk[2], g * wk * depth2 / (z_k * z_k));
     }
     }
+}
+
+template <class FS>
+__global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* __restrict__ depth_map,
+                                                           const int32_t* __restrict__ face_index_map,
+                                                           const float* __restrict__ face_inv_map,
+                                                           const float* __restrict__ weight_map,
+                                                           const float* __restrict__ grad_depth_map,
+                                                           float* __restrict__ grad_faces, int B, int S,
+                                                           const int* __restrict__ only_large, VertexTarget vt,
+                                                           GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0, nullptr},
+                                                           const int* __restrict__ n_large = nullptr) {
+    if (n_large && *n_large == 0) return;          // no face was left to this kernel (uniform exit)
+    backward_depth_map_pixels(fs, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S,
+                              only_large, vt, gs);
 }
 
 }  // namespace d3m

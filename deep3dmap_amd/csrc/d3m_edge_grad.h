@@ -705,6 +705,44 @@ __global__ void __launch_bounds__(256) k_alloc_ranges(const int* __restrict__ co
     if (i < n) line_slice[i] = make_int2(s_base + s_wave[wv] + incl - c, c);
 }
 
+// ---- 2'. both allocations of the plan in ONE launch ---------------------------------------------------------------
+// The count pass leaves two arrays of counts: crossings per workgroup iteration (lane_block: the scatter and gather
+// passes need each iteration's first crossing) and crossings per line (line_count: the scatter pass needs each line's
+// slice of the records).  Neither needs its slices in index order -- only disjoint --, so both are allocated order-free:
+// 256 entries per workgroup, one returning atomic each (a few dozen per launch on one address, not thousands).  Round 3
+// ran an ordered single-workgroup scan for the first (k_scan_small, 11 us of one workgroup on an otherwise idle chip) and
+// k_alloc_ranges for the second; with the step's kernels on one stream that was 15 us of its critical path, now 5.
+// Workgroups [0, blocks_a) take lane_block (in place: count -> first crossing; the grid is sized for EVERY face being
+// visible, the workgroups past ceil(*n_visible / faces per iteration) leave at once), the rest line_count -> line_slice.
+// cursor_a ends as the number of crossings (EdgePlan::alloc[0]: plan_complete()).
+__global__ void __launch_bounds__(256) k_alloc_plan(int* __restrict__ lane_block, const int* __restrict__ n_visible, int per_block,
+                                                   int* __restrict__ cursor_a, int blocks_a,
+                                                   const int* __restrict__ line_count, int2* __restrict__ line_slice,
+                                                   int* __restrict__ cursor_b, long n_lines) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const bool first = (int)blockIdx.x < blocks_a;
+    const long n = first ? (long)((*n_visible + per_block - 1) / per_block) : n_lines;
+    const long i = (long)(first ? blockIdx.x : blockIdx.x - blocks_a) * 256 + threadIdx.x;
+    if (i - threadIdx.x >= n) return;                       // (uniform per workgroup)
+    const int c = i < n ? (first ? lane_block[i] : line_count[i]) : 0;
+    const int incl = wave_inclusive_scan(c);
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t0 = s_wave[0], t1 = s_wave[1], t2 = s_wave[2], t3 = s_wave[3];
+        s_base = atomicAdd(first ? cursor_a : cursor_b, t0 + t1 + t2 + t3);
+        s_wave[0] = 0; s_wave[1] = t0; s_wave[2] = t0 + t1; s_wave[3] = t0 + t1 + t2;
+    }
+    __syncthreads();
+    if (i < n) {
+        const int at = s_base + s_wave[wv] + incl - c;
+        if (first) lane_block[i] = at;
+        else line_slice[i] = make_int2(at, c);
+    }
+}
+
 // ---- 3. the crossings' records, written in line order -------------------------------------------------------
 // Same flattening as the count pass.  The lanes of a wave that share a line take consecutive places under that
 // line's cursor with ONE atomic per distinct line.
@@ -1447,10 +1485,9 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
     const bool window = S <= EG_WINDOW_MAX_S;               // the workgroups' lines fit LDS
     if (window) LAUNCH_SMEM("k_edge_count", k_edge_count_window<FS>, g6, dim3(256), (size_t)2 * (S + 1) * 4, st, fs, S, w);
     else LAUNCH("k_edge_count", k_edge_count<FS>, g6, dim3(256), st, fs, S, w);
-    LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, w.lane_block, 0, (const int*)w.n_visible,
-           EG_FACES_PER_BLOCK, w.alloc);
-    LAUNCH("k_alloc_ranges", k_alloc_ranges, dim3((unsigned)((nl + 255) / 256)), dim3(256), st, (const int*)w.line_count,
-           w.line_slice, w.alloc + 1, nl);
+    const int blocks_a = (int)((g6_full + 255) / 256);
+    LAUNCH("k_alloc_plan", k_alloc_plan, dim3((unsigned)(blocks_a + (nl + 255) / 256)), dim3(256), st, w.lane_block,
+           (const int*)w.n_visible, EG_FACES_PER_BLOCK, w.alloc, blocks_a, (const int*)w.line_count, w.line_slice, w.alloc + 1, nl);
     // (the scatter pass keeps the by-key form: with the ranks taken from LDS cursors it was slower, 0.173 vs 0.150 ms)
     LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g6, dim3(256), st, fs, face_index_map, S, w);
     return hipGetLastError();

@@ -64,6 +64,50 @@ __global__ void __launch_bounds__(256) k_zero_fill(uint32_t* __restrict__ p, siz
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += stride) p[i] = 0;
 }
 
+// Several clears in ONE launch (up to FILL_RANGES): with a step's kernels on one stream every launch is on its critical
+// path, and a clear of a few KB costs what a clear of a few MB does (~4.5 us).  Same rules as zero_async per range
+// (a multiple of 4 bytes), except that a range need only be 4-byte aligned (a view into a flat buffer): the words in front
+// of the first 16-byte boundary are stored singly; empty ranges are skipped.
+constexpr int FILL_RANGES = 6;
+struct FillRanges {
+    uint32_t* p[FILL_RANGES];
+    unsigned long long words[FILL_RANGES];
+};
+__global__ void __launch_bounds__(256) k_zero_ranges(FillRanges r) {
+    const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < FILL_RANGES; k++) {
+        const size_t n_words = r.words[k];
+        size_t head = ((16u - (unsigned)((uintptr_t)r.p[k] & 15u)) & 15u) >> 2;     // words up to the 16-byte boundary
+        if (head > n_words) head = n_words;
+        const size_t n4 = (n_words - head) >> 2;
+        uint4* p4 = reinterpret_cast<uint4*>(r.p[k] + head);
+        if (i0 < head) r.p[k][i0] = 0;
+        for (size_t i = i0; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
+        for (size_t i = head + (n4 << 2) + i0; i < n_words; i += stride) r.p[k][i] = 0;
+    }
+}
+inline hipError_t zero_ranges_async(void* const* ptrs, const size_t* bytes, int n, hipStream_t st) {
+    FillRanges r;
+    size_t most = 0;
+    int used = 0;
+    for (int k = 0; k < n; k++) {
+        if (!ptrs[k] || bytes[k] == 0) continue;
+        if (used == FILL_RANGES || (bytes[k] & 3) || ((uintptr_t)ptrs[k] & 3)) return hipErrorInvalidValue;
+        r.p[used] = (uint32_t*)ptrs[k];
+        r.words[used] = bytes[k] >> 2;
+        most = bytes[k] > most ? bytes[k] : most;
+        used++;
+    }
+    if (used == 0) return hipSuccess;
+    for (int k = used; k < FILL_RANGES; k++) { r.p[k] = nullptr; r.words[k] = 0; }
+    size_t blocks = (most / 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    LAUNCH("k_zero_fill", k_zero_ranges, dim3((unsigned)blocks), dim3(256), st, r);
+    return hipGetLastError();
+}
+
 inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
     if ((bytes & 3) || ((uintptr_t)p & 15)) return hipMemsetAsync(p, 0, bytes, st);     // not used by this library

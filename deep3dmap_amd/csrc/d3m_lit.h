@@ -768,16 +768,14 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
 }
 
 // backward, per pixel with float atomics: any ts, and the faces the gathered form marked LARGE
-__global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const float* __restrict__ faces, LitTextures lt,
-                                                                     const int32_t* __restrict__ face_index_map,
-                                                                     const float* __restrict__ weight_map,
-                                                                     const float* __restrict__ depth_map, RgbGrad grad_rgb,
-                                                                     float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
-                                                                     float* __restrict__ grad_light,
-                                                                     const int* __restrict__ only_large, int B, int S,
-                                                                     float eps, GradScale gs,
-                                                                     const int* __restrict__ n_large) {
-    if (n_large && *n_large == 0) return;          // only_large mode and no such face: nothing to do (uniform exit)
+__device__ __forceinline__ void backward_textures_lit_pixels(const float* __restrict__ faces, const LitTextures& lt,
+                                                             const int32_t* __restrict__ face_index_map,
+                                                             const float* __restrict__ weight_map,
+                                                             const float* __restrict__ depth_map, RgbGrad grad_rgb,
+                                                             float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
+                                                             float* __restrict__ grad_light,
+                                                             const int* __restrict__ only_large, int B, int S, float eps,
+                                                             GradScale gs) {
     // a fixed grid striding over the pixels: in only_large mode the launch normally has nothing to do, and 32 k
     // workgroups that leave at once still cost 12 us of dispatch
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * 256) {
@@ -812,6 +810,40 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const floa
         }
     }
     }
+}
+
+__global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const float* __restrict__ faces, LitTextures lt,
+                                                                     const int32_t* __restrict__ face_index_map,
+                                                                     const float* __restrict__ weight_map,
+                                                                     const float* __restrict__ depth_map, RgbGrad grad_rgb,
+                                                                     float* __restrict__ gtex_view /*[B,F,ts^3,3]*/,
+                                                                     float* __restrict__ grad_light,
+                                                                     const int* __restrict__ only_large, int B, int S,
+                                                                     float eps, GradScale gs,
+                                                                     const int* __restrict__ n_large) {
+    if (n_large && *n_large == 0) return;          // only_large mode and no such face: nothing to do (uniform exit)
+    backward_textures_lit_pixels(faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gtex_view, grad_light,
+                                 only_large, B, S, eps, gs);
+}
+
+// The gathered pass's two fallbacks for the faces it marked LARGE -- texel gradients and the depth gradient, per pixel with
+// float atomics -- as ONE launch: normally there is no such face and the launch leaves at once, and with the step's kernels
+// on one stream every launch that leaves at once is still ~4.5 us of the step.
+__global__ void __launch_bounds__(256) k_lit_large_faces(const float* __restrict__ faces, LitTextures lt,
+                                                        const int32_t* __restrict__ face_index_map,
+                                                        const float* __restrict__ weight_map,
+                                                        const float* __restrict__ depth_map, RgbGrad grad_rgb,
+                                                        float* __restrict__ gtex_view, float* __restrict__ grad_light,
+                                                        const int* __restrict__ flags, int B, int S, float eps, GradScale gs,
+                                                        const int* __restrict__ n_large,
+                                                        const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces,
+                                                        VertexTarget vt) {
+    if (*n_large == 0) return;                     // (uniform exit)
+    backward_textures_lit_pixels(faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gtex_view, grad_light, flags, B, S,
+                                 eps, gs);
+    if (grad_depth_map)
+        backward_depth_map_pixels(DenseFaces{faces, lt.Fp}, depth_map, face_index_map, (const float*)nullptr, weight_map,
+                                  grad_depth_map, grad_faces, B, S, flags, vt, gs);
 }
 
 // out[j] = sum_b in[b, j]  (shared textures: per-view gradients -> one gradient).  With `flags` ([B, F'] visibility

@@ -79,6 +79,14 @@ D3M_EXPORT int d3m_timing_collect(const char** names, int* counts, float* total_
 }
 
 D3M_EXPORT const char* d3m_version(void) { return "d3m_raster 0.1 (gfx950)"; }
+// up to six clears as one launch (a fill KERNEL, never a memset node: d3m_launch.h)
+D3M_EXPORT int d3m_zero_ranges(void* const* ptrs, const size_t* bytes, int count, d3m_stream_t stream) {
+    if (!ptrs || !bytes || count < 0 || count > FILL_RANGES) return D3M_ERR_INVALID;
+    hipError_t e = zero_ranges_async(ptrs, bytes, count, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return D3M_ERR_INVALID;
+    HIP_TRY(e);
+    return check_launch();
+}
 D3M_EXPORT int d3m_last_hip_error(void) { return g_last_hip_error; }
 D3M_EXPORT const char* d3m_error_string(int code) {
     switch (code) {
@@ -282,12 +290,27 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
     if (rc) return rc;
     if (!counters_cleared) HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
+#ifdef D3M_DEV_SKIP
+    {   // developer builds: D3M_ABL_NO_DENSE -- from the third call on the binning pass stops writing the dense face copy
+        // (the buffer keeps the earlier calls' contents: same mesh every step in bench.py), to time the pass without it
+        static const char* abl = getenv("D3M_ABL_NO_DENSE");
+        static int calls = 0;
+        if (abl && ++calls > 2) {
+            LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
+                   (float*)nullptr, (float*)nullptr, out.marks, out.marks_count);
+            goto counted;
+        }
+    }
+#endif
     if (ifs.fill_back)      // one lane per index triple, both copies
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks, out.marks_count);
     else
         LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
                (float*)nullptr, faces_out, out.marks, out.marks_count);
+#ifdef D3M_DEV_SKIP
+counted:
+#endif
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, BIN_ALLOC_THREADS)), dim3(BIN_ALLOC_THREADS), st, bb);
     if (ifs.fill_back) launch_bin_fill<true>(bb, nf / 2, st);
     else launch_bin_fill<false>(bb, nf, st);
@@ -1025,8 +1048,11 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     int* n_large = (int*)((char*)view_mask + mask_bytes);          // zeroed together with the masks (or on its own)
     // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
     const bool skip_zero = texture_size == 2 && textures_batch == 1;
-    if (!skip_zero) HIP_TRY(zero_async(gview, (size_t)B * view_elems * 4, st));
-    if (grad_light) HIP_TRY(zero_async(grad_light, (size_t)light_batch * lt.Fp * 12, st));
+    // every clear of this entry point in one launch (below)
+    void* z_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t z_bytes[4] = {0, 0, 0, 0};
+    if (!skip_zero) { z_ptr[0] = gview; z_bytes[0] = (size_t)B * view_elems * 4; }
+    if (grad_light) { z_ptr[1] = grad_light; z_bytes[1] = (size_t)light_batch * lt.Fp * 12; }
     const int* list = nullptr;
     const int* n_list = nullptr;
     if (visibility) {                                  // flags and the compacted list come from d3m_visibility
@@ -1034,28 +1060,24 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         flags = v.flags; list = v.list; n_list = v.count;
     }
     if (texture_size == 2) {
-        if (!visibility) {
-            HIP_TRY(zero_async(flags, (size_t)nf * 4, st));
-            LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
-        }
         const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
-        if (use_mask) HIP_TRY(zero_async(view_mask, mask_bytes + 256, st));
-        else HIP_TRY(zero_async(n_large, 256, st));
+        if (use_mask) { z_ptr[2] = view_mask; z_bytes[2] = mask_bytes + 256; }
+        else { z_ptr[2] = n_large; z_bytes[2] = 256; }
+        if (!visibility) { z_ptr[3] = flags; z_bytes[3] = (size_t)nf * 4; }
+        HIP_TRY(zero_ranges_async(z_ptr, z_bytes, 4, st));
+        if (!visibility)
+            LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, n_large};
         const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
-        LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, true)), dim3(256), st,
-               faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps,
-               gs, (const int*)n_large);
-        if (grad_depth_map) {                         // the depth gradient of the faces the gathered pass marked LARGE
-            DenseFaces fs{faces, lt.Fp};
-            LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, true)), dim3(256), st, fs,
-                   depth_map, face_index_map, (const float*)nullptr, weight_map, grad_depth_map, grad_faces, B, S,
-                   (const int*)flags, vt, gs, (const int*)n_large);
-        }
+        // the texel and depth gradients of the faces the gathered pass marked LARGE (normally none: leaves at once)
+        LAUNCH("k_lit_large_faces", k_lit_large_faces, dim3(px_grid(n, true)), dim3(256), st, faces, lt, face_index_map,
+               weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)n_large,
+               grad_depth_map, grad_faces, vt);
     } else {
+        HIP_TRY(zero_ranges_async(z_ptr, z_bytes, 4, st));
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, false)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)nullptr, B, S, eps,
                gs, (const int*)nullptr);

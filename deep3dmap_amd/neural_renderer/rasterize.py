@@ -563,7 +563,7 @@ class _RasterizeLit(torch.autograd.Function):
         m = ctx.maps
         dev, B, G = faces.device, faces.shape[0], len(groups)
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
-        grad_sv = torch.zeros(B, V, 3, dtype=torch.float32, device=dev)
+        grad_sv = torch.empty(B, V, 3, dtype=torch.float32, device=dev)     # zeroed below, with the other accumulators
         grad_loss = scratch = mask_sum = None
         records = None
         # A fit objective evaluated on this node's finished images (core.losses.multiview_fit_loss -> LitImagesLink) has left
@@ -610,9 +610,10 @@ class _RasterizeLit(torch.autograd.Function):
         tex_shared, light_shared = textures.shape[0] == 1, Bl == 1
         gt_g = gl_g = None
         sink = ctx.grad_sink
+        if gathered and need_vert:
+            grad_vertices = sink[0] if (sink is not None and ctx.camera is not None) else torch.empty_like(vertices)
+        _lib.zero_(grad_sv, grad_vertices)           # one launch for both accumulators
         if gathered:
-            if need_vert:
-                grad_vertices = sink[0].zero_() if (sink is not None and ctx.camera is not None) else torch.zeros_like(vertices)
             if tex_shared:
                 gt_g = [sink[1] if (sink is not None and sink[1] is not None and G == 1) else torch.empty_like(textures)
                         for _ in groups]

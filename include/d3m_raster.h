@@ -42,6 +42,12 @@ enum { D3M_CAMERA_NONE = 0, D3M_CAMERA_LOOK_AT = 1, D3M_CAMERA_LOOK = 2, D3M_CAM
 
 const char* d3m_version(void);
 int d3m_last_hip_error(void);         /* hipError_t of the most recent failed HIP call, 0 if none */
+/* Zero-fill up to six device ranges with ONE kernel launch (host arrays of `count` device pointers / byte counts; every
+ * range 4-byte aligned and a multiple of 4 bytes, NULL / 0 entries skipped).  The library never uses memset nodes (a
+ * captured hipMemsetAsync was not ordered reliably against the next kernel node on ROCm 7.2); callers that clear several
+ * small scratch buffers per step (the reference does the same with torch.zeros, NR/rasterize.py:111-115) save a launch
+ * per buffer. */
+int d3m_zero_ranges(void* const* ptrs, const size_t* bytes, int count, d3m_stream_t stream);
 const char* d3m_error_string(int code);
 
 /* Per-kernel timing with HIP events recorded on each launch's own stream (used by bench.py for the

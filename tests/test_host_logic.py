@@ -173,7 +173,7 @@ def test_committed_bench_line_and_profiles_are_consistent():
     import json
     sys.path.insert(0, ROOT)
     import bench
-    R = "r03"                                           # the round whose artefacts bench.py reads (the newest)
+    R = "r04"                                           # the round whose artefacts bench.py reads (the newest)
     line = json.load(open(os.path.join(ROOT, "profiles", f"{R}_bench_final.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "dropin"):
