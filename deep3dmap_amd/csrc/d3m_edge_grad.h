@@ -861,11 +861,11 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
 #endif
 constexpr int EG_ROW = D3M_EG_ROW;
 constexpr int EG_SEG_PER_WAVE = 64 / EG_ROW;   // segments walked concurrently by one wave
-constexpr int EG_LINE_THREADS = EG_LINE_WAVES * 64;
-constexpr int EG_CHUNK = EG_LINE_THREADS / 2;  // crossings set up at a time: one thread per (crossing, outward | inward)
-constexpr int EG_QUEUE = EG_LINE_THREADS;      // long segments queued in LDS before they are walked (one sort key per thread)
-constexpr size_t EG_LINE_STATIC_LDS = (size_t)EG_QUEUE * (EG_ITEM_DW * 4 + 2) + 1024;   // queue + order + counters
-static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole waves the inward ones");
+// per workgroup of `waves` waves: EG_CHUNK = 32 * waves crossings set up at a time (one thread per (crossing, outward |
+// inward): whole waves take the outward walks, whole waves the inward ones), EG_QUEUE = 64 * waves long segments queued in
+// LDS before they are walked (one sort key per thread)
+constexpr size_t eg_line_static_lds(int waves) { return (size_t)waves * 64 * (EG_ITEM_DW * 4 + 2) + 1024; }   // queue + order + counters
+constexpr size_t EG_LINE_STATIC_LDS = eg_line_static_lds(EG_LINE_WAVES);
 
 // ---- 5. one workgroup per (view, axis, line): set up the line's crossings, walk their segments ------------------
 // The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a chunk of
@@ -905,9 +905,11 @@ static_assert(EG_CHUNK % 64 == 0, "whole waves take the outward walks, whole wav
 // scratch per lane (335 MB of spill stores per headline launch); since round 4 the walk re-reads what it needs after its
 // loop from the queue item instead of carrying it, the allocation is 62-64 registers without the bound, and
 // tests/test_host_logic.py fails on any scratch in the library.
-template <bool USE_RGB, bool USE_ALPHA>
-__global__ void __launch_bounds__(EG_LINE_THREADS, 8) k_edge_lines(EdgeGradArgs a, EdgePlan w,
-                                                                                   float2* __restrict__ lane_partial) {
+template <bool USE_RGB, bool USE_ALPHA, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, EdgePlan w, float2* __restrict__ lane_partial) {
+    // WAVES per workgroup: 8 where four such workgroups fit a CU beside their lines' LDS images (S <= ~600), 16 above that
+    // (two workgroups = the same eight waves per SIMD, where 8-wave workgroups would leave the CU at four or six)
+    constexpr int EG_LINE_THREADS = WAVES * 64, EG_CHUNK = EG_LINE_THREADS / 2, EG_QUEUE = EG_LINE_THREADS, EG_LINE_WAVES = WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
         const long n = (long)*w.n_visible * 6;
@@ -1594,19 +1596,32 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
-#define D3M_LINES(RGB, ALPHA)                                                                                        \
+#define D3M_LINES(RGB, ALPHA, WV)                                                                                    \
     do {                                                                                                             \
-        if (smem + EG_LINE_STATIC_LDS > 64 * 1024) {                                                                 \
-            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA>,                                           \
+        if (smem + eg_line_static_lds(WV) > 64 * 1024) {                                                             \
+            e = hipFuncSetAttribute((const void*)k_edge_lines<RGB, ALPHA, WV>,                                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA>), glines, dim3(EG_LINE_THREADS), smem, st, a, w,       \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, WV>), glines, dim3(WV * 64), smem, st, a, w,           \
                     lane_partial);                                                                                   \
     } while (0)
-    if (m.use_rgb && m.use_alpha) D3M_LINES(true, true);
-    else if (m.use_rgb) D3M_LINES(true, false);
-    else D3M_LINES(false, true);
+    // Waves per workgroup: the narrow form while its workgroups keep a CU at 24 waves or more (their phases -- stage, set
+    // up, order, walk -- overlap only ACROSS workgroups, and a barrier over 16 waves costs more than one over 8: 16 waves at
+    // 512^2 took 0.60 ms against 0.50), the 16-wave form (two workgroups = 32 waves) where the lines' LDS images leave
+    // fewer (S = 1024: two 8-wave workgroups = 16 waves; 1.08 -> 0.875 ms alone on BASELINE config 5)
+#ifndef D3M_EG_NARROW_WAVES
+#define D3M_EG_NARROW_WAVES 8
+#endif
+    const size_t lds_cu = 160 * 1024;
+    const int wg_narrow = (int)std::min(lds_cu / (smem + eg_line_static_lds(D3M_EG_NARROW_WAVES)), (size_t)(32 / D3M_EG_NARROW_WAVES));
+    const int wg_wide = (int)std::min(lds_cu / (smem + eg_line_static_lds(16)), (size_t)2);
+    const bool wide = wg_narrow * D3M_EG_NARROW_WAVES < 24 && wg_wide * 16 > wg_narrow * D3M_EG_NARROW_WAVES;
+#define D3M_LINES2(RGB, ALPHA) do { if (wide) D3M_LINES(RGB, ALPHA, 16); else D3M_LINES(RGB, ALPHA, D3M_EG_NARROW_WAVES); } while (0)
+    if (m.use_rgb && m.use_alpha) D3M_LINES2(true, true);
+    else if (m.use_rgb) D3M_LINES2(true, false);
+    else D3M_LINES2(false, true);
+#undef D3M_LINES2
 #undef D3M_LINES
     const long g6_full = (nf + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
