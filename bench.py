@@ -596,7 +596,11 @@ def main():
                               ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"),
                        "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
                        "texture_size": ts, "fill_back": True, "anti_aliasing": bool(args.anti_aliasing), "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
-                       "parallelism": f"camera-sharded x{world}"},
+                       "parallelism": f"camera-sharded x{world}",
+                       "exchange": ("none (one rank)" if not dist_on else
+                                    "two all-reduces per step: texture gradient (started between the step's two HIP graphs, "
+                                    "travels beside the edge gradient) | loss + vertex gradient" if fit.split_exchange else
+                                    "one all-reduce of [loss | vertex | texture gradients] behind the step")},
             "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "roofline": roof,

@@ -22,13 +22,30 @@ import torch
 
 
 class CapturedStep:
-    def __init__(self, fn):
-        """fn(): runs one step and returns a tensor / tuple of tensors that stay valid until the next call."""
-        self.fn = fn
+    def __init__(self, fn, between=None):
+        """fn(): runs one step and returns a tensor / tuple of tensors that stay valid until the next call.
+
+        A step in SEVERAL PARTS: fn = [part_0, ..., part_n] (the last one returns the outputs) and between = [cb_0, ...,
+        cb_{n-1}]: cb_i() runs behind part_i on the step's stream, OUTSIDE every capture -- each part becomes a HIP graph
+        of its own (one memory pool for all: what part_i leaves for part_{i+1} lives in it), and cb_i is where a
+        collective goes that should travel while the later parts still compute (multiview.py: the texture gradient's
+        all-reduce between the texture side and the geometry side of the backward pass)."""
+        self.parts = list(fn) if isinstance(fn, (list, tuple)) else [fn]
+        self.between = list(between) if between else []
+        if len(self.between) != len(self.parts) - 1:
+            raise ValueError("a step of n parts takes n - 1 callbacks")
         self.stream = torch.cuda.Stream()
-        self.graph = None
+        self.graph = None               # the parts' graphs once captured
         self._static_out = None
         self._last_eager_out = None
+
+    def _run_parts(self, run):
+        out = None
+        for i in range(len(self.parts)):
+            out = run(i)
+            if i < len(self.between):
+                self.between[i]()
+        return out
 
     def _enter(self):
         cur = torch.cuda.current_stream()
@@ -52,9 +69,9 @@ class CapturedStep:
         eager = self.graph is None
         with torch.cuda.stream(self.stream):
             if eager:
-                out = self.fn()
+                out = self._run_parts(lambda i: self.parts[i]())
             else:
-                self.graph.replay()
+                self._run_parts(lambda i: self.graph[i].replay())
                 out = self._static_out
         return self._exit(cur, out, eager)
 
@@ -64,20 +81,25 @@ class CapturedStep:
         cur = self._enter()
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
-                self.fn()
+                self._run_parts(lambda i: self.parts[i]())
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+        graphs = [torch.cuda.CUDAGraph() for _ in self.parts]
         gc.collect()                        # whatever is dead dies NOW, not inside the capture (see the module text)
         gc_was_on = gc.isenabled()
         gc.disable()
-        try:
+
+        def capture_part(i):
             # thread_local: other threads of the process (e.g. the RCCL watchdog) may touch the HIP runtime meanwhile
-            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
-                self._static_out = self.fn()
+            pool = {} if i == 0 else {"pool": graphs[0].pool()}
+            with torch.cuda.graph(graphs[i], stream=self.stream, capture_error_mode="thread_local", **pool):
+                return self.parts[i]()
+        try:
+            with torch.cuda.stream(self.stream):     # (the callbacks between the parts run on the step's stream, uncaptured)
+                self._static_out = self._run_parts(capture_part)
         finally:
             if gc_was_on:
                 gc.enable()
-        self.graph = graph
+        self.graph = graphs
         cur.wait_stream(self.stream)
         return self
 

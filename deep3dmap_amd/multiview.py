@@ -7,6 +7,7 @@ f32 buffer [3V (+ F*ts^3*3)] per step -- RCCL over xGMI when the process group's
 The reference has no such path (it only runs a different image per rank); this is the north-star's
 "shard by camera + all-reduce of vertex gradients".
 """
+import os
 import weakref
 
 import torch
@@ -45,6 +46,27 @@ def allreduce_sum_(flat, group=None):
     return flat
 
 
+def allreduce_sum_start(flat, group=None):
+    """Start the in-place SUM-all-reduce of a flat device buffer and return a handle for allreduce_wait() -- None when
+    there is nothing to wait for (no process group, one rank, or the gloo debug configuration, which is staged through
+    the host synchronously).  Under "nccl" (= RCCL) the collective runs on the communicator's own stream, ordered behind
+    what the CURRENT stream has been given so far: kernels issued afterwards run beside it."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_world_size(group) == 1 and not COLLECTIVES_WITH_ONE_RANK:
+        return None
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        allreduce_sum_(flat, group)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def allreduce_wait(work):
+    """The current stream waits for a collective started by allreduce_sum_start (no host synchronisation under RCCL)."""
+    if work is not None:
+        work.wait()
+
+
 def allreduce_flat(tensors, group=None):
     """SUM-all-reduce several tensors as one flat buffer (allocates the buffer: for one-off exchanges; the step itself
     uses the persistent buffer of MultiViewFit)."""
@@ -72,7 +94,8 @@ class MultiViewFit:
     """
 
     def __init__(self, vertices, triangles, textures, eyes, image_size=512, anti_aliasing=False, rank=0,
-                 world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True, view_groups=1):
+                 world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True, view_groups=1,
+                 split_exchange=None):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         lo, hi = shard_views(len(eyes), rank, world_size)
@@ -105,7 +128,25 @@ class MultiViewFit:
         # fit a cycle, and a fit with its captured graph, memory pool and streams should die with its last reference, not
         # whenever the collector next runs -- see graph.py on collections inside a capture.)
         me = weakref.ref(self)
-        self._runner = CapturedStep(lambda: me()._forward_backward())
+        # SPLIT EXCHANGE (SURVEY 8e "visible at small per-GPU work"): of the 10.2 MB a headline step exchanges, 9.6 MB are
+        # the texture gradient, and that is final as soon as the gathered texture / depth pass and the sum over views have
+        # run -- before the edge gradient (the longest kernel chain of the step) starts.  The step is then TWO parts (two
+        # HIP graphs when captured): forward + texture side of backward | all-reduce of the texture part STARTED on the
+        # communicator's stream | geometry side of backward beside it | all-reduce of [loss | vertex gradient].  The node's
+        # two halves are called by hand (rasterize.LitFitManual: a capture cannot end on autograd's worker thread).
+        # Default: on whenever gradients are exchanged and the fused objective runs (one pipeline, look_at cameras).
+        if split_exchange is None:
+            split_exchange = (os.environ.get("D3M_SPLIT_EXCHANGE", "1") != "0" and
+                              (world_size > 1 or COLLECTIVES_WITH_ONE_RANK))
+        self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
+                                   and self.renderer._on_the_fly())
+        self._manual = self._tex_work = None
+        if self.split_exchange:
+            self._one = torch.ones(1, dtype=torch.float32, device=self.device)
+            self._runner = CapturedStep([lambda: me()._forward_and_texture_side(), lambda: me()._geometry_side()],
+                                        between=[lambda: me()._start_texture_exchange()])
+        else:
+            self._runner = CapturedStep(lambda: me()._forward_backward())
 
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices
@@ -179,6 +220,32 @@ class MultiViewFit:
             at += part.numel()
         return self._flat
 
+    # ---- the step in two parts (split_exchange) --------------------------------------------------------------------
+    def _forward_and_texture_side(self):
+        from .neural_renderer.rasterize import LitFitManual
+        rgb_t, depth_t, alpha_t = self.targets
+        if self.keep_images and self.images is None:
+            self.images = tuple(torch.empty_like(t) for t in (rgb_t, depth_t, alpha_t))
+        self._manual = LitFitManual(vertices_grad=True, textures_grad=True)
+        # (the loss lands in _flat[0], the gradients in their places behind it: the node's grad_sink)
+        self.renderer.render_fit_loss_manual(self._manual, self.vertices[None], self.triangles[None], self.textures[None],
+                                             (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum),
+                                             images_out=self.images if self.keep_images else None, grad_sink=self._sink)
+        self._manual.backward_texture_side(self._one)
+
+    def _start_texture_exchange(self):
+        nv = self.vertices.numel()
+        self._tex_work = allreduce_sum_start(self._flat[1 + nv:])
+
+    def _geometry_side(self):
+        gv, gt = self._manual.backward_geometry_side()
+        self._manual = None
+        nv = self.vertices.numel()
+        for part, dst in ((gv, self._flat[1:1 + nv]), (gt, self._flat[1 + nv:])):
+            if part.data_ptr() != dst.data_ptr():       # (not reached with a valid grad_sink; kept for safety)
+                dst.copy_(part.reshape(-1))
+        return self._flat
+
     def capture_graph(self, warmup=3):
         """Capture forward + loss + backward of one step into a HIP graph (see deep3dmap_amd/graph.py).
         Vertices / textures / targets are updated IN PLACE between replays."""
@@ -203,8 +270,15 @@ class MultiViewFit:
     def step(self):
         """forward + loss + backward + all-reduce.  Returns (loss, grad_vertices, grad_textures) of the WHOLE objective
         (all ranks' cameras) as views of the persistent flat buffer, valid until the next step."""
-        flat = allreduce_sum_(self._runner())
         nv = self.vertices.numel()
+        if self.split_exchange:
+            flat = self._runner()                   # ... during which the texture part's all-reduce was started
+            rest = allreduce_sum_start(flat[:1 + nv])
+            allreduce_wait(self._tex_work)
+            allreduce_wait(rest)
+            self._tex_work = None
+        else:
+            flat = allreduce_sum_(self._runner())
         gv = flat[1:1 + nv].view_as(self.vertices)
         gt = flat[1 + nv:].view_as(self.textures) if self.textures.requires_grad else None
         return flat[0], gv, gt

@@ -462,7 +462,7 @@ class _RasterizeLit(torch.autograd.Function):
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, bool(anti_aliasing))
         cur = torch.cuda.current_stream()
-        serial = G == 1 and _serial_branches(B, Ft, S)
+        serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
@@ -557,6 +557,22 @@ class _RasterizeLit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
+        halves = _RasterizeLit._backward_halves(ctx, g_rgb, g_alpha, g_depth)
+        next(halves)                    # ... up to the point where the texture gradient is final
+        try:
+            next(halves)                # ... the edge gradient, the light's and the camera's adjoints
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("_backward_halves yields once")
+
+    @staticmethod
+    def _backward_halves(ctx, g_rgb, g_alpha=None, g_depth=None):
+        """The node's backward as a generator with ONE cut: it yields when everything on the TEXTURE side has been
+        issued (the gathered texture / depth pass and the sum over views: grad_textures is final in stream order), and
+        returns the gradients after the GEOMETRY side (edge gradient, light and camera adjoints).  Autograd runs both
+        halves back to back (backward() above); LitFitManual stops in between, so that a camera-sharded fit can send the
+        texture gradient on its way while the geometry side still runs (deep3dmap_amd/multiview.py).  With more than one
+        view group the cut comes after the last group's passes have been issued (nothing to overlap)."""
         L = _lib.lib()
         faces, vertices, tri, textures, light = ctx.saved_tensors
         S, eps, aa, ra, rd, fill_back, (ia, idr, ca, cd, direction), Bl, groups = ctx.cfg
@@ -627,7 +643,7 @@ class _RasterizeLit(torch.autograd.Function):
                     grad_light = torch.empty_like(light)
                     gl_g = [grad_light[lo:hi] for lo, hi in groups]
         cur = torch.cuda.current_stream()
-        serial = G == 1 and _serial_branches(B, Ft, S)
+        serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         plan_ready = m["plan_ready"]
@@ -662,12 +678,16 @@ class _RasterizeLit(torch.autograd.Function):
                         _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis[k]),
                         ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
                         "d3m_backward_textures_lit")
+            if G == 1:
+                yield "textures"        # (one pipeline: the texture side is complete in the order of its stream)
             with torch.cuda.stream(mains[k]):
                 ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
                                        _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S, eps,
                                        True, ra,
                                        vertex_target=target, visibility=vis[k], unscaled=unscaled,
                                        edge_plan=m["edge_plan"][k])
+        if G > 1:
+            yield "textures"
         def light_to_vertices(grad_light):
             # the light gradient -> world-space vertices through the face normals
             _lib.check(L.d3m_face_light_backward(
@@ -720,6 +740,62 @@ class _RasterizeLit(torch.autograd.Function):
                           B, V, _lib.stream_ptr()), what)
             grad_sv = None
         return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 16
+
+
+class _ManualContext:
+    """What _RasterizeLit.forward / _backward_halves use of an autograd context, for calling them WITHOUT the autograd
+    engine (LitFitManual): needs_input_grad, save_for_backward / saved_tensors, free attributes."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = tuple(needs_input_grad)
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tuple(tensors)
+
+
+class LitFitManual:
+    """The fused fit objective of the lit render node (rasterize_lit_fit) driven by hand instead of by the autograd
+    engine: forward(), then the two halves of backward as separate calls on the CALLER's thread and stream --
+
+        loss = m.forward(...)                 # as rasterize_lit_fit(...)
+        m.backward_texture_side(grad_loss)    # grad_textures final (in the grad_sink, if one was given)
+        gv, gt = m.backward_geometry_side()   # grad_vertices final
+
+    -- so that a step can be captured as TWO HIP graphs with a collective issued between them (a capture cannot be ended
+    on autograd's worker thread, and one autograd node cannot be split).  Same kernels, same numbers as the autograd
+    node: it is that node's code (tests/test_gpu_multirank.py)."""
+
+    def __init__(self, vertices_grad=True, textures_grad=True):
+        self._needs = (False, bool(vertices_grad), False, bool(textures_grad)) + (False,) * 16
+        self._ctx = self._halves = None
+
+    def forward(self, vertices, tri, textures, light_cfg, fill_back, targets, image_size, near, far, eps, background_color,
+                camera, grad_sink=None, images_out=None, anti_aliasing=False):
+        fit = tuple(targets)
+        if images_out is not None:
+            fit = (fit + (None,))[:5] + (tuple(images_out),)
+        self._ctx = _ManualContext(self._needs)
+        self._ctx.force_serial = True       # every kernel on the caller's stream: the step is cut BETWEEN kernels of one stream
+        with torch.no_grad():
+            return _RasterizeLit.forward(self._ctx, None, vertices, tri, textures, light_cfg, fill_back, image_size,
+                                         bool(anti_aliasing), near, far, eps, background_color, True, True, True, fit, 1,
+                                         False, camera, grad_sink)
+
+    def backward_texture_side(self, grad_loss):
+        with torch.no_grad():
+            self._halves = _RasterizeLit._backward_halves(self._ctx, grad_loss)
+            next(self._halves)
+
+    def backward_geometry_side(self):
+        with torch.no_grad():
+            try:
+                next(self._halves)
+            except StopIteration as done:
+                grads = done.value
+                self._ctx = self._halves = None
+                return grads[1], grads[3]           # (grad_vertices, grad_textures)
+        raise RuntimeError("_backward_halves yields once")
 
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,

@@ -180,6 +180,16 @@ class Renderer(nn.Module):
                                  camera=cam, grad_sink=grad_sink if cam is not None else None,
                                  anti_aliasing=self.anti_aliasing)
 
+    def render_fit_loss_manual(self, manual, vertices, faces, textures, targets, images_out=None, grad_sink=None):
+        """render_fit_loss driven without the autograd engine: `manual` is a rasterize.LitFitManual whose forward is run
+        here (look_at cameras only: the camera runs inside the node); its two backward halves are the caller's to call."""
+        if not self._on_the_fly() or self.camera_mode != 'look_at':
+            raise ValueError("render_fit_loss_manual needs lighting_on_the_fly and camera_mode 'look_at'")
+        cam = cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None)
+        return manual.forward(vertices, faces, textures, self._light_cfg(), self.fill_back, targets, self.image_size,
+                              self.near, self.far, self.rasterizer_eps, self.background_color, cam, grad_sink=grad_sink,
+                              images_out=images_out, anti_aliasing=self.anti_aliasing)
+
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
             sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)

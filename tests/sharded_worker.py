@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--replays", type=int, default=6)
     ap.add_argument("--materialise-images", type=int, default=0)
+    ap.add_argument("--split-exchange", default="auto", choices=["auto", "0", "1"],
+                    help="the step in two parts with the texture gradient's all-reduce started between them "
+                         "(MultiViewFit(split_exchange=...); auto: on when there is more than one rank)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import numpy as np
@@ -34,13 +37,16 @@ def main():
     tex = synthetic.random_textures(tri.shape[0], 2)
     eyes = synthetic.camera_ring(args.views)
     fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, rank=rank, world_size=world,
-                       objective_in_renderer=not args.materialise_images)
+                       objective_in_renderer=not args.materialise_images,
+                       split_exchange=None if args.split_exchange == "auto" else bool(int(args.split_exchange)))
+    expect_split = (world > 1 if args.split_exchange == "auto" else bool(int(args.split_exchange))) and not args.materialise_images
+    assert fit.split_exchange == expect_split, (fit.split_exchange, expect_split)
     fit.set_targets_from(synthetic.perturb(v))
     loss, gv, gt = fit.step()
     eager = (float(loss), gv.clone(), gt.clone())
     if args.graph:
         fit.capture_graph()
-        assert fit.graph_captured
+        assert fit.graph_captured and len(fit._runner.graph) == (2 if fit.split_exchange else 1)
     for i in range(args.replays):
         loss, gv, gt = fit.step()
         torch.cuda.synchronize()
@@ -49,7 +55,8 @@ def main():
         assert rel < 1e-4, (i, rel)
     np.savez(args.out + f".rank{rank}.npz", loss=float(loss), gv=gv.cpu().numpy(), gt=gt.cpu().numpy(),
              mask_sum=float(fit.mask_sum) if fit.mask_sum is not None else float(fit.targets[2].sum()))
-    print(f"rank {rank}/{world}: loss {float(loss):.7f} graph={bool(args.graph)} replays={args.replays} ok", flush=True)
+    print(f"rank {rank}/{world}: loss {float(loss):.7f} graph={bool(args.graph)} replays={args.replays} "
+          f"split_exchange={fit.split_exchange} ok", flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
