@@ -804,7 +804,8 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
 }
 
 // ---- 4. crossings that have no record: walked by the owning thread, straight from global memory ---------------
-// Only when the workspace is too small for the scene (the default capacity is two crossings per face of the batch).
+// Only when the workspace is too small for the scene (default capacity: eg_default_crossings, two crossings per face of the
+// batch or three per raster pixel).
 // Leaves at once otherwise.  Results: the crossing's own slots when it has them, else the lane's overflow sum.
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, EdgePlan w, float2* __restrict__ lane_partial) {
@@ -1428,7 +1429,15 @@ struct EdgePlanLayout {
     size_t fixed_bytes;
 };
 constexpr size_t EG_BYTES_PER_CROSSING = 32 + 16 + 4;  // record + its two result slots + its position
-constexpr int EG_CROSSINGS_PER_FACE_DEFAULT = 2;       // default capacity per face of the batch (visible or not)
+// Default capacity of a plan, in crossings per view: two per face (visible or not) or three per raster pixel, whichever is
+// more.  A mesh that covers P pixels with triangles of A pixels each has about 6 P / sqrt(A) crossings (every triangle's
+// three edges, both axes, counted once per adjacent face): the 100 k-triangle mesh at 512^2 has 261 k per view of the 401 k
+// its faces grant, but at 1024^2 -- the same faces four times as large -- about a million, and a plan that cannot hold the
+// batch's crossings falls back to k_edge_overflow, which walks them from global memory (correct, and thirty times slower:
+// 8.0 ms instead of 0.3 for eight such views, measured in round 4 when the capacity still went by faces alone).
+inline size_t eg_default_crossings(int B, int F, int S) {
+    return (size_t)B * std::max((size_t)2 * F, (size_t)3 * S * S);
+}
 
 inline EdgePlanLayout edge_plan_layout(int B, int F, int S) {
     const size_t nf = (size_t)B * F, nl = (size_t)B * 2 * S;
@@ -1448,7 +1457,7 @@ inline EdgePlanLayout edge_plan_layout(int B, int F, int S) {
 
 inline size_t edge_plan_min_bytes(int B, int F, int S) { return edge_plan_layout(B, F, S).fixed_bytes + 1024; }
 inline size_t edge_plan_bytes(int B, int F, int S) {
-    return edge_plan_min_bytes(B, F, S) + eg_align((size_t)EG_CROSSINGS_PER_FACE_DEFAULT * B * F * EG_BYTES_PER_CROSSING);
+    return edge_plan_min_bytes(B, F, S) + eg_align(eg_default_crossings(B, F, S) * EG_BYTES_PER_CROSSING);
 }
 
 // the plan as laid out in `blob` (flags / list / count come from a visibility blob)

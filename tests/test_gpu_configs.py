@@ -441,3 +441,23 @@ def test_config5_per_gpu_shard_in_one_batch_equals_its_quarters():
         torch.cuda.empty_cache()
     assert abs(acc[0] - loss) <= 1e-5 * abs(loss), (acc[0], loss)
     assert _rel_l2(acc[1], gv) < 1e-4 and _rel_l2(acc[2], gt) < 1e-5
+
+
+def test_plan_capacity_follows_the_raster_size():
+    """The edge plan's default capacity goes by faces OR pixels (eg_default_crossings): BASELINE config 4's mesh at 1024^2
+    -- the same 100,352 triangles, four times as large on screen, about a million crossings per view where two per face
+    are 401 k -- must still get its records (k_edge_lines walks them) instead of falling back to k_edge_overflow, which
+    walks every crossing from global memory: 8.0 ms instead of 0.3 per 8 views when the capacity went by faces alone."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(225)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(32)[[2, 19]], image_size=1024)
+    fit.set_targets_from(synthetic.perturb(v))
+    fit.step()
+    with kernels_launched() as k:
+        loss, gv, _ = fit.step()
+    assert torch.isfinite(loss) and torch.isfinite(gv).all()
+    lines, overflow = k.times["k_edge_lines"][1], k.times["k_edge_overflow"][1]
+    assert overflow < 0.25 * lines, (lines, overflow)       # (ms; the fallback takes 30x the line kernel's time when it runs)
