@@ -202,6 +202,24 @@ def test_committed_bench_line_and_profiles_are_consistent():
     assert len(replayed) == 9
 
 
+def test_design_figures_are_generated_from_the_committed_profiles():
+    """The measured blocks of DESIGN.md are what tools_dev/refresh_design.py makes of the committed profiles -- no figure of
+    the current round is typed by hand (round 3's text contradicted its own PMC summary) -- and the line kernel's traffic
+    in that summary is back below round 2's (no scratch spills: WRITE_SIZE)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("refresh_design", os.path.join(ROOT, "tools_dev", "refresh_design.py"))
+    rd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rd)
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert "<!-- GENERATED:measured BEGIN -->" in text and "<!-- GENERATED:configs BEGIN -->" in text
+    assert rd.regenerate(text, "r04") == text, "run `python tools_dev/refresh_design.py r04` after updating profiles/"
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic_final.json")))["kernels"]
+    lines = next(v for k, v in pmc.items() if k.startswith("k_edge_lines"))
+    # round 2: 95 MB written / 596 MB in all; round 3 (24 B of scratch per lane): 353 / 884; the results alone are ~90 MB
+    assert lines["write_size_KiB"] * 1024 <= 130e6 and lines["hbm_bytes_per_launch"] <= 650e6, lines
+
+
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
