@@ -633,14 +633,15 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     // the depth gradient (KCU:543-592) rides along when asked for: same pixels, same weights, same depth
     float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
     // 1 / z of the three vertices, once per face: the quotients below (KCU:222, :575, :582) become products -- one more
-    // rounding each, in a gradient held to 1e-3; the forward pass keeps the reference's divisions
-    const float rz[3] = {1.0f / fc[2], 1.0f / fc[5], 1.0f / fc[8]};
+    // rounding each, in a gradient held to 1e-3; the forward pass keeps the reference's divisions.  v_rcp_f32 (1 ulp, one
+    // instruction) instead of the correctly rounded quotient (~10): all eight lanes of a face repeat this set-up.
+    const float rz[3] = {__builtin_amdgcn_rcpf(fc[2]), __builtin_amdgcn_rcpf(fc[5]), __builtin_amdgcn_rcpf(fc[8])};
     if (grad_depth_map) {
         // the x and y columns of the face inverse (face_inverse(): KCU:24-67) over their common denominator
         float px[3], py[3];
 #pragma unroll
         for (int n = 0; n < 3; n++) { px[n] = to_pixel(fc[3 * n], S); py[n] = to_pixel(fc[3 * n + 1], S); }
-        const float rden = 1.0f / (px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
+        const float rden = __builtin_amdgcn_rcpf(px[2] * (py[0] - py[1]) + px[0] * (py[1] - py[2]) + px[1] * (py[2] - py[0]));
         const float ix[3] = {(py[1] - py[2]) * rden, (py[2] - py[0]) * rden, (py[0] - py[1]) * rden};
         const float iy[3] = {(px[2] - px[1]) * rden, (px[0] - px[2]) * rden, (px[1] - px[0]) * rden};
 #pragma unroll
