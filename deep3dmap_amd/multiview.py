@@ -134,10 +134,17 @@ class MultiViewFit:
         # HIP graphs when captured): forward + texture side of backward | all-reduce of the texture part STARTED on the
         # communicator's stream | geometry side of backward beside it | all-reduce of [loss | vertex gradient].  The node's
         # two halves are called by hand (rasterize.LitFitManual: a capture cannot end on autograd's worker thread).
-        # Default: on whenever gradients are exchanged and the fused objective runs (one pipeline, look_at cameras).
+        # Default: on when gradients are exchanged, the fused objective runs (one pipeline, look_at cameras) AND the
+        # rank's batch is one whose step runs on one stream anyway (the lit node's choice, rasterize._serial_branches: the
+        # big batches of ordinary meshes).  Measured on one rank through RCCL (profiles/r04_bench_other_configs.jsonl): the
+        # split form costs a 32-view step 0.03 ms (two graph launches, two collectives) and hides a 9.6 MB all-reduce
+        # (0.07-0.17 ms over xGMI); an 8-view shard it costs 0.08 ms (0.04 of it the side branches it gives up), which is
+        # about what its collective takes -- no gain there, so the small shards keep the one-graph step.
         if split_exchange is None:
+            from .neural_renderer.rasterize import _serial_branches
             split_exchange = (os.environ.get("D3M_SPLIT_EXCHANGE", "1") != "0" and
-                              (world_size > 1 or COLLECTIVES_WITH_ONE_RANK))
+                              (world_size > 1 or COLLECTIVES_WITH_ONE_RANK) and
+                              _serial_branches(self.n_local, self.triangles.shape[0], image_size * (2 if anti_aliasing else 1)))
         self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
                                    and self.renderer._on_the_fly())
         self._manual = self._tex_work = None

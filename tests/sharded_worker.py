@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--materialise-images", type=int, default=0)
     ap.add_argument("--split-exchange", default="auto", choices=["auto", "0", "1"],
                     help="the step in two parts with the texture gradient's all-reduce started between them "
-                         "(MultiViewFit(split_exchange=...); auto: on when there is more than one rank)")
+                         "(MultiViewFit(split_exchange=...); auto: on with more than one rank and a big local batch)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import numpy as np
@@ -39,8 +39,11 @@ def main():
     fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, rank=rank, world_size=world,
                        objective_in_renderer=not args.materialise_images,
                        split_exchange=None if args.split_exchange == "auto" else bool(int(args.split_exchange)))
-    expect_split = (world > 1 if args.split_exchange == "auto" else bool(int(args.split_exchange))) and not args.materialise_images
-    assert fit.split_exchange == expect_split, (fit.split_exchange, expect_split)
+    if args.split_exchange != "auto":
+        expect_split = bool(int(args.split_exchange)) and not args.materialise_images
+        assert fit.split_exchange == expect_split, (fit.split_exchange, expect_split)
+    else:       # on with more than one rank when this rank's batch is big enough to run on one stream anyway (multiview.py)
+        assert not fit.split_exchange or (world > 1 and args.views // world > 16 and not args.materialise_images)
     fit.set_targets_from(synthetic.perturb(v))
     loss, gv, gt = fit.step()
     eager = (float(loss), gv.clone(), gt.clone())

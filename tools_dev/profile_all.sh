@@ -2,7 +2,7 @@
 # on the GPU box: the round's judged measurements in one call -- PMC passes and SQ counters first (bench.py reads their
 # folded summaries from profiles/), then the bench line, the drop-in (--materialise-images) line and the rocprofv3
 # kernel stats of the same command.  R = round tag (r02).
-R=${R:-r03}
+R=${R:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-dropin --steps 3 --warmup 1 --no-graph > $O/pmc_fetch.log 2>&1
@@ -19,7 +19,9 @@ cp $O/${R}_sq_counters_final.csv profiles/
 timeout 600 python bench.py > $O/${R}_bench_final.json 2> $O/bench.err
 tail -c 400 $O/${R}_bench_final.json
 timeout 300 python bench.py --no-cpu-baseline --no-dropin --fit-with-images > $O/${R}_bench_fit_with_images.json 2>> $O/bench.err
+# the lit node's side branches forced off / on (since round 4 the node chooses by the form of coverage: off at 32 views)
 D3M_SERIAL_BRANCHES=1 timeout 300 python bench.py --no-cpu-baseline --no-dropin > $O/${R}_bench_serial_branches.json 2>> $O/bench.err
+D3M_SERIAL_BRANCHES=0 timeout 300 python bench.py --no-cpu-baseline --no-dropin > $O/${R}_bench_side_branches.json 2>> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 bench.py --no-cpu-baseline --steps 30 > $O/stats.log 2>&1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_final.csv
 head -5 $O/${R}_kernel_stats_final.csv | cut -c1-150
