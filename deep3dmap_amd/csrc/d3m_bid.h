@@ -171,11 +171,6 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
         }
         if (front) {
             const int fid = rev ? f0 + Fl : f0;
-            if (faces_dense_out) {
-                float* o = faces_dense_out + ((size_t)b * F + fid) * 9;
-#pragma unroll
-                for (int k = 0; k < 9; k++) o[k] = face[k];
-            }
             if (faces_inv) {                      // the reference's K1 scratch (KCU:24-67), for the callers that pass it
                 face_inverse(face, S, finv);
 #pragma unroll
@@ -183,6 +178,13 @@ __global__ void __launch_bounds__(256) k_bid_faces(FS fs, unsigned long long* __
             }
             int x0, x1, y0, y1;
             const bool boxed = pixel_bbox(face, S, x0, x1, y0, y1);
+            // the dense copy the later passes read: only of faces whose box holds a pixel centre at all -- a face without
+            // one owns no pixel and is never read again (of a 1 M-triangle mesh at 1024^2 that is most of them)
+            if (boxed && faces_dense_out) {
+                float* o = faces_dense_out + ((size_t)b * F + fid) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) o[k] = face[k];
+            }
             if (boxed && (long)(x1 - x0 + 1) * (y1 - y0 + 1) > BID_BIG_AREA) {
                 big_list[atomicAdd(big_count, 1)] = b * F + fid;
             } else if (boxed) {

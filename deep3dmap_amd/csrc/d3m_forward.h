@@ -126,10 +126,6 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
         bool small = false;
         if (in_range) {
             if (!backside(face)) {
-                if (faces_dense_out) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
-                }
                 if (faces_inv) {
                     float fi[9];
                     face_inverse(face, bb.S, fi);
@@ -138,6 +134,10 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
                 }
                 int x0, x1, y0, y1;
                 if (pixel_bbox(face, bb.S, x0, x1, y0, y1)) {
+                    if (faces_dense_out) {            // (only faces whose box holds a pixel centre are ever read again)
+#pragma unroll
+                        for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
+                    }
                     tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE;
                     r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
                     small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
