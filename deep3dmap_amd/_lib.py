@@ -68,6 +68,7 @@ _SIGNATURES = {
     "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
     "d3m_edge_plan_bytes": (_SZ, [_I, _I, _I]),
     "d3m_edge_plan_min_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_edge_plan_extents_offset": (_SZ, [_I, _I, _I, ctypes.POINTER(_SZ)]),
     "d3m_edge_plan": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
     "d3m_visibility_bytes": (_SZ, [_I, _I]),
     "d3m_visibility": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),

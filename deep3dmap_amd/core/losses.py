@@ -130,7 +130,7 @@ class _FitLossOnLitImages(torch.autograd.Function):
         scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(B, S)), dtype=torch.float32, device=dev)]
         g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
                   torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
-                  torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev),          # nz_lo_inv | nz_hi1
+                  tuple(torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev).unbind(0)),   # nz_lo_inv, nz_hi1
                   torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
         fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss, g_maps, mask_sum, False)
         fit_c = _RasterizeLit._fit_struct(fit_state, 0, 0, B, None)

@@ -1424,7 +1424,7 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
 
 // count -> crossing base per workgroup -> record slice per line -> records (geometry only: see struct EdgePlan)
 struct EdgePlanLayout {
-    size_t off_line_count, off_line_cursor, off_alloc, zero_bytes;     // the zeroed prefix
+    size_t off_line_count, off_line_cursor, off_alloc, off_extents, zero_bytes;     // the zeroed prefix
     size_t off_lane_cross, off_lane_block, off_line_slice, off_xrec;   // xrec | results follow, sized by capacity
     size_t fixed_bytes;
 };
@@ -1446,6 +1446,10 @@ inline EdgePlanLayout edge_plan_layout(int B, int F, int S) {
     L.off_line_count = o;  o += eg_align(nl * 4);
     L.off_line_cursor = o; o += eg_align(nl * 4);
     L.off_alloc = o;       o += 256;
+    // room for the lines' non-zero-gradient extents (nz_lo_inv | nz_hi1, [B,2,S] ints each, 256-byte aligned) of a fused fit
+    // objective: they must be zero before the pass that fills them, and a caller that builds the plan BEFORE that pass on the
+    // same stream (d3m_edge_plan_extents_offset) gets them cleared by the plan's own clear instead of by a launch of its own
+    L.off_extents = o;     o += 2 * eg_align(nl * 4);
     L.zero_bytes = o;
     L.off_lane_cross = o;  o += eg_align(nf * 6 * 8);
     L.off_lane_block = o;  o += eg_align((nf / EG_FACES_PER_BLOCK + 2) * 4);

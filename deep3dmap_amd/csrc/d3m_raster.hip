@@ -472,6 +472,11 @@ D3M_EXPORT size_t d3m_edge_plan_min_bytes(int batch_size, int num_faces, int ima
     if (batch_size <= 0 || num_faces <= 0 || image_size <= 0) return 0;
     return edge_plan_min_bytes(batch_size, num_faces, image_size);
 }
+D3M_EXPORT size_t d3m_edge_plan_extents_offset(int batch_size, int num_faces, int image_size, size_t* bytes_each) {
+    if (batch_size <= 0 || num_faces <= 0 || image_size <= 0) return 0;
+    if (bytes_each) *bytes_each = eg_align((size_t)batch_size * 2 * image_size * 4);
+    return edge_plan_layout(batch_size, num_faces, image_size).off_extents;
+}
 D3M_EXPORT int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
                              size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream) {
     if (!faces || !face_index_map || !visibility || !edge_plan || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;

@@ -148,6 +148,7 @@ class MultiViewFit:
         self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
                                    and self.renderer._on_the_fly())
         self._manual = self._tex_work = None
+        self._grad_one = torch.ones(1, dtype=torch.float32, device=self.device)
         if self.split_exchange:
             self._one = torch.ones(1, dtype=torch.float32, device=self.device)
             self._runner = CapturedStep([lambda: me()._forward_and_texture_side(), lambda: me()._geometry_side()],
@@ -210,7 +211,7 @@ class MultiViewFit:
         self._use_sink = True
         try:
             loss = self.fit_loss()
-            loss.backward()
+            loss.backward(self._grad_one.reshape(loss.shape))   # (a constant: autograd's implicit ones_like is a fill launch)
         finally:
             self.renderer.defer_plan_join = False
             self._use_sink = False

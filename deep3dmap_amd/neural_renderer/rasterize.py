@@ -453,7 +453,7 @@ class _RasterizeLit(torch.autograd.Function):
             if need_grad and not anti_aliasing:
                 g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
                           torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
-                          torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev),          # nz_lo_inv | nz_hi1
+                          None,                                                            # (nz_lo_inv, nz_hi1): below
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             elif need_grad:
                 g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),        # grad_rgb_map
@@ -465,6 +465,17 @@ class _RasterizeLit(torch.autograd.Function):
         serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
+        if fit_state is not None and fit_state[6] is not None and not fit_state[8]:      # (records form: no anti-aliasing)
+            # the lines' non-zero extents (zero before the objective's pass fills them): when the plan is built in front of
+            # that pass on the same stream, inside the plan's blob, cleared by the plan's own clear; else a fill of their own
+            if serial and plan is not None:
+                each = ctypes.c_size_t(0)
+                off = int(L.d3m_edge_plan_extents_offset(B, Fp, S, ctypes.byref(each)))
+                nz = tuple(plan[0][off + j * each.value: off + j * each.value + B * 2 * S * 4].view(torch.int32).view(B, 2, S)
+                           for j in range(2))
+            else:
+                nz = tuple(torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev).unbind(0))
+            fit_state = fit_state[:6] + (fit_state[6][:2] + (nz,) + fit_state[6][3:],) + fit_state[7:]
         # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
         # on the same stream and (if captured) in the same capture, may leave that branch open at the end of forward
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
@@ -546,7 +557,7 @@ class _RasterizeLit(torch.autograd.Function):
         eg = ed = nz_lo = nz_hi = gd = g_rgb = g_alpha = None
         if g_maps is not None and not pooled:       # records (no anti-aliasing)
             eg, ed, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
-            nz_lo, nz_hi = g_maps[2][0, lo:hi], g_maps[2][1, lo:hi]
+            nz_lo, nz_hi = g_maps[2][0][lo:hi], g_maps[2][1][lo:hi]
         elif g_maps is not None:                    # unscaled gradient maps at the internal size (anti-aliasing)
             g_rgb, g_alpha, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
         return _lib.D3MFitTargets(
@@ -665,7 +676,7 @@ class _RasterizeLit(torch.autograd.Function):
             elif records is not None:           # final records: no scratch, no scalars to apply
                 unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
                                               _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
-                                              _lib.ptr(records[2][0, lo:hi]), _lib.ptr(records[2][1, lo:hi]), 0)
+                                              _lib.ptr(records[2][0][lo:hi]), _lib.ptr(records[2][1][lo:hi]), 0)
             if gathered:
                 with torch.cuda.stream(auxs[k]):
                     ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)

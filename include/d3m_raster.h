@@ -174,6 +174,11 @@ int d3m_visibility(const int32_t* face_index_map, void* visibility, size_t visib
  * d3m_backward_pixel_map handed the blob (`edge_plan`, NULL = it builds its own in its workspace) starts with the
  * line walk.  `visibility`: the d3m_visibility blob of the same forward result (required). */
 size_t d3m_edge_plan_bytes(int batch_size, int num_faces, int image_size);
+/* Two arrays of [B,2,S] ints inside the plan blob's zeroed prefix, at the returned byte offset and *bytes_each behind it,
+ * which d3m_edge_plan clears together with its own counters: a caller that builds the plan BEFORE it renders with a fused
+ * fit objective on the same stream may use them as d3m_fit_targets.edge_nz_lo_inv / edge_nz_hi1 ("zeroed by the caller")
+ * and saves the launch that clears them.  The plan itself does not use them. */
+size_t d3m_edge_plan_extents_offset(int batch_size, int num_faces, int image_size, size_t* bytes_each);
 size_t d3m_edge_plan_min_bytes(int batch_size, int num_faces, int image_size);
 int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
                   size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream);

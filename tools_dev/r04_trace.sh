@@ -1,0 +1,33 @@
+#!/bin/bash
+# on the GPU box: timestamped kernel trace of the last replayed steps -- the headline (32 views) and the 4-view shard --
+# folded to one step each: kernel, start offset (us from the step's first kernel), duration, queue
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04t; rm -rf $O; mkdir -p $O
+for v in 32 4; do
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr$v -o tr -- python3 bench.py --no-cpu-baseline --no-dropin --steps 6 --warmup 2 --repeats 1 --views-per-gpu $v > $O/log$v.txt 2>&1
+f=$(find $O/tr$v -name "*kernel_trace.csv" | head -1)
+python3 - "$f" $v <<'PY'
+import csv,sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+name=lambda r: r['Kernel_Name'].replace('void ','').replace('d3m::','').split('(')[0].split('<')[0]
+# the replayed steps are the last ones before the instrumented eager pass; find the last run of steps by the camera_basis kernel
+idx=[i for i,r in enumerate(rows) if name(r)=='k_camera_basis']
+# steps: warmup+timed replays (8) then eager instrumented passes; take the 6th-from... use the replay region: pick the step
+# with the smallest span among the last 16
+best=None
+for a,b in zip(idx[:-1],idx[1:]):
+    span=int(rows[b-1]['End_Timestamp'])-int(rows[a]['Start_Timestamp'])
+    if best is None or span<best[0]: best=(span,a,b)
+span,a,b=best
+t0=int(rows[a]['Start_Timestamp'])
+out=open(f'gpurun_out/r04t/step_{sys.argv[2]}views.csv','w')
+out.write('kernel,start_us,duration_us,queue\n')
+busy=0
+for r in rows[a:b]:
+    s,e=int(r['Start_Timestamp'])-t0,int(r['End_Timestamp'])-t0
+    busy+=e-s
+    out.write(f"{name(r)},{s/1e3:.1f},{(e-s)/1e3:.1f},{r.get('Queue_Id','')}\n")
+print(sys.argv[2],'views: step span',span/1e3,'us, kernels',b-a,'sum of durations',busy/1e3)
+PY
+done
