@@ -862,19 +862,18 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
 #endif
 constexpr int EG_ROW = D3M_EG_ROW;
 constexpr int EG_SEG_PER_WAVE = 64 / EG_ROW;   // segments walked concurrently by one wave
-// per workgroup of `waves` waves: EG_CHUNK = 32 * waves crossings set up at a time (one thread per (crossing, outward |
-// inward): whole waves take the outward walks, whole waves the inward ones), EG_QUEUE = 64 * waves long segments queued in
-// LDS before they are walked (one sort key per thread)
+// per workgroup of `waves` waves: 64 * waves crossing records set up at a time (one thread per record), EG_QUEUE = 64 * waves
+// long segments queued in LDS before they are walked (one sort key per thread)
 constexpr size_t eg_line_static_lds(int waves) { return (size_t)waves * 64 * (EG_ITEM_DW * 4 + 2) + 1024; }   // queue + order + counters
 constexpr size_t EG_LINE_STATIC_LDS = eg_line_static_lds(EG_LINE_WAVES);
 
 // ---- 5. one workgroup per (view, axis, line): set up the line's crossings, walk their segments ------------------
-// The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a chunk of
-// EG_CHUNK crossing records at a time:
-//   SET-UP   one thread per (crossing, outward | inward): the segment of KCU:314-362 / :417-431 with the owner test
-//            answered from LDS, clipped to the extent; empty segments store their zero, short ones (and the
-//            inward one whose pixels do not all lie on the expected side of the crossing) are walked by the thread
-//            itself from LDS, long ones are queued in LDS as 48-byte items;
+// The line's per-pixel records are staged in LDS once (only its non-zero-gradient extent).  Then, a pass of
+// EG_LINE_THREADS crossing records at a time:
+//   SET-UP   one thread per record: the two segments of KCU:314-362 (outward) / :417-431 (inward) with the owner test
+//            answered from LDS, clipped to the extent; an empty one stores its zero; the inward one (mean length 2
+//            pixels) is walked by the thread itself from LDS unless it is long AND lies on one side of the crossing; the
+//            outward one, and such a long inward one, are queued in LDS as 32-byte items;
 //   WALK     the queued segments ordered by length (counting sort on length / 16, longest first), sixteen per wave,
 //            four lanes each, FACTORED DISTANCE (below).
 // Item (8 dwords): 0 bits = inward[0] f0[1] f1[2] fix_at_from[3] fix_at_to[4] s_t>0[5] | fn << 6; 1 inv0;
@@ -910,7 +909,7 @@ template <bool USE_RGB, bool USE_ALPHA, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, EdgePlan w, float2* __restrict__ lane_partial) {
     // WAVES per workgroup: 8 where four such workgroups fit a CU beside their lines' LDS images (S <= ~600), 16 above that
     // (two workgroups = the same eight waves per SIMD, where 8-wave workgroups would leave the CU at four or six)
-    constexpr int EG_LINE_THREADS = WAVES * 64, EG_CHUNK = EG_LINE_THREADS / 2, EG_QUEUE = EG_LINE_THREADS, EG_LINE_WAVES = WAVES;
+    constexpr int EG_LINE_THREADS = WAVES * 64, EG_QUEUE = EG_LINE_THREADS, EG_LINE_WAVES = WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
         const long n = (long)*w.n_visible * 6;
@@ -947,33 +946,26 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     // only the line's non-zero-gradient extent is staged: every segment is clipped to it (geometry_segment)
     const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
     const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
-    // One thread per (crossing, outward | inward): threads 0..EG_CHUNK-1 take the outward walk of crossing t, the others
-    // the inward walk of crossing t - EG_CHUNK (the waves of the first half mostly queue -- long walks to the extent's
-    // end --, those of the second mostly walk 1-3 pixels: no divergence between the two kinds).  A segment's set-up needs
-    // its record, the extent and -- for the reference values -- one pixel of the original maps: all of that is requested
-    // BEFORE the line image is staged, so that a workgroup pays two memory round trips (record -> reference values,
-    // beside the image), not four.
-    struct Setup {
-        bool has;
-        Segment sg;
-        int fn;
-        uint32_t slot;      // (a plan holds fewer than 2^31 results: edge_plan_view)
+    // ONE THREAD PER RECORD (round 4; before: one per (record, outward | inward), i.e. every record decoded by two
+    // threads and EG_LINE_THREADS / 2 records per pass -- and the headline mesh puts a median of 260 records on a line,
+    // four more than a pass of the 8-wave form took, so half the lines paid a second pass (three barriers, a round of
+    // record loads) for a handful of crossings).  A thread decodes its record, takes the crossing's inward walk (mean
+    // length 2 pixels: walked on the spot; the rare long one is queued) and classifies the outward one (96 % of the
+    // records have one, nearly all of them long: queued).  Nothing but two wave masks stays live across the queue's
+    // barriers: the threads that queue a segment read their record AGAIN behind them (32 bytes from the L2) and build the
+    // item there -- with the geometry of both walks carried across, the 64-register budget spilled 100 bytes per lane
+    // (and with the first pass's record requested before the line image is staged, as the two-thread form did, 20: the
+    // record's round trip now follows the staging's; still the faster form, 0.50 -> 0.48 ms on the headline step).
+    struct Record {
+        uint4 r0, r1;
     };
-    const int my_which = (int)threadIdx.x >= EG_CHUNK ? 1 : 0, my_x = (int)threadIdx.x - my_which * EG_CHUNK;
-    auto set_up = [&](int ci) {
-        Setup u;
-        u.has = false;
-        u.fn = 0;
-        u.slot = 0;
-        if (ci < n_x) {
-            const uint4 r0 = xrec[2u * (uint32_t)ci], r1 = xrec[2u * (uint32_t)ci + 1u];      // (uniform base + 32-bit offset)
-            u.fn = (int)r1.y;
-            u.slot = 2u * (uint32_t)(x_first + ci) + (uint32_t)my_which;
-            u.has = geometry_segment(record_to_geometry(r0, r1), my_which, axis, d0, is, p_lo, p_hi, u.sg);
-        }
-        return u;
+    auto load_record = [&](int ci) {
+        Record r;
+        r.r0 = make_uint4(0, 0, 0, 0);      // bits 0: not alive -> neither walk exists
+        r.r1 = r.r0;
+        if (ci < n_x) { r.r0 = xrec[2u * (uint32_t)ci]; r.r1 = xrec[2u * (uint32_t)ci + 1u]; }     // (uniform base + 32-bit offset)
+        return r;
     };
-    const Setup first = set_up(my_x);
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
     // T = sum value*grad of the pixel itself, so diff = T - <reference, gradients>: ds_read_b128 + ds_read_b64 per
     // visited pixel, contiguous within a segment's lane group.  T is kept halved (exact) because the two packed fma
@@ -1156,67 +1148,114 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
 
         }
         __syncthreads();                                      // the queue has been read
-        if (threadIdx.x == 0) s_nitems = 0;
-        if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+        if (threadIdx.x == 0) {     // (one lane, constant addresses: a per-thread s_hist address would be one more register
+            s_nitems = 0;           //  carried through the whole kernel -- and was the one that spilled)
+#pragma unroll
+            for (int k = 0; k < 33; k++) s_hist[k] = 0;
+        }
         __syncthreads();
     };
-    if (threadIdx.x == 0) { s_nitems = 0; s_pass[0] = 0; s_pass[1] = 0; }
-    if (threadIdx.x < 33) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_nitems = 0; s_pass[0] = 0; s_pass[1] = 0;
+#pragma unroll
+        for (int k = 0; k < 33; k++) s_hist[k] = 0;
+    }
     __syncthreads();                                          // the image is staged
-    for (int chunk0 = 0, pass = 0; chunk0 < n_x; chunk0 += EG_CHUNK, pass ^= 1) {
-        const Setup u = chunk0 == 0 ? first : set_up(chunk0 + my_x);
-        // ---- empty segments store their zero, short ones are walked here, long ones queued ------------------------
-        bool queued = false;
-        uint4 rec0 = make_uint4(0, 0, 0, 0), rec1 = rec0;
-        if (chunk0 + my_x < n_x) {
-            const Segment& q = u.sg;
-            const int fn = u.fn;
-            float g0 = 0, g1 = 0;
-            if (u.has) {
-                if (segment_queueable(q)) {
-                    const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
-                    const float s_t = (float)(q.inward ? -q.dir : q.dir);
-                    // 1 / qc by v_rcp_f32 (1 ulp), like every quotient of the walk itself
-                    const float rq0 = __builtin_amdgcn_rcpf(qc0), rq1 = __builtin_amdgcn_rcpf(qc1);
-                    const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
-                    const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
-                                          ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u) |
-                                          (0 < s_t ? 32u : 0u);
-                    rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-rq0),
-                                      (uint32_t)q.from | ((uint32_t)q.to << 16), u.slot);
-                    rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(-rq1), (uint32_t)q.ref_pos, 0u);
-                    queued = true;
-                } else {                                      // short (or not oriented): this thread walks it, from LDS
-                    const float4 rv = s_val[q.ref_pos];
-                    const v2f nref_ar = {USE_ALPHA ? -rv.x : 0.0f, USE_RGB ? -rv.y : 0.0f};
-                    const v2f nref_gb = {USE_RGB ? -rv.z : 0.0f, USE_RGB ? -rv.w : 0.0f};
-                    const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
-                    for (int d1 = q.from; d1 <= q.to; d1++) {
-                        const float2 d = s_df[d1];
-                        float diff = diff_of(s_grd[d1], d, nref_ar, nref_gb);
-                        // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
-                        if (q.inward && __float_as_int(d.y) != fn) diff = 0.0f;
-                        visit_pixel(diff, d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is, a.eps, g0, g1);
-                    }
+    // the queue item of a long segment (see "Item" above); 1 / qc by v_rcp_f32 (1 ulp), like every quotient of the walk
+    auto make_item = [&](const Segment& q, int fn, uint32_t slot, uint4& rec0, uint4& rec1) {
+        const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
+        const float s_t = (float)(q.inward ? -q.dir : q.dir);
+        const float rq0 = __builtin_amdgcn_rcpf(qc0), rq1 = __builtin_amdgcn_rcpf(qc1);
+        const bool fix = q.inward && (float)q.d1_in == q.d1_cross && q.from <= q.d1_in && q.d1_in <= q.to;
+        const uint32_t bits = (uint32_t)q.inward | ((uint32_t)q.f0 << 1) | ((uint32_t)q.f1 << 2) |
+                              ((fix && q.dir < 0) ? 8u : 0u) | ((fix && 0 < q.dir) ? 16u : 0u) | (0 < s_t ? 32u : 0u);
+        rec0 = make_uint4(bits | ((uint32_t)fn << 6), __float_as_uint(-rq0), (uint32_t)q.from | ((uint32_t)q.to << 16), slot);
+        rec1 = make_uint4(__float_as_uint(q.d1_cross), __float_as_uint(-rq1), (uint32_t)q.ref_pos, 0u);
+    };
+    // a short (or not oriented) segment, walked by its thread from LDS
+    auto walk_short = [&](const Segment& q, int fn, float& g0, float& g1) {
+        const float4 rv = s_val[q.ref_pos];
+        const v2f nref_ar = {USE_ALPHA ? -rv.x : 0.0f, USE_RGB ? -rv.y : 0.0f};
+        const v2f nref_gb = {USE_RGB ? -rv.z : 0.0f, USE_RGB ? -rv.w : 0.0f};
+        const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
+        for (int d1 = q.from; d1 <= q.to; d1++) {
+            const float2 d = s_df[d1];
+            float diff = diff_of(s_grd[d1], d, nref_ar, nref_gb);
+            // inward walks only count the face's own pixels (KCU:470); dropped by a select, like diff <= 0
+            if (q.inward && __float_as_int(d.y) != fn) diff = 0.0f;
+            visit_pixel(diff, d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is, a.eps, g0, g1);
+        }
+    };
+    for (int chunk0 = 0, pass = 0, step = EG_LINE_THREADS; chunk0 < n_x; chunk0 += step, pass ^= 1) {
+        step = EG_LINE_THREADS;
+        const int ci = chunk0 + (int)threadIdx.x;
+        // ---- both walks classified: empty ones store their zero, short ones are walked here, long ones only flagged ----
+        unsigned long long qm[2];
+        {
+            const Record rc = load_record(ci);
+            const XGeom geo = record_to_geometry(rc.r0, rc.r1);      // (bits 0 past the line's last record: no walk)
+            const int fn = (int)rc.r1.y;
+            // the outward walk: queued whenever it exists -- nearly all of them are long, and the queued walk takes a
+            // segment of any length (outward walks are always oriented), so there is no in-thread form of it
+            {
+                bool queue_it = false;
+                if (ci < n_x) {
+                    Segment q;
+                    queue_it = geometry_segment(geo, 0, axis, d0, is, p_lo, p_hi, q);
+                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci)] = make_float2(0.0f, 0.0f);
                 }
+                qm[0] = __builtin_amdgcn_ballot_w64(queue_it);
             }
-            if (!queued) w.results[u.slot] = make_float2(g0, g1);
+            // the inward walk: short ones (mean length 2 pixels) on the spot, the rare long one flagged for the queue
+            {
+                bool queue_it = false;
+                if (ci < n_x) {
+                    float g0 = 0, g1 = 0;
+                    Segment q;
+                    if (geometry_segment(geo, 1, axis, d0, is, p_lo, p_hi, q)) {
+                        if (segment_queueable(q)) queue_it = true;
+                        else walk_short(q, fn, g0, g1);
+                    }
+                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci) + 1u] = make_float2(g0, g1);
+                }
+                qm[1] = __builtin_amdgcn_ballot_w64(queue_it);
+            }
         }
         // the pass's long segments: if they do not fit behind what is queued already, that is walked first
-        const unsigned long long qm = __builtin_amdgcn_ballot_w64(queued);
-        if (lane == 0 && qm) atomicAdd(&s_pass[pass], __popcll(qm));
+        int n0 = __popcll(qm[0]), n1 = __popcll(qm[1]);
+        if (lane == 0 && (n0 | n1)) atomicAdd(&s_pass[pass], n0 + n1);
         __syncthreads();
-        const bool full = s_nitems + s_pass[pass] > EG_QUEUE;     // uniform: read by everyone before anyone appends
+        const int pass_total = s_pass[pass];
+        const bool full = s_nitems + pass_total > EG_QUEUE;       // uniform: read by everyone before anyone appends
         __syncthreads();
         if (full) walk_queue();
         if (threadIdx.x == 0) s_pass[pass ^ 1] = 0;               // (next read: after the next pass's barrier)
-        {   // queue positions: one LDS atomic per wave, ranks from the ballot
+        // A pass of EG_LINE_THREADS records can hold up to twice as many long segments as the (now empty) queue -- a line
+        // crowded with faces wider than EG_INLINE_MAX pixels.  Then only the records of the first half of the threads
+        // queue theirs now, and the other half is taken AGAIN by the next pass (its short walks are stored twice, the
+        // same values).
+        if (pass_total > EG_QUEUE) {                              // uniform
+            step = EG_LINE_THREADS / 2;
+            if ((int)threadIdx.x >= step) { qm[0] = 0; qm[1] = 0; n0 = 0; n1 = 0; }       // (whole waves)
+        }
+        if ((qm[0] | qm[1]) != 0) {                               // (wave-uniform) this wave queues: its records again
+            const Record rc = load_record(ci);
+            const XGeom geo = record_to_geometry(rc.r0, rc.r1);
+            const int fn = (int)rc.r1.y;
+            // queue positions: one LDS atomic per wave, ranks from the ballots (outward items first, then inward)
             int base = 0;
-            if (lane == 0 && qm) base = atomicAdd(&s_nitems, __popcll(qm));
+            if (lane == 0 && (n0 | n1)) base = atomicAdd(&s_nitems, n0 + n1);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (queued) {
-                uint4* it = (uint4*)(s_items + (size_t)(base + mask_rank(qm)) * EG_ITEM_DW);
-                it[0] = rec0; it[1] = rec1;
+#pragma unroll
+            for (int which = 0; which < 2; which++) {
+                if ((qm[which] >> lane) & 1ull) {
+                    Segment q;
+                    geometry_segment(geo, which, axis, d0, is, p_lo, p_hi, q);
+                    uint4 rec0, rec1;
+                    make_item(q, fn, 2u * (uint32_t)(x_first + ci) + which, rec0, rec1);
+                    uint4* it = (uint4*)(s_items + (size_t)(base + (which ? n0 : 0) + mask_rank(qm[which])) * EG_ITEM_DW);
+                    it[0] = rec0; it[1] = rec1;
+                }
             }
         }
         __syncthreads();

@@ -179,6 +179,38 @@ def test_edge_gradient_crowded_lines_and_clipped_walks(masked):
     assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
 
 
+def test_edge_gradient_pass_with_more_long_segments_than_the_queue_holds():
+    """K4 on rows that carry more LONG segments than one pass of the line kernel can queue: 250 shingled triangles, each
+    8 pixels wide at its base and 2 pixels to the right of (and nearer than) the one before, so that on every row near the
+    base a face's left edge gives a record with a long outward AND a long inward walk and its right edge one with a long
+    inward walk: ~500 records, ~750 queue items in a pass of 512 records against a queue of 512 -- the pass is re-taken by
+    halves (k_edge_lines, "pass_total > EG_QUEUE").  Against the oracle's per-face walk (KCU:245-503)."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    S, n = 512, 250
+    px = 2.0 / S
+    x0 = -1.0 + 2.5 * px + 2 * px * np.arange(n)
+    y0, y1 = -0.5, 0.62                                                   # tall: the rows near the base see ~8 px of width
+    z = 2.0 - 0.003 * np.arange(n)                                        # every face nearer than the one to its left
+    tri = np.stack([np.stack([x0, np.full(n, y0)], -1), np.stack([x0 + 8.2 * px, np.full(n, y0 + 0.3 * px)], -1),
+                    np.stack([x0 + 4.1 * px, np.full(n, y1)], -1)], 1)    # counter-clockwise: front-facing
+    faces = np.concatenate([tri, np.broadcast_to(z[:, None, None], (n, 3, 1))], -1)[None].astype(np.float32)
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
+    rng = np.random.default_rng(11)
+    m = O.raster_forward(faces, rng.uniform(0, 1, (1, 2 * n, 2, 2, 2, 3)).astype(np.float32), S, 0.1, 100.0, 1e-3,
+                         (0.1, 0.2, 0.3), True, True, False)
+    row = m["face_index_map"][0, S // 4 + 8]                              # a row a few pixels above the base
+    assert len(np.unique(row[row >= 0])) > 200                            # ... is shared by more than 200 owners
+    g_rgb = rng.normal(size=(1, S, S, 3)).astype(np.float32)
+    g_alpha = rng.normal(size=(1, S, S)).astype(np.float32)
+    gf_ref, _ = O.raster_backward(m, g_rgb, g_alpha, None, True, True, False)
+    fd = _dev(faces)
+    gf = torch.zeros_like(fd)
+    ops.backward_pixel_map(fd, _dev(m["face_index_map"]), _dev(m["rgb_map"]), _dev(m["alpha_map"]), _dev(g_rgb), _dev(g_alpha),
+                           gf, S, 1e-3, True, True)
+    assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
+
+
 def test_edge_gradient_on_an_image_wider_than_the_line_window():
     """K4 at S = 2304: above 2048 pixels per line the plan's count pass merges its line counters by key instead of in
     the LDS line window, and the line kernel clamps instead of padding -- small and large faces, two views, against
