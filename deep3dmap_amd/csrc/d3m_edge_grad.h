@@ -47,7 +47,10 @@
 
 namespace d3m {
 
-constexpr int EG_INLINE_MAX = 6;   // segments of at most this many pixels are walked by the owning lane
+#ifndef D3M_EG_INLINE_MAX
+#define D3M_EG_INLINE_MAX 6
+#endif
+constexpr int EG_INLINE_MAX = D3M_EG_INLINE_MAX;   // segments of at most this many pixels are walked by the owning lane
 #ifndef D3M_EG_LINE_WAVES
 #define D3M_EG_LINE_WAVES 8
 #endif
