@@ -11,7 +11,17 @@
 
 namespace d3m {
 
-constexpr int TILE = 8;          // screen tile = 8x8 pixels = one wave64, lane = (y&7)*8 + (x&7)
+// Screen tile of the list form of coverage (d3m_forward.h): TILE_W x TILE_H pixels, one wave64 per tile (or four, on small
+// rasters), which resolves it 64 pixels at a time.  8 x 8.  16 x 8 (-DD3M_TILE_W=16) is bit-identical and was measured in
+// round 4 on the expectation that it would halve the staging's idle lanes (a tile's wave stages its listed faces 64 at a
+// time, one lane each, and an 8 x 8 tile of the headline mesh lists ~35) and stage a 4 x 4-pixel face 1.6 times instead of
+// 1.9: the 32-view step took 1.667 ms against 1.640 -- a 16 x 8 tile lists ~65 faces, i.e. one more than a chunk holds about
+// as often as not, and the second chunk's staging costs what the first one's does.
+#ifndef D3M_TILE_W
+#define D3M_TILE_W 8
+#endif
+constexpr int TILE_W = D3M_TILE_W, TILE_H = 8, TILE_PX = TILE_W * TILE_H;
+static_assert(TILE_W == 8 || TILE_W == 16, "the tile pass packs in-tile coordinates in 4 + 3 bits");
 constexpr int WAVE = 64;
 
 // ---- small helpers ---------------------------------------------------------------------------

@@ -12,7 +12,7 @@
 namespace d3m {
 
 struct BinBuffers {
-    int B, F, S, tiles_x, T, kcap;
+    int B, F, S, tiles_x, tiles_y, T, kcap;     // T = tiles_x * tiles_y tiles of TILE_W x TILE_H pixels per view
     uint2* rect;        // [B*F]  tile rectangle of each face (x = tx0 | ty0<<16, y = tx1 | ty1<<16), x = ~0u: none
     int* tile_count;    // [B*T]  zeroed per call
     int* tile_cursor;   // [B*T]  zeroed per call
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
 #pragma unroll
                         for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
                     }
-                    tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE;
+                    tx0 = x0 / TILE_W; tx1 = x1 / TILE_W; ty0 = y0 / TILE_H; ty1 = y1 / TILE_H;
                     r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
                     small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
                     if (!small) {
@@ -298,10 +298,11 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     __shared__ int s_pre_all[W][WAVE + 1];
     constexpr int RING = 2 * WAVE;             // survivors of the cheap tests waiting for the expensive ones
     __shared__ unsigned short s_ring_all[W][RING];
-    constexpr int HEADS = 16 * WAVE;           // candidates per window of the owner marks (one uint4 per lane)
+    constexpr int HEADS = 8 * WAVE;            // candidates per window of the owner marks (one uint2 per lane: with the
+                                               // 128-entry z-buffer of a 16 x 8 tile, 20 workgroups still fit a CU's LDS)
     __shared__ __attribute__((aligned(16))) unsigned char s_head_all[W][HEADS];
-    __shared__ unsigned long long s_z[WAVE];
-    __shared__ float s_cx[TILE], s_cy[TILE];
+    __shared__ unsigned long long s_z[TILE_PX];
+    __shared__ float s_cx[TILE_W], s_cy[TILE_H];
     const int wv = W == 1 ? 0 : (int)(threadIdx.x >> 6);
     float (&s_face)[9][WAVE] = s_face_all[wv];
     float (&s_finv)[9][WAVE] = s_finv_all[wv];
@@ -320,14 +321,15 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     if (tile >= n_tiles) return;
     const int b = tile / bb.T, t = tile % bb.T;
-    const int px0 = (t % bb.tiles_x) * TILE, py0 = (t / bb.tiles_x) * TILE;
+    const int px0 = (t % bb.tiles_x) * TILE_W, py0 = (t / bb.tiles_x) * TILE_H;
     const int S = bb.S;
     const int lane = lane_id();
 
     if (wv == 0) {
-        if (lane < TILE) s_cx[lane] = pixel_center(px0 + lane, S);
-        else if (lane < 2 * TILE) s_cy[lane - TILE] = pixel_center(py0 + lane - TILE, S);
-        s_z[lane] = ~0ull;
+        if (lane < TILE_W) s_cx[lane] = pixel_center(px0 + lane, S);
+        else if (lane < TILE_W + TILE_H) s_cy[lane - TILE_W] = pixel_center(py0 + lane - TILE_W, S);
+#pragma unroll
+        for (int h = 0; h < TILE_PX / WAVE; h++) s_z[h * WAVE + lane] = ~0ull;
     }
     if (lane == 0) s_pre[0] = 0;
     __syncthreads();
@@ -343,8 +345,8 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                 fs.load(b, fid, face);
                 int x0, x1, y0, y1;
                 if (pixel_bbox(face, S, x0, x1, y0, y1)) {
-                    x0 = max(x0, px0); x1 = min(x1, px0 + TILE - 1);
-                    y0 = max(y0, py0); y1 = min(y1, py0 + TILE - 1);
+                    x0 = max(x0, px0); x1 = min(x1, px0 + TILE_W - 1);
+                    y0 = max(y0, py0); y1 = min(y1, py0 + TILE_H - 1);
                     if (x0 <= x1 && y0 <= y1) {
                         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
                         cnt = bw * bh;
@@ -360,8 +362,8 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                         // fill_back half of the listed faces are the far side of the mesh.
                         const float zmin = fminf(face[2], fminf(face[5], face[8]));
                         s_zkey[lane] = (zmin > 0.0f) ? ordered_bits(zmin * 0.99999f) : 0u;
-                        // x | y<<4 | width<<8 | ceil(65536/width)<<12  (exact floor(c/width) for c < 64)
-                        s_box[lane] = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 4) | ((uint32_t)bw << 8) |
+                        // x | y<<4 | (width-1)<<8 | ceil(65536/width)<<12  (exact floor(c/width) for c < 4096 / width)
+                        s_box[lane] = (uint32_t)(x0 - px0) | ((uint32_t)(y0 - py0) << 4) | ((uint32_t)(bw - 1) << 8) |
                                       ((uint32_t)((65536 + bw - 1) / bw) << 12);
                     }
                 }
@@ -378,13 +380,13 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
             auto resolve = [&](int n) {
                 if (lane < n) {
                     const uint32_t ent = s_ring[(head + lane) & (RING - 1)];
-                    const int lo = (int)(ent & 63), lx = (int)((ent >> 6) & 7), ly = (int)(ent >> 9);
+                    const int lo = (int)(ent & 63), lx = (int)((ent >> 6) & 15), ly = (int)(ent >> 10);
                     float face[9], finv[9], w[3], zp;
 #pragma unroll
                     for (int k = 0; k < 9; k++) { face[k] = s_face[k][lo]; finv[k] = s_finv[k][lo]; }
                     if (weights_depth(face, finv, px0 + lx, py0 + ly, near, far, w, zp)) {
                         const unsigned long long key = ((unsigned long long)ordered_bits(zp) << 32) | (uint32_t)s_fid[lo];
-                        atomicMin(&s_z[ly * TILE + lx], key);
+                        atomicMin(&s_z[ly * TILE_W + lx], key);
                     }
                 }
             };
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
             // instead of a binary search through six dependent LDS reads.  Windows of HEADS candidates.
             int carry = 0;                              // wave-uniform: mark of the last candidate so far
             for (int w0 = 0; w0 < total; w0 += HEADS) {
-                reinterpret_cast<uint4*>(s_head)[lane] = make_uint4(0, 0, 0, 0);
+                reinterpret_cast<uint2*>(s_head)[lane] = make_uint2(0, 0);
                 wave_lds_sync();
                 const int start = incl - cnt;
                 if (cnt > 0 && start >= w0 && start < w0 + HEADS) s_head[start - w0] = (unsigned char)(lane + 1);
@@ -410,15 +412,15 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                         const int lo = (int)own - 1;
                         const int local = c - s_pre[lo];
                         const uint32_t box = s_box[lo];
-                        const int bw = (box >> 8) & 15;
+                        const int bw = (int)((box >> 8) & 15) + 1;
                         const int row = (int)(((uint32_t)local * (box >> 12)) >> 16);
                         const int lx = (int)(box & 15) + (local - row * bw), ly = (int)((box >> 4) & 15) + row;
-                        if (!(s_zkey[lo] > (uint32_t)(s_z[ly * TILE + lx] >> 32))) {      // early z (see above)
+                        if (!(s_zkey[lo] > (uint32_t)(s_z[ly * TILE_W + lx] >> 32))) {    // early z (see above)
                             float face[9];
 #pragma unroll
                             for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : s_face[k][lo];
                             pass = inside_face(face, s_cx[lx], s_cy[ly]);
-                            ent = (uint32_t)lo | ((uint32_t)lx << 6) | ((uint32_t)ly << 9);
+                            ent = (uint32_t)lo | ((uint32_t)lx << 6) | ((uint32_t)ly << 10);
                         }
                     }
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
@@ -442,14 +444,17 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store.  Pixels
     // nobody covers get the reference's initial values (rasterize.py:50-58: index -1, weights 0, depth far, inverse
     // 0), so the caller's pre-fill is not relied upon: every pixel of every map is written here.
-    const unsigned long long key = s_z[lane];
-    const int xi = px0 + (lane & 7), yi = py0 + (lane >> 3);
+#pragma unroll 1
+    for (int part = 0; part < TILE_PX / WAVE; part++) {           // 64 pixels at a time: TILE_W wide, 64 / TILE_W rows
+    const int in_tile = part * WAVE + lane;
+    const unsigned long long key = s_z[in_tile];
+    const int xi = px0 + in_tile % TILE_W, yi = py0 + in_tile / TILE_W;
     if (out.marks) {
         // which faces own a pixel (d3m_visibility's first step, for free here): a face's pixels form a small blob, and
-        // only those of them that have neither the same face to their left nor above them within the tile speak up
+        // only those of them that have neither the same face to their left nor above them within this part speak up
         const int fid = key != ~0ull ? (int)(uint32_t)(key & 0xFFFFFFFFull) : -1;
-        const int left = __shfl(fid, lane - 1, 64), up = __shfl(fid, lane - 8, 64);
-        if (fid >= 0 && !((lane & 7) && left == fid) && !(lane >= 8 && up == fid)) out.marks[(size_t)b * bb.F + fid] = 1;
+        const int left = __shfl(fid, lane - 1, 64), up = __shfl(fid, lane - TILE_W, 64);
+        if (fid >= 0 && !((lane % TILE_W) && left == fid) && !(lane >= TILE_W && up == fid)) out.marks[(size_t)b * bb.F + fid] = 1;
     }
     if (xi < S && yi < S) {
         const size_t i = ((size_t)b * S + yi) * S + xi;
@@ -479,7 +484,7 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                 for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = 0.0f;
             }
         }
-    }
+    }    }
 }
 
 // ---- texture sampling (KCU:172-242), one lane per pixel ---------------------------------------------

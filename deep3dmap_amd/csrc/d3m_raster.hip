@@ -103,7 +103,7 @@ D3M_EXPORT const char* d3m_error_string(int code) {
 // ---------------------------------------------------------------------------------------------------
 static const int KCAP_DEFAULT = 16;   // a face covering more tiles than this is "large"
 static const int KCAP_MAX = 64;
-static const int RASTER_SMALL_GRID = 32768;  // up to this many tiles a tile gets 4 waves instead of 1 (d3m_forward.h)
+static const int RASTER_SMALL_GRID = 32768 * 64 / TILE_PX;  // up to this many tiles (2 M pixels) a tile gets 4 waves instead of 1 (d3m_forward.h)
 
 struct FwdLayout {
     size_t zero_bytes;   // prefix that must be zeroed per call
@@ -112,8 +112,8 @@ struct FwdLayout {
 };
 
 static FwdLayout fwd_layout(int B, int F, int S) {
-    const int tiles_x = (S + TILE - 1) / TILE;
-    const size_t nt = (size_t)B * tiles_x * tiles_x;
+    const int tiles_x = (S + TILE_W - 1) / TILE_W, tiles_y = (S + TILE_H - 1) / TILE_H;
+    const size_t nt = (size_t)B * tiles_x * tiles_y;
     FwdLayout L;
     size_t o = 0;
     L.off_count = o;     o += align_up(nt * 4, 256);
@@ -153,8 +153,9 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
     if ((long)B * F >= (1l << 31)) return D3M_ERR_INVALID;
     char* p = (char*)ws;
     bb.B = B; bb.F = F; bb.S = S;
-    bb.tiles_x = (S + TILE - 1) / TILE;
-    bb.T = bb.tiles_x * bb.tiles_x;
+    bb.tiles_x = (S + TILE_W - 1) / TILE_W;
+    bb.tiles_y = (S + TILE_H - 1) / TILE_H;
+    bb.T = bb.tiles_x * bb.tiles_y;
     bb.kcap = (int)kcap;
     bb.tile_count = (int*)(p + L.off_count);
     bb.tile_cursor = (int*)(p + L.off_cursor);
@@ -195,7 +196,7 @@ static inline unsigned px_grid(long n, bool sparse) {
 // the chip with as well (8 views of the 100 k mesh at 512^2: 0.145 ms against 0.21; 32 views: 0.47 against 0.45, so the big
 // batches of ordinary meshes stay binned).  Its z-buffer and big-face list live in the forward
 // workspace: a workspace too small for them means binning.  D3M_BID=1 / 0 forces / forbids it (measurements).
-static const long BID_MAX_TILES = 65536;     // 16 views at 512^2: +1 % there, +1.5 % at 12, -2 % at 24 (A/B, round 3)
+static const long BID_MAX_TILES = 65536;     // (8 x 8-pixel blocks) 16 views at 512^2: +1 % there, +1.5 % at 12, -2 % at 24 (A/B, round 3)
 // which form of coverage the forward takes: -1 chosen per launch (above), 0 binned only, 1 bidding wherever its
 // workspace fits.  Process-wide; D3M_BID=0 / 1 in the environment sets the initial value (measurements), and
 // d3m_set_coverage_form() changes it between launches (the parity tests run every scene in both forms).
@@ -219,8 +220,8 @@ D3M_EXPORT int d3m_set_coverage_form(int form) {
 D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
 static bool bidding_preferred(int B, long triangles, int S) {
     const int form = coverage_form();
-    const int tiles_x = (S + TILE - 1) / TILE;
-    return form >= 0 ? form == 1 : ((double)S * S < 1.5 * (double)triangles || (long)B * tiles_x * tiles_x <= BID_MAX_TILES);
+    const int blocks_x = (S + 7) / 8;            // (the threshold is in blocks of 8 x 8 pixels, whatever the tile pass's tiles)
+    return form >= 0 ? form == 1 : ((double)S * S < 1.5 * (double)triangles || (long)B * blocks_x * blocks_x <= BID_MAX_TILES);
 }
 static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
     return bidding_preferred(B, triangles, S) && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);

@@ -270,7 +270,7 @@ def test_config4_bench_launch_shape_auto_dispatch_against_reference():
     from deep3dmap_amd import _lib, synthetic
     eyes = synthetic.camera_ring(32)
     _, _, _, faces, S = _config_scene(225, eyes, 512, False)
-    assert faces.shape[0] * ((S + 7) // 8) ** 2 == 131072
+    assert faces.shape[0] * ((S + 7) // 8) ** 2 == 131072      # (blocks of 8 x 8 pixels: twice the library's auto-dispatch threshold)
     assert _lib.lib().d3m_get_coverage_form() == -1
     info = _full_size_check(faces, S, 2, "auto", "binned", 41)
     _record("config4_100352tri_512_32views[auto=binned]", info)
