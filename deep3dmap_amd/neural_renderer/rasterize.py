@@ -481,6 +481,7 @@ class _RasterizeLit(torch.autograd.Function):
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
         # under the loss and the first backward passes.  The outputs are then only valid after backward.
         plan_ready = [] if (vis is not None and defer_plan_join and G == 1) else None   # (G > 1: capture crashes, as above)
+        vis_ready = None
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
@@ -506,6 +507,9 @@ class _RasterizeLit(torch.autograd.Function):
                         # (its first step -- which faces own a pixel -- was left by the tile pass above)
                         _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
                                                     _lib.stream_ptr()), "d3m_visibility")
+                        if plan_ready is not None:
+                            vis_ready = torch.cuda.Event()
+                            vis_ready.record(auxs[k])
                         _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
                                                    plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")
                         if plan_ready is not None:
@@ -539,6 +543,7 @@ class _RasterizeLit(torch.autograd.Function):
         m["visibility"] = vis
         m["edge_plan"] = plan
         m["plan_ready"] = plan_ready
+        m["vis_ready"] = vis_ready if plan_ready is not None else None
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
@@ -658,12 +663,23 @@ class _RasterizeLit(torch.autograd.Function):
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         plan_ready = m["plan_ready"]
+        # THE EDGE GRADIENT STAYS ON THE PLAN'S STREAM (round 4).  With the forward's branch left open (plan_ready), the
+        # step's critical chain is coverage -> visibility list -> plan -> line walk -> gather: all but the first on the side
+        # stream if the line walk is issued there too, right behind the plan's last kernel, instead of on the forking stream
+        # behind an event -- a replayed graph pays ~9 us for every cross-queue edge whose producer has only just finished
+        # (trace of the 4-view shard: scatter ends 190.0, the line walk starts 198.6).  The gathered texture / depth pass
+        # takes the forking stream then; it only needs the visibility list (an event behind d3m_visibility).
+        swap = plan_ready is not None and G == 1 and auxs[0] is not cur and m.get("vis_ready") is not None
+        s_edges = [auxs[0]] if swap else mains
+        s_gath = [mains[0]] if swap else auxs
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
             if gathered or plan_ready is not None:
                 auxs[k].wait_stream(cur)
-            if plan_ready is not None:
+            if swap:
+                mains[k].wait_event(m["vis_ready"])
+            elif plan_ready is not None:
                 mains[k].wait_event(plan_ready[k])       # the forward's open branch: visibility + plan of this group
         for k, (lo, hi) in enumerate(groups):
             Bg = hi - lo
@@ -678,7 +694,7 @@ class _RasterizeLit(torch.autograd.Function):
                                               _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
                                               _lib.ptr(records[2][0][lo:hi]), _lib.ptr(records[2][1][lo:hi]), 0)
             if gathered:
-                with torch.cuda.stream(auxs[k]):
+                with torch.cuda.stream(s_gath[k]):
                     ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
                     # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
                     _lib.check(L.d3m_backward_textures_lit(
@@ -691,7 +707,7 @@ class _RasterizeLit(torch.autograd.Function):
                         "d3m_backward_textures_lit")
             if G == 1:
                 yield "textures"        # (one pipeline: the texture side is complete in the order of its stream)
-            with torch.cuda.stream(mains[k]):
+            with torch.cuda.stream(s_edges[k]):
                 ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
                                        _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S, eps,
                                        True, ra,
@@ -709,13 +725,19 @@ class _RasterizeLit(torch.autograd.Function):
         light_done = False
         if gathered and need_vert and G == 1:
             # one pipeline: straight behind the gathered pass on its branch, beside the line walk, not behind the join
-            with torch.cuda.stream(auxs[0]):
+            with torch.cuda.stream(s_gath[0]):
                 light_to_vertices(gl_g[0] if light_shared else grad_light)
             light_done = True
+        # ... and so does the camera's adjoint, the step's last kernel, behind the gather: the side stream waits for the
+        # forking stream's (shorter, by then finished) chain instead of the other way round, and the final join is the
+        # end of the step
+        tail_on_side = swap and gathered and ctx.camera is not None
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
-            if gathered or plan_ready is not None:
+            if tail_on_side:
+                auxs[k].wait_stream(cur)
+            elif gathered or plan_ready is not None:
                 cur.wait_stream(auxs[k])
         if gathered:
             # shared textures / light: the groups' sums add up (a group's pass already summed over its views)
@@ -747,9 +769,12 @@ class _RasterizeLit(torch.autograd.Function):
                 fn, what = L.d3m_camera_backward, "d3m_camera_backward"
             else:
                 fn, what = L.d3m_camera_backward_add, "d3m_camera_backward_add"
-            _lib.check(fn(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(grad_sv), _lib.ptr(grad_vertices),
-                          B, V, _lib.stream_ptr()), what)
+            with torch.cuda.stream(auxs[0] if tail_on_side else cur):
+                _lib.check(fn(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(grad_sv),
+                              _lib.ptr(grad_vertices), B, V, _lib.stream_ptr()), what)
             grad_sv = None
+        if tail_on_side:
+            cur.wait_stream(auxs[0])
         return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 16
 
 
