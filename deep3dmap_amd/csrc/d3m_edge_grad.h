@@ -1091,14 +1091,33 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                     const float4* pg_to = s_grd + to;
                     v2f den = u + t;                                // advances by exact steps of EG_ROW as well
                     if (m_outward == ~0ull) {                       // outward walks only (the common case): no owner test
-                        for (int k = 0; k < n_iter; k++) {
-                            const v2f d2 = diff_of2(*pg, *pd, nref_ar, nref_gb);
-                            const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
-                                                            __builtin_amdgcn_ballot_w64(!(d2.x <= 0));
-                            fma_where(acc, d2, rcp2(den), keep);
-                            pg += EG_ROW;
-                            pd += EG_ROW;
-                            den += (float)EG_ROW;
+                        // two steps per round, each step's LDS reads issued a step ahead of its arithmetic (a wave's step is
+                        // a round trip to LDS and then ~20 dependent vector instructions; with the reads in flight across the
+                        // other step's arithmetic the wave waits for neither).  An odd trip count's extra step is masked.
+                        float4 ga = pg[0];
+                        float2 da = pd[0];
+                        const float4* pg_to1 = pg_to - EG_ROW;
+                        for (int k = 0; k < n_iter; k += 2) {
+                            const float4 gb = pg[EG_ROW];
+                            const float2 db = pd[EG_ROW];
+                            {
+                                const v2f d2 = diff_of2(ga, da, nref_ar, nref_gb);
+                                const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to) &
+                                                                __builtin_amdgcn_ballot_w64(!(d2.x <= 0));
+                                fma_where(acc, d2, rcp2(den), keep);
+                                den += (float)EG_ROW;
+                            }
+                            ga = pg[2 * EG_ROW];
+                            da = pd[2 * EG_ROW];
+                            {
+                                const v2f d2 = diff_of2(gb, db, nref_ar, nref_gb);
+                                const unsigned long long keep = __builtin_amdgcn_ballot_w64(pg <= pg_to1) &
+                                                                __builtin_amdgcn_ballot_w64(!(d2.x <= 0));
+                                fma_where(acc, d2, rcp2(den), keep);
+                                den += (float)EG_ROW;
+                            }
+                            pg += 2 * EG_ROW;
+                            pd += 2 * EG_ROW;
                         }
                     } else {
                         for (int k = 0; k < n_iter; k++) {
@@ -1597,7 +1616,7 @@ struct EdgeRecords {
 // readable up to entry 2*S + 16 (PAD)
 inline size_t edge_lines_lds(int S) {
     const size_t pairs = (size_t)(S + (S & 1)) * 8, body = pairs + (size_t)S * 32;
-    return std::max(body, pairs + (size_t)(2 * S + 16) * 16);
+    return std::max(body, pairs + (size_t)(2 * S + 32) * 16);
 }
 
 template <class FS>
