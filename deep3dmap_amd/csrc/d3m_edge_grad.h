@@ -938,7 +938,10 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
 #endif
     const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // crossing records under this line
     if (n_x <= 0) return;                                     // nothing to do (uniform exit)
-    const int wv = threadIdx.x >> 6, lane = lane_id();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the lane number where it is needed, from the thread index behind an opaque copy: a `lane` kept live through the set-up
+    // passes is one of the registers those do not have
+    auto lane_here = [] { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t & 63; };
     const int d0 = (int)(line % is);
     const int axis = (int)((line / is) & 1);
     const size_t bn = line / ((size_t)2 * is);
@@ -1034,7 +1037,6 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                      : "scc");
 #endif
     };
-    const int row = lane / EG_ROW, rl = lane % EG_ROW;
     // The queue of long segments (EG_QUEUE items in LDS) is filled by as many set-up passes as it takes -- a line of the
     // headline mesh has ~380 crossings, i.e. two passes, of which ~240 segments are long -- and walked when the next
     // pass might not fit, and at the end: the walk wants MANY segments at a time (sixteen per wave, ordered by length).
@@ -1059,6 +1061,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
             __syncthreads();
             // ---- walk: EG_SEG_PER_WAVE segments per wave, EG_ROW lanes each ------------------------------------------
             constexpr int STRIDE = EG_LINE_WAVES * EG_SEG_PER_WAVE;
+            const int row = lane_here() / EG_ROW, rl = lane_here() % EG_ROW;      // (see lane_here)
             for (int base = wv * EG_SEG_PER_WAVE; base < nc; base += STRIDE) {
                 const bool have = base + row < nc;
                 const int it = have ? s_order[base + row] : s_order[base];
@@ -1245,7 +1248,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         }
         // the pass's long segments: if they do not fit behind what is queued already, that is walked first
         int n0 = __popcll(qm[0]), n1 = __popcll(qm[1]);
-        if (lane == 0 && (n0 | n1)) atomicAdd(&s_pass[pass], n0 + n1);
+        if (lane_here() == 0 && (n0 | n1)) atomicAdd(&s_pass[pass], n0 + n1);
         __syncthreads();
         const int pass_total = s_pass[pass];
         const bool full = s_nitems + pass_total > EG_QUEUE;       // uniform: read by everyone before anyone appends
@@ -1266,6 +1269,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
             const int fn = (int)rc.r1.y;
             // queue positions: one LDS atomic per wave, ranks from the ballots (outward items first, then inward)
             int base = 0;
+            const int lane = lane_here();
             if (lane == 0 && (n0 | n1)) base = atomicAdd(&s_nitems, n0 + n1);
             base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
