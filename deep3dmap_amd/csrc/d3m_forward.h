@@ -288,8 +288,17 @@ struct RasterOut {
 // tiles), where the hottest tiles' chunk chains would otherwise run on one wave each with nothing to overlap their
 // latency: the chunks of a tile are dealt to its waves, which share the tile's LDS z-buffer and never wait for one
 // another between chunks (each stages into its own arrays; only the z-buffer is common, through LDS atomics).
-template <class FS, int W>
-__global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
+// STREAM (W == 1, big grids): a wave does not take one tile but a strided sequence of its XCD's tiles, and what a tile's
+// first chunk needs before it can do anything -- its list's position and length, its lane's list entry, that face's nine
+// floats: three DEPENDENT round trips to the L2, a third of the one-tile-per-wave pass's time with nothing of the tile's own
+// to overlap them -- is requested while the tile BEFORE it is worked on: header two tiles ahead, list entry one tile ahead,
+// the face behind the current tile's staging step.  (And 5632 workgroups are launched instead of 131072: 0.03 ms.)
+#ifndef D3M_RT_STREAM_WAVES
+#define D3M_RT_STREAM_WAVES 5      // waves per SIMD the streaming form is held to (its LDS leaves room for 5.5)
+#endif
+template <class FS, int W, bool STREAM = false>
+__global__ void __launch_bounds__(64 * W, STREAM ? D3M_RT_STREAM_WAVES : 1) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
+    static_assert(!STREAM || W == 1, "the streaming form is the one-wave form");
     __shared__ float s_face_all[W][9][WAVE];
     __shared__ float s_finv_all[W][9][WAVE];
     __shared__ int s_fid_all[W][WAVE];
@@ -318,12 +327,38 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
     // lines) stay within one L2.
     const int n_tiles = bb.B * bb.T;
     const int per = (n_tiles + 7) >> 3;
-    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile >= n_tiles) return;
-    const int b = tile / bb.T, t = tile % bb.T;
-    const int px0 = (t % bb.tiles_x) * TILE_W, py0 = (t / bb.tiles_x) * TILE_H;
     const int S = bb.S;
     const int lane = lane_id();
+    // STREAM: the wave takes every (gridDim / 8)-th tile of its XCD's range -- one or two tiles (run_forward*: two thirds as
+    // many waves per XCD as it has tiles, an odd number).  A wave's tiles are a SEQUENCE and tiles differ in cost by orders
+    // of magnitude: as many waves as the chip holds with ~23 tiles each took 0.40-0.49 ms where one tile per workgroup takes
+    // 0.31; tiles handed out from a per-XCD counter in batches of 1 to 8 0.44-0.84; two to four NEIGHBOURING tiles per wave
+    // 0.38-0.48; a stride that pairs the same screen position of two views 0.37; 3 tiles per wave 0.29, 1.5 tiles 0.28.
+    const int xcd = (int)(blockIdx.x & 7);
+    const int tile_stride = STREAM ? (int)(gridDim.x >> 3) : 0;
+    const int tile_end = STREAM ? min((xcd + 1) * per, n_tiles) : n_tiles;
+    int tile = xcd * per + (int)(blockIdx.x >> 3);
+    auto next_tile = [&](int from) { return from + tile_stride; };
+    if (tile >= tile_end) return;
+    // STREAM: (position, length) of the current tile's list, the lane's entry and its face; the same of the next tile
+    int cnt_cur = 0, off_cur = 0, fid_cur = -1, tile_n = 0, cnt_n = 0, off_n = 0;
+    float face_held[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};       // the current tile's until its first chunk is staged, then the next's
+    if (STREAM) {
+        cnt_cur = bb.tile_count[tile]; off_cur = bb.tile_offset[tile];
+        if (lane < cnt_cur) { fid_cur = bb.pairs[off_cur + lane]; fs.load(tile / bb.T, fid_cur, face_held); }
+        tile_n = next_tile(tile);
+        if (tile_n < tile_end) { cnt_n = bb.tile_count[tile_n]; off_n = bb.tile_offset[tile_n]; }
+    }
+  for (;;) {
+    int fid_n = -1, tile_nn = 0, cnt_nn = 0, off_nn = 0;
+    bool next_requested = !STREAM;
+    if (STREAM) {
+        if (lane < cnt_n) fid_n = bb.pairs[off_n + lane];
+        tile_nn = next_tile(tile_n);
+        if (tile_nn < tile_end) { cnt_nn = bb.tile_count[tile_nn]; off_nn = bb.tile_offset[tile_nn]; }
+    }
+    const int b = tile / bb.T, t = tile % bb.T;
+    const int px0 = (t % bb.tiles_x) * TILE_W, py0 = (t / bb.tiles_x) * TILE_H;
 
     if (wv == 0) {
         if (lane < TILE_W) s_cx[lane] = pixel_center(px0 + lane, S);
@@ -332,17 +367,23 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
         for (int h = 0; h < TILE_PX / WAVE; h++) s_z[h * WAVE + lane] = ~0ull;
     }
     if (lane == 0) s_pre[0] = 0;
-    __syncthreads();
+    if (STREAM) wave_lds_sync(); else __syncthreads();
 
     for (int which = 0; which < 2; which++) {
-        const int* list = which == 0 ? bb.pairs + bb.tile_offset[tile] : bb.big_list + (size_t)b * bb.F;
-        const int n = which == 0 ? bb.tile_count[tile] : bb.big_count[b];
+        const int* list = which == 0 ? bb.pairs + (STREAM ? off_cur : bb.tile_offset[tile]) : bb.big_list + (size_t)b * bb.F;
+        const int n = which == 0 ? (STREAM ? cnt_cur : bb.tile_count[tile]) : bb.big_count[b];
         for (int base = wv * WAVE; base < n; base += W * WAVE) {
             int cnt = 0;
             if (base + lane < n) {
-                const int fid = list[base + lane];
+                const bool held = STREAM && which == 0 && base == 0;        // requested while the previous tile was worked on
+                const int fid = held ? fid_cur : list[base + lane];
                 float face[9];
-                fs.load(b, fid, face);
+                if (held) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) face[k] = face_held[k];
+                } else {
+                    fs.load(b, fid, face);
+                }
                 int x0, x1, y0, y1;
                 if (pixel_bbox(face, S, x0, x1, y0, y1)) {
                     x0 = max(x0, px0); x1 = min(x1, px0 + TILE_W - 1);
@@ -367,6 +408,10 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
                                       ((uint32_t)((65536 + bw - 1) / bw) << 12);
                     }
                 }
+            }
+            if (!next_requested) {          // the next tile's faces (its list entries were requested at the top of this tile)
+                next_requested = true;
+                if (fid_n >= 0) fs.load(tile_n / bb.T, fid_n, face_held);
             }
             const int incl = wave_inclusive_scan(cnt);
             s_pre[lane + 1] = incl;
@@ -438,8 +483,11 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
             wave_lds_sync();                        // before this wave restages
         }
     }
-    __syncthreads();                                // every wave's bids are in
-    if (wv != 0) return;
+    if (!next_requested && fid_n >= 0) fs.load(tile_n / bb.T, fid_n, face_held);    // (a tile without a chunk)
+    if (!STREAM) {
+        __syncthreads();                            // every wave's bids are in
+        if (wv != 0) return;
+    }
 
     // resolve: lane = pixel; recompute the winner's weights (same arithmetic -> same bits) and store.  Pixels
     // nobody covers get the reference's initial values (rasterize.py:50-58: index -1, weights 0, depth far, inverse
@@ -485,6 +533,11 @@ __global__ void __launch_bounds__(64 * W) k_raster_tiles(FS fs, BinBuffers bb, R
             }
         }
     }    }
+    if (!STREAM || tile_n >= tile_end) break;
+    tile = tile_n; cnt_cur = cnt_n; off_cur = off_n; fid_cur = fid_n;
+    tile_n = tile_nn; cnt_n = cnt_nn; off_n = off_nn;
+    wave_lds_sync();                                // the z-buffer has been read: the next tile may clear it
+  }
 }
 
 // ---- texture sampling (KCU:172-242), one lane per pixel ---------------------------------------------

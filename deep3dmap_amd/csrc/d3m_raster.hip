@@ -105,6 +105,17 @@ static const int KCAP_DEFAULT = 16;   // a face covering more tiles than this is
 static const int KCAP_MAX = 64;
 static const int RASTER_SMALL_GRID = 32768 * 64 / TILE_PX;  // up to this many tiles (2 M pixels) a tile gets 4 waves instead of 1 (d3m_forward.h)
 
+// the streaming form of the tile pass (d3m_forward.h): waves per XCD for `per` tiles per XCD -- about two thirds as many, so
+// that a wave takes one or two tiles, and such that its second tile lies two thirds of the screen away from its first, in
+// both directions, whatever view it belongs to: the expensive tiles are the object's, in the middle of every view, and a wave
+// that draws two of them is the pass's tail (the same number of waves with the second tile a third of the screen away: no gain)
+static inline int raster_stream_waves(int per, int tiles_x, int tiles_y) {
+    const int T = tiles_x * tiles_y, shift = (2 * tiles_y / 3) * tiles_x + 2 * tiles_x / 3;
+    int w = (2 * per / 3) / T * T + shift;
+    if (w < per / 2) w += T;
+    return std::max(1, w);
+}
+
 struct FwdLayout {
     size_t zero_bytes;   // prefix that must be zeroed per call
     size_t off_count, off_cursor, off_big_count, off_alloc, off_offset, off_rect, off_big, off_pairs;
@@ -271,7 +282,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (n_tiles <= RASTER_SMALL_GRID)
         LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
     else
-        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 1>), dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
+        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 1, true>), dim3(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
@@ -321,7 +332,7 @@ counted:
     if (n_tiles <= RASTER_SMALL_GRID)
         LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
     else
-        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1>), dim3(per * 8), dim3(64), st, fs, bb, out, near, far);
+        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1, true>), dim3(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8), dim3(64), st, fs, bb, out, near, far);
     return check_launch();
 }
 
