@@ -8,3 +8,4 @@ timeout 900 python -m pytest tests/test_gpu_reference.py tests/test_gpu_ops.py -
 cp gpurun_out/parity_full_size.json $O/${R}_parity_full_size.json 2>/dev/null
 R=$R bash tools_dev/profile_all.sh
 R=$R bash tools_dev/other_configs.sh
+R=$R bash tools_dev/sq_counters2.sh > $O/sq2.log 2>&1; cp gpurun_out/sq2/${R}_sq_counters2.csv $O/ 2>/dev/null
