@@ -223,8 +223,8 @@ def test_full_size_workload_properties():
         assert torch.equal(r1(vt[i:i + 1], ft[i:i + 1], mode="silhouettes")[0], sil[i])
 
 
-@pytest.mark.parametrize("S,mesh_n,big", [(512, 40, False), (500, 160, True)])
-def test_one_wave_per_tile_path_equals_four_waves_per_tile_path(S, mesh_n, big):
+@pytest.mark.parametrize("S,mesh_n,big,views", [(512, 40, False, 9), (500, 160, True, 9), (1024, 60, False, 3)])
+def test_one_wave_per_tile_path_equals_four_waves_per_tile_path(S, mesh_n, big, views):
     """The per-tile-list form of coverage runs ONE wave per one or two tiles when a launch has more than 32768 tiles
     (bench.py's 32 views: k_raster_tiles<..., 1, true>, the streaming form: a wave requests its second tile's list entry and
     faces while it works on its first) and FOUR waves per tile below that.  Nine views (36864 / 35721 tiles) rendered in
@@ -232,33 +232,34 @@ def test_one_wave_per_tile_path_equals_four_waves_per_tile_path(S, mesh_n, big):
     bit-identical maps to the same views rendered one by one (four waves per tile), and both to the bidding form of the
     same batch; which kernels ran is read from the launch record, not inferred.  Second case: a raster that is no multiple
     of the tile, a mesh dense enough for tiles with more than one chunk of 64 listed faces, and a screen-filling face in
-    every view (the big-face list)."""
+    every view (the big-face list).  Third case: three views of 16384 tiles each -- an XCD's share of the tiles is less than one
+    view."""
     from conftest import assert_coverage_form_ran, kernels_launched
     from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
     from deep3dmap_amd.neural_renderer.mesh_ops import gather_faces
     from deep3dmap_amd.neural_renderer.rasterize import _raster_forward
     v, tri = synthetic.grid_mesh(mesh_n)
-    eyes = torch.from_numpy(synthetic.camera_ring(9)).cuda()
-    vt = torch.from_numpy(v).cuda()[None].expand(9, -1, -1).contiguous()
-    ft = torch.from_numpy(tri).cuda()[None].expand(9, -1, -1).contiguous()
+    eyes = torch.from_numpy(synthetic.camera_ring(views)).cuda()
+    vt = torch.from_numpy(v).cuda()[None].expand(views, -1, -1).contiguous()
+    ft = torch.from_numpy(tri).cuda()[None].expand(views, -1, -1).contiguous()
     faces = gather_faces(nr.look_at(vt, eyes, _perspective_angle=30), ft, True)
     if big:         # behind everything else, covering the whole raster: listed by every tile of its view
         wall = torch.tensor([[-3.0, -3.0, 50.0], [3.0, -3.0, 50.0], [0.0, 4.0, 50.0]], device="cuda")
-        faces = torch.cat([faces, wall[None, None].expand(9, 1, 3, 3)], dim=1).contiguous()
-    tex = torch.rand(9, faces.shape[1], 2, 2, 2, 3, device="cuda")
+        faces = torch.cat([faces, wall[None, None].expand(views, 1, 3, 3)], dim=1).contiguous()
+    tex = torch.rand(views, faces.shape[1], 2, 2, 2, 3, device="cuda")
     with _lib.coverage_form("binned"), kernels_launched() as k:
         many, _ = _raster_forward(faces, tex, S, 0.1, 100.0, 1e-3, None, True, True, True, False)
     assert_coverage_form_ran(k.names, "binned")
     assert float((many["face_index_map"] >= 0).float().mean()) > 0.05
     if big:
-        assert int((many["face_index_map"] == faces.shape[1] - 1).sum()) > 9 * S * S // 4
+        assert int((many["face_index_map"] == faces.shape[1] - 1).sum()) > views * S * S // 4
     with _lib.coverage_form("bidding"), kernels_launched() as k:
         bid, _ = _raster_forward(faces, tex, S, 0.1, 100.0, 1e-3, None, True, True, True, False)
     assert_coverage_form_ran(k.names, "bidding")
     for key in ("face_index_map", "weight_map", "depth_map"):
         assert torch.equal(many[key], bid[key]), key
     with _lib.coverage_form("binned"), kernels_launched() as k:
-        for i in range(9):
+        for i in range(views):
             one, _ = _raster_forward(faces[i:i + 1].contiguous(), tex[i:i + 1].contiguous(), S, 0.1, 100.0, 1e-3, None, True,
                                      True, True, False)
             for key in ("face_index_map", "weight_map", "depth_map"):
