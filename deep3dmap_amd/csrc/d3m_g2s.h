@@ -288,16 +288,11 @@ __global__ void __launch_bounds__(256) k_g2s_raster(G2S g) {
         return g.zbuf + ((size_t)(owner_pair / Ft) * S + yi) * S + xi;
     };
     bid_rows(st, cnt, S,
-        [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests, then early z against the pixel's bid
+        [&](int lo, int xi, int yi) {              // cheap: the three half-plane tests (no early z: see k_bid_faces)
             float face[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) face[k] = (k % 3 == 2) ? 0.0f : st.face[k][lo];
-            if (!inside_face(face, pixel_center(xi, S), pixel_center(yi, S))) return false;
-            // early z: the interpolated depth cannot fall below the smallest vertex depth by more than a few ulp
-            // (k_raster_tiles), so a triangle whose nearest vertex lies behind the pixel's current winner is skipped
-            const float zmin = fminf(st.face[2][lo], fminf(st.face[5][lo], st.face[8][lo]));
-            const unsigned long long cur = *slot_of(lo, xi, yi);
-            return !(zmin > 0.0f && (uint32_t)(~ordered_bits(zmin * 0.99999f)) < (uint32_t)(cur >> 32));
+            return inside_face(face, pixel_center(xi, S), pixel_center(yi, S));
         },
         [&](int lo, int xi, int yi) {              // costly: barycentrics and depth (seven divisions), the bid
             float face[9], finv[9], w[3], zp;
