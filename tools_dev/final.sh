@@ -2,7 +2,7 @@
 # on the GPU box: the round's artefacts of record in one call -- the whole -m gpu suite (log kept), the reference-parity
 # files with both coverage forms named in the test ids (-v), profile_all.sh, other_configs.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${R:-r04}; O=gpurun_out/final; mkdir -p $O
+R=${R:-r05}; O=gpurun_out/final; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu > $O/${R}_gpu_suite_final.log 2>&1; tail -2 $O/${R}_gpu_suite_final.log
 timeout 900 python -m pytest tests/test_gpu_reference.py tests/test_gpu_ops.py -m gpu -v -k "binned or bidding or auto" 2>&1 | grep -E "PASSED|FAILED|ERROR|passed|failed" | sed "s/ *\[ *[0-9]*%\]//" > $O/${R}_gpu_parity_both_forms.log; tail -1 $O/${R}_gpu_parity_both_forms.log
 cp gpurun_out/parity_full_size.json $O/${R}_parity_full_size.json 2>/dev/null

@@ -1,6 +1,6 @@
 #!/bin/bash
 # on the GPU box: bench lines of BASELINE.json's other configurations and the secondary workloads (one JSON line each)
-R=${R:-r04}
+R=${R:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 : > $O/${R}_bench_other_configs.jsonl

@@ -2,7 +2,7 @@
 # on the GPU box: timestamped kernel trace of the last replayed steps -- the headline (32 views) and the 4-view shard --
 # folded to one step each: kernel, start offset (us from the step's first kernel), duration, queue
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04t; rm -rf $O; mkdir -p $O
+O=gpurun_out/trace; rm -rf $O; mkdir -p $O
 for v in 32 4; do
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/tr$v -o tr -- python3 bench.py --no-cpu-baseline --no-dropin --steps 6 --warmup 2 --repeats 1 --views-per-gpu $v > $O/log$v.txt 2>&1
 f=$(find $O/tr$v -name "*kernel_trace.csv" | head -1)
@@ -21,7 +21,7 @@ for a,b in zip(idx[:-1],idx[1:]):
     if best is None or span<best[0]: best=(span,a,b)
 span,a,b=best
 t0=int(rows[a]['Start_Timestamp'])
-out=open(f'gpurun_out/r04t/step_{sys.argv[2]}views.csv','w')
+out=open(f'gpurun_out/trace/step_{sys.argv[2]}views.csv','w')
 out.write('kernel,start_us,duration_us,queue\n')
 busy=0
 for r in rows[a:b]:
