@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- rendered Mpix/s (forward + backward) of the multi-view fit on a 100k-triangle mesh at
-512x512 (BASELINE.json metric), one rank per GPU, camera-sharded (weak scaling: 8 views per GPU).
+512x512 (BASELINE.json metric), one rank per GPU, camera-sharded.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no torchrun environment: bench.py starts that very command itself)
 
 A step = render (rgb+depth+alpha) of this rank's views of the shared mesh, the loss against fixed
-targets, the backward to per-vertex / per-texel gradients and (N > 1) one RCCL all-reduce of them.
+targets, the backward to per-vertex / per-texel gradients and (N > 1) the RCCL all-reduce of them.
+Default: weak scaling, 32 cameras per GPU (at N = 1 the whole 32-camera configuration BASELINE.json quotes the metric
+on); `--scaling strong --total-views 32` is BASELINE config 4.  With N > 1 the line also carries the strong-scaling
+figures of configs 4 and 5 (`strong_scaling`), and always what the process group really was (`world_size_seen`,
+`collective_backend`, `ranks`: every rank's device and uuid, gathered through the backend).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -114,6 +119,59 @@ def kernel_bytes(name, V, F, S, ts):
         "k_lighting_backward": 12 * V + 12 * F + 2 * F * ts ** 3 * 12 + 12 * V,
     }
     return table.get(name)
+
+
+def owed_bytes(V, F, S, s, ts, api):
+    """The section-8(d) bytes the TIMED api really has to move, per view: `render_fit_loss` evaluates the objective where
+    the pixel values are produced, so the output images (forward: written, 20 B per output pixel) and their gradients
+    (backward: read, 20 B) never exist -- 8(d) counts both.  The drop-in api (render + loss on images) owes all of 8(d)."""
+    a_fwd, a_bwd = algorithmic_bytes(V, F, S, s, ts)
+    if api == "render_fit_loss":
+        a_fwd -= s * s * 20
+        a_bwd -= s * s * 20
+    return a_fwd, a_bwd
+
+
+def rocprof_average_us(kernel):
+    """(average duration in us of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this
+    command, file) or (None, None).  NOT measured by this run: the bench line's own duration is HIP events."""
+    import csv
+    f = _newest_profile("*kernel_stats_final.csv")
+    if not f:
+        return None, None
+    rows = [r for r in csv.DictReader(open(f)) if kernel in r["Name"]]
+    calls = sum(int(r["Calls"]) for r in rows)
+    if not calls:
+        return None, None
+    return sum(float(r["TotalDurationNs"]) for r in rows) / calls / 1e3, os.path.relpath(f, ROOT)
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as FRESH child processes
+    through torch.distributed.run -- the very command the driver uses -- and relay rank 0's line (the children inherit
+    stdout).  This parent has not touched the GPU (importing torch does not), and it never execs: a process that has
+    initialised the GPU must not be replaced (the pool's rule), so the launch happens before anything else."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] --gpus {n_gpus} without WORLD_SIZE: launching {' '.join(cmd[1:])}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rank_identity(rank, local_rank):
+    """what THIS rank runs on, for the line's `ranks` list: proof of which devices the job's ranks really used"""
+    dev = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(dev)
+    return {"rank": rank, "local_rank": local_rank, "device": dev, "name": props.name,
+            "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
 
 
 def _newest_profile(pattern):
@@ -390,6 +448,9 @@ def main():
                     help="weak (default): --views-per-gpu cameras on every GPU; strong: --total-views cameras in all, "
                          "split across the GPUs (BASELINE config 4: 32 cameras, 8 per GPU on 4)")
     ap.add_argument("--total-views", type=int, default=32, help="strong scaling: cameras of the whole job")
+    ap.add_argument("--no-strong-lines", dest="strong_lines", action="store_false",
+                    help="N > 1, headline mesh: do not add the strong-scaling figures of BASELINE configs 4 and 5 "
+                         "(`strong_scaling` in the line)")
     ap.add_argument("--mesh-n", type=int, default=225, help="grid_mesh(n): 225 -> 100,352 triangles")
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--texture-size", type=int, default=2)
@@ -424,9 +485,15 @@ def main():
     if args.workload == "mesh_family":
         return mesh_family_workload(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the bare form: start the ranks ourselves (before this process has touched the GPU) and relay rank 0's line
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks with torch.distributed.run, or call "
+                 f"`python bench.py --gpus N` without a torchrun environment and it launches them itself)")
     # D3M_BENCH_FORCE_DIST=1 (debug, not used by the driver): initialise the process group and run every collective even
     # with ONE rank -- the RCCL calls of the N > 1 path (communicator with device_id, the step's all-reduce on the flat device
     # buffer, barriers, the MAX over ranks) execute on a single-GPU box (tests/test_gpu_multirank.py)
@@ -441,49 +508,38 @@ def main():
     # rank on device 0 and reducing over gloo instead of RCCL.
     if os.environ.get("D3M_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s) -- one process per GPU")
     torch.cuda.set_device(local_rank)
+    backend = None
     if dist_on:
         backend = os.environ.get("D3M_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # what the process group really is: every rank's device, gathered THROUGH the collective backend (outside any timed region)
+    ranks_seen = [rank_identity(rank, local_rank)]
+    world_seen, backend_seen = 1, "none (one process, no process group)"
+    if dist_on:
+        world_seen = dist.get_world_size()
+        backend_seen = dist.get_backend()
+        if backend_seen == "nccl":
+            backend_seen = "nccl (RCCL " + ".".join(str(x) for x in torch.cuda.nccl.version()) + ")"
+        ranks_seen = [None] * world_seen
+        dist.all_gather_object(ranks_seen, rank_identity(rank, local_rank))
+        assert world_seen == world and sorted(r["rank"] for r in ranks_seen) == list(range(world)), ranks_seen
 
     from deep3dmap_amd import _lib, synthetic, multiview
-    from deep3dmap_amd.multiview import MultiViewFit
+    from deep3dmap_amd.multiview import MultiViewFit, shard_views
     multiview.COLLECTIVES_WITH_ONE_RANK = dist_on and world == 1
-
-    if args.scaling == "strong":
-        assert args.total_views % world == 0, "--total-views must split evenly over the GPUs"
-        args.views_per_gpu = args.total_views // world
-    n_views = args.views_per_gpu * world
-    v, tri = synthetic.grid_mesh(args.mesh_n)
-    tex = synthetic.random_textures(tri.shape[0], args.texture_size)
-    eyes = synthetic.camera_ring(n_views)
-    fit = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=args.anti_aliasing, rank=rank,
-                       world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=not args.materialise_images,
-                       view_groups=args.view_groups)
-    fit.set_targets_from(synthetic.perturb(v))
-    fit.keep_images = args.fit_with_images
+    dev = f"cuda:{local_rank}"
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss_eager, gv_eager, _ = fit.step()
-    gv_eager = gv_eager.clone()
-    graph_on = not args.no_graph
-    if graph_on:
-        try:
-            fit.capture_graph()
-        except Exception as e:      # keep the benchmark alive: fall back to eager launches (still all-HIP kernels)
-            print(f"[bench] HIP graph capture failed on rank {rank} ({type(e).__name__}: {e}); running eagerly",
-                  file=sys.stderr)
-            fit.release_graph()
-            graph_on = False
-            torch.cuda.synchronize()
     def max_over_ranks(seconds):
         if not dist_on:
             return list(seconds)
@@ -491,22 +547,65 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return [float(x) for x in tmax.tolist()]
 
-    with _own_stream(fit.stream):
-        for _ in range(args.warmup):
-            fit.step()
-        regions, (loss, gv, gt) = timed_repeats(fit.step, barrier, max(1, args.repeats), args.steps)
-    regions = max_over_ranks(regions)                   # every region: the slowest rank's time
-    elapsed = float(np.median(regions))
-    if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):
-        assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
-    # the replayed graph must reproduce the eager step (same inputs every step: no optimiser in the loop)
-    rel = float(torch.linalg.norm(gv - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
-    if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):      # (kernel-timing experiments with deliberately wrong results)
-        assert rel < 1e-3 and abs(float(loss) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)) + 1e-7, \
-            (rel, loss, loss_eager)
+    def measure(mesh_n, image_size, n_views, steps, warmup, repeats, objective_in_renderer=True, share=None, want_graph=True):
+        """One camera-sharded fit of `n_views` cameras in all: eager step, capture, warm-up, `repeats` barrier-bracketed
+        regions of `steps` steps (MAX over ranks, median).  Returns (fit, results dict); the fit is left in eager mode."""
+        v, tri = synthetic.grid_mesh(mesh_n)
+        tex = synthetic.random_textures(tri.shape[0], args.texture_size)
+        eyes = synthetic.camera_ring(n_views)
+        fit = MultiViewFit(v, tri, tex, eyes, image_size=image_size, anti_aliasing=args.anti_aliasing, rank=rank,
+                           world_size=world, device=dev, objective_in_renderer=objective_in_renderer,
+                           view_groups=args.view_groups)
+        if share is not None:       # the same targets as another fit of the same shard (the drop-in pass)
+            fit.targets, fit.mask_sum, fit._mask_sum_local = share.targets, share.mask_sum, share._mask_sum_local
+        else:
+            fit.set_targets_from(synthetic.perturb(v))
+        fit.keep_images = args.fit_with_images and objective_in_renderer
+        loss_eager, gv_eager, _ = fit.step()
+        gv_eager = gv_eager.clone()
+        graph_on = want_graph
+        if graph_on:
+            try:
+                fit.capture_graph()
+            except Exception as e:      # keep the benchmark alive: fall back to eager launches (still all-HIP kernels)
+                print(f"[bench] HIP graph capture failed on rank {rank} ({type(e).__name__}: {e}); running eagerly",
+                      file=sys.stderr)
+                fit.release_graph()
+                graph_on = False
+                torch.cuda.synchronize()
+        with _own_stream(fit.stream):
+            for _ in range(warmup):
+                fit.step()
+            regions, (loss, gv, gt) = timed_repeats(fit.step, barrier, max(1, repeats), steps)
+        regions = max_over_ranks(regions)                   # every region: the slowest rank's time
+        if not os.environ.get("D3M_BENCH_TIMING_EXPERIMENT"):      # (kernel-timing experiments with deliberately wrong results)
+            assert torch.isfinite(loss).item() and torch.isfinite(gv).all().item()
+            # the replayed graph must reproduce the eager step (same inputs every step: no optimiser in the loop)
+            rel = float(torch.linalg.norm(gv - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
+            assert rel < 1e-3 and abs(float(loss) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)) + 1e-7, \
+                (rel, loss, loss_eager)
+        fit.release_graph()
+        el = float(np.median(regions)) / steps
+        shards = [shard_views(n_views, r, world) for r in range(world)]
+        return fit, {"seconds_per_step": el, "regions": regions, "graph_on": graph_on, "n_views": n_views,
+                     "views_per_rank": [hi - lo for lo, hi in shards], "V": int(v.shape[0]), "F": int(tri.shape[0]),
+                     "loss_eager": float(loss_eager), "gv_eager": gv_eager,
+                     "value": n_views * image_size ** 2 / el / 1e6,
+                     "ms_per_step": el * 1e3, "ms_per_step_min": min(regions) / steps * 1e3,
+                     "ms_per_step_max": max(regions) / steps * 1e3, "split_exchange": fit.split_exchange}
+
+    if args.scaling == "strong":
+        if args.total_views < world:
+            sys.exit("--total-views: every rank renders at least one camera")
+        n_views = args.total_views
+        args.views_per_gpu = shard_views(n_views, 0, world)[1]          # the largest shard (rank 0's)
+    else:
+        n_views = args.views_per_gpu * world
+    fit, res = measure(args.mesh_n, args.image_size, n_views, args.steps, args.warmup, args.repeats,
+                       objective_in_renderer=not args.materialise_images, want_graph=not args.no_graph)
+    graph_on, regions, elapsed_step = res["graph_on"], res["regions"], res["seconds_per_step"]
 
     # instrumented pass (not part of `value`), eager: per-kernel HIP-event durations on the launch stream
-    fit.release_graph()
     _lib.kernel_timing(True)
     n_inst = max(3, min(args.steps, 10))
     for _ in range(n_inst):
@@ -518,38 +617,61 @@ def main():
     # images, multiview_fit_loss is evaluated on them, their gradients come back through the epilogue's adjoint.
     dropin = None
     if not args.materialise_images and not args.no_dropin:
-        fit2 = MultiViewFit(v, tri, tex, eyes, image_size=args.image_size, anti_aliasing=args.anti_aliasing, rank=rank,
-                            world_size=world, device=f"cuda:{local_rank}", objective_in_renderer=False,
-                            view_groups=args.view_groups)
-        fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
-        loss2, gv2, _ = fit2.step()
-        rel2 = float(torch.linalg.norm(gv2 - gv_eager) / (torch.linalg.norm(gv_eager) + 1e-20))
-        assert rel2 < 1e-3 and abs(float(loss2) - float(loss_eager)) <= 1e-4 * abs(float(loss_eager)), (rel2, loss2, loss_eager)
-        if graph_on:
-            fit2.capture_graph()
-        with _own_stream(fit2.stream):
-            for _ in range(args.warmup):
-                fit2.step()
-            regions2, _ = timed_repeats(fit2.step, barrier, max(1, args.repeats), args.steps)
-        regions2 = max_over_ranks(regions2)
-        el2 = float(np.median(regions2))
-        fit2.release_graph()
-        dropin = {"api": "Renderer.render + multiview_fit_loss + backward",
-                  "value": round(n_views * args.image_size ** 2 / (el2 / args.steps) / 1e6, 2), "unit": "Mpix/s",
-                  "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                  "ms_per_step_min": round(min(regions2) / args.steps * 1e3, 4),
-                  "ms_per_step_max": round(max(regions2) / args.steps * 1e3, 4)}
-        del fit2
+        fit2, r2 = measure(args.mesh_n, args.image_size, n_views, args.steps, args.warmup, args.repeats,
+                           objective_in_renderer=False, share=fit, want_graph=graph_on)
+        rel2 = float(torch.linalg.norm(r2["gv_eager"] - res["gv_eager"]) / (torch.linalg.norm(res["gv_eager"]) + 1e-20))
+        assert rel2 < 1e-3 and abs(r2["loss_eager"] - res["loss_eager"]) <= 1e-4 * abs(res["loss_eager"]), (rel2, r2["loss_eager"])
+        dropin = {"api": "Renderer.render + multiview_fit_loss + backward", "value": round(r2["value"], 2), "unit": "Mpix/s",
+                  "ms_per_step": round(r2["ms_per_step"], 4), "ms_per_step_min": round(r2["ms_per_step_min"], 4),
+                  "ms_per_step_max": round(r2["ms_per_step_max"], 4),
+                  "over_fused": round(r2["ms_per_step"] / res["ms_per_step"], 4)}
+        del fit2, r2
+    split_exchange = res["split_exchange"]
+    del fit
+    torch.cuda.empty_cache()
+
+    # N > 1: the STRONG-scaling lines of BASELINE.json's sharded configurations ride in the same JSON line (the contract is
+    # one line per run): config 4 = 32 cameras in all of the 100k mesh @512 (when this run is not that already), config 5 =
+    # 256 cameras of the 1M-triangle mesh @1024.  Fewer steps; per-GPU shards above 64 views of config 5 are not run (a
+    # 128-view shard holds ~75 GB of per-view scratch: a memory sweep is not what a bench run is for).
+    strong = None
+    if world > 1 and args.strong_lines and (args.mesh_n, args.image_size) == (225, 512):
+        strong = {}
+        todo = [("config4", 225, 512, 32, args.steps, args.warmup, args.repeats),
+                ("config5", 709, 1024, 256, max(2, args.steps // 4), 2, max(1, args.repeats // 2))]
+        for name, mesh_n, size, total, k, w, reps in todo:
+            per = shard_views(total, 0, world)[1]
+            if args.scaling == "strong" and (mesh_n, size, total) == (args.mesh_n, args.image_size, n_views):
+                strong[name] = {"same_as": "this line"}
+                continue
+            if per > 64:
+                strong[name] = {"skipped": f"{per} cameras per GPU at {world} GPUs (run where a shard is <= 64 cameras)"}
+                continue
+            try:
+                f3, r3 = measure(mesh_n, size, total, k, w, reps)
+                strong[name] = {"scaling": "strong", "total_views": total, "views_per_gpu": r3["views_per_rank"],
+                                "triangles": r3["F"], "image_size": size, "steps": k, "warmup": w,
+                                "value": round(r3["value"], 2), "unit": "Mpix/s", "ms_per_step": round(r3["ms_per_step"], 4),
+                                "ms_per_step_min": round(r3["ms_per_step_min"], 4),
+                                "ms_per_step_max": round(r3["ms_per_step_max"], 4), "split_exchange": r3["split_exchange"]}
+                del f3, r3
+                torch.cuda.empty_cache()
+            except Exception as e:          # never lose the headline line to a secondary one
+                strong[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         lib_path, lib_sha = library_identity()
-        V, F, S, ts = v.shape[0], tri.shape[0], args.image_size, args.texture_size
-        ms_per_step = elapsed / args.steps * 1e3
-        pix = n_views * S * S
-        value = pix / (elapsed / args.steps) / 1e6
+        V, F, S, ts = res["V"], res["F"], args.image_size, args.texture_size
+        ms_per_step = elapsed_step * 1e3
+        value = res["value"]
         Si = 2 * S if args.anti_aliasing else S                       # internal raster size
+        api = ("render+loss" if args.materialise_images else
+               ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"))
         a_fwd, a_bwd = algorithmic_bytes(V, F, Si, S, ts)
-        step_bytes = (a_fwd + a_bwd) * args.views_per_gpu
+        o_fwd, o_bwd = owed_bytes(V, F, Si, S, ts, api)
+        # the whole job's bytes over the whole job's peak (N GPUs): per GPU when the shards are equal
+        step_bytes = (a_fwd + a_bwd) * n_views
+        step_owed = (o_fwd + o_bwd) * n_views
         # dominant kernel = largest summed duration in the instrumented pass
         per_kernel = {k: (c, ms) for k, (c, ms) in ktimes.items()}
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
@@ -567,48 +689,67 @@ def main():
                     "duration_source": "HIP events around every launch of an eager pass of the same step, after the "
                                        "timed region (a replayed graph cannot carry events)",
                     "algorithmic_bytes_per_launch": kb * args.views_per_gpu}
+            # the same fraction from the COMMITTED rocprofv3 average of this kernel (profiles/: graph replays of this very
+            # command), so that the line and profiles/ can be compared without a footnote; not measured by this run
+            rp_us, rp_src = rocprof_average_us(dom)
+            if rp_us and (args.mesh_n, S, args.views_per_gpu) == (225, 512, 32):
+                roof["avg_launch_us_rocprof"] = round(rp_us, 2)
+                roof["frac_rocprof"] = round(kb * args.views_per_gpu / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                roof["rocprof_source"] = rp_src
             # The kernel is not bandwidth-bound: what fraction of its duration the counted VALU
             # instructions need on 256 CUs x 4 SIMD-32 at 2.4 GHz, TWO cycles per wave64 instruction (MI355X_MICROARCH.md,
             # "Wave scheduling": a SIMD takes a wave's 64 lanes over 2 cycles, one wave alone issues every 4; packed-f32
-            # and transcendental instructions cost twice that and are counted once here).  Informational.  (Up to round
-            # 4's first profiles this field assumed 4 cycles and read twice as high.)
+            # and transcendental instructions cost twice that and are counted once here).  Informational.
             valu, valu_src = measured_valu(dom)
             if valu:
                 roof["valu_wave_instructions"] = valu
                 roof["valu_source"] = valu_src
                 roof["valu_issue_frac"] = round(valu * 2 / (1024 * 2.4e9) / dom_avg_s, 3)
+        n_launch = sum(c for c, _ in per_kernel.values()) / n_inst
         out = {
             "metric": ("rendered Mpix/s fwd+bwd, 100k-tri mesh @512x512" if (args.mesh_n, S) == (225, 512) else
                        f"rendered Mpix/s fwd+bwd, {F}-tri mesh @{S}x{S}"), "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             # value / ms_per_step: the MEDIAN of `repeats` barrier-bracketed regions of `steps` steps each
-            "repeats": len(regions), "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
-            "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "repeats": len(regions), "ms_per_step_min": round(res["ms_per_step_min"], 4),
+            "ms_per_step_max": round(res["ms_per_step_max"], 4),
             "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
             "library": lib_path, "library_sha16": lib_sha, "dev_switches": dev_switches,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"multi-view fit: grid_mesh({args.mesh_n}) = {F} triangles / {V} vertices, "
-                                   f"{args.views_per_gpu} look_at cameras per GPU @ {S}x{S}, render(rgb+depth+alpha) "
+                                   + (f"{args.views_per_gpu} look_at cameras per GPU" if args.scaling == "weak" else
+                                      f"{n_views} look_at cameras in all, {res['views_per_rank']} per GPU")
+                                   + f" @ {S}x{S}, render(rgb+depth+alpha) "
                                    f"+ photometric/silhouette/depth loss + backward (vertex+texture grads)"
                                    + ("; output images materialised, objective evaluated on them"
                                       if args.materialise_images else
                                       "; the objective is evaluated in the pass that produces the pixel values "
                                       "(MultiViewFit.fit_loss), the rendered images stay in the internal HWC maps")
                                    + (", RCCL all-reduce of grads" if world > 1 else ""),
-                       "api": "render+loss" if args.materialise_images else
-                              ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"),
-                       "views_per_gpu": args.views_per_gpu, "total_views": n_views, "triangles": int(F), "image_size": S,
+                       "api": api,
+                       "views_per_gpu": args.views_per_gpu, "views_per_rank": res["views_per_rank"], "total_views": n_views,
+                       "triangles": int(F), "image_size": S,
                        "texture_size": ts, "fill_back": True, "anti_aliasing": bool(args.anti_aliasing), "hip_graph": graph_on, "view_groups": args.view_groups, "objective_in_renderer": not args.materialise_images,
                        "parallelism": f"camera-sharded x{world}",
                        "exchange": ("none (one rank)" if not dist_on else
                                     "two all-reduces per step: texture gradient (started between the step's two HIP graphs, "
-                                    "travels beside the edge gradient) | loss + vertex gradient" if fit.split_exchange else
+                                    "travels beside the edge gradient) | loss + vertex gradient" if split_exchange else
                                     "one all-reduce of [loss | vertex | texture gradients] behind the step")},
-            "hbm_roofline_frac_step": round(step_bytes / (elapsed / args.steps) / 8e12, 5),
+            # what the process group really was (gathered through the collective backend before the timed region)
+            "world_size_seen": world_seen, "collective_backend": backend_seen, "ranks": ranks_seen,
+            "launches_per_step": n_launch,
+            # section 8(d)'s bytes of all views over the time and the peak of all GPUs ...
+            "hbm_roofline_frac_step": round(step_bytes / elapsed_step / (8e12 * world), 5),
+            # ... and the bytes the timed api really owes (render_fit_loss writes no output images and reads no image
+            # gradients: 2 x 20 B per output pixel less than 8(d) counts)
+            "hbm_roofline_frac_step_owed": round(step_owed / elapsed_step / (8e12 * world), 5),
+            "algorithmic_bytes_per_step": step_bytes, "owed_bytes_per_step": step_owed,
             "kernel_ms_per_step": {k: round(ms / n_inst, 4) for k, (c, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1])},
             "roofline": roof,
             "dropin": dropin,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mesh_n, S, ts)
         print(json.dumps(out))

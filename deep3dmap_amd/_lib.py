@@ -215,10 +215,23 @@ class coverage_form:
         return False
 
 
+ZERO_RANGES_MAX = 6       # FILL_RANGES of csrc/d3m_launch.h
+
+
 def zero_(*tensors):
-    """Zero-fill up to six contiguous device tensors with one launch (d3m_zero_ranges); returns them."""
-    ts = [t for t in tensors if t is not None and t.numel() > 0]
-    if ts:
+    """Zero-fill contiguous device tensors, up to six per launch (d3m_zero_ranges); returns them.  The kernel takes raw
+    (pointer, byte count) ranges of whole 4-byte words: a tensor that is not contiguous (its data_ptr + numel would
+    cover its neighbours) or whose size is not a multiple of four bytes is cleared by torch instead."""
+    raw = []
+    for t in tensors:
+        if t is None or t.numel() == 0:
+            continue
+        if t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0:
+            raw.append(t)
+        else:
+            t.zero_()
+    for at in range(0, len(raw), ZERO_RANGES_MAX):
+        ts = raw[at:at + ZERO_RANGES_MAX]
         ptrs = (_P * len(ts))(*[t.data_ptr() for t in ts])
         sizes = (_SZ * len(ts))(*[t.numel() * t.element_size() for t in ts])
         check(lib().d3m_zero_ranges(ptrs, sizes, len(ts), stream_ptr()), "d3m_zero_ranges")

@@ -148,13 +148,30 @@ class _FitLossOnLitImages(torch.autograd.Function):
     def backward(ctx, g):
         link = ctx.link
         link.grad_loss = f32c(g).reshape(1)
-        link.pending = True
         link.images = ctx.saved_tensors         # lent until the render node's backward has run (see LitImagesLink)
+        if any(_observed(t) for t in ctx.saved_tensors):
+            # somebody looks at the images' gradients (retain_grad / register_hook set after the loss was built): zero-stride
+            # zeros would be what they see -- hand out the objective's real gradient images instead (no records route)
+            g_rgb, g_alpha, g_depth = link.add_gradient_images(None, None, None)
+            link.images = None
+            return g_rgb, g_depth, g_alpha, None, None, None, None, None, None
+        link.pending = True
+        # `pending` belongs to THIS backward pass.  If the render node is not part of it (torch.autograd.grad(loss, rgb),
+        # backward(inputs=[rgb])), the dummies below are what the caller receives -- silently wrong -- and a later,
+        # unrelated backward through the render node would find the stale flag and add this objective's gradient to a loss
+        # that never contained it.  The engine calls this at the end of the pass: a flag still set then is an error, and is
+        # cleared either way.
+        torch.autograd.Variable._execution_engine.queue_callback(link.end_of_pass)
         g_rgb, g_depth, g_alpha = link.dummies()
         return g_rgb, g_depth, g_alpha, None, None, None, None, None, None
 
 
-def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum=None):
+def _observed(t):
+    """whether a tensor's gradient is looked at from outside the graph: retain_grad() or a tensor hook"""
+    return torch.is_tensor(t) and (t.retains_grad or bool(getattr(t, "_backward_hooks", None)))
+
+
+def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum=None, link=True):
     """photometric_loss(rgb, rgb_target, mask) + silhouette_loss(alpha, alpha_target) / (H*W) +
     photometric_loss(depth, depth_target, mask): the multi-view fit objective as ONE autograd node (a reduction and a
     finish launch forward, one gradient launch backward) instead of three loss nodes and their eager glue.
@@ -163,8 +180,11 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
     of a camera-sharded objective (deep3dmap_amd/multiview.py).
 
     When rgb, depth and alpha are the three images of one Renderer.render() call (NR/renderer.py:200-246) on the lit path
-    without anti-aliasing, the objective's gradient never exists as images: see _FitLossOnLitImages."""
-    if torch.is_grad_enabled() and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    without anti-aliasing, the objective's gradient never exists as images: see _FitLossOnLitImages.  That route is not
+    taken when an image's gradient is observed (retain_grad, tensor hooks) or with `link=False`; asking autograd for the
+    gradient with respect to the images themselves WITHOUT back-propagating through the render node
+    (torch.autograd.grad(loss, rgb)) needs `link=False` and raises otherwise."""
+    if link and torch.is_grad_enabled() and not any(_observed(x) for x in (rgb, depth, alpha)) and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
                                        for x in (rgb, depth, alpha)):
         from ..neural_renderer.rasterize import lit_images_link
         lit = lit_images_link(rgb, depth, alpha)

@@ -19,11 +19,16 @@ from .core.losses import multiview_fit_loss, photometric_loss, silhouette_loss
 
 
 def shard_views(n_views, rank, world_size):
-    """Contiguous split: rank r owns views [r*n/R, (r+1)*n/R)."""
-    if n_views % world_size != 0:
-        raise ValueError(f"{n_views} views do not split evenly over {world_size} ranks")
-    per = n_views // world_size
-    return rank * per, (rank + 1) * per
+    """Contiguous split of the cameras: rank r owns views [lo, hi).  A camera count that does not divide leaves its
+    remainder with the LOW ranks (the first n % R ranks take one camera more), so shard sizes differ by at most one and
+    rank 0 always holds a largest shard.  Every rank needs at least one camera."""
+    if world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} of {world_size}")
+    if n_views < world_size:
+        raise ValueError(f"{n_views} views cannot be shared among {world_size} ranks (every rank renders at least one)")
+    per, extra = divmod(n_views, world_size)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
 
 
 COLLECTIVES_WITH_ONE_RANK = False      # debug (bench.py D3M_BENCH_FORCE_DIST): issue the collective even in a group of one
@@ -142,9 +147,12 @@ class MultiViewFit:
         # about what its collective takes -- no gain there, so the small shards keep the one-graph step.
         if split_exchange is None:
             from .neural_renderer.rasterize import _serial_branches
+            # (decided on the LARGEST shard, rank 0's: the ranks of one job must agree on the form of the exchange --
+            #  with shards of unequal size a per-rank decision could pair one rank's two collectives with another's one)
+            n_largest = shard_views(len(eyes), 0, world_size)[1]
             split_exchange = (os.environ.get("D3M_SPLIT_EXCHANGE", "1") != "0" and
                               (world_size > 1 or COLLECTIVES_WITH_ONE_RANK) and
-                              _serial_branches(self.n_local, self.triangles.shape[0], image_size * (2 if anti_aliasing else 1)))
+                              _serial_branches(n_largest, self.triangles.shape[0], image_size * (2 if anti_aliasing else 1)))
         self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
                                    and self.renderer._on_the_fly())
         self._manual = self._tex_work = None
@@ -242,7 +250,11 @@ class MultiViewFit:
         self._manual.backward_texture_side(self._one)
 
     def _start_texture_exchange(self):
+        """Between the step's two parts, never inside a capture.  One texture all-reduce is in flight at a time: a
+        collective still pending from the previous call (warm-up iterations, the call between the two captures) is
+        waited for before the buffer is handed to the next one."""
         nv = self.vertices.numel()
+        allreduce_wait(self._tex_work)
         self._tex_work = allreduce_sum_start(self._flat[1 + nv:])
 
     def _geometry_side(self):
@@ -260,6 +272,13 @@ class MultiViewFit:
         self.vertices.grad = None
         self.textures.grad = None
         self._runner.capture(warmup)
+        if self.split_exchange:
+            # capture() ran the callback between the parts for real (warm-up, and once between the two captures): that
+            # last in-place all-reduce of the texture part must have finished on EVERY rank before the first replay of
+            # part A writes the buffer again -- otherwise, under rank skew, it sums (and overwrites) the fresh gradient
+            allreduce_wait(self._tex_work)
+            self._tex_work = None
+            torch.cuda.synchronize(self.device)
         return self
 
     def release_graph(self):

@@ -284,6 +284,18 @@ class LitImagesLink:
     def dummies(self):
         return tuple(self.zero.expand(s) for s in self.shapes)
 
+    def end_of_pass(self):
+        """Queued by the loss node's backward on the autograd engine (queue_callback): runs when that backward pass ends.
+        `pending` still set = the render node was not part of the pass, so whoever asked for the images' gradients got
+        the zero-stride zeros: fail loudly, and never leave the flag (or the lent images) for a later, unrelated pass."""
+        stale, self.pending, self.images = self.pending, False, None
+        if stale:
+            raise RuntimeError(
+                "multiview_fit_loss was linked to the lit render node that produced its images, but this backward pass "
+                "stopped at the images (torch.autograd.grad(loss, images) / backward(inputs=images)): their gradient only "
+                "exists as the render node's walk records.  Build the loss with multiview_fit_loss(..., link=False) to "
+                "differentiate with respect to the images themselves.")
+
     def is_dummy(self, g):
         return g is not None and g.data_ptr() == self.zero.data_ptr() and all(st == 0 for st in g.stride())
 
@@ -400,7 +412,8 @@ class _RasterizeLit(torch.autograd.Function):
         G = len(groups)
         # Everything the branches write is allocated here, on the current stream: no tensor changes its owning stream.
         # Coverage comes straight from the indexed mesh: the binning pass reads the faces through `tri` and leaves the
-        # dense copy of the front-facing ones in `faces` (no vertices_to_faces pass); culled entries are never read.
+        # dense copy of those that can own a pixel in `faces` (no vertices_to_faces pass); every other entry stays
+        # UNINITIALISED (torch.empty: possibly NaN) and is never read -- later passes only touch pixel owners.
         faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
         m = {"face_index_map": torch.empty((B, S, S), dtype=torch.int32, device=dev),
              "weight_map": torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),
@@ -679,6 +692,9 @@ class _RasterizeLit(torch.autograd.Function):
                 auxs[k].wait_stream(cur)
             if swap:
                 mains[k].wait_event(m["vis_ready"])
+                # the line walk reads the plan: recorded on this very stream when backward runs under the stream forward
+                # forked from (autograd restores it; the wait is then a no-op), an ordering edge otherwise
+                auxs[k].wait_event(plan_ready[k])
             elif plan_ready is not None:
                 mains[k].wait_event(plan_ready[k])       # the forward's open branch: visibility + plan of this group
         for k, (lo, hi) in enumerate(groups):

@@ -99,9 +99,11 @@ int d3m_forward_face_index_map(const float* faces, int32_t* face_index_map, floa
 /* d3m_forward_face_index_map on an INDEXED mesh (an addition): vertices [B,V,3] (screen space), tri [Bt,Ft,3]
  * (Bt = 1: shared), fill_back appends the reversed-winding copies (renderer.py:86), i.e. num_faces =
  * (fill_back ? 2 : 1) * num_tri.  The faces are read through the indices and faces_out [B,num_faces,3,3] receives
- * the dense copy of every FRONT-FACING face -- what vertices_to_faces would have produced for the faces any later
- * operator can touch -- so the gather needs no pass of its own.  Workspace as d3m_forward_workspace_bytes(B,
- * num_faces, S). */
+ * the dense copy of the faces that CAN OWN A PIXEL -- front-facing, and with a pixel centre inside their (dilated) box:
+ * what vertices_to_faces would have produced for the faces any later operator can touch -- so the gather needs no
+ * pass of its own.  Every other entry of faces_out is left UNDEFINED (whatever the buffer held: it may be NaN); a
+ * caller that sweeps the whole array must fill it first, or use d3m_gather_faces.  Workspace as
+ * d3m_forward_workspace_bytes(B, num_faces, S). */
 int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, int tri_batch, int num_vertices,
                                     int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,

@@ -60,7 +60,7 @@ def test_sharded_fit_equals_unsharded_with_graph_replay(tmp_path, world, materia
             assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (r, k, np.abs(a - b).max(), np.abs(b).max())
 
 
-def _bench(world, scaling, extra=()):
+def _bench(world, scaling, extra=(), bare=False):
     """bench.py exactly as the driver launches it -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` for N > 1 -- in FRESH child processes, with the two
     debug switches that let N ranks share this box's one GPU (every rank on device 0, gloo instead of RCCL)."""
@@ -70,7 +70,9 @@ def _bench(world, scaling, extra=()):
         env.pop(k, None)
     args = ["--gpus", str(world), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-dropin", "--scaling", scaling,
             *extra]
-    if world == 1:
+    if not bare and "--no-strong-lines" not in args:
+        args.append("--no-strong-lines")
+    if world == 1 or bare:      # bare: `python bench.py --gpus N` -- bench.py launches torch.distributed.run itself
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
@@ -102,6 +104,26 @@ def test_bench_two_ranks_through_torch_distributed_run(scaling):
     assert two["metric"] == one["metric"] and two["unit"] == "Mpix/s"
     assert two["value"] == pytest.approx(two["config"]["total_views"] * 512 * 512 / (two["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert 0.01 * one["value"] < two["value"] < 2.5 * one["value"], (one["value"], two["value"])
+    # what the process group really was: two ranks, their devices (both on this box's one GPU here), the backend
+    assert two["world_size_seen"] == 2 and [r["rank"] for r in two["ranks"]] == [0, 1] and "gloo" in two["collective_backend"]
+    assert all(r["uuid"] and r["pid"] for r in two["ranks"]) and two["ranks"][0]["pid"] != two["ranks"][1]["pid"]
+    assert one["world_size_seen"] == 1 and len(one["ranks"]) == 1
+    assert "hbm_roofline_frac_step_owed" in two and two["hbm_roofline_frac_step_owed"] < two["hbm_roofline_frac_step"]
+
+
+def test_bench_bare_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (the form the driver uses for N = 1): bench.py starts the
+    two ranks itself through torch.distributed.run, before touching the GPU, and relays rank 0's ONE line -- weak scaling
+    with the strong-scaling figures of BASELINE configs 4 (32 cameras in all: 16 per rank) riding in it; config 5's
+    128-camera shards are named as not run.  An odd camera count splits 3 + 2."""
+    two = _bench(2, "weak", bare=True)
+    assert two["n_gpus"] == 2 and two["world_size_seen"] == 2 and len(two["ranks"]) == 2
+    assert two["config"]["views_per_gpu"] == 32 and two["config"]["total_views"] == 64
+    st = two["strong_scaling"]
+    assert st["config4"]["total_views"] == 32 and st["config4"]["views_per_gpu"] == [16, 16] and st["config4"]["value"] > 0
+    assert "skipped" in st["config5"]
+    odd = _bench(2, "strong", extra=("--total-views", "5", "--no-strong-lines"), bare=True)
+    assert odd["config"]["views_per_rank"] == [3, 2] and odd["config"]["total_views"] == 5 and odd["value"] > 0
 
 
 def test_bench_one_rank_through_rccl():

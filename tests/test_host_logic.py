@@ -142,8 +142,18 @@ def test_shard_views_and_synthetic_workloads():
     from deep3dmap_amd import synthetic
     from deep3dmap_amd.multiview import shard_views
     assert [shard_views(32, r, 4) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    # a camera count that does not divide: the remainder goes to the low ranks, shards stay contiguous and complete
+    assert [shard_views(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_views(8, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    for n, w in ((32, 8), (33, 8), (7, 7), (256, 8), (5, 3)):
+        parts = [shard_views(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [hi - lo for lo, hi in parts]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True) and min(sizes) >= 1
     with pytest.raises(ValueError):
-        shard_views(10, 0, 4)
+        shard_views(3, 0, 4)                # fewer cameras than ranks
+    with pytest.raises(ValueError):
+        shard_views(8, 4, 4)
     v, t = synthetic.grid_mesh(225)
     assert v.shape == (50625, 3) and t.shape == (100352, 3) and t.dtype == np.int32
     assert t.min() == 0 and t.max() == 50624 and np.abs(v).max() <= 1.0 + 1e-6
@@ -240,7 +250,7 @@ assert torch.equal(out_t, torch.arange(4.0).reshape(2, 2) * 36.0), out_t
 g = torch.Generator().manual_seed(5)
 n, hw = 8, 6
 rgb_t, alpha_t = torch.rand(n, 3, hw, hw, generator=g), (torch.rand(n, hw, hw, generator=g) > 0.4).float()
-alpha_t[:4] *= (torch.rand(4, hw, hw, generator=g) > 0.5).float()         # unequal masks across the two shards
+alpha_t[:4] *= (torch.rand(4, hw, hw, generator=g) > 0.5).float()         # unequal masks across the shards
 x0 = torch.rand(n, 3, hw, hw, generator=g)
 def objective(x, a, sl, den):
     return ((x[sl] - rgb_t[sl]).abs() * alpha_t[sl, None]).sum() / (3 * den) + ((a[sl] - alpha_t[sl]) ** 2).sum() / (hw * hw)
@@ -264,13 +274,15 @@ print("rank", rank, "ok")
 """
 
 
-def test_gradient_allreduce_world_size_2_gloo(tmp_path):
-    """N>1 path on CPU: two processes, gloo, camera shards -> one flat SUM all-reduce."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_gradient_allreduce_over_gloo(tmp_path, world):
+    """N>1 path on CPU: `world` processes, gloo, camera shards -> one flat SUM all-reduce.  World size 3: the 8 cameras do
+    not divide (shards of 3, 3 and 2) and the sharded objective still equals the unsharded one."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29529 + world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=120)[0] for p in procs]
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert all(f"rank {r} ok" in outs[r] for r in range(2))
+    assert all(f"rank {r} ok" in outs[r] for r in range(world))
