@@ -557,6 +557,7 @@ class _RasterizeLit(torch.autograd.Function):
         m["edge_plan"] = plan
         m["plan_ready"] = plan_ready
         m["vis_ready"] = vis_ready if plan_ready is not None else None
+        m["plan_stream"] = auxs[0]
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
@@ -692,9 +693,12 @@ class _RasterizeLit(torch.autograd.Function):
                 auxs[k].wait_stream(cur)
             if swap:
                 mains[k].wait_event(m["vis_ready"])
-                # the line walk reads the plan: recorded on this very stream when backward runs under the stream forward
-                # forked from (autograd restores it; the wait is then a no-op), an ordering edge otherwise
-                auxs[k].wait_event(plan_ready[k])
+                # the line walk reads the plan.  Backward normally runs under the stream forward forked from (autograd
+                # restores it), so auxs[k] IS the stream the plan was recorded on and needs no edge -- and must not get
+                # one: a wait on an event of the waiting stream itself inside a capture makes hipStreamEndCapture segfault
+                # (ROCm 7.2).  Driven under another current stream the side stream is another object: then it waits.
+                if auxs[k].cuda_stream != m["plan_stream"].cuda_stream:
+                    auxs[k].wait_event(plan_ready[k])
             elif plan_ready is not None:
                 mains[k].wait_event(plan_ready[k])       # the forward's open branch: visibility + plan of this group
         for k, (lo, hi) in enumerate(groups):

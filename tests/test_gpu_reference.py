@@ -28,6 +28,30 @@ def _rel_max(got, ref):
     return float((got.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
+ELEM_RTOL, ELEM_ATOL_OF_MAX = 1e-3, 1e-5     # element-wise: |d| <= 1e-3 |ref| + 1e-5 max|ref|
+ELEM_VIOLATING_FRAC = 1e-5                  # ... for all but this fraction of the entries
+
+
+def _grad_stats(got, ref):
+    """How a gradient tensor's error is DISTRIBUTED (a bound relative to the largest entry alone lets
+    an entry 100x below the maximum be off by 4 %): the largest deviation over the largest entry, the fraction of entries
+    violating |d| <= 1e-3 |ref| + 1e-5 max|ref|, the 99.9th percentile and the maximum of |d| / (|ref| + 1e-5 max|ref|)
+    over the entries the reference writes, and where the worst entry sits."""
+    got, ref = got.float().reshape(-1), ref.float().reshape(-1)
+    scale = float(ref.abs().max().clamp_min(1e-30))
+    d = (got - ref).abs()
+    viol = d > ELEM_RTOL * ref.abs() + ELEM_ATOL_OF_MAX * scale
+    nz = ref != 0
+    rel = (d[nz] / (ref[nz].abs() + ELEM_ATOL_OF_MAX * scale)).sort().values
+    worst = int(d.argmax())
+    return {"rel_max": float(d.max() / scale), "violating_frac": float(viol.float().mean()),
+            "violating_frac_of_written": float(viol[nz].float().mean()) if int(nz.sum()) else 0.0,
+            "rel_p999": float(rel[min(rel.numel() - 1, int(0.999 * rel.numel()))]) if rel.numel() else 0.0,
+            "rel_elementwise_max": float(rel[-1]) if rel.numel() else 0.0, "entries": int(ref.numel()),
+            "entries_written": int(nz.sum()), "worst_index": worst,
+            "worst_ref_over_max": float(ref[worst].abs() / scale), "worst_rel_to_itself": float(d[worst] / ref[worst].abs().clamp_min(1e-30))}
+
+
 # ------------------------------------------------------------------------------------------------------------
 # 1. the CPU oracle (port) is the reference: fresh random scenes, port vs device reference, every kernel
 # ------------------------------------------------------------------------------------------------------------
@@ -80,6 +104,13 @@ def _product_forward(faces, tex, S, near, far, eps, background):
 def _product_backward(faces, tex, m, S, eps, g_rgb, g_alpha, g_depth):
     from deep3dmap_amd.neural_renderer.rasterize import _raster_backward
     return _raster_backward(faces, tex, m, S, eps, g_rgb, g_alpha, g_depth, True, True, True, True)
+
+
+def _raster_backward_parts(faces, tex, m, S, eps, g_rgb, g_alpha, g_depth):
+    """the product's backward with only some of the output gradients (K4 alone / K6 alone)"""
+    from deep3dmap_amd.neural_renderer.rasterize import _raster_backward
+    rr, rd = g_rgb is not None, g_depth is not None
+    return _raster_backward(faces, tex, m, S, eps, g_rgb, g_alpha, g_depth, rr, rr, rd, False)
 
 
 def _assert_maps_equal(m, ref, keys=("face_index_map", "weight_map", "depth_map", "rgb_map", "alpha_map")):
@@ -229,7 +260,28 @@ def _full_size_check(faces, S, ts, form, ran, seed, textures_batch=None):
     assert torch.isfinite(gf_ref).all() and torch.isfinite(gf).all()
     errs = {"grad_faces": _rel_max(gf, gf_ref), "grad_textures": _rel_max(gt, gt_ref)}
     assert errs["grad_faces"] <= GRAD_RTOL and errs["grad_textures"] <= GRAD_RTOL, errs
-    del gf, gt, gf_ref, gt_ref, g_rgb, g_alpha, g_depth
+    # ... and element by element (recorded per configuration and form in the parity file)
+    dist = {"grad_faces": _grad_stats(gf, gf_ref), "grad_textures": _grad_stats(gt, gt_ref)}
+    # which operator the face gradient's error belongs to: K4 alone (rgb + alpha gradients; x, y entries) and K6 alone
+    # (depth gradient); and what kind of face carries the worst entry (its area in pixels: K4 divides by edge lengths,
+    # K6 by the inverse's determinant)
+    gf4_ref, _ = RH.backward(ref, g_rgb, g_alpha, None, True, True, False)
+    gf4, _ = _raster_backward_parts(faces, tex, m, S, eps, g_rgb, g_alpha, None)
+    dist["grad_faces_K4_alone"] = _grad_stats(gf4, gf4_ref)
+    gf6_ref, _ = RH.backward(ref, None, None, g_depth, False, False, True)
+    gf6, _ = _raster_backward_parts(faces, tex, m, S, eps, None, None, g_depth)
+    dist["grad_faces_K6_alone"] = _grad_stats(gf6, gf6_ref)
+    f_worst = dist["grad_faces"]["worst_index"] // 9
+    fw = faces.reshape(-1, 3, 3)[f_worst].double()
+    area_px = float(((fw[1, 0] - fw[0, 0]) * (fw[2, 1] - fw[0, 1]) - (fw[2, 0] - fw[0, 0]) * (fw[1, 1] - fw[0, 1])).abs() * S * S / 8)
+    dist["worst_face"] = {"face": int(f_worst % Fp), "view": int(f_worst // Fp), "area_px": area_px,
+                          "pixels_owned": int((ref["face_index_map"].reshape(B, -1)[f_worst // Fp] == f_worst % Fp).sum()),
+                          "entry": int(dist["grad_faces"]["worst_index"] % 9),
+                          "K4_err_there": float((gf4 - gf4_ref).reshape(-1)[dist["grad_faces"]["worst_index"]].abs()),
+                          "K6_err_there": float((gf6 - gf6_ref).reshape(-1)[dist["grad_faces"]["worst_index"]].abs())}
+    for name in ("grad_faces", "grad_textures"):
+        assert dist[name]["violating_frac"] <= ELEM_VIOLATING_FRAC, (name, dist[name])
+    del gf, gt, gf_ref, gt_ref, g_rgb, g_alpha, g_depth, gf4, gf4_ref, gf6, gf6_ref
     # INFORMATIONAL: the default (FMA-contracted) build of the same reference text -- what a stock build of its setup.py
     # computes.  The reference's arithmetic is ill-conditioned on small / sliver triangles (face_inv divides by twice
     # the signed area, KCU:52-61; a 1-pixel triangle's barycentrics amplify one ulp of its vertices by ~1e3), so its own
@@ -250,7 +302,8 @@ def _full_size_check(faces, S, ts, form, ran, seed, textures_batch=None):
              "fma_weight_max": float(d_w.max())}
     assert flipped < 1e-3 and stats["fma_depth_median"] < 1e-5 and stats["fma_depth_over_1e-4_frac"] < 5e-3, stats
     return {"coverage": cov, "pixels": B * S * S, "faces": Fp, "mismatched_pixels": mismatched, "coverage_form": ran,
-            "coverage_kernels": sorted(n for n in k.names if n.startswith(("k_bin", "k_bid", "k_raster"))), **stats, **errs}
+            "coverage_kernels": sorted(n for n in k.names if n.startswith(("k_bin", "k_bid", "k_raster"))), **stats, **errs,
+            "gradient_error_distribution": dist}
 
 
 def test_config4_nine_views_against_reference(coverage):

@@ -156,9 +156,74 @@ def _rel_max(a, b):
 IMG_TOL, GRAD_TOL = 2e-6, 1e-3
 
 
+def _record_association(name, info):
+    """one case's numbers into gpurun_out/camera_association.json (copied to profiles/ by hand)"""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "camera_association.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[name] = info
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+class _association:
+    """The oracle's cameras in the product's f32 association ("product": oracle.nr_oracle.EXACT, the default -- both
+    sides rasterize bit-identical vertices) or in torch's = the reference modules' own (NR/look_at.py:48-60,
+    NR/projection.py:19-42: "reference") -- the independent end-to-end pin of the camera stage (missing 3)."""
+
+    def __init__(self, which):
+        self.exact = which == "product"
+
+    def __enter__(self):
+        from oracle import nr_oracle as O
+        self.saved, O.EXACT = O.EXACT, self.exact
+
+    def __exit__(self, *exc):
+        from oracle import nr_oracle as O
+        O.EXACT = self.saved
+        return False
+
+
+FLIP_FRAC, AWAY_IMG_TOL = 5e-4, 1e-4       # reference association: flipped pixels, and image error away from them
+
+
+def _compare_end_to_end(ref, got, association, name):
+    """ref / got = [rgb, depth, alpha, loss, grad_vertices, grad_textures] of the oracle / the product."""
+    if association == "product":
+        assert torch.equal(ref[2], got[2])
+        assert _rel_max(got[0], ref[0]) < IMG_TOL and _rel_max(got[1], ref[1]) < IMG_TOL
+        assert abs(float(got[3] - ref[3])) / float(ref[3]) < 1e-5
+        assert _rel_max(got[5], ref[5]) < GRAD_TOL
+        assert _rel_max(got[4], ref[4]) < GRAD_TOL
+        return
+    # The reference's own association: vertices differ in the last bit, so a pixel centre within an ulp of an edge may
+    # change owner.  Count those (silhouette: alpha differs; interior: another face's texels), and hold everything
+    # else to 1e-4 (images) / 1e-3 (gradients; of a case in which no pixel flipped -- a flipped pixel's whole
+    # contribution moves, which is not an error of either side).
+    sil = ref[2] != got[2]
+    rgb_d = (got[0] - ref[0]).abs().amax(1)
+    interior = (~sil) & (rgb_d > 1e-3 * float(ref[0].abs().max()))
+    flipped = sil | interior
+    away = ~flipped
+    info = {"pixels": int(sil.numel()), "flipped_silhouette": int(sil.sum()), "flipped_interior": int(interior.sum()),
+            "rgb_err_away": float(rgb_d[away].max() / ref[0].abs().max()),
+            "depth_err_away": float(((got[1] - ref[1]).abs() / ref[1].abs().clamp_min(1e-6))[away].max()),
+            "loss_rel": abs(float(got[3] - ref[3])) / float(ref[3]),
+            "grad_vertices_rel_max": _rel_max(got[4], ref[4]), "grad_textures_rel_max": _rel_max(got[5], ref[5])}
+    _record_association(name, info)
+    assert int(flipped.sum()) <= max(2, FLIP_FRAC * flipped.numel()), info
+    assert info["rgb_err_away"] <= AWAY_IMG_TOL and info["depth_err_away"] <= AWAY_IMG_TOL, info
+    if not int(flipped.sum()):
+        assert info["grad_vertices_rel_max"] < GRAD_TOL and info["grad_textures_rel_max"] < GRAD_TOL, info
+    else:
+        assert info["grad_vertices_rel_max"] < 0.2 and info["grad_textures_rel_max"] < 0.2, info
+
+
+@pytest.mark.parametrize("association", ["product", "reference"])
 @pytest.mark.parametrize("camera", ["look_at", "look", "projection"])
 @pytest.mark.parametrize("aa", [False, True])
-def test_renderer_end_to_end_against_oracle(camera, aa):
+def test_renderer_end_to_end_against_oracle(camera, aa, association):
     nr = _nr()
     from oracle import nr_oracle as O
     v, tri, tex = _scene()
@@ -190,16 +255,15 @@ def test_renderer_end_to_end_against_oracle(camera, aa):
         loss.backward()
         return [x.detach().cpu() for x in (rgb, depth, alpha, loss, vv.grad, tt.grad)]
 
-    ref, got = run(ro, "cpu"), run(rg, "cuda")
-    assert torch.equal(ref[2], got[2])
-    assert _rel_max(got[0], ref[0]) < IMG_TOL and _rel_max(got[1], ref[1]) < IMG_TOL
-    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 1e-5
-    assert _rel_max(got[5], ref[5]) < GRAD_TOL
-    assert _rel_max(got[4], ref[4]) < GRAD_TOL
+    with _association(association):
+        ref = run(ro, "cpu")
+    got = run(rg, "cuda")
+    _compare_end_to_end(ref, got, association, f"end_to_end[{camera},aa={int(aa)}]")
 
 
+@pytest.mark.parametrize("association", ["product", "reference"])
 @pytest.mark.parametrize("seed", range(12))
-def test_renderer_differential_fuzz(seed):
+def test_renderer_differential_fuzz(seed, association):
     """Random meshes, cameras and settings through Renderer.render + a loss + backward on the lit path (fill_back and
     lighting on the fly, rasterization from the indexed mesh, side-stream branches, vertex-target gradients) against
     the oracle's Renderer: shared or per-view mesh, anti-aliasing on/off, several views, odd image sizes."""
@@ -238,12 +302,10 @@ def test_renderer_differential_fuzz(seed):
             gv, gt = gv.sum(0, keepdim=True), gt.sum(0, keepdim=True)
         return [x.detach().cpu() for x in (rgb, depth, alpha, loss, gv, gt)]
 
-    ref, got = run(O, "cpu", False), run(nr, "cuda", shared)
-    assert torch.equal(ref[2], got[2])
-    assert _rel_max(got[0], ref[0]) < IMG_TOL and _rel_max(got[1], ref[1]) < IMG_TOL
-    assert abs(float(got[3] - ref[3])) / float(ref[3]) < 1e-5
-    assert _rel_max(got[5], ref[5]) < GRAD_TOL
-    assert _rel_max(got[4], ref[4]) < GRAD_TOL
+    with _association(association):
+        ref = run(O, "cpu", False)
+    got = run(nr, "cuda", shared)
+    _compare_end_to_end(ref, got, association, f"fuzz[{seed}]")
 
 
 @pytest.mark.parametrize("mode", ["silhouettes", "depth", "rgb"])
@@ -780,3 +842,69 @@ def test_dropin_render_plus_fit_loss_takes_the_records_route():
         loss2, gv2, gt2 = fit2.step()
     assert abs(float(loss2) - float(loss0)) <= 1e-6 * abs(float(loss0)) and _rel_max(gv2, gv0) < 1e-5 and _rel_max(gt2, gt0) < 1e-5
     fit2.release_graph()
+
+
+def test_linked_fit_loss_with_observed_image_gradients():
+    """the linked objective returns zero-stride ZERO gradient images and sends the real gradient through the
+    link -- so nobody may be looking at those images' gradients.  retain_grad() / register_hook (before OR after the loss
+    is built) get the objective's real gradient images; torch.autograd.grad(loss, rgb) -- a pass that stops at the images --
+    fails loudly instead of returning zeros, needs link=False, and leaves NOTHING behind for a later backward through
+    the render node."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core.losses import _MultiViewFitLoss, multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(16)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=64)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    rgb_t, depth_t, alpha_t = fit.targets
+    args = (rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+
+    def reference():
+        fit.vertices.grad = fit.textures.grad = None
+        rgb, depth, alpha = fit.render()
+        for t in (rgb, depth, alpha):
+            t.retain_grad()
+        _MultiViewFitLoss.apply(rgb, depth, alpha, *args).backward()
+        return [t.grad.clone() for t in (rgb, depth, alpha)], fit.vertices.grad.clone(), fit.textures.grad.clone()
+    g_img, gv0, gt0 = reference()
+    assert all(float(g.abs().max()) > 0 for g in g_img)
+
+    # retain_grad BEFORE the loss is built: no link, real gradient images
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    rgb.retain_grad()
+    multiview_fit_loss(rgb, depth, alpha, *args).backward()
+    assert _rel_max(rgb.grad, g_img[0]) < 1e-6 and _rel_max(fit.vertices.grad, gv0) < 1e-5
+
+    # retain_grad / a hook AFTER the loss is built (the link exists): the loss node's backward hands out real images
+    for observe in ("retain", "hook"):
+        fit.vertices.grad = fit.textures.grad = None
+        rgb, depth, alpha = fit.render()
+        loss = multiview_fit_loss(rgb, depth, alpha, *args)
+        seen = []
+        if observe == "retain":
+            depth.retain_grad()
+        else:
+            depth.register_hook(lambda g: seen.append(g.clone()))
+        loss.backward()
+        got = depth.grad if observe == "retain" else seen[0]
+        assert _rel_max(got, g_img[1]) < 1e-6, observe
+        assert _rel_max(fit.vertices.grad, gv0) < 1e-5 and _rel_max(fit.textures.grad, gt0) < 1e-5, observe
+
+    # a pass that stops at the images: loud, not zeros; link=False is the way; and the next backward is clean
+    w = torch.randn_like(rgb_t)
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    loss = multiview_fit_loss(rgb, depth, alpha, *args)
+    with pytest.raises(RuntimeError, match="link=False"):
+        torch.autograd.grad(loss, rgb, retain_graph=True)
+    (rgb * w).mean().backward()                    # unrelated to the objective: nothing of it may be added
+    polluted = fit.vertices.grad.clone()
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    (rgb * w).mean().backward()
+    assert _rel_max(polluted, fit.vertices.grad) < 1e-5
+    rgb, depth, alpha = fit.render()
+    (g,) = torch.autograd.grad(multiview_fit_loss(rgb, depth, alpha, *args, link=False), rgb)
+    assert _rel_max(g, g_img[0]) < 1e-6
