@@ -18,6 +18,11 @@ class D3MCamera(ctypes.Structure):
                 ("rot_batch", _I), ("eye_batch", _I), ("K_batch", _I), ("dist_batch", _I)]
 
 
+class D3MBasis(ctypes.Structure):
+    _fields_ = [("eye", _P), ("at_or_direction", _P), ("up", _P), ("eye_batch", _I), ("at_batch", _I), ("up_batch", _I),
+                ("is_look_at", _I)]
+
+
 class D3MVertexTarget(ctypes.Structure):
     _fields_ = [("grad_vertices", _P), ("tri", _P), ("num_vertices", _I), ("num_tri", _I), ("tri_batch", _I),
                 ("fill_back", _I)]
@@ -26,7 +31,7 @@ class D3MVertexTarget(ctypes.Structure):
 class D3MFitTargets(ctypes.Structure):
     _fields_ = [("rgb_target", _P), ("depth_target", _P), ("alpha_target", _P), ("mask", _P), ("scratch", _P),
                 ("loss", _P), ("grad_rgb_map", _P), ("grad_alpha_map", _P), ("grad_depth_map", _P), ("grad_loss", _P),
-                ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P), ("defer_finish", _I)]
+                ("mask_sum", _P), ("edge_grad", _P), ("edge_dot", _P), ("edge_nz_lo_inv", _P), ("edge_nz_hi1", _P), ("flags", _I)]
 
 
 class D3MG2SBlock(ctypes.Structure):
@@ -47,6 +52,9 @@ class D3MG2SBlock(ctypes.Structure):
 
 
 CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
+PRECLEARED = 1            # D3M_PRECLEARED: the caller has zeroed what the operator would clear (include/d3m_raster.h, "Clears")
+FIT_FINISH_DEFERRED = 2   # D3M_FIT_FINISH_DEFERRED: the fused objective's finish is left to d3m_backward_textures_lit
+FRONT_RANGES = 10         # clears d3m_lit_front takes
 
 _SIGNATURES = {
     "d3m_version": (ctypes.c_char_p, []),
@@ -61,7 +69,8 @@ _SIGNATURES = {
     "d3m_get_coverage_form": (_I, []),
     "d3m_forward_coverage_form": (_I, [_I, _I, _I]),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
-    "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ, _P]),
+    "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ, _I, _P]),
+    "d3m_forward_clear_bytes": (_SZ, [_I, _I, _I, _I, _SZ]),
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
     "d3m_backward_pixel_map_workspace_min_bytes": (_SZ, [_I, _I, _I]),
@@ -69,7 +78,8 @@ _SIGNATURES = {
     "d3m_edge_plan_bytes": (_SZ, [_I, _I, _I]),
     "d3m_edge_plan_min_bytes": (_SZ, [_I, _I, _I]),
     "d3m_edge_plan_extents_offset": (_SZ, [_I, _I, _I, ctypes.POINTER(_SZ)]),
-    "d3m_edge_plan": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _I, _P]),
+    "d3m_edge_plan": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _I, _I, _P]),
+    "d3m_edge_plan_clear_bytes": (_SZ, [_I, _I, _I]),
     "d3m_visibility_bytes": (_SZ, [_I, _I]),
     "d3m_visibility": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),
     "d3m_backward_faces_workspace_bytes": (_SZ, [_I, _I]),
@@ -100,10 +110,14 @@ _SIGNATURES = {
     "d3m_render_lit_epilogue": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I,
                                      _P, _P]),
     "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
-    "d3m_fit_finish": (_I, [ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
+    "d3m_render_fit_scratch_clear_range": (_SZ, [_I, _I, ctypes.POINTER(_SZ)]),
     "d3m_fit_loss_records": (_I, [_P, _P, _P, _P, ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
-                                       _P, _P, _P, _P]),
+                                       _P, _P, _P, _I, _P]),
+    "d3m_backward_textures_lit_clear_ranges": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, ctypes.POINTER(_P),
+                                                    ctypes.POINTER(_SZ)]),
+    "d3m_lit_front": (_I, [_P, _I, ctypes.POINTER(D3MCamera), ctypes.POINTER(D3MBasis), _P, _I, _I, _P, _I, _I, _I, _P, _I,
+                           _F, _F, _P, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_SZ), _I, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_output_epilogue_backward_records": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -236,6 +250,22 @@ def zero_(*tensors):
         sizes = (_SZ * len(ts))(*[t.numel() * t.element_size() for t in ts])
         check(lib().d3m_zero_ranges(ptrs, sizes, len(ts), stream_ptr()), "d3m_zero_ranges")
     return tensors
+
+
+def zero_raw(ranges):
+    """Zero (device pointer, bytes) ranges -- 4-byte multiples -- with as few launches as d3m_zero_ranges allows."""
+    ranges = [(int(p), int(n)) for p, n in ranges if p and n]
+    for at in range(0, len(ranges), ZERO_RANGES_MAX):
+        part = ranges[at:at + ZERO_RANGES_MAX]
+        ptrs = (_P * len(part))(*[p for p, _ in part])
+        sizes = (_SZ * len(part))(*[n for _, n in part])
+        check(lib().d3m_zero_ranges(ptrs, sizes, len(part), stream_ptr()), "d3m_zero_ranges")
+
+
+def tensor_range(t):
+    """(device pointer, bytes) of a contiguous tensor whose size is a multiple of four bytes"""
+    assert t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0
+    return t.data_ptr(), t.numel() * t.element_size()
 
 
 def kernel_timing(enable):

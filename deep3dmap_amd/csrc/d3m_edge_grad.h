@@ -1553,9 +1553,9 @@ inline bool edge_plan_view(void* blob, size_t bytes, const VisibilityView& v, in
 
 template <class FS>
 inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const EdgePlan& w, void* blob, int B, int S,
-                                hipStream_t st) {
+                                hipStream_t st, bool cleared = false) {
     const EdgePlanLayout L = edge_plan_layout(B, fs.num_faces(), S);
-    hipError_t e = zero_async(blob, L.zero_bytes, st);
+    hipError_t e = cleared ? hipSuccess : zero_async(blob, L.zero_bytes, st);      // (cleared: by the caller, D3M_PRECLEARED)
     if (e != hipSuccess) return e;
     // the passes walk the compacted list with a fixed grid (n_visible is only known on the device); workgroups past
     // it leave on their first load

@@ -40,16 +40,46 @@ inline bool d3m_dev_skip(const char* name) {
 #else
 inline bool d3m_dev_skip(const char*) { return false; }
 #endif
+// D3M_TRACE_LAUNCHES=1 in the environment (debugging a hang; eager launches only, never inside a capture): every launch is
+// announced on stderr, the stream synchronised behind it and the result reported -- the last line names the kernel that
+// does not come back.
+#include <cstdio>
+#include <cstdlib>
+inline bool d3m_trace_launches() {
+    static const bool on = [] { const char* e = getenv("D3M_TRACE_LAUNCHES"); return e && e[0] == '1'; }();
+    return on;
+}
+#include <chrono>
+inline std::chrono::steady_clock::time_point g_trace_t0;
+inline void d3m_trace_begin(const char* name, dim3 g, dim3 b) {
+    if (d3m_trace_launches()) {
+        fprintf(stderr, "[d3m] launch %s grid (%u,%u,%u) block %u ... ", name, g.x, g.y, g.z, b.x);
+        fflush(stderr);
+        g_trace_t0 = std::chrono::steady_clock::now();
+    }
+}
+inline void d3m_trace_end(hipStream_t st) {
+    if (d3m_trace_launches()) {
+        hipError_t e = hipStreamSynchronize(st);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_t0).count();
+        fprintf(stderr, "%s (%.3f ms incl. the host round trip)\n", e == hipSuccess ? "done" : hipGetErrorString(e), ms);
+        fflush(stderr);
+    }
+}
 #define LAUNCH(name, kernel, grid, block, stream, ...)                          \
     do {                                                                        \
         LaunchTimer lt__(name, stream);                                         \
+        d3m_trace_begin(name, grid, block);                                     \
         if (!d3m_dev_skip(name)) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);        \
+        d3m_trace_end(stream);                                                  \
     } while (0)
 
 #define LAUNCH_SMEM(name, kernel, grid, block, smem, stream, ...)               \
     do {                                                                        \
         LaunchTimer lt__(name, stream);                                         \
+        d3m_trace_begin(name, grid, block);                                     \
         if (!d3m_dev_skip(name)) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);     \
+        d3m_trace_end(stream);                                                  \
     } while (0)
 
 // Zero-fill as a KERNEL (not hipMemsetAsync): inside a captured HIP graph a memset becomes a memset node, and on

@@ -8,6 +8,7 @@
 // colours are bit-identical.  The backward gathers per visible face (no atomics for ts == 2).
 #pragma once
 #include "d3m_aux.h"
+#include "d3m_tail.h"
 #include "d3m_face_major.h"
 
 namespace d3m {
@@ -209,6 +210,68 @@ struct FitTargets {
     float *g_rgb, *g_alpha, *g_depth;
 };
 
+// The objective's last step: per-workgroup partial sums -> totals and *loss, in two levels and in a FIXED order
+// (deterministic): workgroup g adds up the partials of group g (a view's tiles; 256 consecutive workgroups of the 1-D pass)
+// and publishes the sum (sc1) behind a ticket; the workgroup whose ticket is the last adds up the group sums -- nobody
+// waits (d3m_tail.h).  Round 4's one-workgroup kernel took 69 us on average (337 at worst) behind the 32768 partials of
+// BASELINE config 5.  Run either by k_fit_finish behind the pass that leaves the partials, or -- a caller that runs the
+// backward pass right behind the forward pass -- by the first workgroups of a kernel the backward pass launches anyway and
+// that normally has nothing to do (k_lit_large_faces): then it costs the step no launch at all.
+struct FitFin {
+    const float4* partials;   // NULL: nothing to finish
+    float4* group_sums;       // [n_groups]
+    unsigned* tickets;        // [1] ZEROED: groups done
+    int n_partials, group_size, n_groups;
+    float pixels;             // output pixels per view (the silhouette term's divisor)
+    const float* mask_sum;    // NULL: the batch's own sum of the mask
+    float* totals;            // [8]: the four sums, the objective
+    float* loss;
+};
+__device__ __forceinline__ float4 block_sum4_256(float4 v, float4* s_part /*[4]*/) {      // -> every thread
+    const float4 w = make_float4(wave_sum(v.x), wave_sum(v.y), wave_sum(v.z), wave_sum(v.w));
+    if (lane_id() == 0) s_part[threadIdx.x >> 6] = w;
+    __syncthreads();
+    float4 t = s_part[0];
+    for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+    __syncthreads();
+    return t;
+}
+// called by all 256 threads of workgroup `block` of a launch of `blocks` workgroups (uniformly)
+__device__ __forceinline__ void fit_finish_groups(const FitFin& f, unsigned block, unsigned blocks) {
+    __shared__ float4 s_part[4];
+    __shared__ int s_last;
+    for (unsigned g = block; g < (unsigned)f.n_groups; g += blocks) {
+        const int first = (int)g * f.group_size, size = min(f.group_size, f.n_partials - first);
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < size; i += 256) {
+            const float4 v = f.partials[first + i];           // (written by an earlier launch)
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc = block_sum4_256(acc, s_part);
+        if (threadIdx.x == 0) {
+            tail_store4(&f.group_sums[g], acc);               // sc1: read by another workgroup of this launch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = __hip_atomic_fetch_add(f.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)f.n_groups - 1;
+        }
+        __syncthreads();
+        if (!s_last) continue;                                // (uniform)
+        acc = make_float4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < f.n_groups; i += 256) {
+            const float4 v = tail_load4(&f.group_sums[i]);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc = block_sum4_256(acc, s_part);
+        if (threadIdx.x == 0) {
+            if (f.mask_sum) acc.z = *f.mask_sum;     // this batch is a shard: normalise by the mask of the whole objective
+            f.totals[0] = acc.x; f.totals[1] = acc.y; f.totals[2] = acc.z; f.totals[3] = acc.w;
+            const float l = (acc.x / (3.0f * acc.z) + acc.w / f.pixels) + acc.y / acc.z;
+            f.totals[4] = l;
+            *f.loss = l;
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_fit_finish(FitFin f) { fit_finish_groups(f, blockIdx.x, gridDim.x); }
+
 #ifndef D3M_EPI_MINWAVES
 #define D3M_EPI_MINWAVES 4
 #endif
@@ -298,14 +361,8 @@ __global__ void __launch_bounds__(256, D3M_EPI_MINWAVES) k_render_lit_epilogue(c
         }
     }
     if (fit.partials) {                                   // four wave sums (DPP), one exchange through LDS
-        const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
-        if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float4 t = s_part[0];
-            for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
-            reinterpret_cast<float4*>(fit.partials)[blockIdx.x] = t;
-        }
+        const float4 t = block_sum4_256(make_float4(t_rgb, t_d, t_m, t_sse), s_part);
+        if (threadIdx.x == 0) reinterpret_cast<float4*>(fit.partials)[blockIdx.x] = t;
     }
 }
 
@@ -421,15 +478,10 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
         atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
         atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);
     }
-    // four wave sums (DPP), one exchange through LDS
-    const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
-    if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float4 t = s_part[0];
-        for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+    // four wave sums (DPP), one exchange through LDS (a view's tiles are consecutive: one group of the finish)
+    const float4 t = block_sum4_256(make_float4(t_rgb, t_d, t_m, t_sse), s_part);
+    if (threadIdx.x == 0)
         reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
-    }
 }
 
 // The same objective and the same records from FINISHED images: what multiview_fit_loss(*Renderer.render(...)) runs when
@@ -504,45 +556,10 @@ __global__ void __launch_bounds__(256) k_fit_loss_records(const float* __restric
         atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
         atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);
     }
-    const float4 wsum = make_float4(wave_sum(t_rgb), wave_sum(t_d), wave_sum(t_m), wave_sum(t_sse));
-    if (lane_id() == 0) s_part[threadIdx.x >> 6] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float4 t = s_part[0];
-        for (int k = 1; k < 4; k++) { t.x += s_part[k].x; t.y += s_part[k].y; t.z += s_part[k].z; t.w += s_part[k].w; }
+    // four wave sums (DPP), one exchange through LDS (a view's tiles are consecutive: one group of the finish)
+    const float4 t = block_sum4_256(make_float4(t_rgb, t_d, t_m, t_sse), s_part);
+    if (threadIdx.x == 0)
         reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
-    }
-}
-
-// totals[0..3] = the four sums over `n` workgroup partials, totals[4] = *loss = the objective (k_fit_loss_finish for
-// the tens of thousands of partials the fused epilogue leaves: 1024 lanes, 16-byte loads)
-__global__ void __launch_bounds__(1024) k_fit_finish_wide(const float4* __restrict__ partials, int n, float pixels,
-                                                         const float* __restrict__ mask_sum,
-                                                         float* __restrict__ totals, float* __restrict__ loss) {
-    __shared__ float4 s_wave[16];
-    float4 acc = make_float4(0, 0, 0, 0);
-    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {            // eight loads in flight per lane
-        float4 v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int i = i0 + j * 1024 + (int)threadIdx.x;
-            v[j] = i < n ? partials[i] : make_float4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
-    }
-    acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
-    if (lane_id() == 0) s_wave[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float4 t = make_float4(0, 0, 0, 0);
-        for (int k = 0; k < 16; k++) { t.x += s_wave[k].x; t.y += s_wave[k].y; t.z += s_wave[k].z; t.w += s_wave[k].w; }
-        if (mask_sum) t.z = *mask_sum;       // this batch is a shard: normalise by the mask of the whole objective
-        totals[0] = t.x; totals[1] = t.y; totals[2] = t.z; totals[3] = t.w;
-        const float l = (t.x / (3.0f * t.z) + t.w / pixels) + t.y / t.z;
-        totals[4] = l;
-        *loss = l;
-    }
 }
 
 // backward, gathered per visible face (ts == 2): sampling weights are recomputed, the 24 sums of
@@ -838,7 +855,9 @@ __global__ void __launch_bounds__(256) k_lit_large_faces(const float* __restrict
                                                         const int* __restrict__ flags, int B, int S, float eps, GradScale gs,
                                                         const int* __restrict__ n_large,
                                                         const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces,
-                                                        VertexTarget vt) {
+                                                        VertexTarget vt, FitFin fin) {
+    // (a fused objective whose finish the forward pass left to the backward pass: this launch's first workgroups do it)
+    if (fin.partials) fit_finish_groups(fin, blockIdx.x, gridDim.x);
     if (*n_large == 0) return;                     // (uniform exit)
     backward_textures_lit_pixels(faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gtex_view, grad_light, flags, B, S,
                                  eps, gs);

@@ -19,6 +19,7 @@
 #include "d3m_lit.h"
 #include "d3m_g2s.h"
 #include "d3m_bid.h"
+#include "d3m_front.h"
 #include <cstdlib>
 #include <atomic>
 
@@ -144,6 +145,8 @@ static FwdLayout fwd_layout(int B, int F, int S) {
 static size_t bid_workspace_bytes(int B, int F, int S) {
     return align_up((size_t)B * S * S * 8, 256) + 256 + align_up((size_t)B * F * 4, 256);
 }
+// z-buffer | big-face count: what a bidding launch needs zeroed
+static size_t bid_clear_bytes(int B, int F, int S) { (void)F; return align_up((size_t)B * S * S * 8, 256) + 256; }
 D3M_EXPORT size_t d3m_forward_workspace_bytes(int B, int F, int S) {
     if (B <= 0 || F <= 0 || S <= 0) return 0;
     return std::max(fwd_layout(B, F, S).fixed_bytes + (size_t)KCAP_DEFAULT * B * F * 4, bid_workspace_bytes(B, F, S));
@@ -244,12 +247,12 @@ D3M_EXPORT int d3m_forward_coverage_form(int batch_size, int num_triangles, int 
 // FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)
 template <class FS, bool PAIRED>
 static int run_bidding(FS fs, float* faces_dense, float* faces_dense_out, float* faces_inv, int B, int F, int S, float near,
-                       float far, RasterOut out, void* ws, hipStream_t st) {
+                       float far, RasterOut out, void* ws, hipStream_t st, bool cleared = false) {
     const size_t zbytes = align_up((size_t)B * S * S * 8, 256);
     unsigned long long* zbuf = (unsigned long long*)ws;
     int* big_count = (int*)((char*)ws + zbytes);
     int* big_list = (int*)((char*)ws + zbytes + 256);
-    HIP_TRY(zero_async(zbuf, zbytes + 256, st));
+    if (!cleared) HIP_TRY(zero_async(zbuf, bid_clear_bytes(B, F, S), st));
     constexpr int PW = 64;          // a lane per face (pair) for the set-up: the boxes are a few rows each
     const long units = (long)B * (PAIRED ? F / 2 : F);
     LAUNCH("k_bid_faces", (k_bid_faces<FS, PW, PAIRED>), dim3(blocks_for(units, 4 * PW)), dim3(256), st, fs, zbuf, faces_dense_out,
@@ -288,19 +291,20 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
 
 // The same with the faces of an indexed mesh: the first pass reads them through the indices and leaves the dense
 // copy (front-facing faces only) that the tile pass and every later operator use.
+// cleared: the caller has zeroed the workspace's first d3m_forward_clear_bytes() bytes (of the form this launch takes)
 static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, float near, float far, RasterOut out, void* ws,
-                            size_t ws_bytes, hipStream_t st, bool counters_cleared = false) {
+                            size_t ws_bytes, hipStream_t st, bool cleared = false) {
     // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
-    if (!counters_cleared && bidding_wanted(B, ifs.Ft, S, ws, ws_bytes, F)) {
-        if (ifs.fill_back) return run_bidding<IndexedFaces, true>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st);
-        return run_bidding<IndexedFaces, false>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st);
+    if (bidding_wanted(B, ifs.Ft, S, ws, ws_bytes, F)) {
+        if (ifs.fill_back) return run_bidding<IndexedFaces, true>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared);
+        return run_bidding<IndexedFaces, false>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared);
     }
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
     if (rc) return rc;
-    if (!counters_cleared) HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
+    if (!cleared) HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
 #ifdef D3M_DEV_SKIP
     {   // developer builds: D3M_ABL_NO_DENSE -- from the third call on the binning pass stops writing the dense face copy
@@ -396,7 +400,7 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
                                                float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                                int image_size, float near, float far, void* workspace,
                                                size_t workspace_bytes, void* visibility, size_t visibility_size,
-                                               d3m_stream_t stream) {
+                                               int flags, d3m_stream_t stream) {
     if (!vertices || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
         num_vertices <= 0 || num_tri <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
@@ -411,7 +415,16 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
         out.marks_count = visibility_view(visibility, nf).count;
     }
     return run_forward_mesh(ifs, faces_out, batch_size, image_size, near, far, out, workspace, workspace_bytes,
-                            (hipStream_t)stream);
+                            (hipStream_t)stream, (flags & D3M_PRECLEARED) != 0);
+}
+// The leading bytes of the forward workspace that d3m_forward_face_index_map_mesh zeroes in front of its kernels -- for the
+// form of coverage THAT launch takes (it depends on the workspace's size too) --, or 0 for an invalid / too small workspace.
+D3M_EXPORT size_t d3m_forward_clear_bytes(int batch_size, int num_tri, int fill_back, int image_size, size_t workspace_bytes) {
+    if (batch_size <= 0 || num_tri <= 0 || image_size <= 0) return 0;
+    const int F = (fill_back ? 2 : 1) * num_tri;
+    if (bidding_wanted(batch_size, num_tri, image_size, (const void*)1, workspace_bytes, F)) return bid_clear_bytes(batch_size, F, image_size);
+    const FwdLayout L = fwd_layout(batch_size, F, image_size);
+    return workspace_bytes >= L.fixed_bytes + (size_t)batch_size * F * 4 ? L.zero_bytes : 0;
 }
 
 D3M_EXPORT int d3m_forward_texture_sampling(const float* faces, const float* textures, const int32_t* face_index_map,
@@ -489,15 +502,21 @@ D3M_EXPORT size_t d3m_edge_plan_extents_offset(int batch_size, int num_faces, in
     if (bytes_each) *bytes_each = eg_align((size_t)batch_size * 2 * image_size * 4);
     return edge_plan_layout(batch_size, num_faces, image_size).off_extents;
 }
+D3M_EXPORT size_t d3m_edge_plan_clear_bytes(int batch_size, int num_faces, int image_size) {
+    if (batch_size <= 0 || num_faces <= 0 || image_size <= 0) return 0;
+    return edge_plan_layout(batch_size, num_faces, image_size).zero_bytes;
+}
 D3M_EXPORT int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
-                             size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream) {
+                             size_t edge_plan_size, int batch_size, int num_faces, int image_size, int flags,
+                             d3m_stream_t stream) {
     if (!faces || !face_index_map || !visibility || !edge_plan || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
     if (image_size > 65535 || num_faces > (1 << 26) || (long)batch_size * 2 * image_size >= (1l << 31)) return D3M_ERR_INVALID;
     const VisibilityView vis = visibility_view(visibility, (long)batch_size * num_faces);
     EdgePlan w;
     if (!edge_plan_view(edge_plan, edge_plan_size, vis, batch_size, num_faces, image_size, w)) return D3M_ERR_WORKSPACE;
     DenseFaces fs{faces, num_faces};
-    HIP_TRY(run_edge_plan(fs, face_index_map, w, edge_plan, batch_size, image_size, (hipStream_t)stream));
+    HIP_TRY(run_edge_plan(fs, face_index_map, w, edge_plan, batch_size, image_size, (hipStream_t)stream,
+                          (flags & D3M_PRECLEARED) != 0));
     return check_launch();
 }
 
@@ -885,6 +904,63 @@ D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch
     return check_launch();
 }
 
+// ---- the first launch of a lit render step: camera + per-face light + every clear (d3m_front.h) ------------------------
+D3M_EXPORT int d3m_lit_front(const float* vertices, int vertices_batch, const d3m_camera* cam, const d3m_basis* basis,
+                             float* screen_out, int batch_size, int num_vertices, const int32_t* tri, int tri_batch,
+                             int num_tri, int fill_back, float* light, int light_batch, float intensity_ambient,
+                             float intensity_directional, const float* color_ambient, const float* color_directional,
+                             const float* direction, void* const* zero_ptrs, const size_t* zero_bytes, int zero_count,
+                             d3m_stream_t stream) {
+    if (!vertices || batch_size <= 0 || num_vertices <= 0 || zero_count < 0 || zero_count > FRONT_RANGES) return D3M_ERR_INVALID;
+    if (zero_count && (!zero_ptrs || !zero_bytes)) return D3M_ERR_INVALID;
+    FrontArgs a;
+    memset(&a, 0, sizeof(a));
+    a.vertices = vertices; a.vb = vertices_batch; a.B = batch_size; a.V = num_vertices;
+    if (cam) {                                          // the camera part
+        if (!screen_out || (vertices_batch != 1 && vertices_batch != batch_size)) return D3M_ERR_INVALID;
+        d3m_camera c = *cam;
+        if (basis) {                                    // the basis is computed here and left in cam->rot for the adjoint
+            if (!basis->eye || !basis->at_or_direction || !basis->up || !cam->rot) return D3M_ERR_INVALID;
+            if (cam->mode != D3M_CAMERA_LOOK_AT && cam->mode != D3M_CAMERA_LOOK) return D3M_ERR_INVALID;
+            const int nb = cam->rot_batch;
+            if ((nb != 1 && nb != batch_size) || (basis->eye_batch != 1 && basis->eye_batch != nb) ||
+                (basis->at_batch != 1 && basis->at_batch != nb) || (basis->up_batch != 1 && basis->up_batch != nb))
+                return D3M_ERR_INVALID;
+            a.basis = FrontBasis{basis->eye, basis->at_or_direction, basis->up, basis->eye_batch, basis->at_batch,
+                                 basis->up_batch, basis->is_look_at ? 1 : 0, const_cast<float*>(cam->rot)};
+        }
+        if (int rc = to_cam(&c, batch_size, a.cam)) return rc;
+        a.screen = screen_out;
+        a.nb_cam = blocks_for((long)batch_size * num_vertices, 256);
+    }
+    if (light) {                                        // the light part
+        if (!color_ambient || !color_directional || !direction || light_batch <= 0 || num_tri <= 0) return D3M_ERR_INVALID;
+        int grid_w;
+        if (!tri_source_ok(tri, tri_batch, tri_batch, num_vertices, num_tri, grid_w)) return D3M_ERR_INVALID;
+        a.faces = IndexedFaces{vertices, tri, num_vertices, num_tri, tri ? tri_batch : 1, fill_back ? 1 : 0, vertices_batch, grid_w};
+        a.lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+        a.light = light; a.light_b = light_batch;
+        a.nb_light = blocks_for((long)light_batch * a.faces.num_faces(), 256);
+    }
+    size_t most = 0;
+    int used = 0;
+    for (int k = 0; k < zero_count; k++) {
+        if (!zero_ptrs[k] || zero_bytes[k] == 0) continue;
+        if ((zero_bytes[k] & 3) || ((uintptr_t)zero_ptrs[k] & 3)) return D3M_ERR_INVALID;
+        a.z_ptr[used] = (uint32_t*)zero_ptrs[k];
+        a.z_words[used] = zero_bytes[k] >> 2;
+        most = zero_bytes[k] > most ? zero_bytes[k] : most;
+        used++;
+    }
+    size_t nb_zero = used ? (most / 16 + 255) / 256 : 0;
+    if (nb_zero > 2048) nb_zero = 2048;
+    if (used && nb_zero == 0) nb_zero = 1;
+    const unsigned grid = a.nb_cam + a.nb_light + (unsigned)nb_zero;
+    if (grid == 0) return D3M_OK;
+    LAUNCH("k_lit_front", k_lit_front, dim3(grid), dim3(256), (hipStream_t)stream, a);
+    return check_launch();
+}
+
 static int make_lit(LitTextures& lt, const float* textures, int textures_batch, const float* light, int light_batch,
                     int num_tri, int texture_size, int fill_back, int B) {
     if (!textures || !light || num_tri <= 0 || texture_size <= 0) return D3M_ERR_INVALID;
@@ -920,13 +996,37 @@ D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float*
     return check_launch();
 }
 
+// scratch of a fused objective: totals [8] | per-workgroup partial sums (float4) | group sums (float4) | ticket.
+// One float4 of partials per 256-pixel workgroup of the plain epilogue, or per 32x32 tile and view of the records form
+// (k_render_lit_fit_records) -- more of them than pixels / 256 when the image is smaller than a tile; a group (the unit of
+// the objective's two-level finish, d3m_lit.h fit_finish_groups) is a view's tiles, or 256 consecutive workgroups.
+struct FitScratch {
+    size_t off_partials, off_group_sums, off_tickets, ticket_words, floats;
+};
+static FitScratch fit_scratch_layout(int B, int S) {
+    const size_t per_pixels = blocks_for((long)B * S * S, 256);
+    const size_t tiles = (size_t)B * ((S + 31) / 32) * ((S + 31) / 32);
+    const size_t P = per_pixels > tiles ? per_pixels : tiles;
+    const size_t G = std::max((size_t)B, (per_pixels + 255) / 256);
+    FitScratch L;
+    L.off_partials = 8;
+    L.off_group_sums = 8 + 4 * P;
+    L.off_tickets = L.off_group_sums + 4 * G;
+    L.ticket_words = 4;
+    L.floats = L.off_tickets + L.ticket_words;
+    return L;
+}
 D3M_EXPORT size_t d3m_render_fit_scratch_floats(int batch_size, int image_size) {
     if (batch_size <= 0 || image_size <= 0) return 0;
-    // totals | partials: one float4 per 256-pixel workgroup of the plain epilogue, or per 32x32 tile and view of the
-    // records form (k_render_lit_fit_records) -- more of them than pixels / 256 when the image is smaller than a tile
-    const size_t per_pixels = blocks_for((long)batch_size * image_size * image_size, 256);
-    const size_t tiles = (size_t)batch_size * ((image_size + 31) / 32) * ((image_size + 31) / 32);
-    return 8 + 4 * (per_pixels > tiles ? per_pixels : tiles);
+    return fit_scratch_layout(batch_size, image_size).floats;
+}
+// the part of that scratch which must be ZERO when a pass with a fused objective starts (the finish's ticket): cleared by the
+// pass's entry point itself unless the caller did (fit->flags & D3M_PRECLEARED)
+D3M_EXPORT size_t d3m_render_fit_scratch_clear_range(int batch_size, int image_size, size_t* offset_floats) {
+    if (batch_size <= 0 || image_size <= 0) return 0;
+    const FitScratch L = fit_scratch_layout(batch_size, image_size);
+    if (offset_floats) *offset_floats = L.off_tickets;
+    return L.ticket_words;
 }
 
 static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {
@@ -938,6 +1038,24 @@ static int to_fit_targets(const d3m_fit_targets* fit, FitTargets& ft) {
     if (any && !fit->edge_grad && !(fit->grad_rgb_map && fit->grad_alpha_map && fit->grad_depth_map)) return D3M_ERR_INVALID;
     ft = FitTargets{fit->rgb_target, fit->depth_target, fit->alpha_target, fit->mask, fit->scratch + 8,
                     fit->grad_rgb_map, fit->grad_alpha_map, fit->grad_depth_map};
+    return D3M_OK;
+}
+// the finish of an objective whose pass left n_partials partial sums in groups of group_size (B views at internal size S,
+// the objective on s x s output pixels per view)
+static FitFin make_fit_fin(const d3m_fit_targets* fit, int B, int S, int s, int n_partials, int group_size) {
+    const FitScratch L = fit_scratch_layout(B, S);
+    return FitFin{(const float4*)(fit->scratch + L.off_partials), (float4*)(fit->scratch + L.off_group_sums),
+                  (unsigned*)(fit->scratch + L.off_tickets), n_partials, group_size, (n_partials + group_size - 1) / group_size,
+                  (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss};
+}
+static FitFin fit_fin_of_tiles(const d3m_fit_targets* fit, int B, int S) {     // the records form: a view's 32x32 tiles
+    const int tiles = ((S + 31) / 32) * ((S + 31) / 32);
+    return make_fit_fin(fit, B, S, S, B * tiles, tiles);
+}
+static int clear_fit_tickets(const d3m_fit_targets* fit, int B, int S, hipStream_t st) {
+    if (fit->flags & D3M_PRECLEARED) return D3M_OK;
+    const FitScratch L = fit_scratch_layout(B, S);
+    HIP_TRY(zero_async(fit->scratch + L.off_tickets, L.ticket_words * 4, st));
     return D3M_OK;
 }
 
@@ -959,11 +1077,12 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
     if (rc) return rc;
     FitTargets ft;
-    if ((rc = to_fit_targets(fit, ft))) return rc;
     const int s = anti_aliasing ? image_size / 2 : image_size;
+    if ((rc = to_fit_targets(fit, ft))) return rc;
     const long n = (long)batch_size * s * s;
     hipStream_t st = (hipStream_t)stream;
     const int threads = 256;
+    if (fit && (rc = clear_fit_tickets(fit, batch_size, image_size, st))) return rc;
     if (fit && fit->edge_grad) {
         // the objective's gradient leaves as the edge gradient's per-pixel records (and the depth gradient map)
         if (!fit->edge_dot || !fit->edge_nz_lo_inv || !fit->edge_nz_hi1 || !fit->mask_sum || !fit->grad_depth_map)
@@ -974,29 +1093,22 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
                weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out, depth_out,
                batch_size, image_size, eps, ft, rec);
-        if (!fit->defer_finish)
-            LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-                   (int)(tiles.x * tiles.y * tiles.z), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
+        // *fit->loss: a launch of its own (k_fit_finish, two levels), or -- D3M_FIT_FINISH_DEFERRED -- left to the caller's
+        // d3m_backward_textures_lit, handed the same struct as `unscaled`
+        if (!(fit->flags & D3M_FIT_FINISH_DEFERRED)) {
+            const FitFin fin = fit_fin_of_tiles(fit, batch_size, image_size);
+            LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
+        }
         return check_launch();
     }
-    if (fit && fit->defer_finish) return D3M_ERR_INVALID;      // only the records form splits the reduction off
+    if (fit && (fit->flags & D3M_FIT_FINISH_DEFERRED)) return D3M_ERR_INVALID;      // only the records form defers its finish
     LAUNCH("k_render_lit_epilogue", k_render_lit_epilogue, dim3(blocks_for(n, threads)), dim3(threads), st, faces, lt,
            face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
            depth_out, batch_size, image_size, anti_aliasing ? 1 : 0, eps, ft);
-    if (fit)
-        LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-               (int)blocks_for(n, threads), (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss);
-    return check_launch();
-}
-
-// The last step of the fused objective (partial sums -> *fit->loss) for a d3m_render_lit_epilogue call made with
-// fit->defer_finish: a one-workgroup kernel.  Behind a pass that fills the chip it waits for a free slot, so a caller
-// whose backward pass does not need the value (records + mask_sum: see GradScale) runs it on another stream.
-D3M_EXPORT int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream) {
-    if (!fit || !fit->scratch || !fit->loss || !fit->edge_grad || batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
-    const int tiles = ((image_size + 31) / 32) * ((image_size + 31) / 32) * batch_size;
-    LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), (hipStream_t)stream, (const float4*)(fit->scratch + 8),
-           tiles, (float)((long)image_size * image_size), fit->mask_sum, fit->scratch, fit->loss);
+    if (fit) {
+        const FitFin fin = make_fit_fin(fit, batch_size, image_size, s, (int)blocks_for(n, threads), 256);
+        LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
+    }
     return check_launch();
 }
 
@@ -1010,23 +1122,69 @@ D3M_EXPORT int d3m_fit_loss_records(const float* rgb, const float* depth, const 
         return D3M_ERR_INVALID;
     FitTargets ft;
     if (int rc = to_fit_targets(fit, ft)) return rc;
+    if (fit->flags & D3M_FIT_FINISH_DEFERRED) return D3M_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = clear_fit_tickets(fit, batch_size, image_size, st)) return rc;
     const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
     FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
                    fit->grad_depth_map};
     LAUNCH("k_fit_loss_records", k_fit_loss_records, tiles, dim3(256), st, rgb, depth, alpha, face_index_map, batch_size,
            image_size, ft, rec);
-    LAUNCH("k_fit_finish_wide", k_fit_finish_wide, dim3(1), dim3(1024), st, (const float4*)ft.partials,
-           (int)(tiles.x * tiles.y * tiles.z), (float)((long)image_size * image_size), fit->mask_sum, fit->scratch, fit->loss);
+    const FitFin fin = fit_fin_of_tiles(fit, batch_size, image_size);
+    LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
     return check_launch();
 }
 
+// workspace of the gathered lit backward: per-view gradients | flags | view masks | counter
+struct LitWorkspace {
+    float* gview;           // per-view texel gradients (shared textures)
+    int* flags;             // when the caller brings no visibility blob
+    unsigned* view_mask;
+    size_t mask_bytes;
+    int* n_large;           // 256 bytes
+    size_t total;
+};
+static LitWorkspace lit_workspace(void* ws, int B, int num_tri, int fill_back, int texture_size) {
+    const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
+    const size_t nf = (size_t)B * num_tri * (fill_back ? 2 : 1);
+    char* p = (char*)ws;
+    LitWorkspace L;
+    L.gview = (float*)p;              p += align_up((size_t)B * num_tri * ts3 * 12, 256);
+    L.flags = (int*)p;                p += align_up(nf * 4, 256);
+    L.view_mask = (unsigned*)p;       L.mask_bytes = align_up((size_t)num_tri * ((B + 31) / 32) * 4, 256); p += L.mask_bytes;
+    L.n_large = (int*)p;              p += 256;
+    L.total = (size_t)(p - (char*)ws);
+    return L;
+}
 D3M_EXPORT size_t d3m_backward_textures_lit_workspace_bytes(int batch_size, int num_tri, int fill_back, int texture_size) {
     if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0) return 0;
-    const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
-    return align_up((size_t)batch_size * num_tri * ts3 * 12, 256) +
-           align_up((size_t)batch_size * num_tri * (fill_back ? 2 : 1) * 4, 256) +
-           align_up((size_t)num_tri * ((batch_size + 31) / 32) * 4, 256) + 256;  // per-view gradients | flags | view masks | counter
+    return lit_workspace(nullptr, batch_size, num_tri, fill_back, texture_size).total;
+}
+// what d3m_backward_textures_lit zeroes in front of its kernels (up to four ranges; returns how many)
+static int lit_clear_ranges(const LitWorkspace& W, float* grad_textures, int textures_batch, float* grad_light, int light_batch,
+                            int B, int num_tri, int fill_back, int texture_size, bool has_visibility, void** ptr, size_t* bytes) {
+    const size_t ts3 = (size_t)texture_size * texture_size * texture_size, view_elems = (size_t)num_tri * ts3 * 3;
+    const int Fp = (fill_back ? 2 : 1) * num_tri;
+    const bool skip_zero = texture_size == 2 && textures_batch == 1;
+    int n = 0;
+    if (!skip_zero) { ptr[n] = textures_batch > 1 ? grad_textures : W.gview; bytes[n++] = (size_t)B * view_elems * 4; }
+    if (grad_light) { ptr[n] = grad_light; bytes[n++] = (size_t)light_batch * Fp * 12; }
+    if (texture_size == 2) {
+        // shared textures: the view masks (the sum over views reads only what was written) | counter, adjacent
+        if (skip_zero) { ptr[n] = W.view_mask; bytes[n++] = W.mask_bytes + 256; }
+        else { ptr[n] = W.n_large; bytes[n++] = 256; }
+        if (!has_visibility) { ptr[n] = W.flags; bytes[n++] = (size_t)B * Fp * 4; }
+    }
+    return n;
+}
+D3M_EXPORT int d3m_backward_textures_lit_clear_ranges(float* grad_textures, int textures_batch, float* grad_light,
+                                                      int light_batch, int batch_size, int num_tri, int fill_back,
+                                                      int texture_size, void* workspace, int has_visibility, void** ptrs,
+                                                      size_t* bytes) {
+    if (batch_size <= 0 || num_tri <= 0 || texture_size <= 0 || !workspace || !ptrs || !bytes) return 0;
+    const LitWorkspace W = lit_workspace(workspace, batch_size, num_tri, fill_back, texture_size);
+    return lit_clear_ranges(W, grad_textures, textures_batch, grad_light, light_batch, batch_size, num_tri, fill_back,
+                            texture_size, has_visibility != 0, ptrs, bytes);
 }
 
 D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textures, int textures_batch, const float* light,
@@ -1035,7 +1193,7 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
                                          float* grad_light, const float* grad_depth_map, float* grad_faces, int batch_size,
                                          int num_tri, int fill_back, int image_size, int texture_size, float eps,
                                          void* workspace, size_t workspace_bytes, const d3m_vertex_target* vertex_target,
-                                         void* visibility, const d3m_fit_targets* unscaled, d3m_stream_t stream) {
+                                         void* visibility, const d3m_fit_targets* unscaled, int flags_in, d3m_stream_t stream) {
     if ((grad_depth_map != nullptr) != (grad_faces != nullptr || vertex_target != nullptr)) return D3M_ERR_INVALID;
     VertexTarget vt;
     if (int rcv = to_vertex_target(vertex_target, (fill_back ? 2 : 1) * num_tri, vt)) return rcv;
@@ -1056,20 +1214,23 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     const GradScale gs = to_grad_scale(unscaled, S);
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size;
     const size_t view_elems = (size_t)num_tri * ts3 * 3;
+    const LitWorkspace W = lit_workspace(workspace, B, num_tri, fill_back, texture_size);
     // per-view gradients: straight into grad_textures when every view has its own textures
-    float* gview = textures_batch > 1 ? grad_textures : (float*)workspace;
-    int* flags = (int*)((char*)workspace + align_up((size_t)B * view_elems * 4, 256));
+    float* gview = textures_batch > 1 ? grad_textures : W.gview;
+    int* flags = W.flags;
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
-    unsigned* view_mask = (unsigned*)((char*)flags + align_up((size_t)nf * 4, 256));
-    const size_t mask_bytes = align_up((size_t)num_tri * ((B + 31) / 32) * 4, 256);
-    int* n_large = (int*)((char*)view_mask + mask_bytes);          // zeroed together with the masks (or on its own)
+    unsigned* view_mask = W.view_mask;
     // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
     const bool skip_zero = texture_size == 2 && textures_batch == 1;
-    // every clear of this entry point in one launch (below)
-    void* z_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t z_bytes[4] = {0, 0, 0, 0};
-    if (!skip_zero) { z_ptr[0] = gview; z_bytes[0] = (size_t)B * view_elems * 4; }
-    if (grad_light) { z_ptr[1] = grad_light; z_bytes[1] = (size_t)light_batch * lt.Fp * 12; }
+    // every clear of this entry point in one launch -- or none: a caller that zeroed the ranges of
+    // d3m_backward_textures_lit_clear_ranges itself says so (D3M_PRECLEARED)
+    if (!(flags_in & D3M_PRECLEARED)) {
+        void* z_ptr[4];
+        size_t z_bytes[4];
+        const int nz = lit_clear_ranges(W, grad_textures, textures_batch, grad_light, light_batch, B, num_tri, fill_back,
+                                        texture_size, visibility != nullptr, z_ptr, z_bytes);
+        HIP_TRY(zero_ranges_async(z_ptr, z_bytes, nz, st));
+    }
     const int* list = nullptr;
     const int* n_list = nullptr;
     if (visibility) {                                  // flags and the compacted list come from d3m_visibility
@@ -1078,23 +1239,23 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     }
     if (texture_size == 2) {
         const bool use_mask = skip_zero;               // shared textures: the sum over views reads only what was written
-        if (use_mask) { z_ptr[2] = view_mask; z_bytes[2] = mask_bytes + 256; }
-        else { z_ptr[2] = n_large; z_bytes[2] = 256; }
-        if (!visibility) { z_ptr[3] = flags; z_bytes[3] = (size_t)nf * 4; }
-        HIP_TRY(zero_ranges_async(z_ptr, z_bytes, 4, st));
         if (!visibility)
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, n_large};
+                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
         const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
         LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
                dim3(256), st, fa);
-        // the texel and depth gradients of the faces the gathered pass marked LARGE (normally none: leaves at once)
+        // the texel and depth gradients of the faces the gathered pass marked LARGE (normally none: leaves at once) -- and, for
+        // a fused objective whose forward pass deferred it (D3M_FIT_FINISH_DEFERRED), the objective's finish
+        FitFin fin;
+        memset(&fin, 0, sizeof(fin));
+        if (records && unscaled->scratch && unscaled->loss && (unscaled->flags & D3M_FIT_FINISH_DEFERRED))
+            fin = fit_fin_of_tiles(unscaled, B, S);
         LAUNCH("k_lit_large_faces", k_lit_large_faces, dim3(px_grid(n, true)), dim3(256), st, faces, lt, face_index_map,
-               weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)n_large,
-               grad_depth_map, grad_faces, vt);
+               weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)W.n_large,
+               grad_depth_map, grad_faces, vt, fin);
     } else {
-        HIP_TRY(zero_ranges_async(z_ptr, z_bytes, 4, st));
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, false)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)nullptr, B, S, eps,
                gs, (const int*)nullptr);

@@ -123,18 +123,36 @@ def _vec_param(x, device):
     return t[None, :].contiguous() if t.dim() == 1 else t
 
 
-def look_at_params(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):
+def look_at_params(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None, defer_basis=False):
     """The fused camera kernels' parameter block of look_at(vertices, eye, at, up) -- for callers that run
     d3m_camera_forward / _backward inside a larger node (rasterize._RasterizeLit) -- or None when a camera parameter
-    requires grad (those go through the torch composition in look_at)."""
+    requires grad (those go through the torch composition in look_at).  defer_basis: the frame is NOT computed here
+    (d3m_camera_basis, a launch of its own) but by the caller's d3m_lit_front, which leaves it in `rot`: the block then
+    carries the vectors it is made of (`basis`)."""
     if _learnable(eye, at, up):
         return None
     device = vertices.device
     eye_t, at_t, up_t = _vec_param(eye, device), _vec_param(at, device), _vec_param(up, device)
     nb = max(eye_t.shape[0], at_t.shape[0], up_t.shape[0])
-    return dict(mode=_lib.CAMERA_LOOK_AT, batch=max(vertices.shape[0], nb), rot=_basis(eye_t, at_t, up_t, True, nb, device),
-                eye_or_t=eye_t, perspective=_perspective_angle is not None,
-                width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+    p = dict(mode=_lib.CAMERA_LOOK_AT, batch=max(vertices.shape[0], nb), eye_or_t=eye_t,
+             perspective=_perspective_angle is not None,
+             width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+    if defer_basis:
+        p["rot"] = torch.empty(nb, 3, 3, dtype=torch.float32, device=device)
+        p["basis"] = (eye_t, at_t, up_t, True)
+    else:
+        p["rot"] = _basis(eye_t, at_t, up_t, True, nb, device)
+    return p
+
+
+def basis_struct(p):
+    """(D3MBasis, tensors to keep alive) of a parameter block made with defer_basis, else (None, [])"""
+    b = p.get("basis")
+    if b is None:
+        return None, []
+    eye, at, up, is_look_at = b
+    return _lib.D3MBasis(eye.data_ptr(), at.data_ptr(), up.data_ptr(), eye.shape[0], at.shape[0], up.shape[0],
+                         int(bool(is_look_at))), [eye, at, up]
 
 
 def look_at(vertices, eye, at=[0, 0, 0], up=[0, 1, 0], _perspective_angle=None):

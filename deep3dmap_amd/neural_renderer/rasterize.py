@@ -332,6 +332,15 @@ def lit_images_link(rgb, depth, alpha):
     return fn
 
 
+def _lit_clear_ranges(L, grad_textures, textures_batch, grad_light, light_batch, B, Ft, fill_back, ts, workspace):
+    """[(device pointer, bytes)]: what d3m_backward_textures_lit (with a visibility blob) zeroes in front of its kernels"""
+    ptrs, sizes = (ctypes.c_void_p * 4)(), (ctypes.c_size_t * 4)()
+    n = L.d3m_backward_textures_lit_clear_ranges(_lib.ptr(grad_textures), int(textures_batch), _lib.ptr(grad_light),
+                                                 int(light_batch), B, Ft, int(bool(fill_back)), ts, _lib.ptr(workspace), 1,
+                                                 ptrs, sizes)
+    return [(ptrs[i], sizes[i]) for i in range(n)]
+
+
 def _checked_sink(grad_sink, vertices, textures):
     """`grad_sink` = (grad_vertices, grad_textures | None, loss [1]): caller-owned buffers the lit node writes its results
     into in place (MultiViewFit: views of the flat all-reduce buffer).  They are RAW destinations of kernels that write
@@ -377,18 +386,19 @@ class _RasterizeLit(torch.autograd.Function):
         tri = tri.to(torch.int32).contiguous()
         dev = vertices.device
         grad_sink = _checked_sink(grad_sink, vertices, textures)
-        cam_keep = None
+        cam = cam_keep = basis = None
         if camera is not None:
             # THE CAMERA INSIDE THE NODE (`camera` = the parameter block of cameras._camera_struct, screen_vertices None):
             # the mesh is both projected and lit, i.e. `vertices` would receive two gradients that autograd then adds
             # with a kernel of its own; here the camera's adjoint is accumulated onto the light's (d3m_camera_backward_add)
             # and the node returns ONE gradient.  `grad_sink` = (grad_vertices [1,V,3], grad_textures, loss [1]) buffers
             # of the caller (MultiViewFit's flat all-reduce buffer): the results are produced in place, no packing copy.
+            # The transform itself is part of the step's first launch (d3m_lit_front, below).
             from . import cameras
             cam, cam_keep = cameras._camera_struct(camera, dev)
+            basis, basis_keep = cameras.basis_struct(camera)
+            cam_keep = list(cam_keep) + basis_keep
             sv = torch.empty(camera["batch"], vertices.shape[1], 3, dtype=torch.float32, device=dev)
-            _lib.check(L.d3m_camera_forward(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(sv),
-                                            camera["batch"], vertices.shape[1], _lib.stream_ptr()), "d3m_camera_forward")
         else:
             sv = f32c(screen_vertices)
         B = sv.shape[0]
@@ -402,10 +412,7 @@ class _RasterizeLit(torch.autograd.Function):
         ia, idr, ca, cd, direction = light_cfg
         cca, ccd, cdir = _vec3_host(ca), _vec3_host(cd), _vec3_host(direction)
         Bl = 1 if (vertices.shape[0] == 1 and tri.shape[0] == 1) else B
-        light = torch.empty(Bl, Fp, 3, dtype=torch.float32, device=dev)
-        _lib.check(L.d3m_face_light(_lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(light),
-                                    float(ia), float(idr), cca, ccd, cdir, Bl, V, Ft, int(bool(fill_back)),
-                                    _lib.stream_ptr()), "d3m_face_light")
+        light = torch.empty(Bl, Fp, 3, dtype=torch.float32, device=dev)        # (filled by the first launch, below)
         background = _background_tensor(background_color, dev)
         need_grad = any(ctx.needs_input_grad[:4])
         groups = _group_bounds(B, view_groups)
@@ -478,6 +485,7 @@ class _RasterizeLit(torch.autograd.Function):
         serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
+        nz_own = None
         if fit_state is not None and fit_state[6] is not None and not fit_state[8]:      # (records form: no anti-aliasing)
             # the lines' non-zero extents (zero before the objective's pass fills them): when the plan is built in front of
             # that pass on the same stream, inside the plan's blob, cleared by the plan's own clear; else a fill of their own
@@ -487,8 +495,55 @@ class _RasterizeLit(torch.autograd.Function):
                 nz = tuple(plan[0][off + j * each.value: off + j * each.value + B * 2 * S * 4].view(torch.int32).view(B, 2, S)
                            for j in range(2))
             else:
-                nz = tuple(torch.zeros(2, B, 2, S, dtype=torch.int32, device=dev).unbind(0))
+                nz_own = torch.empty(2, B, 2, S, dtype=torch.int32, device=dev)       # (zeroed by the first launch, below)
+                nz = tuple(nz_own.unbind(0))
             fit_state = fit_state[:6] + (fit_state[6][:2] + (nz,) + fit_state[6][3:],) + fit_state[7:]
+        # THE STEP'S FIRST LAUNCH (d3m_lit_front): the camera transform (with its look_at basis), the per-face light and
+        # every clear the operators below would otherwise each launch for themselves -- the forward workspace's counters (or
+        # z-buffer), the plan's, the objective's arrival tickets, the lines' extents -- and, for a caller that runs backward
+        # right behind forward (defer_plan_join: MultiViewFit's step; LitFitManual), the backward pass's accumulators and
+        # masks too, allocated here for that purpose (`ctx.pre`): five launches of round 4's step are block ranges of one.
+        # One pipeline only: view groups keep their own clears.
+        clears, pre = [], None
+        flags_fwd = flags_plan = flags_fit = 0
+        ws0 = ops._workspace("fwd", L.d3m_forward_workspace_bytes(groups[0][1] - groups[0][0], Fp, S), dev)
+        if G == 1 and os.environ.get("D3M_NO_PRECLEAR") != "1":      # (D3M_NO_PRECLEAR=1: every operator clears for itself; debugging)
+            nb = int(L.d3m_forward_clear_bytes(B, Ft, int(bool(fill_back)), S, ws0.numel()))
+            if nb:
+                clears.append((ws0.data_ptr(), nb))
+                flags_fwd = _lib.PRECLEARED
+            if plan is not None:
+                clears.append((plan[0].data_ptr(), int(L.d3m_edge_plan_clear_bytes(B, Fp, S))))
+                flags_plan = _lib.PRECLEARED
+            if fit_state is not None:
+                off = ctypes.c_size_t(0)
+                nfl = int(L.d3m_render_fit_scratch_clear_range(B, S, ctypes.byref(off)))
+                clears.append((fit_state[4][0].data_ptr() + 4 * off.value, 4 * nfl))
+                flags_fit = _lib.PRECLEARED
+        if nz_own is not None:
+            clears.append(_lib.tensor_range(nz_own))
+        step_mode = G == 1 and need_grad and (defer_plan_join or getattr(ctx, "force_serial", False)) and \
+            os.environ.get("D3M_NO_PRECLEAR") != "1"
+        if step_mode:
+            pre = _RasterizeLit._backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera is not None,
+                                                  B, V, Ft, ts, Bl, fill_back, idr)
+            if len(clears) + len(pre["clears"]) <= _lib.FRONT_RANGES:
+                clears += pre["clears"]
+            else:
+                pre = None
+        assert len(clears) <= _lib.FRONT_RANGES
+        # ... and the objective's finish (partial sums -> value) is left to a kernel that backward pass launches anyway
+        if pre is not None and pre["gathered"] and fit_state is not None and fit_state[6] is not None and not fit_state[8]:
+            flags_fit |= _lib.FIT_FINISH_DEFERRED
+        ctx.fit_flags = flags_fit & _lib.FIT_FINISH_DEFERRED
+        zp = (ctypes.c_void_p * max(1, len(clears)))(*[c[0] for c in clears])
+        zb = (ctypes.c_size_t * max(1, len(clears)))(*[c[1] for c in clears])
+        _lib.check(L.d3m_lit_front(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam) if cam is not None else None,
+                                   ctypes.byref(basis) if basis is not None else None,
+                                   _lib.ptr(sv) if cam is not None else None, B, V, _lib.ptr(tri), tri.shape[0], Ft,
+                                   int(bool(fill_back)), _lib.ptr(light), Bl, float(ia), float(idr), cca, ccd, cdir,
+                                   zp, zb, len(clears), _lib.stream_ptr()), "d3m_lit_front")
+        ctx.pre = pre
         # The visibility list and the plan are only read by backward.  A caller that runs backward right behind forward,
         # on the same stream and (if captured) in the same capture, may leave that branch open at the end of forward
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
@@ -507,12 +562,12 @@ class _RasterizeLit(torch.autograd.Function):
             with torch.cuda.stream(mains[k]):
                 tri_g, tex_g, light_g, bg_g = (_bslice(t, lo, hi) for t in (tri, textures, light, background))
                 fi_g, wm_g, dm_g = m["face_index_map"][lo:hi], m["weight_map"][lo:hi], m["depth_map"][lo:hi]
-                ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(Bg, Fp, S), dev)
+                ws = ws0 if k == 0 else ops._workspace("fwd", L.d3m_forward_workspace_bytes(Bg, Fp, S), dev)
                 _lib.check(L.d3m_forward_face_index_map_mesh(
                     _lib.ptr(sv[lo:hi]), _lib.ptr(tri_g), tri_g.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces[lo:hi]),
                     _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), None, Bg, S, float(near), float(far), _lib.ptr(ws),
                     ws.numel(), _lib.ptr(vis[k]) if vis is not None else None, vis[k].numel() if vis is not None else 0,
-                    _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+                    flags_fwd, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
                 if vis is not None:
                     if auxs[k] is not mains[k]:
                         auxs[k].wait_stream(mains[k])
@@ -524,18 +579,14 @@ class _RasterizeLit(torch.autograd.Function):
                             vis_ready = torch.cuda.Event()
                             vis_ready.record(auxs[k])
                         _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
-                                                   plan[k].numel(), Bg, Fp, S, _lib.stream_ptr()), "d3m_edge_plan")
+                                                   plan[k].numel(), Bg, Fp, S, flags_plan, _lib.stream_ptr()), "d3m_edge_plan")
                         if plan_ready is not None:
                             plan_ready.append(torch.cuda.Event())
                             plan_ready[k].record(auxs[k])
                 fit_c = None
                 if fit_state is not None:
-                    # with records the backward pass does not read the objective's value: its one-workgroup last step
-                    # (which would wait for a free slot behind the plan's kernels) goes to the end of the side branch
-                    # (one pipeline only: a second cross-stream edge into a group's side branch makes graph REPLAY
-                    #  segfault on ROCm 7.2, like the fork of a fork above)
-                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None,
-                                                      defer_finish=vis is not None and G == 1 and not anti_aliasing)
+                    # (the objective's value is completed by the pass's own last workgroups: no finishing launch)
+                    fit_c = _RasterizeLit._fit_struct(fit_state, k, lo, hi, None, flags=flags_fit)
                 # texture sampling + background blend + alpha + flip / pooling in one pass (no rgb_sampled round trip)
                 _lib.check(L.d3m_render_lit_epilogue(
                     _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -544,10 +595,6 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(_bslice(rgb, lo, hi)), _lib.ptr(_bslice(alpha, lo, hi)), _lib.ptr(_bslice(depth, lo, hi)), Bg, Ft,
                     int(bool(fill_back)), S, ts, float(eps), int(bool(anti_aliasing)),
                     ctypes.byref(fit_c) if fit_c is not None else None, _lib.stream_ptr()), "d3m_render_lit_epilogue")
-                if fit_c is not None and vis is not None and G == 1 and not anti_aliasing:
-                    auxs[k].wait_stream(mains[k])
-                    with torch.cuda.stream(auxs[k]):
-                        _lib.check(L.d3m_fit_finish(ctypes.byref(fit_c), Bg, S, _lib.stream_ptr()), "d3m_fit_finish")
         for k in range(G):
             if mains[k] is not cur:
                 cur.wait_stream(mains[k])
@@ -570,7 +617,33 @@ class _RasterizeLit(torch.autograd.Function):
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
     @staticmethod
-    def _fit_struct(fit_state, k, lo, hi, grad_loss, defer_finish=False):
+    def _backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera_inside, B, V, Ft, ts, Bl, fill_back, idr):
+        """The backward pass's accumulators and the gathered pass's workspace, allocated in FORWARD for a caller that runs
+        backward right behind it: the forward's first launch zeroes what they need zeroed (`clears`), so the backward
+        pass starts without a clear of its own.  Mirrors the allocations of _backward_halves (one pipeline)."""
+        dev = vertices.device
+        need_tex = ctx.needs_input_grad[3]
+        need_vert = ctx.needs_input_grad[1] and idr != 0
+        gathered = need_tex or need_vert
+        pre = {"clears": [], "gathered": gathered, "grad_vertices": None}
+        pre["grad_sv"] = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+        pre["clears"].append(_lib.tensor_range(pre["grad_sv"]))
+        if gathered and need_vert:
+            gv = grad_sink[0] if (grad_sink is not None and camera_inside) else torch.empty_like(vertices)
+            pre["grad_vertices"] = gv
+            pre["clears"].append(_lib.tensor_range(gv))
+        if gathered:
+            gt = grad_sink[1] if (textures.shape[0] == 1 and grad_sink is not None and grad_sink[1] is not None) \
+                else torch.empty_like(textures)
+            gl = torch.empty_like(light) if need_vert else None
+            ws = torch.empty(int(L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(bool(fill_back)), ts)),
+                             dtype=torch.uint8, device=dev)
+            pre["clears"] += _lit_clear_ranges(L, gt, textures.shape[0], gl, Bl, B, Ft, fill_back, ts, ws)
+            pre.update(gt=gt, gl=gl, lit_ws=ws)
+        return pre
+
+    @staticmethod
+    def _fit_struct(fit_state, k, lo, hi, grad_loss, flags=0):
         """d3m_fit_targets of view group k (views lo..hi): forward's `fit` (grad_loss None) / backward's `unscaled`."""
         rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, pooled = fit_state
         eg = ed = nz_lo = nz_hi = gd = g_rgb = g_alpha = None
@@ -583,7 +656,7 @@ class _RasterizeLit(torch.autograd.Function):
             _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
             _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(g_rgb), _lib.ptr(g_alpha), _lib.ptr(gd),
             _lib.ptr(grad_loss), _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi),
-            int(defer_finish))
+            int(flags))
 
     @staticmethod
     def backward(ctx, g_rgb, g_alpha=None, g_depth=None):
@@ -609,7 +682,11 @@ class _RasterizeLit(torch.autograd.Function):
         m = ctx.maps
         dev, B, G = faces.device, faces.shape[0], len(groups)
         Ft, V, ts = tri.shape[1], vertices.shape[1], textures.shape[2]
-        grad_sv = torch.empty(B, V, 3, dtype=torch.float32, device=dev)     # zeroed below, with the other accumulators
+        # a caller that runs backward right behind forward had its accumulators allocated AND zeroed by the forward's first
+        # launch (ctx.pre: one use -- a second backward over the same graph allocates and clears its own)
+        pre = getattr(ctx, "pre", None)
+        ctx.pre = None
+        grad_sv = pre["grad_sv"] if pre is not None else torch.empty(B, V, 3, dtype=torch.float32, device=dev)
         grad_loss = scratch = mask_sum = None
         records = None
         # A fit objective evaluated on this node's finished images (core.losses.multiview_fit_loss -> LitImagesLink) has left
@@ -656,22 +733,35 @@ class _RasterizeLit(torch.autograd.Function):
         tex_shared, light_shared = textures.shape[0] == 1, Bl == 1
         gt_g = gl_g = None
         sink = ctx.grad_sink
+        if pre is not None and (pre["gathered"] != gathered or G != 1):
+            pre = None
+            _lib.zero_(grad_sv)                      # (cannot happen: the same inputs decide both; stay correct anyway)
         if gathered and need_vert:
-            grad_vertices = sink[0] if (sink is not None and ctx.camera is not None) else torch.empty_like(vertices)
-        _lib.zero_(grad_sv, grad_vertices)           # one launch for both accumulators
+            grad_vertices = pre["grad_vertices"] if pre is not None else \
+                (sink[0] if (sink is not None and ctx.camera is not None) else torch.empty_like(vertices))
         if gathered:
-            if tex_shared:
-                gt_g = [sink[1] if (sink is not None and sink[1] is not None and G == 1) else torch.empty_like(textures)
-                        for _ in groups]
-            else:
-                grad_textures = torch.empty_like(textures)
-                gt_g = [grad_textures[lo:hi] for lo, hi in groups]
-            if need_vert:
-                if light_shared:
-                    gl_g = [torch.empty_like(light) for _ in groups]
+            if pre is not None:
+                if tex_shared:
+                    gt_g = [pre["gt"]]
                 else:
-                    grad_light = torch.empty_like(light)
-                    gl_g = [grad_light[lo:hi] for lo, hi in groups]
+                    grad_textures, gt_g = pre["gt"], [pre["gt"]]
+                if need_vert:
+                    gl_g = [pre["gl"]]
+                    if not light_shared:
+                        grad_light = pre["gl"]
+            else:
+                if tex_shared:
+                    gt_g = [sink[1] if (sink is not None and sink[1] is not None and G == 1) else torch.empty_like(textures)
+                            for _ in groups]
+                else:
+                    grad_textures = torch.empty_like(textures)
+                    gt_g = [grad_textures[lo:hi] for lo, hi in groups]
+                if need_vert:
+                    if light_shared:
+                        gl_g = [torch.empty_like(light) for _ in groups]
+                    else:
+                        grad_light = torch.empty_like(light)
+                        gl_g = [grad_light[lo:hi] for lo, hi in groups]
         cur = torch.cuda.current_stream()
         serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
@@ -686,6 +776,23 @@ class _RasterizeLit(torch.autograd.Function):
         swap = plan_ready is not None and G == 1 and auxs[0] is not cur and m.get("vis_ready") is not None
         s_edges = [auxs[0]] if swap else mains
         s_gath = [mains[0]] if swap else auxs
+        # The backward pass's clears -- the two vertex accumulators and what the gathered pass needs zeroed -- as ONE launch
+        # in front of the branches (round 4: one here and one inside d3m_backward_textures_lit), or none at all (`pre`).
+        lit_ws, lit_flags = None, 0
+        if pre is not None:
+            if gathered:
+                lit_ws, lit_flags = [pre["lit_ws"]], _lib.PRECLEARED
+        else:
+            ranges = [_lib.tensor_range(grad_sv)]
+            if grad_vertices is not None:
+                ranges.append(_lib.tensor_range(grad_vertices))
+            if gathered and G == 1:
+                with torch.cuda.stream(s_gath[0]):     # (scratch is cached per stream: the stream the pass will run on)
+                    ws1 = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
+                ranges += _lit_clear_ranges(L, grad_textures if grad_textures is not None else gt_g[0], textures.shape[0],
+                                            gl_g[0] if gl_g is not None else None, light.shape[0], B, Ft, fill_back, ts, ws1)
+                lit_ws, lit_flags = [ws1], _lib.PRECLEARED
+            _lib.zero_raw(ranges)
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
@@ -708,14 +815,15 @@ class _RasterizeLit(torch.autograd.Function):
             target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back))
             unscaled = None
             if fit is not None:
-                unscaled = _RasterizeLit._fit_struct(fit, k, lo, hi, grad_loss)
+                unscaled = _RasterizeLit._fit_struct(fit, k, lo, hi, grad_loss, flags=getattr(ctx, "fit_flags", 0))
             elif records is not None:           # final records: no scratch, no scalars to apply
                 unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
                                               _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
                                               _lib.ptr(records[2][0][lo:hi]), _lib.ptr(records[2][1][lo:hi]), 0)
             if gathered:
                 with torch.cuda.stream(s_gath[k]):
-                    ws = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
+                    ws = lit_ws[k] if lit_ws is not None else \
+                        ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
                     # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
                     _lib.check(L.d3m_backward_textures_lit(
                         _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
@@ -723,7 +831,7 @@ class _RasterizeLit(torch.autograd.Function):
                         _lib.ptr(gl_g[k]) if gl_g is not None else None,
                         _lib.ptr(g_depth_map[lo:hi]) if rd else None, None, Bg, Ft, int(fill_back), S, ts, eps,
                         _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis[k]),
-                        ctypes.byref(unscaled) if unscaled is not None else None, _lib.stream_ptr()),
+                        ctypes.byref(unscaled) if unscaled is not None else None, lit_flags, _lib.stream_ptr()),
                         "d3m_backward_textures_lit")
             if G == 1:
                 yield "textures"        # (one pipeline: the texture side is complete in the order of its stream)
@@ -856,14 +964,16 @@ class LitFitManual:
 
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
                   anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
-                  background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True, view_groups=1):
+                  background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True, view_groups=1,
+                  camera=None):
     """rgb (+alpha, depth) images of the mesh (`screen_vertices` [B,V,3] after the camera transform, triangles
     `tri` [1|B,F,3]) textured with the ORIGINAL `textures` [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face
     light (computed from world-space `vertices`) are applied on the fly.  Same outputs as vertices_to_faces() +
-    lighting() + rasterize_rgbad() on the materialised arrays."""
+    lighting() + rasterize_rgbad() on the materialised arrays.  `camera` (with screen_vertices None): the fused camera
+    kernels' parameter block (cameras.look_at_params) -- the transform then runs inside the node."""
     rgb, alpha, depth = _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size,
                                             anti_aliasing, near, far, eps, background_color, True, return_alpha,
-                                            return_depth, None, view_groups)
+                                            return_depth, None, view_groups, False, camera)
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
 
 
@@ -900,7 +1010,7 @@ def rasterize_lit_image_grid(screen_vertices, vertices, grid_hw, image, light_cf
     ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
     _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), None, -w, V, Ft, 1, _lib.ptr(faces), _lib.ptr(fim), _lib.ptr(wm),
                                                  _lib.ptr(dm), None, B, S, float(near), float(far), _lib.ptr(ws), ws.numel(),
-                                                 None, 0, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+                                                 None, 0, 0, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
     background = _background_tensor(background_color, dev)
     rgb_map = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
     rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)

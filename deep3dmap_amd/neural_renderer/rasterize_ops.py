@@ -42,7 +42,7 @@ def edge_plan(faces, face_index_map, visibility_blob, image_size, out=None):
     blob = out if out is not None else torch.empty(int(L.d3m_edge_plan_bytes(B, F, int(image_size))), dtype=torch.uint8,
                                                    device=faces.device)
     _lib.check(L.d3m_edge_plan(_lib.ptr(faces), _lib.ptr(face_index_map), _lib.ptr(visibility_blob), _lib.ptr(blob), blob.numel(), B, F,
-                               int(image_size), _lib.stream_ptr()), "d3m_edge_plan")
+                               int(image_size), 0, _lib.stream_ptr()), "d3m_edge_plan")
     return blob
 
 

@@ -135,12 +135,21 @@ class Renderer(nn.Module):
         return self.lighting_on_the_fly and not mesh_ops.per_batch_light(
             self.light_color_ambient, self.light_color_directional, self.light_direction)
 
+    def _camera_in_node(self, vertices):
+        """look_at cameras with constant parameters run INSIDE the lit render node (its first launch projects, lights and
+        clears; one gradient for the mesh instead of the camera's plus the light's): their parameter block, else None."""
+        if self.camera_mode == 'look_at' and vertices.ndimension() == 3:
+            return cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None,
+                                          defer_basis=True)
+        return None
+
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
-            sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+            cam = self._camera_in_node(vertices)
+            sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             return rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                  self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                 False, False, view_groups=self.view_groups)['rgb']
+                                 False, False, view_groups=self.view_groups, camera=cam)['rgb']
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         textures = self._lit_textures(vertices, faces, textures)
         return rasterize(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
@@ -170,9 +179,7 @@ class Renderer(nn.Module):
             raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch)")
         # look_at cameras with constant parameters run INSIDE the node (one gradient for the mesh instead of the camera's
         # plus the light's; results straight into the caller's grad_sink buffers when it has set them)
-        cam = None
-        if self.camera_mode == 'look_at':
-            cam = cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None)
+        cam = self._camera_in_node(vertices)
         sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
@@ -185,17 +192,20 @@ class Renderer(nn.Module):
         here (look_at cameras only: the camera runs inside the node); its two backward halves are the caller's to call."""
         if not self._on_the_fly() or self.camera_mode != 'look_at':
             raise ValueError("render_fit_loss_manual needs lighting_on_the_fly and camera_mode 'look_at'")
-        cam = cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None)
+        cam = self._camera_in_node(vertices)
+        if cam is None:
+            raise ValueError("render_fit_loss_manual: the camera's parameters must be constants (no requires_grad)")
         return manual.forward(vertices, faces, textures, self._light_cfg(), self.fill_back, targets, self.image_size,
                               self.near, self.far, self.rasterizer_eps, self.background_color, cam, grad_sink=grad_sink,
                               images_out=images_out, anti_aliasing=self.anti_aliasing)
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
-            sv = self._transform(vertices, K, R, t, dist_coeffs, orig_size)
+            cam = self._camera_in_node(vertices)
+            sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                view_groups=self.view_groups)
+                                view_groups=self.view_groups, camera=cam)
         else:
             f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
             textures = self._lit_textures(vertices, faces, textures)

@@ -48,6 +48,12 @@ int d3m_last_hip_error(void);         /* hipError_t of the most recent failed HI
  * small scratch buffers per step (the reference does the same with torch.zeros, NR/rasterize.py:111-115) save a launch
  * per buffer. */
 int d3m_zero_ranges(void* const* ptrs, const size_t* bytes, int count, d3m_stream_t stream);
+/* CLEARS.  An operator that needs zeroed scratch (counters, arrival tickets, accumulators) clears it itself with one fill
+ * launch in front of its kernels.  A caller that runs a whole step may do all of a step's clears in ONE launch instead --
+ * d3m_lit_front, the step's first kernel, takes a list of ranges beside the camera and the light -- : it asks every operator
+ * for what that operator would clear (d3m_forward_clear_bytes, d3m_edge_plan_clear_bytes, d3m_render_fit_scratch_clear_range,
+ * d3m_backward_textures_lit_clear_ranges), zeroes those ranges, and passes D3M_PRECLEARED in the operator's `flags`. */
+#define D3M_PRECLEARED 1
 const char* d3m_error_string(int code);
 
 /* Per-kernel timing with HIP events recorded on each launch's own stream (used by bench.py for the
@@ -108,7 +114,11 @@ int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, i
                                     int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                     int image_size, float near, float far, void* workspace, size_t workspace_bytes,
-                                    void* visibility, size_t visibility_size, d3m_stream_t stream);
+                                    void* visibility, size_t visibility_size, int flags, d3m_stream_t stream);
+/* flags: D3M_PRECLEARED -- the caller has zeroed the first d3m_forward_clear_bytes(...) bytes of `workspace` (the tile
+ * counters and arrival tickets of the per-tile lists, or the z-buffer of the bidding form: whichever form a launch with
+ * THIS workspace size takes); 0: the operator clears them itself. */
+size_t d3m_forward_clear_bytes(int batch_size, int num_tri, int fill_back, int image_size, size_t workspace_bytes);
 /* tri == NULL with tri_batch = -W (here, in d3m_face_light(_backward) and in d3m_vertex_target): the IMPLICIT topology of
  * a depth map's grid mesh with W vertices per row (deep3dmap/core/renderer/utils.py:74-78: num_vertices = H*W, num_tri =
  * 2 (H-1)(W-1), cell (y, x) carries (tl, bl, tr) in the first half of the list and (tr, bl, br) in the second) -- NrRenderer's
@@ -182,8 +192,11 @@ size_t d3m_edge_plan_bytes(int batch_size, int num_faces, int image_size);
  * and saves the launch that clears them.  The plan itself does not use them. */
 size_t d3m_edge_plan_extents_offset(int batch_size, int num_faces, int image_size, size_t* bytes_each);
 size_t d3m_edge_plan_min_bytes(int batch_size, int num_faces, int image_size);
+/* flags: D3M_PRECLEARED -- the caller has zeroed the blob's first d3m_edge_plan_clear_bytes() bytes (line counters,
+ * cursors, arrival tickets and the extents above). */
+size_t d3m_edge_plan_clear_bytes(int batch_size, int num_faces, int image_size);
 int d3m_edge_plan(const float* faces, const int32_t* face_index_map, void* visibility, void* edge_plan,
-                  size_t edge_plan_size, int batch_size, int num_faces, int image_size, d3m_stream_t stream);
+                  size_t edge_plan_size, int batch_size, int num_faces, int image_size, int flags, d3m_stream_t stream);
 
 /* Scratch for the two entry points below: one int per face.  With it the sums are GATHERED per visible
  * face (no atomics; faces with a very large bounding box still use the per-pixel atomic kernel);
@@ -237,6 +250,24 @@ int d3m_camera_basis(const float* eye, int eye_batch, const float* at_or_directi
                      int up_batch, int is_look_at, float* rot_out, int batch_size, d3m_stream_t stream);
 
 /* vertices [Bv,V,3] (Bv = 1 broadcasts one mesh to every view) -> out [B,V,3] in NDC + depth. */
+/* d3m_lit_front -- the FIRST launch of a lit render step, three jobs in one grid (each optional):
+ *   camera   screen_out [B,V,3] = camera(vertices) as d3m_camera_forward (cam NULL: none).  `basis` (look_at / look only,
+ *            NULL: cam->rot holds the basis): the basis is computed here from eye / at_or_direction / up exactly as
+ *            d3m_camera_basis does and ALSO stored to cam->rot ([rot_batch,3,3], writable) for d3m_camera_backward;
+ *   light    light [light_batch, F', 3] as d3m_face_light (light NULL: none);
+ *   clears   up to 10 (pointer, bytes) ranges zeroed (4-byte multiples, 4-byte aligned) -- see "Clears" above.
+ * (NR/look_at.py:48-60 + NR/lighting.py:33-56 + the torch.zeros of NR/rasterize.py:50-58,111-115, as one kernel.) */
+typedef struct d3m_basis {
+    const float* eye;             /* [eye_batch,3] */
+    const float* at_or_direction; /* [at_batch,3]: `at` (look_at) or the viewing direction (look) */
+    const float* up;              /* [up_batch,3] */
+    int eye_batch, at_batch, up_batch, is_look_at;
+} d3m_basis;
+int d3m_lit_front(const float* vertices, int vertices_batch, const d3m_camera* cam, const d3m_basis* basis, float* screen_out,
+                  int batch_size, int num_vertices, const int32_t* tri, int tri_batch, int num_tri, int fill_back,
+                  float* light, int light_batch, float intensity_ambient, float intensity_directional,
+                  const float* color_ambient, const float* color_directional, const float* direction,
+                  void* const* zero_ptrs, const size_t* zero_bytes, int zero_count, d3m_stream_t stream);
 int d3m_camera_forward(const float* vertices, int vertices_batch, const d3m_camera* cam, float* out,
                        int batch_size, int num_vertices, d3m_stream_t stream);
 /* grad_vertices [Bv,V,3] = d(out)/d(vertices)^T grad_out; with Bv == 1 the B views are summed. */
@@ -401,11 +432,17 @@ struct d3m_fit_targets {
     void* edge_dot;
     int* edge_nz_lo_inv;
     int* edge_nz_hi1;
-    int defer_finish;            /* records form only: d3m_render_lit_epilogue leaves the partial sums in `scratch` and the
-                                  * caller completes *loss with d3m_fit_finish (on any stream ordered behind the pass) */
+    int flags;                   /* D3M_PRECLEARED: the caller has zeroed the scratch's ticket word
+                                  * (d3m_render_fit_scratch_clear_range) -- see "Clears" above; else the pass does it.
+                                  * D3M_FIT_FINISH_DEFERRED (records form of d3m_render_lit_epilogue only): the pass leaves
+                                  * its partial sums in `scratch` and does NOT complete *loss; d3m_backward_textures_lit,
+                                  * handed this struct (same flag) as `unscaled`, completes it in a kernel it launches anyway --
+                                  * for callers that run the backward pass right behind the forward pass: no finishing launch */
 };
+#define D3M_FIT_FINISH_DEFERRED 2
+/* scratch: totals | partial sums | group sums | ticket. */
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
-int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
+size_t d3m_render_fit_scratch_clear_range(int batch_size, int image_size, size_t* offset_floats);   /* returns a count of floats */
 /* The same objective evaluated on FINISHED images -- rgb [B,3,S,S], depth / alpha [B,S,S], row 0 = top: what
  * d3m_render_lit_epilogue wrote as rgb_out / depth_out / alpha_out without anti-aliasing -- with its gradient left as the
  * edge gradient's per-pixel records, exactly as the fused pass leaves them (fit->edge_grad, edge_dot, edge_nz_* zeroed by
@@ -436,7 +473,13 @@ int d3m_backward_textures_lit(const float* faces, const float* textures, int tex
                               const float* grad_depth_map, float* grad_faces, int batch_size, int num_tri, int fill_back,
                               int image_size, int texture_size, float eps, void* workspace, size_t workspace_bytes,
                               const d3m_vertex_target* vertex_target, void* visibility,
-                              const d3m_fit_targets* unscaled, d3m_stream_t stream);
+                              const d3m_fit_targets* unscaled, int flags, d3m_stream_t stream);
+/* flags: D3M_PRECLEARED -- the caller has zeroed the (up to four) ranges d3m_backward_textures_lit_clear_ranges reports for
+ * the same arguments: grad_light, the workspace's view masks / counter / arrival tickets (and, where they apply, the
+ * per-view gradients and the flags).  Returns the number of ranges written to ptrs / bytes (room for four). */
+int d3m_backward_textures_lit_clear_ranges(float* grad_textures, int textures_batch, float* grad_light, int light_batch,
+                                           int batch_size, int num_tri, int fill_back, int texture_size, void* workspace,
+                                           int has_visibility, void** ptrs, size_t* bytes);
 
 /* Output epilogue of rasterize_rgbad (rasterize.py:305-326) in one pass: background blend + alpha
  * (rasterize.py:181-195), HWC->CHW, vertical flip, optional 2x2 average pool.

@@ -347,12 +347,12 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
     assert L.d3m_warp_resample(p, p, 1, p, 1, p, p, 1.0, p, 0, None, 0, p, None, 1, 8, 8, 8, 8, st) == INVALID     # no channels
     assert L.d3m_warp_resample_partials(0, 8) <= 0 < L.d3m_warp_resample_partials(8, 8)
     # coverage on an index-free mesh: the row length must divide the vertex count and fix the triangle count
-    args = lambda tri, tb, V, Ft: (p, tri, tb, V, Ft, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, z.numel() * 4, None, 0, st)
+    args = lambda tri, tb, V, Ft: (p, tri, tb, V, Ft, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, z.numel() * 4, None, 0, 0, st)
     assert L.d3m_forward_face_index_map_mesh(*args(None, 1, 16, 18)) == INVALID        # neither indices nor a row length
     assert L.d3m_forward_face_index_map_mesh(*args(None, -5, 16, 18)) == INVALID       # 16 vertices are no rows of 5
     assert L.d3m_forward_face_index_map_mesh(*args(None, -4, 16, 17)) == INVALID       # a 4x4 grid has 18 triangles
     assert L.d3m_forward_face_index_map_mesh(*args(pi, 3, 16, 18)) == INVALID          # index batch 3 of 1
-    tiny = (p, None, -4, 16, 18, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, 64, None, 0, st)
+    tiny = (p, None, -4, 16, 18, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, 64, None, 0, 0, st)
     assert L.d3m_forward_face_index_map_mesh(*tiny) == WORKSPACE
     # the camera's adjoint onto an existing gradient; the objective's scratch for small rasters
     cam = _lib.D3MCamera()
@@ -369,7 +369,7 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
     wm, dm = torch.empty(1, 8, 8, 3, device=dev), torch.empty(1, 8, 8, device=dev)
     ws = torch.empty(int(L.d3m_forward_workspace_bytes(1, 36, 8)), dtype=torch.uint8, device=dev)
     rc = L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), None, -4, 16, 18, 1, _lib.ptr(faces), _lib.ptr(fi), _lib.ptr(wm), _lib.ptr(dm),
-                                           None, 1, 8, 0.1, 100.0, _lib.ptr(ws), ws.numel(), None, 0, st)
+                                           None, 1, 8, 0.1, 100.0, _lib.ptr(ws), ws.numel(), None, 0, 0, st)
     torch.cuda.synchronize()
     assert rc == 0 and int((fi >= 0).sum()) > 0 and L.d3m_last_hip_error() == 0
 
@@ -408,7 +408,7 @@ def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, s
     with kernels_launched() as k:
         _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), _lib.ptr(tr), 1, V, Ft, int(fill_back), _lib.ptr(faces), _lib.ptr(fi),
                                                      _lib.ptr(wm), _lib.ptr(dm), _lib.ptr(fim), B, S, 0.5, 3.5, _lib.ptr(ws), ws.numel(),
-                                                     _lib.ptr(vis), vis.numel(), _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+                                                     _lib.ptr(vis), vis.numel(), 0, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
     assert_coverage_form_ran(k.names, coverage)
     _lib.check(L.d3m_visibility(None, _lib.ptr(vis), vis.numel(), B, Fp, S, _lib.stream_ptr()), "d3m_visibility")
     # the reference composition: vertices_to_faces (+ the reversed copies), then the operator

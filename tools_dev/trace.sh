@@ -12,7 +12,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 name=lambda r: r['Kernel_Name'].replace('void ','').replace('d3m::','').split('(')[0].split('<')[0]
 # the replayed steps are the last ones before the instrumented eager pass; find the last run of steps by the camera_basis kernel
-idx=[i for i,r in enumerate(rows) if name(r)=='k_camera_basis']
+idx=[i for i,r in enumerate(rows) if name(r) in ('k_lit_front','k_camera_basis')]
 # steps: warmup+timed replays (8) then eager instrumented passes; take the 6th-from... use the replay region: pick the step
 # with the smallest span among the last 16
 best=None
