@@ -111,11 +111,13 @@ _SIGNATURES = {
                                      _P, _P]),
     "d3m_render_fit_scratch_floats": (_SZ, [_I, _I]),
     "d3m_render_fit_scratch_clear_range": (_SZ, [_I, _I, ctypes.POINTER(_SZ)]),
+    "d3m_fit_finish": (_I, [ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
     "d3m_fit_loss_records": (_I, [_P, _P, _P, _P, ctypes.POINTER(D3MFitTargets), _I, _I, _P]),
     "d3m_backward_textures_lit": (_I, [_P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _SZ,
                                        _P, _P, _P, _I, _P]),
     "d3m_backward_textures_lit_clear_ranges": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, ctypes.POINTER(_P),
                                                     ctypes.POINTER(_SZ)]),
+    "d3m_lit_back": (_I, [_P, _I, ctypes.POINTER(D3MCamera), _P, _P, _I, _I, _P, _I, _I, _I, _P, _I, _F, _F, _P, _P, _P, _P]),
     "d3m_lit_front": (_I, [_P, _I, ctypes.POINTER(D3MCamera), ctypes.POINTER(D3MBasis), _P, _I, _I, _P, _I, _I, _I, _P, _I,
                            _F, _F, _P, _P, _P, ctypes.POINTER(_P), ctypes.POINTER(_SZ), _I, _P]),
     "d3m_output_epilogue": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -166,6 +166,32 @@ class _FitLossOnLitImages(torch.autograd.Function):
         return g_rgb, g_depth, g_alpha, None, None, None, None, None, None
 
 
+class _FitLossFromRenderNode(torch.autograd.Function):
+    """multiview_fit_loss on the images of a lit render node that was given the objective's targets up front
+    (Renderer.fit_targets): the pass that wrote the images has evaluated the objective and left its gradient as walk
+    records already -- nothing is launched here.  Backward as _FitLossOnLitImages: the scalar through the link, zero-stride
+    zero images back."""
+
+    @staticmethod
+    def forward(ctx, rgb, depth, alpha, lit):
+        from ..neural_renderer.rasterize import LitImagesLink
+        hs = lit.hint_state
+        link = LitImagesLink(hs, (tuple(rgb.shape), tuple(depth.shape), tuple(alpha.shape)),
+                             torch.zeros(1, dtype=torch.float32, device=rgb.device))
+        link.finish_pending = bool(getattr(lit, "fit_flags", 0))      # the value is complete behind the render node's backward
+        lit.linked_fit = link
+        ctx.link = link
+        ctx.save_for_backward(rgb, depth, alpha)
+        return hs[5].reshape(())
+
+    backward = staticmethod(_FitLossOnLitImages.backward)
+
+
+def _same(a, b):
+    return torch.is_tensor(a) and torch.is_tensor(b) and a.data_ptr() == b.data_ptr() and a.shape == b.shape and \
+        a.dtype == b.dtype and a.stride() == b.stride()
+
+
 def _observed(t):
     """whether a tensor's gradient is looked at from outside the graph: retain_grad() or a tensor hook"""
     return torch.is_tensor(t) and (t.retains_grad or bool(getattr(t, "_backward_hooks", None)))
@@ -192,6 +218,10 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
         if lit is not None and rgb.dim() == 4 and rgb.shape[1] == 3 and rgb.shape[2] == rgb.shape[3] and all(
                 tuple(x.shape) == (B,) + tuple(rgb.shape[2:]) for x in (depth, alpha, depth_target, alpha_target, mask)) \
                 and tuple(rgb_target.shape) == tuple(rgb.shape):
+            hs = getattr(lit, "hint_state", None)
+            if hs is not None and _same(hs[0], rgb_target) and _same(hs[1], depth_target) and _same(hs[2], alpha_target) \
+                    and _same(hs[3], mask) and (mask_sum is None or _same(hs[7], mask_sum.reshape(1))):
+                return _FitLossFromRenderNode.apply(rgb, depth, alpha, lit)
             return _FitLossOnLitImages.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum, lit)
     return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum)
 

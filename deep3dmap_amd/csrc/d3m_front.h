@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) k_lit_front(FrontArgs a) {
             }
             if (v == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) a.basis.rot_out[(size_t)b * 9 + k] = rot[k];
+                for (int k = 0; k < 9; k++) a.basis.rot_out[(size_t)(a.cam.rot_b > 1 ? b : 0) * 9 + k] = rot[k];   // (one camera for all views: the same nine floats from every view)
             }
             c.rot = rot; c.rot_b = 1;               // camera_point reads the basis through the pointer: this lane's copy
             const float* p = a.vertices + ((size_t)(a.vb > 1 ? b : 0) * a.V + v) * 3;
@@ -119,6 +119,92 @@ __global__ void __launch_bounds__(256) k_lit_front(FrontArgs a) {
         if (i0 < head) a.z_ptr[k][i0] = 0;
         for (size_t i = i0; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
         for (size_t i = head + (n4 << 2) + i0; i < n_words; i += stride) a.z_ptr[k][i] = 0;
+    }
+}
+
+// ---- ... and its LAST launch: the camera's adjoint and the light's, both into the mesh's gradient ------------------------
+// Round 4 ended a step with k_face_light_backward (float atomics into grad_vertices) and, behind it, k_camera_backward_add
+// (one writer per entry, a plain read-modify-write): two launches of 11 and 13 us.  As block ranges of one grid both ADD with
+// float atomics into a gradient that is zero when the launch starts (the step's first launch cleared it) -- a vertex gets the
+// camera's sum over views from one lane and the light's contributions from its ~6 faces, in any order.
+//   blocks [0, nb_cam)       k_camera_backward's body (eight lanes per vertex of a shared mesh, DPP sum over the views)
+//   the rest                 k_face_light_backward's body
+struct BackArgs {
+    const float* vertices; int vb; Cam cam; const float* grad_screen; float* grad_vertices; int B, V;
+    IndexedFaces faces; LightParams lp; const float* grad_light; int light_b;
+    unsigned nb_cam;
+};
+__global__ void __launch_bounds__(256) k_lit_back(BackArgs a) {
+    if (blockIdx.x < a.nb_cam) {
+        const long t = (long)blockIdx.x * 256 + threadIdx.x;
+        const bool shared = a.vb <= 1;
+        const long i = shared ? t >> 3 : t;
+        const int sub = shared ? (int)(t & 7) : 0;
+        const long n = (long)(shared ? 1 : a.B) * a.V;
+        const bool on = i < n;
+        const int v = on ? (int)(i % a.V) : 0;
+        const int b_lo = shared ? sub : (int)(i / a.V), b_hi = shared ? a.B : b_lo + 1, b_step = shared ? 8 : 1;
+        float acc[3] = {0, 0, 0};
+        if (on) {
+            const float* p = a.vertices + (size_t)i * 3;
+            const float in[3] = {p[0], p[1], p[2]};
+            for (int b = b_lo; b < b_hi; b += b_step) {
+                const float* gp = a.grad_screen + ((size_t)b * a.V + v) * 3;
+                const float g[3] = {gp[0], gp[1], gp[2]};
+                float gv[3];
+                camera_point_adjoint(a.cam, b, in, g, gv);
+                acc[0] += gv[0]; acc[1] += gv[1]; acc[2] += gv[2];
+            }
+        }
+        if (shared) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                acc[k] += dpp_f32<0xB1>(acc[k]);      // quad_perm [1,0,3,2]
+                acc[k] += dpp_f32<0x4E>(acc[k]);      // quad_perm [2,3,0,1]
+                acc[k] += dpp_f32<0x141>(acc[k]);     // row_half_mirror: the other quad of the 8
+            }
+        }
+        if (on && sub == 0) {
+            atomicAdd(&a.grad_vertices[i * 3 + 0], acc[0]);
+            atomicAdd(&a.grad_vertices[i * 3 + 1], acc[1]);
+            atomicAdd(&a.grad_vertices[i * 3 + 2], acc[2]);
+        }
+        return;
+    }
+    // the light's adjoint: k_face_light_backward's body
+    const long i = (long)(blockIdx.x - a.nb_cam) * 256 + threadIdx.x;
+    const IndexedFaces& fs = a.faces;
+    const LightParams& lp = a.lp;
+    const int Fp = fs.num_faces();
+    if (i >= (long)a.light_b * Fp || lp.id == 0) return;
+    const float gl[3] = {a.grad_light[3 * i], a.grad_light[3 * i + 1], a.grad_light[3 * i + 2]};
+    if (gl[0] == 0 && gl[1] == 0 && gl[2] == 0) return;
+    const int b = (int)(i / Fp), f = (int)(i % Fp);
+    float fc[9], l[3], nrm[3], len, cs;
+    fs.load(b, f, fc);
+    face_light(fc, lp, l, nrm, &len, &cs);
+    if (!(cs > 0)) return;
+    const float g_cos = lp.id * (lp.cd[0] * gl[0] + lp.cd[1] * gl[1] + lp.cd[2] * gl[2]);
+    const float gn[3] = {g_cos * lp.dir[0], g_cos * lp.dir[1], g_cos * lp.dir[2]};
+    float gc[3];
+    if (len > 1e-5f) {
+        const float dot = nrm[0] * gn[0] + nrm[1] * gn[1] + nrm[2] * gn[2];
+        for (int k = 0; k < 3; k++) gc[k] = (gn[k] - nrm[k] * dot) / len;
+    } else {
+        for (int k = 0; k < 3; k++) gc[k] = gn[k] / 1e-5f;
+    }
+    const float ea[3] = {fc[0] - fc[3], fc[1] - fc[4], fc[2] - fc[5]};
+    const float eb[3] = {fc[6] - fc[3], fc[7] - fc[4], fc[8] - fc[5]};
+    float ga[3], gb[3];
+    cross3(eb, gc, ga);
+    cross3(gc, ea, gb);
+    int ids[3];
+    fs.vertex_ids(b, f, ids);
+    float* base = a.grad_vertices + (size_t)(a.vb > 1 ? b : 0) * fs.V * 3;
+    for (int k = 0; k < 3; k++) {
+        atomicAdd(&base[(size_t)ids[0] * 3 + k], ga[k]);
+        atomicAdd(&base[(size_t)ids[2] * 3 + k], gb[k]);
+        atomicAdd(&base[(size_t)ids[1] * 3 + k], -(ga[k] + gb[k]));
     }
 }
 

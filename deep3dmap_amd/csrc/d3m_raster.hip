@@ -961,6 +961,33 @@ D3M_EXPORT int d3m_lit_front(const float* vertices, int vertices_batch, const d3
     return check_launch();
 }
 
+// ---- ... and its last launch: the camera's and the light's adjoints ADDED into grad_vertices (d3m_front.h k_lit_back) ------
+D3M_EXPORT int d3m_lit_back(const float* vertices, int vertices_batch, const d3m_camera* cam, const float* grad_screen,
+                            float* grad_vertices, int batch_size, int num_vertices, const int32_t* tri, int tri_batch,
+                            int num_tri, int fill_back, const float* grad_light, int light_batch, float intensity_ambient,
+                            float intensity_directional, const float* color_ambient, const float* color_directional,
+                            const float* direction, d3m_stream_t stream) {
+    if (!vertices || !cam || !grad_screen || !grad_vertices || !grad_light || !color_ambient || !color_directional ||
+        !direction || batch_size <= 0 || num_vertices <= 0 || num_tri <= 0 || light_batch <= 0)
+        return D3M_ERR_INVALID;
+    if (vertices_batch != 1 && vertices_batch != batch_size) return D3M_ERR_INVALID;
+    BackArgs a;
+    memset(&a, 0, sizeof(a));
+    if (int rc = to_cam(cam, batch_size, a.cam)) return rc;
+    int grid_w;
+    if (!tri_source_ok(tri, tri_batch, tri_batch, num_vertices, num_tri, grid_w)) return D3M_ERR_INVALID;
+    a.vertices = vertices; a.vb = vertices_batch; a.grad_screen = grad_screen; a.grad_vertices = grad_vertices;
+    a.B = batch_size; a.V = num_vertices;
+    a.faces = IndexedFaces{vertices, tri, num_vertices, num_tri, tri ? tri_batch : 1, fill_back ? 1 : 0, vertices_batch, grid_w};
+    a.lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    a.grad_light = grad_light; a.light_b = light_batch;
+    const long n_cam = vertices_batch > 1 ? (long)batch_size * num_vertices : 8l * num_vertices;     // lanes: see the kernel
+    a.nb_cam = blocks_for(n_cam, 256);
+    const unsigned nb_light = blocks_for((long)light_batch * a.faces.num_faces(), 256);
+    LAUNCH("k_lit_back", k_lit_back, dim3(a.nb_cam + nb_light), dim3(256), (hipStream_t)stream, a);
+    return check_launch();
+}
+
 static int make_lit(LitTextures& lt, const float* textures, int textures_batch, const float* light, int light_batch,
                     int num_tri, int texture_size, int fill_back, int B) {
     if (!textures || !light || num_tri <= 0 || texture_size <= 0) return D3M_ERR_INVALID;
@@ -1109,6 +1136,15 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         const FitFin fin = make_fit_fin(fit, batch_size, image_size, s, (int)blocks_for(n, threads), 256);
         LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
     }
+    return check_launch();
+}
+
+// The objective's finish as a call of its own, for a records-form pass made with D3M_FIT_FINISH_DEFERRED whose backward pass
+// does not take the route that would have finished it (k_fit_finish: partial sums -> totals, *fit->loss).
+D3M_EXPORT int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream) {
+    if (!fit || !fit->scratch || !fit->loss || !fit->edge_grad || batch_size <= 0 || image_size <= 0) return D3M_ERR_INVALID;
+    const FitFin fin = fit_fin_of_tiles(fit, batch_size, image_size);
+    LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), (hipStream_t)stream, fin);
     return check_launch();
 }
 

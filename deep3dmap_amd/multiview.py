@@ -167,6 +167,12 @@ class MultiViewFit:
     def render(self, vertices=None, textures=None):
         v = self.vertices if vertices is None else vertices
         t = self.textures if textures is None else textures
+        # the drop-in form (render, then the objective on the images): the objective is REGISTERED with the renderer, whose
+        # pass then leaves value and walk records behind for multiview_fit_loss to find (Renderer.fit_targets)
+        self.renderer.fit_targets = None
+        if not self.objective_in_renderer and self.targets is not None and vertices is None:
+            rgb_t, depth_t, alpha_t = self.targets
+            self.renderer.fit_targets = (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum)
         # one mesh, one texture set, n_local cameras (renderer.eye is [n_local, 3]): batch-1 inputs are shared
         return self.renderer(v[None], self.triangles[None], t[None])
 

@@ -275,6 +275,7 @@ class LitImagesLink:
     def __init__(self, fit_state, shapes, zero):
         self.fit_state, self.shapes, self.zero = fit_state, shapes, zero
         self.grad_loss = None
+        self.finish_pending = False     # the objective's totals are still partial sums (D3M_FIT_FINISH_DEFERRED)
         self.pending = False            # the loss node's backward ran and the render node's has not consumed it yet
         # The images themselves are NOT kept here: the render node's context holds this link, and an image holds that
         # context as its grad_fn -- a reference cycle through the autograd graph.  The loss node (which saved them) lends
@@ -305,6 +306,10 @@ class LitImagesLink:
         rgb, depth, alpha = self.images
         rgb_t, depth_t, alpha_t, mask, scratch = self.fit_state[:5]
         B, _, H, W = rgb.shape
+        if self.finish_pending:         # (a registered objective whose finish was left to the records route: do it now)
+            self.finish_pending = False
+            fit_c = _RasterizeLit._fit_struct(self.fit_state, 0, 0, B, None)
+            _lib.check(_lib.lib().d3m_fit_finish(ctypes.byref(fit_c), B, H, _lib.stream_ptr()), "d3m_fit_finish")
         own = [torch.empty_like(t) for t in (rgb, depth, alpha)]
         t = (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)
         _lib.check(_lib.lib().d3m_fit_loss_backward(*[_lib.ptr(x) for x in t], _lib.ptr(scratch[0]), _lib.ptr(self.grad_loss),
@@ -380,7 +385,7 @@ class _RasterizeLit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size, anti_aliasing, near,
                 far, eps, background_color, return_rgb, return_alpha, return_depth, fit=None, view_groups=1,
-                defer_plan_join=False, camera=None, grad_sink=None):
+                defer_plan_join=False, camera=None, grad_sink=None, fit_hint=None):
         L = _lib.lib()
         vertices, textures = f32c(vertices), f32c(textures)
         tri = tri.to(torch.int32).contiguous()
@@ -439,11 +444,19 @@ class _RasterizeLit(torch.autograd.Function):
         s_out = S // 2 if anti_aliasing else S
         rgb = alpha = depth = loss_g = None
         fit_state = None
+        # A REGISTERED objective (Renderer.fit_targets -> `fit_hint`): the node returns the IMAGES, as render() does, and the
+        # pass that writes them also evaluates the objective the caller is about to evaluate on them and leaves its gradient
+        # as walk records (the fused objective's pass with images_out): core.losses.multiview_fit_loss, handed these very
+        # images and targets, then finds value and records here instead of re-reading the images (`hint_state`).
+        hinted = (fit is None and fit_hint is not None and not anti_aliasing and return_alpha and return_depth and need_grad
+                  and G == 1)
         if fit is None:
             rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
             alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
             depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
-        else:
+            if hinted:
+                fit = (tuple(fit_hint) + (None,))[:5] + ((rgb, depth, alpha),)
+        if fit is not None:
             # the fit objective is evaluated where the images are produced: they are never written (rasterize_lit_fit)
             if not (return_alpha and return_depth):
                 raise ValueError("the fused fit objective needs rgb, alpha and depth")
@@ -608,10 +621,11 @@ class _RasterizeLit(torch.autograd.Function):
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
         ctx.maps = m
-        ctx.fit = fit_state
+        ctx.fit = None if hinted else fit_state
+        ctx.hint_state = fit_state if hinted else None
         ctx.camera, ctx.cam_keep, ctx.grad_sink = camera, cam_keep, grad_sink
         ctx.save_for_backward(faces, vertices, tri, textures, light)
-        if fit is not None:
+        if fit is not None and not hinted:
             return loss_g.sum() if G > 1 else loss_g.reshape(())
         empty = torch.tensor([])
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
@@ -850,8 +864,12 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward")
 
-        light_done = False
-        if gathered and need_vert and G == 1:
+        # One pipeline on one stream with the camera inside the node: the light's adjoint and the camera's are the step's last
+        # two kernels -- ONE launch then (d3m_lit_back: both add into the zeroed grad_vertices with float atomics).  With
+        # branches the light's adjoint runs beside the line walk instead (below), where it costs the step nothing.
+        fused_tail = serial and G == 1 and gathered and need_vert and ctx.camera is not None
+        light_done = fused_tail
+        if gathered and need_vert and G == 1 and not fused_tail:
             # one pipeline: straight behind the gathered pass on its branch, beside the line walk, not behind the join
             with torch.cuda.stream(s_gath[0]):
                 light_to_vertices(gl_g[0] if light_shared else grad_light)
@@ -888,7 +906,15 @@ class _RasterizeLit(torch.autograd.Function):
                                    g_depth_map, grad_faces, S)
             _lib.check(L.d3m_scatter_face_grads(_lib.ptr(grad_faces), _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_sv), B, V,
                                                 Ft, int(fill_back), _lib.stream_ptr()), "d3m_scatter_face_grads")
-        if ctx.camera is not None:
+        if fused_tail:
+            from . import cameras
+            cam, _keep = cameras._camera_struct(ctx.camera, dev)
+            _lib.check(L.d3m_lit_back(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(grad_sv),
+                                      _lib.ptr(grad_vertices), B, V, _lib.ptr(tri), tri.shape[0], Ft, int(fill_back),
+                                      _lib.ptr(gl_g[0] if light_shared else grad_light), Bl, ia, idr, _vec3_host(ca),
+                                      _vec3_host(cd), _vec3_host(direction), _lib.stream_ptr()), "d3m_lit_back")
+            grad_sv = None
+        elif ctx.camera is not None:
             # the camera's adjoint joins the light's in the same buffer (or writes it, when there is none)
             from . import cameras
             cam, _keep = cameras._camera_struct(ctx.camera, dev)
@@ -903,7 +929,7 @@ class _RasterizeLit(torch.autograd.Function):
             grad_sv = None
         if tail_on_side:
             cur.wait_stream(auxs[0])
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 16
+        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 17
 
 
 class _ManualContext:
@@ -931,7 +957,7 @@ class LitFitManual:
     node: it is that node's code (tests/test_gpu_multirank.py)."""
 
     def __init__(self, vertices_grad=True, textures_grad=True):
-        self._needs = (False, bool(vertices_grad), False, bool(textures_grad)) + (False,) * 16
+        self._needs = (False, bool(vertices_grad), False, bool(textures_grad)) + (False,) * 17
         self._ctx = self._halves = None
 
     def forward(self, vertices, tri, textures, light_cfg, fill_back, targets, image_size, near, far, eps, background_color,
@@ -965,15 +991,17 @@ class LitFitManual:
 def rasterize_lit(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size=DEFAULT_IMAGE_SIZE,
                   anti_aliasing=DEFAULT_ANTI_ALIASING, near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS,
                   background_color=DEFAULT_BACKGROUND_COLOR, return_alpha=True, return_depth=True, view_groups=1,
-                  camera=None):
+                  camera=None, fit_hint=None, defer_plan_join=False):
     """rgb (+alpha, depth) images of the mesh (`screen_vertices` [B,V,3] after the camera transform, triangles
     `tri` [1|B,F,3]) textured with the ORIGINAL `textures` [1|B,F,ts,ts,ts,3]; the fill_back copy and the per-face
     light (computed from world-space `vertices`) are applied on the fly.  Same outputs as vertices_to_faces() +
     lighting() + rasterize_rgbad() on the materialised arrays.  `camera` (with screen_vertices None): the fused camera
-    kernels' parameter block (cameras.look_at_params) -- the transform then runs inside the node."""
+    kernels' parameter block (cameras.look_at_params) -- the transform then runs inside the node.  `fit_hint` = the targets
+    (rgb, depth, alpha, mask[, mask_sum]) of a multi-view fit objective the caller is about to evaluate on the returned
+    images: see _RasterizeLit.forward, "a REGISTERED objective"."""
     rgb, alpha, depth = _RasterizeLit.apply(screen_vertices, vertices, tri, textures, light_cfg, fill_back, image_size,
                                             anti_aliasing, near, far, eps, background_color, True, return_alpha,
-                                            return_depth, None, view_groups, False, camera)
+                                            return_depth, None, view_groups, defer_plan_join, camera, None, fit_hint)
     return {'rgb': rgb, 'alpha': alpha if return_alpha else None, 'depth': depth if return_depth else None}
 
 

@@ -68,6 +68,13 @@ class Renderer(nn.Module):
         # render_fit_loss only: leave the forward's side branch (visibility list, edge-gradient plan) open for backward
         # to join.  ONLY for callers that run backward right behind forward on the same stream (MultiViewFit does).
         self.defer_plan_join = False
+        # A fit objective REGISTERED with the renderer: (rgb_target [B,3,s,s], depth_target, alpha_target, mask [B,s,s]
+        # [, mask_sum]).  render() (lit path, no anti-aliasing) then evaluates it in the pass that writes the images and
+        # leaves its gradient as the edge gradient's walk records; core.losses.multiview_fit_loss called on those images
+        # with these very tensors returns that value and back-propagates through the records -- the reference-shaped
+        # composition  loss(*renderer.render(...))  at the price of the fused objective plus the images' 20 B per pixel.
+        # Any other use of the images stays correct (they are ordinary differentiable outputs).  None: off.
+        self.fit_targets = None
 
     def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
                 orig_size=None):
@@ -205,7 +212,8 @@ class Renderer(nn.Module):
             sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                view_groups=self.view_groups, camera=cam)
+                                view_groups=self.view_groups, camera=cam, fit_hint=self.fit_targets,
+                                defer_plan_join=self.defer_plan_join)
         else:
             f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
             textures = self._lit_textures(vertices, faces, textures)

@@ -268,6 +268,14 @@ int d3m_lit_front(const float* vertices, int vertices_batch, const d3m_camera* c
                   float* light, int light_batch, float intensity_ambient, float intensity_directional,
                   const float* color_ambient, const float* color_directional, const float* direction,
                   void* const* zero_ptrs, const size_t* zero_bytes, int zero_count, d3m_stream_t stream);
+/* d3m_lit_back -- the LAST launch of such a step: grad_vertices [vertices_batch,V,3] += the camera's adjoint of grad_screen
+ * [B,V,3] (d3m_camera_backward) + the light's adjoint of grad_light [light_batch,F',3] (d3m_face_light_backward), both with
+ * float atomics in one grid: grad_vertices must hold zeros (or other contributions) when the launch starts. */
+int d3m_lit_back(const float* vertices, int vertices_batch, const d3m_camera* cam, const float* grad_screen,
+                 float* grad_vertices, int batch_size, int num_vertices, const int32_t* tri, int tri_batch, int num_tri,
+                 int fill_back, const float* grad_light, int light_batch, float intensity_ambient,
+                 float intensity_directional, const float* color_ambient, const float* color_directional,
+                 const float* direction, d3m_stream_t stream);
 int d3m_camera_forward(const float* vertices, int vertices_batch, const d3m_camera* cam, float* out,
                        int batch_size, int num_vertices, d3m_stream_t stream);
 /* grad_vertices [Bv,V,3] = d(out)/d(vertices)^T grad_out; with Bv == 1 the B views are summed. */
@@ -440,6 +448,8 @@ struct d3m_fit_targets {
                                   * for callers that run the backward pass right behind the forward pass: no finishing launch */
 };
 #define D3M_FIT_FINISH_DEFERRED 2
+/* ... or, should the backward pass not come that way after all, by this call (the ticket must still be zero: one finish). */
+int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
 /* scratch: totals | partial sums | group sums | ticket. */
 size_t d3m_render_fit_scratch_floats(int batch_size, int image_size);
 size_t d3m_render_fit_scratch_clear_range(int batch_size, int image_size, size_t* offset_floats);   /* returns a count of floats */

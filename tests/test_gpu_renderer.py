@@ -908,3 +908,77 @@ def test_linked_fit_loss_with_observed_image_gradients():
     rgb, depth, alpha = fit.render()
     (g,) = torch.autograd.grad(multiview_fit_loss(rgb, depth, alpha, *args, link=False), rgb)
     assert _rel_max(g, g_img[0]) < 1e-6
+
+
+def test_registered_objective_rides_in_the_render_pass():
+    """the reference-shaped composition with the objective REGISTERED on the renderer (Renderer.fit_targets):
+    render() returns the same images bit for bit, the pass that writes them has evaluated the objective and left walk
+    records, and multiview_fit_loss on those images with those targets launches NOTHING (no k_fit_loss_records) -- value
+    and gradients equal to the fused objective; other targets, other consumers and observed image gradients fall back to
+    the ordinary routes and stay correct."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core.losses import _MultiViewFitLoss, multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(20)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(4), image_size=96)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    loss0, gv0, gt0 = (t.clone() for t in fit.step())                # the fused objective (render_fit_loss)
+    rgb_t, depth_t, alpha_t = fit.targets
+    args = (rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+    with torch.no_grad():
+        ref_images = fit.render()
+    r = fit.renderer
+
+    def render_registered():
+        fit.vertices.grad = fit.textures.grad = None
+        r.fit_targets = args
+        try:
+            return r(fit.vertices[None], fit.triangles[None], fit.textures[None])
+        finally:
+            r.fit_targets = None
+
+    with kernels_launched() as k:
+        rgb, depth, alpha = render_registered()
+        loss = multiview_fit_loss(rgb, depth, alpha, *args)
+        loss.backward()
+    assert "k_render_lit_fit_records" in k.names and not ({"k_fit_loss_records", "k_fit_loss_grad", "k_pack_maps"} & k.names), sorted(k.names)
+    for got, ref in zip((rgb, depth, alpha), ref_images):
+        assert torch.equal(got.detach(), ref)
+    assert abs(float(loss.detach()) - float(loss0)) <= 1e-6 * abs(float(loss0))
+    assert _rel_max(fit.vertices.grad, gv0) < 1e-5 and _rel_max(fit.textures.grad, gt0) < 1e-5
+    # OTHER targets than the registered ones: the ordinary linked objective (its own pass over the images)
+    other = (rgb_t * 0.5, depth_t, alpha_t, alpha_t, fit.mask_sum)
+    grads = []
+    for registered in (True, False):
+        if registered:
+            rgb, depth, alpha = render_registered()
+        else:
+            fit.vertices.grad = fit.textures.grad = None
+            rgb, depth, alpha = fit.render()
+        multiview_fit_loss(rgb, depth, alpha, *other).backward()
+        grads.append((fit.vertices.grad.clone(), fit.textures.grad.clone()))
+    assert _rel_max(grads[0][0], grads[1][0]) < 1e-5 and _rel_max(grads[0][1], grads[1][1]) < 1e-5
+    # another consumer beside the objective, and an observed image gradient: gradient images after all
+    w = torch.randn_like(rgb_t)
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    (_MultiViewFitLoss.apply(rgb, depth, alpha, *args) + (rgb * w).mean()).backward()
+    want = (fit.vertices.grad.clone(), fit.textures.grad.clone())
+    rgb, depth, alpha = render_registered()
+    (multiview_fit_loss(rgb, depth, alpha, *args) + (rgb * w).mean()).backward()
+    assert _rel_max(fit.vertices.grad, want[0]) < 1e-5 and _rel_max(fit.textures.grad, want[1]) < 1e-5
+    rgb, depth, alpha = render_registered()
+    loss = multiview_fit_loss(rgb, depth, alpha, *args)
+    depth.retain_grad()
+    loss.backward()
+    assert float(depth.grad.abs().max()) > 0 and _rel_max(fit.vertices.grad, gv0) < 1e-5
+    # the images alone, objective registered and never asked for: ordinary image gradients
+    rgb, depth, alpha = render_registered()
+    (rgb * w).mean().backward()
+    only = fit.vertices.grad.clone()
+    fit.vertices.grad = fit.textures.grad = None
+    rgb, depth, alpha = fit.render()
+    (rgb * w).mean().backward()
+    assert _rel_max(only, fit.vertices.grad) < 1e-5
