@@ -13,7 +13,7 @@ namespace d3m {
 
 struct BinBuffers {
     int B, F, S, tiles_x, tiles_y, T, kcap;     // T = tiles_x * tiles_y tiles of TILE_W x TILE_H pixels per view
-    uint2* rect;        // [B*F]  tile rectangle of each face (x = tx0 | ty0<<16, y = tx1 | ty1<<16), x = ~0u: none
+    void* rect;         // [B*F]  tile rectangle of each face: 4 bytes (Rect32) on rasters of up to 1024 x 1024 tiles, else 8 (Rect64)
     int* tile_count;    // [B*T]  zeroed per call
     int* tile_cursor;   // [B*T]  zeroed per call
     int* big_count;     // [B]    zeroed per call
@@ -24,6 +24,44 @@ struct BinBuffers {
 };
 
 constexpr uint32_t RECT_NONE = 0xFFFFFFFFu;
+// A face's tile rectangle as the counting pass leaves it for the list-filling pass: origin and extent in tiles, "none"
+// (culled, or no pixel centre in its box) or "big" (more than kcap tiles: listed per view instead).  The 8-byte form
+// (origin | far corner, 16 bits each) was 51 MB of stores and as many bytes of loads per headline step; on rasters of up to
+// 1024 x 1024 tiles (S <= 8192) origin (10 + 10 bits) and extent - 1 (6 + 6 bits: a listed rectangle has at most kcap <= 64
+// tiles) fit four bytes.
+struct TileRect { int tx0, ty0, w, h; bool none, big; };
+struct Rect64 {
+    typedef uint2 T;
+    static __device__ __forceinline__ T pack(int tx0, int ty0, int tx1, int ty1, bool big) {
+        (void)big;
+        return make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
+    }
+    static __device__ __forceinline__ T none() { return make_uint2(RECT_NONE, 0); }
+    static __device__ __forceinline__ TileRect unpack(T r, int kcap) {
+        TileRect t;
+        t.none = r.x == RECT_NONE;
+        t.tx0 = r.x & 0xFFFF; t.ty0 = r.x >> 16;
+        t.w = (int)(r.y & 0xFFFF) - t.tx0 + 1; t.h = (int)(r.y >> 16) - t.ty0 + 1;
+        t.big = !t.none && t.w * t.h > kcap;
+        return t;
+    }
+};
+struct Rect32 {
+    typedef uint32_t T;
+    static constexpr uint32_t BIG = 0xFFFFFFFEu;          // (extent - 1 = 63 x 63: no listed rectangle)
+    static __device__ __forceinline__ T pack(int tx0, int ty0, int tx1, int ty1, bool big) {
+        if (big) return BIG;
+        return (uint32_t)tx0 | ((uint32_t)ty0 << 10) | ((uint32_t)(tx1 - tx0) << 20) | ((uint32_t)(ty1 - ty0) << 26);
+    }
+    static __device__ __forceinline__ T none() { return RECT_NONE; }
+    static __device__ __forceinline__ TileRect unpack(T r, int kcap) {
+        (void)kcap;
+        TileRect t;
+        t.none = r == RECT_NONE; t.big = r == BIG;
+        t.tx0 = r & 0x3FF; t.ty0 = (r >> 10) & 0x3FF; t.w = (int)((r >> 20) & 0x3F) + 1; t.h = (int)(r >> 26) + 1;
+        return t;
+    }
+};
 
 // Conservative pixel bounding box of a face, in the raster's pixel grid.  NDC -> pixel is
 // p = (v*S + S - 1)/2 (KCU:47).  The box is dilated by a rounding margin so that no pixel that passes
@@ -100,7 +138,7 @@ __device__ __forceinline__ int ta_add(TileAgg& t, int tile, int& rank) {
 // PAIRED (an indexed mesh with fill_back): face Ft+f is face f with its vertices in reverse order, and at most one
 // of the two is front-facing -- one lane loads the three vertices once and handles both copies, instead of a second
 // lane repeating the index and vertex gathers only to find its copy culled.
-template <class FS, bool PAIRED>
+template <class FS, bool PAIRED, class RECT>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb, float* __restrict__ faces_inv,
                                                   float* __restrict__ faces_dense_out,
                                                   unsigned char* __restrict__ marks = nullptr,
@@ -121,7 +159,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
         float face[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) face[k] = side == 0 ? loaded[k] : loaded[(2 - k / 3) * 3 + k % 3];
-        uint2 r = make_uint2(RECT_NONE, 0);
+        typename RECT::T r = RECT::none();
         int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;     // empty
         bool small = false;
         if (in_range) {
@@ -139,15 +177,15 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
                         for (int k = 0; k < 9; k++) faces_dense_out[i * 9 + k] = face[k];
                     }
                     tx0 = x0 / TILE_W; tx1 = x1 / TILE_W; ty0 = y0 / TILE_H; ty1 = y1 / TILE_H;
-                    r = make_uint2((uint32_t)tx0 | ((uint32_t)ty0 << 16), (uint32_t)tx1 | ((uint32_t)ty1 << 16));
                     small = (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= bb.kcap;
+                    r = RECT::pack(tx0, ty0, tx1, ty1, !small);
                     if (!small) {
                         const int pos = atomicAdd(&bb.big_count[b], 1);
                         bb.big_list[(size_t)b * F + pos] = f;
                     }
                 }
             }
-            bb.rect[i] = r;
+            reinterpret_cast<typename RECT::T*>(bb.rect)[i] = r;
             if (marks) marks[i] = 0;                  // "owns a pixel": set by the tile pass (RasterOut::marks)
         }
         // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
@@ -192,8 +230,9 @@ __global__ void __launch_bounds__(BIN_ALLOC_THREADS) k_bin_alloc(BinBuffers bb) 
 // distinct tile and workgroup, what bounds this pass on dense meshes (a workgroup's consecutive sub-pixel faces are a
 // thin strip through hundreds of tiles) -- are shared by FPT x as many pairs.  (Reading a rectangle is cheap; the count
 // pass, which loads and tests the faces, was slower with more than one face per thread.)
-template <bool PAIRED, int FPT>
+template <bool PAIRED, int FPT, class RECT>
 __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
+    const typename RECT::T* __restrict__ rects = reinterpret_cast<const typename RECT::T*>(bb.rect);
     __shared__ TileAgg agg;
     ta_clear(agg);
     const int Fl = PAIRED ? bb.F / 2 : bb.F;
@@ -206,27 +245,24 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
         if (lane_i < (long)bb.B * Fl) {
             b = (int)(lane_i / Fl);
             const int f0 = (int)(lane_i % Fl);
-            uint2 r = bb.rect[(size_t)b * bb.F + f0];
+            TileRect r = RECT::unpack(rects[(size_t)b * bb.F + f0], bb.kcap);
             f = f0;
             if (PAIRED) {
-                const uint2 r1 = bb.rect[(size_t)b * bb.F + f0 + Fl];
-                if (r.x == RECT_NONE) { r = r1; f = f0 + Fl; }
-                else if (r1.x != RECT_NONE) {             // both copies listed: the second one the plain way
-                    const int ax0 = r1.x & 0xFFFF, ay0 = r1.x >> 16, aw = (int)(r1.y & 0xFFFF) - ax0 + 1;
-                    const int an = aw * ((int)(r1.y >> 16) - ay0 + 1);
-                    for (int s2 = 0; s2 < (an > bb.kcap ? 0 : an); s2++) {
-                        const int tile = b * bb.T + (ay0 + s2 / aw) * bb.tiles_x + ax0 + s2 % aw;
+                const TileRect r1 = RECT::unpack(rects[(size_t)b * bb.F + f0 + Fl], bb.kcap);
+                if (r.none) { r = r1; f = f0 + Fl; }
+                else if (!r1.none && !r1.big) {           // both copies listed: the second one the plain way
+                    const int an = r1.w * r1.h;
+                    for (int s2 = 0; s2 < an; s2++) {
+                        const int tile = b * bb.T + (r1.ty0 + s2 / r1.w) * bb.tiles_x + r1.tx0 + s2 % r1.w;
                         const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
                         bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f0 + Fl;
                     }
                 }
             }
-            if (r.x != RECT_NONE) {
-                tx0 = r.x & 0xFFFF; ty0 = r.x >> 16;
-                const int tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-                w = tx1 - tx0 + 1;
-                nt = w * (ty1 - ty0 + 1);
-                if (nt > bb.kcap) nt = 0;                 // lives in big_list
+            if (!r.none && !r.big) {                      // (a big face lives in big_list)
+                tx0 = r.tx0; ty0 = r.ty0;
+                w = r.w;
+                nt = w * r.h;
             }
         }
         // ranks within the workgroup from the LDS table (first TA_LOCAL tiles of a face; the rare further ones and a

@@ -176,7 +176,7 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
     bb.big_count = (int*)(p + L.off_big_count);
     bb.alloc_cursor = (int*)(p + L.off_alloc);
     bb.tile_offset = (int*)(p + L.off_offset);
-    bb.rect = (uint2*)(p + L.off_rect);
+    bb.rect = p + L.off_rect;            // (laid out for the 8-byte form; the 4-byte form uses the first half)
     bb.big_list = (int*)(p + L.off_big);
     bb.pairs = (int*)(p + L.off_pairs);
     return D3M_OK;
@@ -185,16 +185,29 @@ static int make_bins(BinBuffers& bb, int B, int F, int S, void* ws, size_t ws_by
 // binning workgroup: 1024 lanes (fewest global atomics on the tile counters) once that still fills the chip
 static inline unsigned bin_threads(long lanes) { return lanes >= 1024l * 1024 ? BIN_THREADS : BIN_THREADS_SMALL; }
 
+// the faces' tile rectangles in four bytes (d3m_forward.h Rect32) where the raster allows it
+static inline bool rect32_ok(const BinBuffers& bb) { return bb.tiles_x <= 1024 && bb.tiles_y <= 1024 && bb.kcap <= 64; }
 // the list-filling pass: more face (pairs) per thread once the launch stays large (see k_bin_fill)
-template <bool PAIRED>
-static inline void launch_bin_fill(const BinBuffers& bb, long lanes, hipStream_t st) {
+template <bool PAIRED, class RECT>
+static inline void launch_bin_fill_r(const BinBuffers& bb, long lanes, hipStream_t st) {
     const unsigned th = bin_threads(lanes);
     if (lanes >= 4l * 1024 * 1024)
-        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 4>), dim3(blocks_for(lanes, th * 4)), dim3(th), st, bb);
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 4, RECT>), dim3(blocks_for(lanes, th * 4)), dim3(th), st, bb);
     else if (lanes >= 2l * 1024 * 1024)
-        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 2>), dim3(blocks_for(lanes, th * 2)), dim3(th), st, bb);
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 2, RECT>), dim3(blocks_for(lanes, th * 2)), dim3(th), st, bb);
     else
-        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 1>), dim3(blocks_for(lanes, th)), dim3(th), st, bb);
+        LAUNCH("k_bin_fill", (k_bin_fill<PAIRED, 1, RECT>), dim3(blocks_for(lanes, th)), dim3(th), st, bb);
+}
+template <bool PAIRED>
+static inline void launch_bin_fill(const BinBuffers& bb, long lanes, hipStream_t st) {
+    if (rect32_ok(bb)) launch_bin_fill_r<PAIRED, Rect32>(bb, lanes, st);
+    else launch_bin_fill_r<PAIRED, Rect64>(bb, lanes, st);
+}
+template <class FS, bool PAIRED, class... Args>
+static inline void launch_bin_count(const BinBuffers& bb, long lanes, hipStream_t st, FS fs, Args... args) {
+    const unsigned th = bin_threads(lanes);
+    if (rect32_ok(bb)) LAUNCH("k_bin_count", (k_bin_count<FS, PAIRED, Rect32>), dim3(blocks_for(lanes, th)), dim3(th), st, fs, bb, args...);
+    else LAUNCH("k_bin_count", (k_bin_count<FS, PAIRED, Rect64>), dim3(blocks_for(lanes, th)), dim3(th), st, fs, bb, args...);
 }
 
 // grid of the per-pixel backward kernels (they stride): `sparse` = only the pixels of a few large faces have work, and
@@ -276,8 +289,7 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     if (rc) return rc;
     HIP_TRY(zero_async(ws, fwd_layout(B, F, S).zero_bytes, st));
     const long nf = (long)B * F;
-    LAUNCH("k_bin_count", (k_bin_count<FS, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, fs, bb, faces_inv,
-           (float*)nullptr);
+    launch_bin_count<FS, false>(bb, nf, st, fs, faces_inv, (float*)nullptr, (unsigned char*)nullptr, (int*)nullptr);
     LAUNCH("k_bin_alloc", k_bin_alloc, dim3(blocks_for((long)B * bb.T, BIN_ALLOC_THREADS)), dim3(BIN_ALLOC_THREADS), st, bb);
     launch_bin_fill<false>(bb, nf, st);
     const int n_tiles = B * bb.T;
@@ -312,18 +324,15 @@ static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, fl
         static const char* abl = getenv("D3M_ABL_NO_DENSE");
         static int calls = 0;
         if (abl && ++calls > 2) {
-            LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
-                   (float*)nullptr, (float*)nullptr, out.marks, out.marks_count);
+            launch_bin_count<IndexedFaces, true>(bb, nf / 2, st, ifs, (float*)nullptr, (float*)nullptr, out.marks, out.marks_count);
             goto counted;
         }
     }
 #endif
     if (ifs.fill_back)      // one lane per index triple, both copies
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, true>), dim3(blocks_for(nf / 2, bin_threads(nf / 2))), dim3(bin_threads(nf / 2)), st, ifs, bb,
-               (float*)nullptr, faces_out, out.marks, out.marks_count);
+        launch_bin_count<IndexedFaces, true>(bb, nf / 2, st, ifs, (float*)nullptr, faces_out, out.marks, out.marks_count);
     else
-        LAUNCH("k_bin_count", (k_bin_count<IndexedFaces, false>), dim3(blocks_for(nf, bin_threads(nf))), dim3(bin_threads(nf)), st, ifs, bb,
-               (float*)nullptr, faces_out, out.marks, out.marks_count);
+        launch_bin_count<IndexedFaces, false>(bb, nf, st, ifs, (float*)nullptr, faces_out, out.marks, out.marks_count);
 #ifdef D3M_DEV_SKIP
 counted:
 #endif
