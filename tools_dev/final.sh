@@ -9,3 +9,8 @@ cp gpurun_out/parity_full_size.json $O/${R}_parity_full_size.json 2>/dev/null
 R=$R bash tools_dev/profile_all.sh
 R=$R bash tools_dev/other_configs.sh
 R=$R bash tools_dev/sq_counters2.sh > $O/sq2.log 2>&1; cp gpurun_out/sq2/${R}_sq_counters2.csv $O/ 2>/dev/null
+R=$R timeout 300 python tools_dev/spread.py > $O/spread.log 2>&1; tail -1 $O/spread.log | cut -c1-400
+bash tools_dev/trace.sh > $O/trace.log 2>&1; cp gpurun_out/trace/step_32views.csv $O/${R}_kernel_trace_step_32views.csv; cp gpurun_out/trace/step_4views.csv $O/${R}_kernel_trace_step_4views.csv
+cp gpurun_out/camera_association.json $O/${R}_camera_association.json 2>/dev/null
+# bench.py --gpus 2 in its bare form (it launches its own ranks; both on this box's one GPU, gloo: the debug switches)
+D3M_BENCH_SINGLE_DEVICE=1 D3M_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline --no-dropin > $O/${R}_bench_bare_two_ranks_single_device.log 2>&1; tail -c 600 $O/${R}_bench_bare_two_ranks_single_device.log
