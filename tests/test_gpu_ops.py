@@ -431,3 +431,71 @@ def test_indexed_mesh_coverage_equals_the_operator_on_gathered_faces(S, V, Ft, s
     assert np.array_equal(faces.reshape(-1, 9)[owners].cpu().numpy(), fd.reshape(-1, 9)[owners].cpu().numpy(), equal_nan=True)
     flags = vis.view(torch.int32)[:B * Fp]                                       # the blob starts with one flag per face
     assert torch.equal(flags.nonzero().flatten(), owners)
+
+
+def test_first_and_last_launch_of_a_lit_step_through_the_c_abi():
+    """d3m_lit_front (camera basis + transform, per-face light, clears as ONE launch) against the operators it stands for --
+    d3m_camera_basis + d3m_camera_forward + d3m_face_light + d3m_zero_ranges: the same floats bit for bit (shared and per-view
+    cameras, shared and per-view meshes, a mesh smaller than a workgroup), ranges that start off a 16-byte boundary cleared
+    exactly; d3m_lit_back against d3m_face_light_backward + d3m_camera_backward_add (float atomics: to rounding); bad
+    arguments rejected before any launch."""
+    import ctypes
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.neural_renderer import cameras
+    L = _lib.lib()
+    dev = torch.device("cuda")
+    st = _lib.stream_ptr()
+    INVALID = 1
+    for B, V, Ft, vb, eyes_b in ((3, 700, 1100, 1, 3), (2, 40, 50, 2, 1), (5, 300, 400, 1, 5)):
+        rng = np.random.default_rng(B * 100 + V)
+        verts = torch.from_numpy(rng.uniform(-0.8, 0.8, (vb, V, 3)).astype(np.float32)).to(dev)
+        tri = torch.from_numpy(rng.integers(0, V, (1, Ft, 3)).astype(np.int32)).to(dev)
+        eye = torch.from_numpy((rng.uniform(-1, 1, (eyes_b, 3)) + np.array([0, 0, -2.7])).astype(np.float32)).to(dev)
+        p = cameras.look_at_params(verts.expand(B, -1, -1) if vb == 1 and False else verts, eye, _perspective_angle=30)
+        p["batch"] = B
+        cam, keep = cameras._camera_struct(p, dev)
+        want_sv = torch.empty(B, V, 3, device=dev)
+        _lib.check(L.d3m_camera_forward(_lib.ptr(verts), vb, ctypes.byref(cam), _lib.ptr(want_sv), B, V, st), "camera")
+        Fp = 2 * Ft
+        want_light = torch.empty(vb, Fp, 3, device=dev)
+        ca = (ctypes.c_float * 3)(1, 0.9, 0.8); cd = (ctypes.c_float * 3)(0.7, 1, 0.6); di = (ctypes.c_float * 3)(0.3, 0.8, -0.5)
+        _lib.check(L.d3m_face_light(_lib.ptr(verts), vb, _lib.ptr(tri), 1, _lib.ptr(want_light), 0.4, 0.6, ca, cd, di, vb, V, Ft, 1,
+                                    st), "light")
+        # the front launch: basis deferred, two ranges to clear (one starting 4 bytes into an allocation)
+        pd = cameras.look_at_params(verts, eye, _perspective_angle=30, defer_basis=True)
+        pd["batch"] = B
+        camd, keepd = cameras._camera_struct(pd, dev)
+        basis, bkeep = cameras.basis_struct(pd)
+        sv = torch.full((B, V, 3), 7.0, device=dev)
+        light = torch.full((vb, Fp, 3), 7.0, device=dev)
+        z1, z2 = torch.full((1031,), 5.0, device=dev), torch.full((77,), 5.0, device=dev)
+        zp = (ctypes.c_void_p * 2)(z1.data_ptr() + 4, z2.data_ptr())
+        zb = (ctypes.c_size_t * 2)(1029 * 4, 77 * 4)
+        _lib.check(L.d3m_lit_front(_lib.ptr(verts), vb, ctypes.byref(camd), ctypes.byref(basis), _lib.ptr(sv), B, V, _lib.ptr(tri), 1,
+                                   Ft, 1, _lib.ptr(light), vb, 0.4, 0.6, ca, cd, di, zp, zb, 2, st), "d3m_lit_front")
+        assert torch.equal(sv, want_sv) and torch.equal(light, want_light), (B, V)
+        assert torch.equal(pd["rot"], p["rot"])                                   # the basis left for the adjoint
+        assert float(z1[0]) == 5.0 and float(z1[1:1030].abs().max()) == 0.0 and float(z1[1030]) == 5.0 and float(z2.abs().max()) == 0.0
+        # the last launch
+        g_sv = torch.from_numpy(rng.normal(size=(B, V, 3)).astype(np.float32)).to(dev)
+        g_light = torch.from_numpy(rng.normal(size=(vb, Fp, 3)).astype(np.float32)).to(dev)
+        want = torch.zeros(vb, V, 3, device=dev)
+        _lib.check(L.d3m_face_light_backward(_lib.ptr(verts), vb, _lib.ptr(tri), 1, _lib.ptr(g_light), _lib.ptr(want), 0.4, 0.6, ca, cd,
+                                             di, vb, V, Ft, 1, st), "light backward")
+        _lib.check(L.d3m_camera_backward_add(_lib.ptr(verts), vb, ctypes.byref(cam), _lib.ptr(g_sv), _lib.ptr(want), B, V, st), "camera backward")
+        got = torch.zeros(vb, V, 3, device=dev)
+        _lib.check(L.d3m_lit_back(_lib.ptr(verts), vb, ctypes.byref(cam), _lib.ptr(g_sv), _lib.ptr(got), B, V, _lib.ptr(tri), 1, Ft, 1,
+                                  _lib.ptr(g_light), vb, 0.4, 0.6, ca, cd, di, st), "d3m_lit_back")
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), (B, V)
+    # rejected before any launch
+    a = torch.zeros(64, device=dev)
+    pa = _lib.ptr(a)
+    assert L.d3m_lit_front(None, 1, None, None, None, 1, 4, None, 1, 0, 0, None, 1, 0.5, 0.5, None, None, None, None, None, 0, st) == INVALID
+    assert L.d3m_lit_front(pa, 1, None, None, None, 1, 4, None, 1, 0, 0, None, 1, 0.5, 0.5, None, None, None, None, None, 11, st) == INVALID   # too many ranges
+    cam0 = _lib.D3MCamera()
+    assert L.d3m_lit_front(pa, 1, ctypes.byref(cam0), None, None, 1, 4, None, 1, 0, 0, None, 1, 0.5, 0.5, None, None, None, None, None, 0, st) == INVALID  # no output
+    assert L.d3m_lit_back(pa, 1, None, pa, pa, 1, 4, pa, 1, 2, 0, pa, 1, 0.5, 0.5, pa, pa, pa, st) == INVALID                  # no camera
+    zb1 = (ctypes.c_size_t * 1)(6)
+    zp1 = (ctypes.c_void_p * 1)(a.data_ptr())
+    assert L.d3m_lit_front(pa, 1, None, None, None, 1, 4, None, 1, 0, 0, None, 1, 0.5, 0.5, None, None, None, zp1, zb1, 1, st) == INVALID   # not a multiple of 4 bytes
+    assert L.d3m_last_hip_error() == 0
