@@ -484,6 +484,109 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
         reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
 }
 
+// The records form WITH anti-aliasing: the objective is taken on the 2x2-pooled images (s = S / 2), the records stay per
+// INTERNAL pixel -- the adjoint of the 2x2 mean hands each of an output pixel's four internal pixels a quarter of its
+// gradient, and 1 / pixels of the silhouette term times that quarter is 1 / S^2:
+//   grad = (2 (alpha_o - alpha_t) / S^2,  sign(rgb_o - rgb_t) mask / 4 / (3 mask_sum))      (the same for all four)
+//   dot  = (<(alpha_i, rgb_i), grad>, owner_i)                                              (per internal pixel)
+// One thread per output pixel of a 32x32 internal tile (16x16 output pixels); the four internal pixels are sampled in the
+// order of k_render_lit_epilogue (upper row first), so the pooled images are bit-identical to its own.  Round 4 wrote
+// unscaled gradient MAPS here and packed them in backward (a clear + k_pack_maps: 52 B per internal pixel moved twice).
+__global__ void __launch_bounds__(256, 3) k_render_lit_fit_records_pooled(
+    const float* __restrict__ faces, LitTextures lt, const int32_t* __restrict__ face_index_map,
+    const float* __restrict__ weight_map, const float* __restrict__ depth_map, const float* __restrict__ background, int bg_b,
+    float* __restrict__ rgb_blended, float* __restrict__ alpha_map, float* __restrict__ rgb_out, float* __restrict__ alpha_out,
+    float* __restrict__ depth_out, int B, int S, float eps, FitTargets fit, FitRecords rec) {
+    __shared__ float4 s_part[4];
+    __shared__ int s_lo_inv[2][32], s_hi1[2][32];              // [axis][line of the tile]: axis 0 = columns, 1 = rows
+    if (threadIdx.x < 64) { (&s_lo_inv[0][0])[threadIdx.x] = 0; (&s_hi1[0][0])[threadIdx.x] = 0; }
+    __syncthreads();
+    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32, s = S / 2;
+    const int ox = threadIdx.x & 15, oy = threadIdx.x >> 4;    // 16 x 16 output pixels
+    const int xi0 = x0 + 2 * ox, yi0 = y0 + 2 * oy;            // the lower left of the four internal pixels
+    const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
+    const float inv_pixels = 1.0f / (float)((long)S * S), inv_3den = 1.0f / (3.0f * *rec.mask_sum);
+    float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
+    auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
+    if (xi0 < S && yi0 < S) {
+        const int xo = xi0 >> 1, yo = s - 1 - (yi0 >> 1);      // output pixel; internal row 0 = bottom (rasterize.py:311-317)
+        const size_t o = ((size_t)b * s + yo) * s + xo;
+        float tg[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) tg[k] = fit.rgb_t[(((size_t)b * 3 + k) * s + yo) * s + xo];
+        tg[3] = fit.depth_t[o]; tg[4] = fit.alpha_t[o]; tg[5] = fit.mask[o];
+        float vv[4][3], aa[4], acc_rgb[3] = {0, 0, 0}, acc_a = 0, acc_d = 0;
+        int own[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                          // q = dy * 2 + dx of k_render_lit_epilogue: yi = S-1-(2 yo + dy)
+            const int yi = yi0 + 1 - (q >> 1), xi = xi0 + (q & 1);
+            const size_t p = ((size_t)b * S + yi) * S + xi;
+            const int fi = face_index_map[p];
+            const float depth = depth_map[p];
+            float v[3] = {bg[0], bg[1], bg[2]};
+            if (fi >= 0) {
+                const float weight[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
+                sample_pixel_lit(faces, lt, B, b, fi, weight, depth, eps, v);
+            }
+            const float alpha = fi >= 0 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { rgb_blended[3 * p + k] = v[k]; acc_rgb[k] += v[k]; vv[q][k] = v[k]; }
+            alpha_map[p] = alpha;
+            acc_a += alpha; acc_d += depth;
+            aa[q] = alpha; own[q] = fi;
+        }
+        const float inv = 0.25f;
+        if (rgb_out) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) rgb_out[(((size_t)b * 3 + k) * s + yo) * s + xo] = acc_rgb[k] * inv;
+        }
+        if (alpha_out) alpha_out[o] = acc_a * inv;
+        if (depth_out) depth_out[o] = acc_d * inv;
+        const float m = tg[5], d = acc_a * inv - tg[4];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t_rgb += fabsf(acc_rgb[k] * inv - tg[k]) * m;      // same terms as k_render_lit_epilogue
+        t_d = fabsf(acc_d * inv - tg[3]) * m;
+        t_m = m;
+        t_sse = d * d;
+        float4 g;
+        g.x = (2.0f * d) * inv_pixels;
+        g.y = (sgn(acc_rgb[0] * inv - tg[0]) * m * inv) * inv_3den;
+        g.z = (sgn(acc_rgb[1] * inv - tg[1]) * m * inv) * inv_3den;
+        g.w = (sgn(acc_rgb[2] * inv - tg[2]) * m * inv) * inv_3den;
+        const float gd = sgn(acc_d * inv - tg[3]) * m * inv;
+        const bool g_nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int yi = yi0 + 1 - (q >> 1), xi = xi0 + (q & 1);
+            const size_t p = ((size_t)b * S + yi) * S + xi;
+            float dot = aa[q] * g.x;
+            dot += vv[q][0] * g.y;
+            dot += vv[q][1] * g.z;
+            dot += vv[q][2] * g.w;
+            rec.grad[p] = g;
+            rec.dot[p] = make_float2(dot, __int_as_float(own[q]));
+            rec.g_depth[p] = gd;
+            if (g_nz || dot != 0) {                            // this tile's share of the pixel's row and column extents
+                const int r = yi - y0, c = xi - x0;
+                atomicMax(&s_lo_inv[1][r], S - xi); atomicMax(&s_hi1[1][r], xi + 1);
+                atomicMax(&s_lo_inv[0][c], S - yi); atomicMax(&s_hi1[0][c], yi + 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int axis = threadIdx.x >> 5, l = threadIdx.x & 31, d0 = (axis ? y0 : x0) + l;
+        if (s_hi1[axis][l] != 0 && d0 < S) {
+            const size_t line = ((size_t)b * 2 + axis) * S + d0;
+            atomicMax(&rec.nz_lo_inv[line], s_lo_inv[axis][l]);
+            atomicMax(&rec.nz_hi1[line], s_hi1[axis][l]);
+        }
+    }
+    const float4 t = block_sum4_256(make_float4(t_rgb, t_d, t_m, t_sse), s_part);
+    if (threadIdx.x == 0)
+        reinterpret_cast<float4*>(fit.partials)[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+}
+
 // The same objective and the same records from FINISHED images: what multiview_fit_loss(*Renderer.render(...)) runs when
 // its three images come straight from one lit render node (core/losses.py).  The images hold the very floats the fused pass
 // above has in registers (rgb_out = the blended colour, alpha_out = covered, depth_out = the depth map; no anti-aliasing:

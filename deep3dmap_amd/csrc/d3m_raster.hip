@@ -1086,7 +1086,7 @@ static FitFin make_fit_fin(const d3m_fit_targets* fit, int B, int S, int s, int 
 }
 static FitFin fit_fin_of_tiles(const d3m_fit_targets* fit, int B, int S) {     // the records form: a view's 32x32 tiles
     const int tiles = ((S + 31) / 32) * ((S + 31) / 32);
-    return make_fit_fin(fit, B, S, S, B * tiles, tiles);
+    return make_fit_fin(fit, B, S, (fit->flags & D3M_FIT_POOLED) ? S / 2 : S, B * tiles, tiles);
 }
 static int clear_fit_tickets(const d3m_fit_targets* fit, int B, int S, hipStream_t st) {
     if (fit->flags & D3M_PRECLEARED) return D3M_OK;
@@ -1107,7 +1107,8 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         return D3M_ERR_INVALID;
     if (anti_aliasing && (image_size & 1)) return D3M_ERR_INVALID;
     if (fit && !alpha_map) return D3M_ERR_INVALID;
-    if (fit && anti_aliasing && fit->edge_grad) return D3M_ERR_INVALID;   // the records form has no pooled variant: gradient maps
+    // the records form of a pooled objective says so in the struct (its finish may run from another entry point)
+    if (fit && fit->edge_grad && (anti_aliasing != 0) != ((fit->flags & D3M_FIT_POOLED) != 0)) return D3M_ERR_INVALID;
     if (background_batch != 1 && background_batch != batch_size) return D3M_ERR_INVALID;
     LitTextures lt;
     int rc = make_lit(lt, textures, textures_batch, light, light_batch, num_tri, texture_size, fill_back, batch_size);
@@ -1126,9 +1127,14 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
         FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
                        fit->grad_depth_map};
-        LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
-               weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out, depth_out,
-               batch_size, image_size, eps, ft, rec);
+        if (anti_aliasing)
+            LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records_pooled, tiles, dim3(256), st, faces, lt,
+                   face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out,
+                   alpha_out, depth_out, batch_size, image_size, eps, ft, rec);
+        else
+            LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
+                   weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
+                   depth_out, batch_size, image_size, eps, ft, rec);
         // *fit->loss: a launch of its own (k_fit_finish, two levels), or -- D3M_FIT_FINISH_DEFERRED -- left to the caller's
         // d3m_backward_textures_lit, handed the same struct as `unscaled`
         if (!(fit->flags & D3M_FIT_FINISH_DEFERRED)) {
@@ -1301,6 +1307,11 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
                weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)W.n_large,
                grad_depth_map, grad_faces, vt, fin);
     } else {
+        // (no kernel here for a deferred finish to ride in: a launch of its own)
+        if (records && unscaled->scratch && unscaled->loss && (unscaled->flags & D3M_FIT_FINISH_DEFERRED)) {
+            const FitFin fin = fit_fin_of_tiles(unscaled, B, S);
+            LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
+        }
         LAUNCH("k_backward_textures_lit_pixels", k_backward_textures_lit_pixels, dim3(px_grid(n, false)), dim3(256), st,
                faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)nullptr, B, S, eps,
                gs, (const int*)nullptr);

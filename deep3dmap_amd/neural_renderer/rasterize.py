@@ -478,20 +478,16 @@ class _RasterizeLit(torch.autograd.Function):
             scratch = [torch.empty(int(L.d3m_render_fit_scratch_floats(hi - lo, S)), dtype=torch.float32, device=dev)
                        for lo, hi in groups]
             # with a backward pass to come, the same pass leaves the objective's gradient behind -- minus the gradient of the
-            # loss, only known later -- in the form its readers want.  Without anti-aliasing: the edge gradient's per-pixel
-            # records (what d3m_backward_pixel_map would otherwise pack from gradient maps: no pixel pass in backward at
-            # all), the lines' non-zero extents, and the depth gradient as a map.  With anti-aliasing (an output pixel
-            # is the mean of four internal ones): unscaled gradient MAPS at the internal size, packed by backward.
+            # loss, only known later -- in the form its readers want: the edge gradient's per-pixel records at the internal
+            # size (what d3m_backward_pixel_map would otherwise pack from gradient maps: no pixel pass in backward at all),
+            # the lines' non-zero extents, and the depth gradient as a map.  With anti-aliasing an output pixel is the mean
+            # of four internal ones: each gets a quarter of its gradient (D3M_FIT_POOLED; round 4 left unscaled maps here
+            # and packed them in backward).
             g_maps = None
-            if need_grad and not anti_aliasing:
+            if need_grad:
                 g_maps = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),        # edge_grad
                           torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),        # edge_dot
                           None,                                                            # (nz_lo_inv, nz_hi1): below
-                          torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
-            elif need_grad:
-                g_maps = (torch.empty(B, S, S, 3, dtype=torch.float32, device=dev),        # grad_rgb_map
-                          torch.empty(B, S, S, dtype=torch.float32, device=dev),           # grad_alpha_map
-                          None,
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, bool(anti_aliasing))
         cur = torch.cuda.current_stream()
@@ -499,7 +495,7 @@ class _RasterizeLit(torch.autograd.Function):
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         nz_own = None
-        if fit_state is not None and fit_state[6] is not None and not fit_state[8]:      # (records form: no anti-aliasing)
+        if fit_state is not None and fit_state[6] is not None:      # (records form)
             # the lines' non-zero extents (zero before the objective's pass fills them): when the plan is built in front of
             # that pass on the same stream, inside the plan's blob, cleared by the plan's own clear; else a fill of their own
             if serial and plan is not None:
@@ -546,7 +542,7 @@ class _RasterizeLit(torch.autograd.Function):
                 pre = None
         assert len(clears) <= _lib.FRONT_RANGES
         # ... and the objective's finish (partial sums -> value) is left to a kernel that backward pass launches anyway
-        if pre is not None and pre["gathered"] and fit_state is not None and fit_state[6] is not None and not fit_state[8]:
+        if pre is not None and pre["gathered"] and fit_state is not None and fit_state[6] is not None:
             flags_fit |= _lib.FIT_FINISH_DEFERRED
         ctx.fit_flags = flags_fit & _lib.FIT_FINISH_DEFERRED
         zp = (ctypes.c_void_p * max(1, len(clears)))(*[c[0] for c in clears])
@@ -660,15 +656,15 @@ class _RasterizeLit(torch.autograd.Function):
     def _fit_struct(fit_state, k, lo, hi, grad_loss, flags=0):
         """d3m_fit_targets of view group k (views lo..hi): forward's `fit` (grad_loss None) / backward's `unscaled`."""
         rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, pooled = fit_state
-        eg = ed = nz_lo = nz_hi = gd = g_rgb = g_alpha = None
-        if g_maps is not None and not pooled:       # records (no anti-aliasing)
+        eg = ed = nz_lo = nz_hi = gd = None
+        if g_maps is not None:                      # the gradient as per-pixel records at the internal size
             eg, ed, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
             nz_lo, nz_hi = g_maps[2][0][lo:hi], g_maps[2][1][lo:hi]
-        elif g_maps is not None:                    # unscaled gradient maps at the internal size (anti-aliasing)
-            g_rgb, g_alpha, gd = g_maps[0][lo:hi], g_maps[1][lo:hi], g_maps[3][lo:hi]
+            if pooled:
+                flags = int(flags) | _lib.FIT_POOLED
         return _lib.D3MFitTargets(
             _lib.ptr(rgb_t[lo:hi]), _lib.ptr(depth_t[lo:hi]), _lib.ptr(alpha_t[lo:hi]), _lib.ptr(mask[lo:hi]),
-            _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), _lib.ptr(g_rgb), _lib.ptr(g_alpha), _lib.ptr(gd),
+            _lib.ptr(scratch[k]), _lib.ptr(loss_g[k:k + 1]), None, None, _lib.ptr(gd),
             _lib.ptr(grad_loss), _lib.ptr(mask_sum), _lib.ptr(eg), _lib.ptr(ed), _lib.ptr(nz_lo), _lib.ptr(nz_hi),
             int(flags))
 
@@ -731,9 +727,7 @@ class _RasterizeLit(torch.autograd.Function):
                 _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward_records")
         else:       # g_rgb is the gradient of the scalar objective; the maps were left by forward, minus their scalars
             scratch, g_depth_map = fit[4], fit[6][3]
-            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (fit[6][:3]) ...
-            if fit[8]:                                  # ... or, with anti-aliasing, as unscaled maps
-                g_rgb_map, g_alpha_map = fit[6][0], fit[6][1]
+            g_rgb_map = g_alpha_map = None              # they exist as per-pixel records (fit[6][:3])
             grad_loss = f32c(g_rgb).reshape(1)
         # K4 -> textures (separate buffers) -> K6, as NR/rasterize.py:141-151; both face gradients land in grad_sv,
         # and both passes run over the compacted list of the faces that own a pixel.  The edge gradient (K4: ~8

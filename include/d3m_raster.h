@@ -405,9 +405,8 @@ int d3m_forward_texture_sampling_lit(const float* faces, const float* textures, 
  *     photometric_loss(rgb, rgb_target, mask) + sum((alpha - alpha_target)^2) / (s*s) + photometric_loss(depth, ...)
  * (deep3dmap/core/utils/utils.py:105-114 composed as d3m_fit_loss_forward does) evaluated in the same pass, where
  * the images are produced: *fit->loss receives the value, the images themselves need not be written (rgb_out NULL)
- * and are not read again.  alpha_map is required.  With anti_aliasing the targets are at the output size s = S/2, the
- * objective is that of the pooled images, and its gradient leaves as grad_*_map only (the records form below is for
- * anti_aliasing == 0).
+ * and are not read again.  alpha_map is required.  With anti_aliasing the targets are at the output size s = S/2 and the
+ * objective is that of the pooled images (the records form below then carries D3M_FIT_POOLED).
  * With fit->grad_*_map set the pass also leaves the objective's gradient wrt the internal-resolution maps
  * (rgb_blended, alpha_map, depth_map) there, WITHOUT the scalar factors that are only known later - sign(rgb - target)
  * * mask, 2 (alpha - target), sign(depth - target) * mask - so that backward needs no pass over the pixels of its
@@ -435,7 +434,10 @@ struct d3m_fit_targets {
      *   edge_dot  = (<(alpha, rgb), edge_grad>, face index bits)                               float2 [B,S,S]
      * and per image line (b*2 + axis)*S + d0 the extent of its non-zero records (caller-zeroed int [B,2,S] each:
      * S - first, last + 1).  Everything but grad_loss is in there; d3m_backward_pixel_map / d3m_backward_textures_lit
-     * handed the struct as `unscaled` read the records instead of packing the maps (no pass over the pixels). */
+     * handed the struct as `unscaled` read the records instead of packing the maps (no pass over the pixels).
+     * With anti_aliasing (flags & D3M_FIT_POOLED, required then and only then) the records stay per INTERNAL pixel: each of
+     * an output pixel's four gets a quarter of its gradient -- (2 (alpha_o - target) / (S*S), sign(rgb_o - target) mask / 4 /
+     * (3 mask_sum)) -- and grad_depth_map sign(depth_o - target) mask / 4. */
     void* edge_grad;
     void* edge_dot;
     int* edge_nz_lo_inv;
@@ -445,9 +447,11 @@ struct d3m_fit_targets {
                                   * D3M_FIT_FINISH_DEFERRED (records form of d3m_render_lit_epilogue only): the pass leaves
                                   * its partial sums in `scratch` and does NOT complete *loss; d3m_backward_textures_lit,
                                   * handed this struct (same flag) as `unscaled`, completes it in a kernel it launches anyway --
-                                  * for callers that run the backward pass right behind the forward pass: no finishing launch */
+                                  * for callers that run the backward pass right behind the forward pass: no finishing launch
+                                  * D3M_FIT_POOLED: the records belong to an objective on the 2x2-pooled images (see above) */
 };
 #define D3M_FIT_FINISH_DEFERRED 2
+#define D3M_FIT_POOLED 4
 /* ... or, should the backward pass not come that way after all, by this call (the ticket must still be zero: one finish). */
 int d3m_fit_finish(const d3m_fit_targets* fit, int batch_size, int image_size, d3m_stream_t stream);
 /* scratch: totals | partial sums | group sums | ticket. */

@@ -509,6 +509,28 @@ def test_fit_objective_inside_the_rendering_node(ts):
         assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
 
 
+@pytest.mark.parametrize("ts", [1, 4])
+@pytest.mark.parametrize("aa", [False, True])
+def test_step_finishes_its_objective_at_every_texture_size(ts, aa):
+    """A MultiViewFit step defers the objective's finish (partial sums -> value) to the backward pass
+    (D3M_FIT_FINISH_DEFERRED).  Only the texture_size == 2 form of that pass has a kernel for it to ride in; at other
+    sizes it must still happen (round 5 shipped a step whose loss stayed 0 there until this test)."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(12)
+    tex = synthetic.random_textures(tri.shape[0], ts)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=48, anti_aliasing=aa)
+    fit.set_targets_from(synthetic.perturb(v, 0.04))
+    l0, gv0, gt0 = fit.step()
+    l0, gv0, gt0 = float(l0), gv0.clone(), gt0.clone()
+    fit2 = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=48, anti_aliasing=aa, objective_in_renderer=False)
+    fit2.targets, fit2.mask_sum, fit2._mask_sum_local = fit.targets, fit.mask_sum, fit._mask_sum_local
+    l1, gv1, gt1 = fit2.step()
+    assert l0 > 0 and abs(l0 - float(l1)) <= 2e-6 * abs(float(l1))
+    assert float((gv0 - gv1).abs().max()) <= 2e-5 * float(gv1.abs().max())
+    assert float((gt0 - gt1).abs().max()) <= 2e-5 * float(gt1.abs().max())
+
+
 @pytest.mark.parametrize("ts,frozen_tex", [(2, False), (1, False), (2, True)])
 def test_fit_objective_inside_the_rendering_node_with_anti_aliasing(ts, frozen_tex):
     """The same with anti-aliasing (SURVEY C2 is AA-on): the objective of the 2x2-pooled images, evaluated in the pass that

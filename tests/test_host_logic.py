@@ -74,7 +74,7 @@ def test_no_kernel_spills_to_scratch():
         assert got, prefix
         return got
     assert all(r["vgprs"] <= 64 and r["occupancy"] == 8 for r in rows("k_edge_lines<"))
-    assert all(r["vgprs"] <= 128 for r in rows("k_render_lit_fit_records")) and all(r["vgprs"] <= 128 for r in rows("k_backward_textures_lit_faces"))
+    assert all(r["vgprs"] <= 128 for r in rows("k_render_lit_fit_records(")) and all(r["vgprs"] <= 128 for r in rows("k_backward_textures_lit_faces"))
     for name in ("k_raster_tiles<", "k_bid_faces<", "k_edge_scatter<", "k_edge_count_window<", "k_edge_gather<", "k_bin_count<"):
         assert all(r["scratch"] == 0 for r in rows(name))
 
