@@ -7,11 +7,12 @@
 // than the work it does.  Here they are block ranges of ONE grid: nothing in them depends on another, the operators behind
 // are told that their scratch is already zero (D3M_PRECLEARED), and the step's first dependent kernel starts ~35 us earlier.
 //
-//   blocks [0, nb_cam)                   camera_point per (view, vertex); the look_at / look basis is recomputed per block
+//   the first blocks (as many as the   zero fill of up to FRONT_RANGES ranges, strided
+//    largest range needs, <= 2 048)
+//   the next nb_cam                      camera_point per (view, vertex); the look_at / look basis is recomputed per block
 //                                        from eye / at / up (~60 flops, the block's first lane) instead of being a launch of
 //                                        its own, and the block that holds a view's vertex 0 stores it for the backward pass
-//   blocks [nb_cam, nb_cam + nb_light)   face_light per (light batch entry, face)
-//   the rest                             zero fill of up to FRONT_RANGES ranges, strided
+//   the last nb_light                    face_light per (light batch entry, face)
 #pragma once
 #include "d3m_aux.h"
 #include "d3m_lit.h"
@@ -49,10 +50,33 @@ __device__ __forceinline__ void front_basis(const FrontBasis& fb, int b, float* 
     for (int k = 0; k < 3; k++) { rot[k] = x[k]; rot[3 + k] = y[k]; rot[6 + k] = z[k]; }
 }
 
+// Block ranges: the clears FIRST -- their stores leave the CUs at once and drain while the camera blocks, which wait for
+// their view's basis (a chain of dependent loads, three normalisations), occupy them: 26.3 -> 23.9 us at 32 views.
+// (Camera blocks of 1 024 entries, four per thread with their loads issued together, to get through the chip in one round
+// of blocks instead of three: 35.7 us.  Dropped.)
 __global__ void __launch_bounds__(256) k_lit_front(FrontArgs a) {
-    if (blockIdx.x < a.nb_cam) {
+    const unsigned nb_zero = gridDim.x - a.nb_cam - a.nb_light;
+    if (blockIdx.x < nb_zero) {
+        // as k_zero_ranges (d3m_launch.h), over this part's blocks
+        const size_t stride = (size_t)nb_zero * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < FRONT_RANGES; k++) {
+            const size_t n_words = a.z_words[k];
+            if (n_words == 0) continue;
+            size_t head = ((16u - (unsigned)((uintptr_t)a.z_ptr[k] & 15u)) & 15u) >> 2;     // words up to the 16-byte boundary
+            if (head > n_words) head = n_words;
+            const size_t n4 = (n_words - head) >> 2;
+            uint4* p4 = reinterpret_cast<uint4*>(a.z_ptr[k] + head);
+            if (i0 < head) a.z_ptr[k][i0] = 0;
+            for (size_t i = i0; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
+            for (size_t i = head + (n4 << 2) + i0; i < n_words; i += stride) a.z_ptr[k][i] = 0;
+        }
+        return;
+    }
+    const unsigned bx = blockIdx.x - nb_zero;
+    if (bx < a.nb_cam) {
         __shared__ float s_rot[2][9];
-        const long i0 = (long)blockIdx.x * 256, n = (long)a.B * a.V;
+        const long i0 = (long)bx * 256, n = (long)a.B * a.V;
         const int b0 = (int)(i0 / a.V);
         Cam c = a.cam;
         if (a.basis.eye) {
@@ -95,8 +119,8 @@ __global__ void __launch_bounds__(256) k_lit_front(FrontArgs a) {
         a.screen[i * 3 + 0] = o[0]; a.screen[i * 3 + 1] = o[1]; a.screen[i * 3 + 2] = o[2];
         return;
     }
-    if (blockIdx.x < a.nb_cam + a.nb_light) {
-        const long i = (long)(blockIdx.x - a.nb_cam) * 256 + threadIdx.x;
+    {
+        const long i = (long)(bx - a.nb_cam) * 256 + threadIdx.x;
         const int Fp = a.faces.num_faces();
         if (i >= (long)a.light_b * Fp) return;
         float fc[9], l[3];
@@ -104,21 +128,6 @@ __global__ void __launch_bounds__(256) k_lit_front(FrontArgs a) {
         face_light(fc, a.lp, l, nullptr, nullptr, nullptr);
         a.light[3 * i + 0] = l[0]; a.light[3 * i + 1] = l[1]; a.light[3 * i + 2] = l[2];
         return;
-    }
-    // the clears: as k_zero_ranges (d3m_launch.h), over this part's blocks
-    const size_t nb = gridDim.x - a.nb_cam - a.nb_light, stride = nb * 256;
-    const size_t i0 = (size_t)(blockIdx.x - a.nb_cam - a.nb_light) * 256 + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < FRONT_RANGES; k++) {
-        const size_t n_words = a.z_words[k];
-        if (n_words == 0) continue;
-        size_t head = ((16u - (unsigned)((uintptr_t)a.z_ptr[k] & 15u)) & 15u) >> 2;     // words up to the 16-byte boundary
-        if (head > n_words) head = n_words;
-        const size_t n4 = (n_words - head) >> 2;
-        uint4* p4 = reinterpret_cast<uint4*>(a.z_ptr[k] + head);
-        if (i0 < head) a.z_ptr[k][i0] = 0;
-        for (size_t i = i0; i < n4; i += stride) p4[i] = make_uint4(0, 0, 0, 0);
-        for (size_t i = head + (n4 << 2) + i0; i < n_words; i += stride) a.z_ptr[k][i] = 0;
     }
 }
 
