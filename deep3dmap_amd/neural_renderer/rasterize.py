@@ -558,7 +558,7 @@ class _RasterizeLit(torch.autograd.Function):
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
         # under the loss and the first backward passes.  The outputs are then only valid after backward.
         plan_ready = [] if (vis is not None and defer_plan_join and G == 1) else None   # (G > 1: capture crashes, as above)
-        vis_ready = None
+        vis_ready, vis_on_main = None, False
         for k in range(G):
             if mains[k] is not cur:
                 mains[k].wait_stream(cur)
@@ -578,13 +578,27 @@ class _RasterizeLit(torch.autograd.Function):
                     ws.numel(), _lib.ptr(vis[k]) if vis is not None else None, vis[k].numel() if vis is not None else 0,
                     flags_fwd, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
                 if vis is not None:
+                    # ONE FORK, BEHIND THE VISIBILITY LIST (round 5).  The list has two readers -- the plan (side branch) and
+                    # backward's gathered pass (this stream) -- and the coverage pass two as well (the list, the sampling
+                    # pass).  Forked behind coverage, a replayed graph's critical chain (coverage -> list -> plan -> line
+                    # walk) carried two kernels with a second successor each, and each cost it ~5 us (trace of the 4-view
+                    # shard: 5.8 us between k_bid_resolve and the list, 5.1 behind the list).  With the list on this
+                    # stream, in front of the fork, only it has two successors; the sampling pass starts 5 us later on a
+                    # chain that has 40 us to spare.  4 views 0.2747 -> 0.2709 ms, 8 views 0.4687 -> 0.4660 (same box).
+                    vis_first = plan_ready is not None and auxs[k] is not mains[k] and \
+                        os.environ.get("D3M_FORK_BEHIND_LIST", "1") != "0"
+                    if vis_first:
+                        _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
+                                                    _lib.stream_ptr()), "d3m_visibility")
+                        vis_on_main = True
                     if auxs[k] is not mains[k]:
                         auxs[k].wait_stream(mains[k])
                     with torch.cuda.stream(auxs[k]):
                         # (its first step -- which faces own a pixel -- was left by the tile pass above)
-                        _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
-                                                    _lib.stream_ptr()), "d3m_visibility")
-                        if plan_ready is not None:
+                        if not vis_first:
+                            _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S,
+                                                        _lib.stream_ptr()), "d3m_visibility")
+                        if plan_ready is not None and not vis_first:
                             vis_ready = torch.cuda.Event()
                             vis_ready.record(auxs[k])
                         _lib.check(L.d3m_edge_plan(_lib.ptr(faces[lo:hi]), _lib.ptr(fi_g), _lib.ptr(vis[k]), _lib.ptr(plan[k]),
@@ -613,6 +627,7 @@ class _RasterizeLit(torch.autograd.Function):
         m["edge_plan"] = plan
         m["plan_ready"] = plan_ready
         m["vis_ready"] = vis_ready if plan_ready is not None else None
+        m["vis_on_main"] = vis_on_main       # (the list was built on the forking stream: its readers there need no event)
         m["plan_stream"] = auxs[0]
         ctx.cfg = (S, float(eps), bool(anti_aliasing), bool(return_alpha), bool(return_depth), bool(fill_back),
                    (float(ia), float(idr), ca, cd, direction), Bl, groups)
@@ -781,7 +796,8 @@ class _RasterizeLit(torch.autograd.Function):
         # behind an event -- a replayed graph pays ~9 us for every cross-queue edge whose producer has only just finished
         # (trace of the 4-view shard: scatter ends 190.0, the line walk starts 198.6).  The gathered texture / depth pass
         # takes the forking stream then; it only needs the visibility list (an event behind d3m_visibility).
-        swap = plan_ready is not None and G == 1 and auxs[0] is not cur and m.get("vis_ready") is not None
+        swap = plan_ready is not None and G == 1 and auxs[0] is not cur and \
+            (m.get("vis_ready") is not None or m.get("vis_on_main", False))
         s_edges = [auxs[0]] if swap else mains
         s_gath = [mains[0]] if swap else auxs
         # The backward pass's clears -- the two vertex accumulators and what the gathered pass needs zeroed -- as ONE launch
@@ -807,7 +823,8 @@ class _RasterizeLit(torch.autograd.Function):
             if gathered or plan_ready is not None:
                 auxs[k].wait_stream(cur)
             if swap:
-                mains[k].wait_event(m["vis_ready"])
+                if m.get("vis_ready") is not None:
+                    mains[k].wait_event(m["vis_ready"])
                 # the line walk reads the plan.  Backward normally runs under the stream forward forked from (autograd
                 # restores it), so auxs[k] IS the stream the plan was recorded on and needs no edge -- and must not get
                 # one: a wait on an event of the waiting stream itself inside a capture makes hipStreamEndCapture segfault
