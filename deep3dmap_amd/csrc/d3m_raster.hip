@@ -1173,7 +1173,7 @@ D3M_EXPORT int d3m_fit_loss_records(const float* rgb, const float* depth, const 
         return D3M_ERR_INVALID;
     FitTargets ft;
     if (int rc = to_fit_targets(fit, ft)) return rc;
-    if (fit->flags & D3M_FIT_FINISH_DEFERRED) return D3M_ERR_INVALID;
+    if (fit->flags & (D3M_FIT_FINISH_DEFERRED | D3M_FIT_POOLED)) return D3M_ERR_INVALID;      // (finished images: no pooling here)
     hipStream_t st = (hipStream_t)stream;
     if (int rc = clear_fit_tickets(fit, batch_size, image_size, st)) return rc;
     const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);

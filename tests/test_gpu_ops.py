@@ -499,3 +499,86 @@ def test_first_and_last_launch_of_a_lit_step_through_the_c_abi():
     zp1 = (ctypes.c_void_p * 1)(a.data_ptr())
     assert L.d3m_lit_front(pa, 1, None, None, None, 1, 4, None, 1, 0, 0, None, 1, 0.5, 0.5, None, None, None, zp1, zb1, 1, st) == INVALID   # not a multiple of 4 bytes
     assert L.d3m_last_hip_error() == 0
+
+
+def test_pooled_fit_records_through_the_c_abi():
+    """d3m_render_lit_epilogue with anti-aliasing and a fused objective, called raw, in its two gradient forms on the same
+    coverage: unscaled gradient MAPS (round 4's form: fit->grad_*_map) and per-pixel RECORDS (D3M_FIT_POOLED, round 5).
+    Same pooled images bit for bit, same objective (to the order of its partial sums), and the records are the maps with the
+    scalars the readers no longer apply -- 1 / S^2 on alpha, 1 / (3 mask_sum) on rgb -- plus <values, gradient>, the owner
+    and the lines' non-zero extents.  Without the flag the records form of an anti-aliased pass is refused."""
+    import ctypes
+    from deep3dmap_amd import _lib
+    L = _lib.lib()
+    dev, st = "cuda", _lib.stream_ptr()
+    gen = torch.Generator().manual_seed(5)
+    row, S, ts = 12, 64, 2
+    V, Ft = row * row, 2 * (row - 1) * (row - 1)
+    Fp, s = 2 * Ft, S // 2
+    yy, xx = torch.meshgrid(torch.linspace(-0.8, 0.8, row), torch.linspace(-0.8, 0.8, row), indexing="ij")
+    sv = torch.stack([xx + 0.03 * torch.randn(row, row, generator=gen), yy + 0.03 * torch.randn(row, row, generator=gen),
+                      1.5 + 0.2 * torch.rand(row, row, generator=gen)], -1).reshape(1, V, 3).contiguous().to(dev)
+    faces = torch.empty(1, Fp, 3, 3, device=dev)
+    fi = torch.empty(1, S, S, dtype=torch.int32, device=dev)
+    wm, dm = torch.empty(1, S, S, 3, device=dev), torch.empty(1, S, S, device=dev)
+    ws = torch.empty(int(L.d3m_forward_workspace_bytes(1, Fp, S)), dtype=torch.uint8, device=dev)
+    _lib.check(L.d3m_forward_face_index_map_mesh(_lib.ptr(sv), None, -row, V, Ft, 1, _lib.ptr(faces), _lib.ptr(fi), _lib.ptr(wm),
+                                                 _lib.ptr(dm), None, 1, S, 0.1, 100.0, _lib.ptr(ws), ws.numel(), None, 0, 0, st),
+               "d3m_forward_face_index_map_mesh")
+    assert 0.3 < float((fi >= 0).float().mean()) < 0.95          # a silhouette inside the image
+    tex = torch.rand(1, Ft, ts, ts, ts, 3, generator=gen).to(dev)
+    light = (0.3 + 0.7 * torch.rand(1, Fp, 3, generator=gen)).to(dev)
+    bg = torch.tensor([[0.1, 0.2, 0.3]], device=dev)
+    rgb_t = torch.rand(1, 3, s, s, generator=gen).to(dev)
+    depth_t = (1.4 + 0.3 * torch.rand(1, s, s, generator=gen)).to(dev)
+    alpha_t = (torch.rand(1, s, s, generator=gen) > 0.4).float().to(dev)
+    mask = (torch.rand(1, s, s, generator=gen) > 0.2).float().to(dev)
+    mask_sum = mask.sum().reshape(1)
+
+    def run(records, flags):
+        out = {"rgb_blended": torch.empty(1, S, S, 3, device=dev), "alpha_map": torch.empty(1, S, S, device=dev),
+               "rgb": torch.empty(1, 3, s, s, device=dev), "alpha": torch.empty(1, s, s, device=dev),
+               "depth": torch.empty(1, s, s, device=dev), "loss": torch.zeros(1, device=dev),
+               "g_depth": torch.empty(1, S, S, device=dev),
+               "scratch": torch.empty(int(L.d3m_render_fit_scratch_floats(1, S)), device=dev)}
+        if records:
+            out.update(grad=torch.empty(1, S, S, 4, device=dev), dot=torch.empty(1, S, S, 2, device=dev),
+                       nz=torch.zeros(2, 1, 2, S, dtype=torch.int32, device=dev))
+            maps = (None, None, out["g_depth"])
+            rec = (out["grad"], out["dot"], out["nz"][0], out["nz"][1])
+        else:
+            out.update(g_rgb=torch.empty(1, S, S, 3, device=dev), g_alpha=torch.empty(1, S, S, device=dev))
+            maps = (out["g_rgb"], out["g_alpha"], out["g_depth"])
+            rec = (None, None, None, None)
+        fit = _lib.D3MFitTargets(_lib.ptr(rgb_t), _lib.ptr(depth_t), _lib.ptr(alpha_t), _lib.ptr(mask), _lib.ptr(out["scratch"]),
+                                 _lib.ptr(out["loss"]), *[_lib.ptr(t) for t in maps], None, _lib.ptr(mask_sum),
+                                 *[_lib.ptr(t) for t in rec], flags)
+        rc = L.d3m_render_lit_epilogue(_lib.ptr(faces), _lib.ptr(tex), 1, _lib.ptr(light), 1, _lib.ptr(fi), _lib.ptr(wm), _lib.ptr(dm),
+                                       _lib.ptr(bg), 1, _lib.ptr(out["rgb_blended"]), _lib.ptr(out["alpha_map"]), _lib.ptr(out["rgb"]),
+                                       _lib.ptr(out["alpha"]), _lib.ptr(out["depth"]), 1, Ft, 1, S, ts, 1e-5, 1,
+                                       ctypes.byref(fit), st)
+        torch.cuda.synchronize()
+        return rc, out
+
+    assert run(True, 0)[0] == 1                                   # D3M_ERR_INVALID: records of a pooled pass without the flag
+    rc_m, a = run(False, 0)
+    rc_r, b = run(True, _lib.FIT_POOLED)
+    assert rc_m == 0 and rc_r == 0 and L.d3m_last_hip_error() == 0
+    for name in ("rgb", "alpha", "depth", "rgb_blended", "alpha_map", "g_depth"):
+        assert torch.equal(a[name], b[name]), name
+    assert float(a["loss"]) > 0 and abs(float(a["loss"]) - float(b["loss"])) <= 2e-6 * float(a["loss"])
+    # the records against the maps
+    grad, dot = b["grad"][0], b["dot"][0]
+    assert torch.allclose(grad[..., 0] * float(S * S), a["g_alpha"][0], rtol=1e-6, atol=0)
+    assert torch.allclose(grad[..., 1:] * (3.0 * float(mask_sum)), a["g_rgb"][0], rtol=1e-6, atol=1e-12)
+    want = b["alpha_map"][0] * grad[..., 0] + (b["rgb_blended"][0] * grad[..., 1:]).sum(-1)
+    assert torch.allclose(dot[..., 0], want, rtol=1e-5, atol=1e-9)
+    assert torch.equal(dot[..., 1].contiguous().view(torch.int32), fi[0])
+    nzp = ((grad != 0).any(-1) | (dot[..., 0] != 0)).cpu().numpy()              # [y, x], row 0 = bottom
+    assert nzp.any() and not nzp.all()
+    lo_inv, hi1 = b["nz"][0][0].cpu().numpy(), b["nz"][1][0].cpu().numpy()       # [axis, line]
+    for axis, lines in ((1, nzp), (0, nzp.T)):                                    # axis 1: rows (along x), axis 0: columns
+        for d0 in range(S):
+            idx = np.flatnonzero(lines[d0])
+            exp = (0, 0) if idx.size == 0 else (S - int(idx[0]), int(idx[-1]) + 1)
+            assert (int(lo_inv[axis, d0]), int(hi1[axis, d0])) == exp, (axis, d0)
