@@ -1,5 +1,5 @@
 // d3m_g2s.h -- the renderer block of the gan2shape training step (deep3dmap/models/frameworks/gan2shape.py:444,463-497,
-// "G2S" below; NrRenderer = deep3dmap/core/renderer/renderer_nr.py, "CR") as nine fused passes:
+// "G2S" below; NrRenderer = deep3dmap/core/renderer/renderer_nr.py, "CR") as eight launches (nine fused passes: the last two share a grid):
 //
 //   forward   k_g2s_front     per canonical pixel: the view's (R, t) (CR/utils.py:54-71), normal (CR:127-139) -> diffuse
 //                             shading -> texture (G2S:463-466), and the pixel as a mesh vertex: back-projection, rigid
@@ -20,8 +20,7 @@
 //             k_g2s_depth_faces       K6 (KCU:543-592) gathered per triangle pair, stored per triangle (no atomics)
 //             k_g2s_front_backward    per canonical pixel: its six incident triangles' gradients -> camera -> rigid
 //                                     motion -> depth, view; texture gradient -> albedo, light, normal
-//             k_g2s_depth_backward    normals' adjoint + smooth loss -> depth
-//             k_g2s_finish_backward   per-entry sums; (R, t) -> view
+//             k_g2s_depth_backward    normals' adjoint + smooth loss -> depth; its last B workgroups: per-entry sums, (R, t) -> view
 //
 // The reference runs this block as ~150 eager kernels forward and as many again in backward.  Every map of the block is
 // a few hundred KB, so the passes are latency-bound: what counts is the number of launches, that nothing is
@@ -620,8 +619,13 @@ __global__ void __launch_bounds__(256) k_g2s_front_backward(G2S g) {
 
 // per canonical pixel: the normals' adjoint gathered from the four neighbours (as k_depth_normals_backward), the mesh
 // path's share and the smooth loss of the depth map itself
+// ... and, as the last B workgroups of the same grid (round 5: they read the partial sums of the two passes in FRONT of this
+// one and nothing of its own -- a launch of ~4 us less on a nine-launch step), k_g2s_finish_backward's body, below.
+__device__ __forceinline__ void g2s_finish_backward(const G2S& g, int b);
 __global__ void __launch_bounds__(256) k_g2s_depth_backward(G2S g) {
     const int HW = g.H * g.W, H = g.H, W = g.W;
+    const unsigned nb_depth = gridDim.x - (unsigned)g.B;
+    if (blockIdx.x >= nb_depth) { g2s_finish_backward(g, (int)(blockIdx.x - nb_depth)); return; }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)g.B * HW) return;
     const int b = (int)(i / HW), pix = (int)(i - (long)b * HW);
@@ -647,9 +651,9 @@ __global__ void __launch_bounds__(256) k_g2s_depth_backward(G2S g) {
 // one workgroup per batch entry: add up the passes' partial sums (eight lanes per sum); the gradient of the inverse
 // view's (A', t') = (R^T, -(t R)) joins that of (R, t); with a view vector, (R, t)'s gradient goes on to it
 // (k_view_transform_backward's arithmetic)
-__global__ void __launch_bounds__(256) k_g2s_finish_backward(G2S g) {
+__device__ __forceinline__ void g2s_finish_backward(const G2S& g, int b) {      // (all 256 threads of a workgroup)
     __shared__ float s_sum[32];
-    const int b = blockIdx.x, j = threadIdx.x >> 3, sub = threadIdx.x & 7;      // sum j of 29, eight lanes each
+    const int j = threadIdx.x >> 3, sub = threadIdx.x & 7;      // sum j of 29, eight lanes each
     float v = 0.0f;
     if (j < G2S_FRONT_SUMS) {
         for (int k = sub; k < g.split_f; k += 8) v += g.scratch[g.off_front + G2S_FRONT_SUMS * ((size_t)b * g.split_f + k) + j];

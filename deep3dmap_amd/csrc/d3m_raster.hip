@@ -1599,8 +1599,8 @@ D3M_EXPORT int d3m_g2s_backward(const d3m_g2s_block* block, d3m_stream_t stream)
     LAUNCH("k_g2s_sample_backward", k_g2s_sample_backward, dim3(g.split_s, B), dim3(256), st, g);
     LAUNCH("k_g2s_depth_faces", k_g2s_depth_faces, dim3(blocks_for((long)B * Ft, 4 * G2S_PW)), dim3(256), st, g);
     LAUNCH("k_g2s_front_backward", k_g2s_front_backward, dim3(g.split_f, B), dim3(256), st, g);
-    LAUNCH("k_g2s_depth_backward", k_g2s_depth_backward, dim3(blocks_for((long)B * HW, 256)), dim3(256), st, g);
-    LAUNCH("k_g2s_finish_backward", k_g2s_finish_backward, dim3(B), dim3(256), st, g);
+    // (+ B workgroups: the per-entry sums of the two passes above and the view's gradient -- g2s_finish_backward)
+    LAUNCH("k_g2s_depth_backward", k_g2s_depth_backward, dim3(blocks_for((long)B * HW, 256) + B), dim3(256), st, g);
     return check_launch();
 }
 

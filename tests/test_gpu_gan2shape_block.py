@@ -199,4 +199,4 @@ def test_block_in_a_captured_step_launches_only_library_kernels():
         torch.cuda.synchronize()
     kernels = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     foreign = [k for k in kernels if "k_g2s_" not in k and "Memcpy" not in k and "Memset" not in k]
-    assert len([k for k in kernels if "k_g2s_" in k]) == 9 and not foreign, kernels
+    assert len([k for k in kernels if "k_g2s_" in k]) == 8 and not foreign, kernels
