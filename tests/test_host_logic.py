@@ -216,7 +216,7 @@ def test_committed_bench_line_and_profiles_are_consistent():
     assert g2s["launches_per_step"] <= 20 and g2s["ms_per_step"] <= 0.20 and "roofline" in g2s
     stats = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{R}_kernel_stats_gan2shape.csv")))]
     replayed = [n for n in stats if "k_g2s_" in n]
-    assert len(replayed) <= 9
+    assert len(replayed) == 8
 
 
 def test_design_figures_are_generated_from_the_committed_profiles():
