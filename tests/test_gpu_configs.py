@@ -372,8 +372,9 @@ def test_graph_capture_with_retained_autograd_state():
         assert _rel_l2(depth.grad, gd0) < 1e-4 and _rel_l2(view.grad, gv0) < 1e-4
 
 
+@pytest.mark.parametrize("aa", [False, True])
 @pytest.mark.parametrize("groups", [2, 3])
-def test_view_groups_equal_one_pipeline(groups):
+def test_view_groups_equal_one_pipeline(groups, aa):
     """The lit render node run as concurrent view groups (rasterize._RasterizeLit, "VIEW GROUPS"): the fused fit
     objective and its gradients (the groups are shards of it), and plain render() with per-view textures -- images
     bit for bit, gradients to rounding -- against the single pipeline."""
@@ -384,7 +385,7 @@ def test_view_groups_equal_one_pipeline(groups):
     eyes = synthetic.camera_ring(5)
     res = []
     for g in (1, groups):
-        fit = MultiViewFit(v, tri, tex, eyes, image_size=96, view_groups=g)
+        fit = MultiViewFit(v, tri, tex, eyes, image_size=96, view_groups=g, anti_aliasing=aa)    # (aa: the pooled records)
         fit.set_targets_from(synthetic.perturb(v, 0.03))
         loss, gv, gt = fit.step()
         eager = (float(loss), gv.clone(), gt.clone())
@@ -397,6 +398,8 @@ def test_view_groups_equal_one_pipeline(groups):
     assert abs(lg - l1) <= 1e-5 * abs(l1)
     assert float((gvg - gv1).abs().max()) <= 1e-4 * float(gv1.abs().max())      # float atomics meet in another order
     assert float((gtg - gt1).abs().max()) <= 1e-4 * float(gt1.abs().max())
+    if aa:
+        return
     # render(): per-view textures and world vertices with gradients (light gradient path), anti-aliasing on
     B = 5
     vt = torch.from_numpy(v).cuda()[None].repeat(B, 1, 1) * torch.linspace(0.9, 1.1, B, device="cuda")[:, None, None]
