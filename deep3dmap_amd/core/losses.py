@@ -206,7 +206,8 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
     of a camera-sharded objective (deep3dmap_amd/multiview.py).
 
     When rgb, depth and alpha are the three images of one Renderer.render() call (NR/renderer.py:200-246) on the lit path
-    without anti-aliasing, the objective's gradient never exists as images: see _FitLossOnLitImages.  That route is not
+    -- without anti-aliasing, or with the objective registered on the renderer (Renderer.fit_targets) -- the objective's
+    gradient never exists as images: see _FitLossOnLitImages / _FitLossFromRenderNode.  That route is not
     taken when an image's gradient is observed (retain_grad, tensor hooks) or with `link=False`; asking autograd for the
     gradient with respect to the images themselves WITHOUT back-propagating through the render node
     (torch.autograd.grad(loss, rgb)) needs `link=False` and raises otherwise."""
@@ -222,7 +223,8 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
             if hs is not None and _same(hs[0], rgb_target) and _same(hs[1], depth_target) and _same(hs[2], alpha_target) \
                     and _same(hs[3], mask) and (mask_sum is None or _same(hs[7], mask_sum.reshape(1))):
                 return _FitLossFromRenderNode.apply(rgb, depth, alpha, lit)
-            return _FitLossOnLitImages.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum, lit)
+            if not lit.cfg[2]:      # (the objective on FINISHED images takes them at the internal size: no anti-aliasing)
+                return _FitLossOnLitImages.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum, lit)
     return _MultiViewFitLoss.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum)
 
 

@@ -309,7 +309,9 @@ class LitImagesLink:
         if self.finish_pending:         # (a registered objective whose finish was left to the records route: do it now)
             self.finish_pending = False
             fit_c = _RasterizeLit._fit_struct(self.fit_state, 0, 0, B, None)
-            _lib.check(_lib.lib().d3m_fit_finish(ctypes.byref(fit_c), B, H, _lib.stream_ptr()), "d3m_fit_finish")
+            # (the pass ran at the INTERNAL size: twice the images' with anti-aliasing)
+            _lib.check(_lib.lib().d3m_fit_finish(ctypes.byref(fit_c), B, H * (2 if self.fit_state[8] else 1),
+                                                 _lib.stream_ptr()), "d3m_fit_finish")
         own = [torch.empty_like(t) for t in (rgb, depth, alpha)]
         t = (rgb, rgb_t, depth, depth_t, alpha, alpha_t, mask)
         _lib.check(_lib.lib().d3m_fit_loss_backward(*[_lib.ptr(x) for x in t], _lib.ptr(scratch[0]), _lib.ptr(self.grad_loss),
@@ -321,8 +323,8 @@ class LitImagesLink:
 
 def lit_images_link(rgb, depth, alpha):
     """The lit render node (its autograd context) whose three output images these are -- rgb, depth and alpha exactly as
-    rasterize_lit() / Renderer.render() returned them, without anti-aliasing, one pipeline, gradients wanted, no objective
-    linked yet -- or None."""
+    rasterize_lit() / Renderer.render() returned them, one pipeline, gradients wanted, no objective linked yet (with
+    anti-aliasing only a node that was given the objective's targets up front: fit_hint) -- or None."""
     fn = rgb.grad_fn
     if fn is None or fn is not depth.grad_fn or fn is not alpha.grad_fn or not isinstance(fn, _RasterizeLit._backward_cls):
         return None
@@ -332,7 +334,8 @@ def lit_images_link(rgb, depth, alpha):
     if cfg is None or fn.fit is not None or getattr(fn, "linked_fit", None) is not None:
         return None
     S, _eps, aa, ra, rd, _fb, _light, _Bl, groups = cfg
-    if aa or not (ra and rd) or len(groups) != 1 or fn.maps.get("visibility") is None:
+    if (aa and getattr(fn, "hint_state", None) is None) or not (ra and rd) or len(groups) != 1 or \
+            fn.maps.get("visibility") is None:
         return None
     return fn
 
@@ -448,8 +451,7 @@ class _RasterizeLit(torch.autograd.Function):
         # pass that writes them also evaluates the objective the caller is about to evaluate on them and leaves its gradient
         # as walk records (the fused objective's pass with images_out): core.losses.multiview_fit_loss, handed these very
         # images and targets, then finds value and records here instead of re-reading the images (`hint_state`).
-        hinted = (fit is None and fit_hint is not None and not anti_aliasing and return_alpha and return_depth and need_grad
-                  and G == 1)
+        hinted = fit is None and fit_hint is not None and return_alpha and return_depth and need_grad and G == 1
         if fit is None:
             rgb = torch.empty(B, 3, s_out, s_out, dtype=torch.float32, device=dev)
             alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None

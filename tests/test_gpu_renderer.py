@@ -932,7 +932,8 @@ def test_linked_fit_loss_with_observed_image_gradients():
     assert _rel_max(g, g_img[0]) < 1e-6
 
 
-def test_registered_objective_rides_in_the_render_pass():
+@pytest.mark.parametrize("aa", [False, True])
+def test_registered_objective_rides_in_the_render_pass(aa):
     """the reference-shaped composition with the objective REGISTERED on the renderer (Renderer.fit_targets):
     render() returns the same images bit for bit, the pass that writes them has evaluated the objective and left walk
     records, and multiview_fit_loss on those images with those targets launches NOTHING (no k_fit_loss_records) -- value
@@ -944,7 +945,7 @@ def test_registered_objective_rides_in_the_render_pass():
     from deep3dmap_amd.multiview import MultiViewFit
     v, tri = synthetic.grid_mesh(20)
     tex = synthetic.random_textures(tri.shape[0], 2)
-    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(4), image_size=96)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(4), image_size=96, anti_aliasing=aa)     # (aa: the pooled records)
     fit.set_targets_from(synthetic.perturb(v, 0.03))
     loss0, gv0, gt0 = (t.clone() for t in fit.step())                # the fused objective (render_fit_loss)
     rgb_t, depth_t, alpha_t = fit.targets
