@@ -384,6 +384,81 @@ def gan2shape_workload(args):
         "roofline": roof}))
 
 
+def modes_workload(args):
+    """SURVEY 8(d), "modes timed": the silhouette-only and depth-only modes of the renderer (NR/renderer.py:114-183:
+    render_silhouettes / render_depth) on the headline mesh and cameras -- look_at transform, fill_back gather, coverage, the
+    output epilogue, the mode's loss against a target rendered from a perturbed mesh (silhouettes: sum((a - a_t)^2) / P,
+    NR/examples/example2.py:43-47; depth: photometric_loss with the target's silhouette as mask), backward to the vertices
+    (K4 for the silhouette, K6 for the depth).  Single GPU; one JSON line; no objective is fused into these modes: they run
+    the reference's operator sequence through rasterize_ops (include/d3m_raster.h section A)."""
+    from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
+    from deep3dmap_amd.core.losses import photometric_loss, silhouette_loss
+    from deep3dmap_amd.graph import CapturedStep
+    torch.cuda.set_device(0)
+    mode, B, s = args.workload, args.views_per_gpu, args.image_size
+    v_np, tri_np = synthetic.grid_mesh(args.mesh_n)
+    r = nr.Renderer(image_size=s, anti_aliasing=args.anti_aliasing, camera_mode="look_at", fill_back=True)
+    r.eye = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    render = r.render_silhouettes if mode == "silhouettes" else r.render_depth
+    with torch.no_grad():
+        moved = torch.from_numpy(synthetic.perturb(v_np, 0.02)).float().cuda()[None]
+        target = render(moved, tri)
+        mask = r.render_silhouettes(moved, tri) if mode == "depth" else None
+    v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+    one = torch.ones((), device="cuda")
+    P = float(s * s)
+
+    def step():
+        v.grad = None
+        image = render(v, tri)
+        loss = silhouette_loss(image, target) / P if mode == "silhouettes" else photometric_loss(image, target, mask)
+        torch.autograd.backward([loss], [one])
+        return loss.detach()
+
+    runner = CapturedStep(step)
+    loss_eager = float(runner())
+    g_eager = v.grad.clone()
+    assert float(g_eager.abs().max()) > 0
+    if not args.no_graph:
+        runner.capture()
+    with _own_stream(runner.stream):
+        for _ in range(args.warmup):
+            runner()
+        regions, loss = timed_repeats(runner, torch.cuda.synchronize, max(1, args.repeats), args.steps)
+        elapsed = float(np.median(regions))
+    assert abs(float(loss) - loss_eager) <= 1e-5 * abs(loss_eager), (float(loss), loss_eager)
+    assert float((v.grad - g_eager).abs().max()) <= 1e-3 * float(g_eager.abs().max())
+    runner.release()
+    _lib.kernel_timing(True)
+    n_inst = 3
+    for _ in range(n_inst):
+        runner()
+    ktimes = _lib.collect_kernel_times()
+    _lib.kernel_timing(False)
+    step_s = elapsed / args.steps
+    V, F = v_np.shape[0], tri_np.shape[0]
+    S = 2 * s if args.anti_aliasing else s
+    step_bytes = B * sum(algorithmic_bytes(V, F, S, s, args.texture_size, alpha=int(mode == "silhouettes"),
+                                           depth=int(mode == "depth"), rgb=0, tex_grad=0))
+    print(json.dumps({
+        "metric": f"rendered Mpix/s fwd+bwd, {mode} mode",
+        "value": round(B * s * s / step_s / 1e6, 2), "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "repeats": len(regions), "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+        "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+        "library": library_identity()[0], "library_sha16": library_identity()[1], "dev_switches": args.dev_switches,
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{F}-triangle mesh @{s}x{s}{' with anti-aliasing' if args.anti_aliasing else ''}, {B} views, "
+                               f"{mode} only: Renderer.render_{mode} + loss + backward (vertex gradient)",
+                   "api": f"Renderer.render_{mode} + {'silhouette_loss' if mode == 'silhouettes' else 'photometric_loss'} + backward",
+                   "views": B, "hip_graph": not args.no_graph},
+        "launches_per_step": sum(c for c, _ in ktimes.values()) / n_inst,
+        "hbm_roofline_frac_step": round(step_bytes / step_s / 8e12, 5), "algorithmic_bytes_per_step": step_bytes,
+        "d3m_kernel_ms_per_step": round(sum(m for _, m in ktimes.values()) / n_inst, 4),
+        "kernel_ms_per_step": {k: round(m / n_inst, 4) for k, (c, m) in sorted(ktimes.items(), key=lambda kv: -kv[1][1])}}))
+
+
 def mesh_family_workload(args):
     """the face3d utility rasterizer (mesh_cython) at the size its caller uses (tools/data_gen/prnet.py:
     a BFM-sized mesh, 52,900 vertices / 104,882 triangles, 256x256): render_colors + get_triangle_buffer +
@@ -468,7 +543,7 @@ def main():
     ap.add_argument("--view-groups", type=int, default=1,
                     help="run each GPU's views as this many concurrent pipelines inside the rendering node")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
-    ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape", "mesh_family"],
+    ap.add_argument("--workload", default="multiview", choices=["multiview", "gan2shape", "mesh_family", "silhouettes", "depth"],
                     help="multiview = the headline metric (default); gan2shape = BASELINE config 3 (secondary line)")
     ap.add_argument("--batch", type=int, default=16, help="gan2shape workload: batch size")
     ap.add_argument("--flip", action="store_true",
@@ -484,6 +559,8 @@ def main():
         return gan2shape_workload(args)
     if args.workload == "mesh_family":
         return mesh_family_workload(args)
+    if args.workload in ("silhouettes", "depth"):
+        return modes_workload(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the bare form: start the ranks ourselves (before this process has touched the GPU) and relay rank 0's line

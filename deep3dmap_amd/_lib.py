@@ -75,6 +75,7 @@ _SIGNATURES = {
     "d3m_forward_texture_sampling": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "d3m_backward_pixel_map_workspace_bytes": (_SZ, [_I, _I, _I]),
     "d3m_backward_pixel_map_workspace_min_bytes": (_SZ, [_I, _I, _I]),
+    "d3m_backward_depth_map_mesh": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P]),
     "d3m_backward_pixel_map": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P, _SZ, _P, _P, _P, _SZ, _P, _P]),
     "d3m_edge_plan_bytes": (_SZ, [_I, _I, _I]),
     "d3m_edge_plan_min_bytes": (_SZ, [_I, _I, _I]),

@@ -58,25 +58,26 @@ __global__ void __launch_bounds__(256) k_mark_visible(const int32_t* __restrict_
     if (fi >= 0) flags[(size_t)(i / ((long)S * S)) * F + fi] = FLAG_VISIBLE;
 }
 
-// Depth backward, gathered: KCU:543-592 summed over the pixels a face owns.  grad_faces += .
+// Depth backward, gathered: KCU:543-592 summed over the pixels a face owns.  The sums go to grad_faces (+=) or, with a
+// vertex target, straight into the gradient of the vertices the faces were gathered from (float atomics).
 template <class FS>
-__global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float* __restrict__ depth_map,
-                                                             const int32_t* __restrict__ face_index_map,
-                                                             const float* __restrict__ weight_map,
-                                                             const float* __restrict__ grad_depth_map,
-                                                             float* __restrict__ grad_faces, int* __restrict__ flags, int B,
-                                                             int S) {
-    const long gi = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES;
-    const int sub = threadIdx.x % FM_LANES;
-    const int F = fs.num_faces();
-    if (gi >= (long)B * F || flags[gi] == FLAG_HIDDEN) return;      // the FM_LANES lanes of a face leave together
+__device__ __forceinline__ void backward_depth_face(FS fs, const float* __restrict__ depth_map,
+                                                    const int32_t* __restrict__ face_index_map,
+                                                    const float* __restrict__ weight_map,
+                                                    const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces,
+                                                    int* __restrict__ flags, int S, long gi, int sub, int F,
+                                                    const VertexTarget& vt, int* __restrict__ n_large) {
     const int bn = (int)(gi / F), fn = (int)(gi % F);
     float face[9], finv[9];
     fs.load(bn, fn, face);
     int x0, x1, y0, y1;
     if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-    if (area > FM_MAX_BBOX_AREA) { flags[gi] = FLAG_LARGE; return; }
+    if (area > FM_MAX_BBOX_AREA) {                      // left to the per-pixel pass (counted, so that it can leave at once)
+        flags[gi] = FLAG_LARGE;
+        if (n_large && sub == 0) atomicAdd(n_large, 1);
+        return;
+    }
     face_inverse(face, S, finv);
     float tmp[3] = {0, 0, 0};
 #pragma unroll
@@ -107,9 +108,41 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
 #pragma unroll
     for (int k = 0; k < 9; k++) acc[k] = quad_sum(acc[k]);
     if (sub == 0) {
-        float* gf = grad_faces + (size_t)gi * 9;
+        if (vt.gv) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) gf[k] += acc[k];
+            for (int v = 0; v < 3; v++) {
+                float* g = vt.vertex(bn, fn, v);
+#pragma unroll
+                for (int k = 0; k < 3; k++) atomicAdd(&g[k], acc[3 * v + k]);
+            }
+        } else {
+            float* gf = grad_faces + (size_t)gi * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) gf[k] += acc[k];
+        }
+    }
+}
+
+// Over every face of the batch (flags decide), or -- `list`, the compacted list of d3m_visibility -- over the faces that own
+// a pixel: a fixed grid striding either way (the FM_LANES lanes of a face stay together).
+template <class FS>
+__global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float* __restrict__ depth_map,
+                                                             const int32_t* __restrict__ face_index_map,
+                                                             const float* __restrict__ weight_map,
+                                                             const float* __restrict__ grad_depth_map,
+                                                             float* __restrict__ grad_faces, int* __restrict__ flags, int B,
+                                                             int S, const int* __restrict__ list,
+                                                             const int* __restrict__ n_list, VertexTarget vt,
+                                                             int* __restrict__ n_large) {
+    const int sub = threadIdx.x % FM_LANES;
+    const int F = fs.num_faces();
+    const long n_units = list ? (long)*n_list : (long)B * F;
+    for (long u = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES; u < n_units;
+         u += (long)gridDim.x * FM_FACES_PER_BLOCK) {
+        const long gi = list ? (long)list[u] : u;
+        if (!list && flags[gi] == FLAG_HIDDEN) continue;
+        backward_depth_face(fs, depth_map, face_index_map, weight_map, grad_depth_map, grad_faces, flags, S, gi, sub, F, vt,
+                            n_large);
     }
 }
 

@@ -569,7 +569,8 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, F, S);
         }
         LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs, depth_map,
-               face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S);
+               face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S, (const int*)nullptr, (const int*)nullptr,
+               VertexTarget{nullptr, nullptr, 0, 0, 1}, (int*)nullptr);
     }
     LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags,
@@ -604,6 +605,35 @@ D3M_EXPORT int d3m_backward_depth_map(const float* faces, const float* depth_map
     DenseFaces fs{faces, num_faces};
     return run_backward_depth(fs, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces,
                               batch_size, image_size, flags, false, (hipStream_t)stream);
+}
+
+// The same operator for a mesh pipeline: over the compacted list of the faces that own a pixel (`visibility`, after
+// d3m_visibility) instead of every face of the batch, and with its sums added straight into the gradient of the vertices the
+// faces were gathered from (`vertex_target`) instead of a dense [B,F,3,3] array that a scatter-add pass then folds.
+// large_counter: 256 zeroed bytes (the entry clears them unless flags & D3M_PRECLEARED).
+D3M_EXPORT int d3m_backward_depth_map_mesh(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                                           const float* weight_map, const float* grad_depth_map, int batch_size, int num_faces,
+                                           int image_size, const d3m_vertex_target* vertex_target, void* visibility,
+                                           void* large_counter, int flags, d3m_stream_t stream) {
+    if (!faces || !depth_map || !face_index_map || !weight_map || !grad_depth_map || !vertex_target || !visibility ||
+        !large_counter || batch_size <= 0 || num_faces <= 0 || image_size <= 0)
+        return D3M_ERR_INVALID;
+    VertexTarget vt;
+    if (int rc = to_vertex_target(vertex_target, num_faces, vt)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch_size, S = image_size;
+    const long n = (long)B * S * S, nf = (long)B * num_faces;
+    if (!(flags & D3M_PRECLEARED)) HIP_TRY(zero_async(large_counter, 256, st));
+    const VisibilityView v = visibility_view(visibility, nf);
+    DenseFaces fs{faces, num_faces};
+    const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
+    LAUNCH("k_backward_depth_faces", k_backward_depth_faces<DenseFaces>, dim3(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8),
+           dim3(256), st, fs, depth_map, face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S,
+           (const int*)v.list, (const int*)v.count, vt, (int*)large_counter);
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
+           face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S, (const int*)v.flags, vt,
+           GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter);
+    return check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------------

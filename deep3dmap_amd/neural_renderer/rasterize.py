@@ -945,6 +945,133 @@ class _RasterizeLit(torch.autograd.Function):
         return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 17
 
 
+class _RasterizeMeshModes(torch.autograd.Function):
+    """render_silhouettes / render_depth (NR/renderer.py:114-183) of an indexed mesh as ONE node, camera inside: the
+    reference's sequence for these modes -- look_at / look / projection, vertices_to_faces (+ the fill_back copy), the
+    rasterizer with alpha or depth output, its backward and the gather's scatter-add adjoint -- run through the pipeline the
+    lit node uses: the step's first launch transforms the vertices (d3m_lit_front), coverage reads the faces through the
+    index tensor and leaves the dense copy, the visibility list and the edge plan behind, and backward adds the edge
+    gradient (K4, alpha) and the depth gradient (K6, over the listed faces) straight into the screen-space gradient of
+    the VERTICES (d3m_vertex_target), which the camera's adjoint takes to the mesh.  No [B,F',3,3] gather, no dense
+    grad_faces, no scatter-add pass, no pass over face_index_map for the visibility flags: the 32-view silhouette step
+    1.57 -> see profiles/, same images bit for bit (tests/test_gpu_renderer.py)."""
+
+    @staticmethod
+    def forward(ctx, vertices, tri, camera, fill_back, image_size, anti_aliasing, near, far, eps, return_alpha, return_depth):
+        from . import cameras
+        L = _lib.lib()
+        vertices = f32c(vertices)
+        tri = tri.to(torch.int32).contiguous()
+        dev = vertices.device
+        cam, cam_keep = cameras._camera_struct(camera, dev)
+        basis, basis_keep = cameras.basis_struct(camera)
+        B, V, Ft = camera["batch"], vertices.shape[1], tri.shape[1]
+        Fp = 2 * Ft if fill_back else Ft
+        if vertices.shape[0] not in (1, B) or tri.shape[0] not in (1, B):
+            raise ValueError("vertices must be [1 or B, V, 3] and faces [1 or B, F, 3]")
+        S = int(image_size) * 2 if anti_aliasing else int(image_size)
+        s_out = int(image_size)
+        need_grad = ctx.needs_input_grad[0]
+        sv = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+        faces = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)      # (the dense copy of faces that can own a pixel)
+        fi = torch.empty(B, S, S, dtype=torch.int32, device=dev)
+        wm = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+        dm = torch.empty(B, S, S, dtype=torch.float32, device=dev)
+        alpha_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if return_alpha else None
+        alpha = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_alpha else None
+        depth = torch.empty(B, s_out, s_out, dtype=torch.float32, device=dev) if return_depth else None
+        vis = torch.empty(int(L.d3m_visibility_bytes(B, Fp)), dtype=torch.uint8, device=dev) if need_grad else None
+        plan = torch.empty(int(L.d3m_edge_plan_bytes(B, Fp, S)), dtype=torch.uint8, device=dev) \
+            if (need_grad and return_alpha) else None
+        ws = ops._workspace("fwd", L.d3m_forward_workspace_bytes(B, Fp, S), dev)
+        # the first launch: camera (+ basis) and the clears of the operators behind it
+        clears, flags_fwd, flags_plan = [], 0, 0
+        nb = int(L.d3m_forward_clear_bytes(B, Ft, int(bool(fill_back)), S, ws.numel()))
+        if nb:
+            clears.append((ws.data_ptr(), nb))
+            flags_fwd = _lib.PRECLEARED
+        if plan is not None:
+            clears.append((plan.data_ptr(), int(L.d3m_edge_plan_clear_bytes(B, Fp, S))))
+            flags_plan = _lib.PRECLEARED
+        zp = (ctypes.c_void_p * max(1, len(clears)))(*[c[0] for c in clears])
+        zb = (ctypes.c_size_t * max(1, len(clears)))(*[c[1] for c in clears])
+        zero3 = _vec3_host((0.0, 0.0, 0.0))
+        _lib.check(L.d3m_lit_front(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam),
+                                   ctypes.byref(basis) if basis is not None else None, _lib.ptr(sv), B, V, _lib.ptr(tri),
+                                   tri.shape[0], Ft, int(bool(fill_back)), None, 0, 0.0, 0.0, zero3, zero3, zero3, zp, zb,
+                                   len(clears), _lib.stream_ptr()), "d3m_lit_front")
+        _lib.check(L.d3m_forward_face_index_map_mesh(
+            _lib.ptr(sv), _lib.ptr(tri), tri.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces), _lib.ptr(fi), _lib.ptr(wm),
+            _lib.ptr(dm), None, B, S, float(near), float(far), _lib.ptr(ws), ws.numel(), _lib.ptr(vis),
+            vis.numel() if vis is not None else 0, flags_fwd, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
+        _lib.check(L.d3m_output_epilogue(_lib.ptr(fi), None, _lib.ptr(dm if return_depth else None), None, 1, None,
+                                         _lib.ptr(alpha_map), None, _lib.ptr(alpha), _lib.ptr(depth), B, S,
+                                         int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_output_epilogue")
+        if need_grad:
+            # (the first step of the visibility list -- which faces own a pixel -- was left by the coverage pass)
+            _lib.check(L.d3m_visibility(None, _lib.ptr(vis), vis.numel(), B, Fp, S, _lib.stream_ptr()), "d3m_visibility")
+            if plan is not None:
+                _lib.check(L.d3m_edge_plan(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(vis), _lib.ptr(plan), plan.numel(), B, Fp, S,
+                                           flags_plan, _lib.stream_ptr()), "d3m_edge_plan")
+        ctx.cfg = (B, V, Ft, Fp, S, bool(anti_aliasing), float(eps), bool(fill_back), bool(return_alpha), bool(return_depth))
+        ctx.camera, ctx.keep = camera, (cam_keep, basis_keep)
+        ctx.maps = (faces, fi, wm, dm, alpha_map, vis, plan)
+        ctx.save_for_backward(vertices, tri)
+        empty = torch.tensor([])
+        return (alpha if return_alpha else empty, depth if return_depth else empty)
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_depth):
+        from . import cameras
+        L = _lib.lib()
+        vertices, tri = ctx.saved_tensors
+        B, V, Ft, Fp, S, aa, eps, fill_back, ra, rd = ctx.cfg
+        faces, fi, wm, dm, alpha_map, vis, plan = ctx.maps
+        dev = vertices.device
+        grad_sv = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+        counter = torch.empty(64, dtype=torch.int32, device=dev)
+        _lib.zero_raw([_lib.tensor_range(grad_sv), _lib.tensor_range(counter)])      # (one launch)
+        target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
+        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
+        if ra:
+            # the adjoint of the output epilogue writes the alpha gradient straight as the edge gradient's per-pixel records
+            # (and the depth gradient as the map K6 reads)
+            records = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),
+                       torch.empty(B, S, S, 2, dtype=torch.float32, device=dev),
+                       torch.empty(2, B, 2, S, dtype=torch.int32, device=dev))
+            _lib.check(L.d3m_output_epilogue_backward_records(
+                None, _lib.ptr(f32c(g_alpha)), _lib.ptr(f32c(g_depth) if rd else None), _lib.ptr(fi), None, _lib.ptr(alpha_map),
+                _lib.ptr(records[0]), _lib.ptr(records[1]), _lib.ptr(records[2][0]), _lib.ptr(records[2][1]),
+                _lib.ptr(g_depth_map), B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward_records")
+            unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
+                                          _lib.ptr(records[0]), _lib.ptr(records[1]), _lib.ptr(records[2][0]),
+                                          _lib.ptr(records[2][1]), 0)
+            ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
+                                   visibility=vis, unscaled=unscaled, edge_plan=plan)
+        elif rd:
+            _lib.check(L.d3m_output_epilogue_backward(None, None, _lib.ptr(f32c(g_depth)), None, None, _lib.ptr(g_depth_map),
+                                                      B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward")
+        if rd:
+            _lib.check(L.d3m_backward_depth_map_mesh(_lib.ptr(faces), _lib.ptr(dm), _lib.ptr(fi), _lib.ptr(wm),
+                                                     _lib.ptr(g_depth_map), B, Fp, S, ctypes.byref(target), _lib.ptr(vis),
+                                                     _lib.ptr(counter), _lib.PRECLEARED, _lib.stream_ptr()),
+                       "d3m_backward_depth_map_mesh")
+        cam, _keep = cameras._camera_struct(ctx.camera, dev)
+        grad_vertices = torch.empty_like(vertices)
+        _lib.check(L.d3m_camera_backward(_lib.ptr(vertices), vertices.shape[0], ctypes.byref(cam), _lib.ptr(grad_sv),
+                                         _lib.ptr(grad_vertices), B, V, _lib.stream_ptr()), "d3m_camera_backward")
+        return (grad_vertices,) + (None,) * 10
+
+
+def rasterize_mesh_modes(vertices, tri, camera, fill_back, image_size, anti_aliasing, return_alpha, return_depth,
+                         near=DEFAULT_NEAR, far=DEFAULT_FAR, eps=DEFAULT_EPS):
+    """(alpha, depth) images -- either may be left out -- of an indexed mesh seen through `camera` (the parameter block of
+    cameras.look_at_params & co): the silhouette / depth modes of the renderer as one node.  See _RasterizeMeshModes."""
+    alpha, depth = _RasterizeMeshModes.apply(vertices, tri, camera, bool(fill_back), int(image_size), bool(anti_aliasing),
+                                             float(near), float(far), float(eps), bool(return_alpha), bool(return_depth))
+    return (alpha if return_alpha else None), (depth if return_depth else None)
+
+
 class _ManualContext:
     """What _RasterizeLit.forward / _backward_halves use of an autograd context, for calling them WITHOUT the autograd
     engine (LitFitManual): needs_input_grad, save_for_backward / saved_tensors, free attributes."""

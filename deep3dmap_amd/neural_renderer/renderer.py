@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import cameras, mesh_ops
 from .rasterize import (rasterize, rasterize_depth, rasterize_lit, rasterize_lit_fit, rasterize_lit_image_grid,
-                        rasterize_rgbad, rasterize_silhouettes)
+                        rasterize_mesh_modes, rasterize_rgbad, rasterize_silhouettes)
 
 
 class Renderer(nn.Module):
@@ -75,6 +75,7 @@ class Renderer(nn.Module):
         # composition  loss(*renderer.render(...))  at the price of the fused objective plus the images' 20 B per pixel.
         # Any other use of the images stays correct (they are ordinary differentiable outputs).  None: off.
         self.fit_targets = None
+        self.mesh_modes = True      # render_silhouettes / render_depth of look_at cameras as one node over the indexed mesh
 
     def forward(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None,
                 orig_size=None):
@@ -124,11 +125,17 @@ class Renderer(nn.Module):
 
     # ---- public render methods ------------------------------------------------------------------------
     def render_silhouettes(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        cam = self._camera_in_node(vertices) if self.mesh_modes else None
+        if cam is not None:     # the whole mode as one node over the indexed mesh (rasterize._RasterizeMeshModes)
+            return rasterize_mesh_modes(vertices, faces, cam, self.fill_back, self.image_size, self.anti_aliasing, True, False)[0]
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         # rasterizer defaults, not self.near / self.far (NR/renderer.py:114)
         return rasterize_silhouettes(f, self.image_size, self.anti_aliasing)
 
     def render_depth(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        cam = self._camera_in_node(vertices) if self.mesh_modes else None
+        if cam is not None:
+            return rasterize_mesh_modes(vertices, faces, cam, self.fill_back, self.image_size, self.anti_aliasing, False, True)[1]
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
         return rasterize_depth(f, self.image_size, self.anti_aliasing)          # NR/renderer.py:149
 

@@ -218,6 +218,15 @@ int d3m_backward_depth_map(const float* faces, const float* depth_map, const int
                            float* grad_faces, int batch_size, int num_faces, int image_size, void* workspace,
                            size_t workspace_bytes, d3m_stream_t stream);
 
+/* d3m_backward_depth_map for a mesh pipeline (faces = the dense copy d3m_forward_face_index_map_mesh left, visibility = the
+ * blob it marked and d3m_visibility finished): runs over the listed faces only and ADDS its sums straight into
+ * vertex_target->grad_vertices (float atomics) -- no dense grad_faces, no scatter-add pass behind it.  large_counter: 256
+ * bytes, zero when the kernels start (cleared here unless flags & D3M_PRECLEARED). */
+int d3m_backward_depth_map_mesh(const float* faces, const float* depth_map, const int32_t* face_index_map,
+                                const float* weight_map, const float* grad_depth_map, int batch_size, int num_faces,
+                                int image_size, const d3m_vertex_target* vertex_target, void* visibility,
+                                void* large_counter, int flags, d3m_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * B. The eager-torch steps either side of those operators, as single HIP passes.
  * ---------------------------------------------------------------------------------------------- */

@@ -1005,3 +1005,44 @@ def test_registered_objective_rides_in_the_render_pass(aa):
     rgb, depth, alpha = fit.render()
     (rgb * w).mean().backward()
     assert _rel_max(only, fit.vertices.grad) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["silhouettes", "depth"])
+@pytest.mark.parametrize("aa", [False, True])
+@pytest.mark.parametrize("per_view_mesh", [False, True])
+def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mesh):
+    """Renderer.render_silhouettes / render_depth (NR/renderer.py:114-183) with a look_at camera run as ONE node over the
+    indexed mesh (rasterize._RasterizeMeshModes: camera inside, coverage through the index tensor, K4 / K6 straight into the
+    vertices' gradient) -- against the reference's operator sequence, which the same Renderer runs with mesh_modes off
+    (look_at -> vertices_to_faces -> rasterize_* -> scatter-add; itself pinned to the oracle by the tests above): images bit
+    for bit, vertex gradients to the order of their float atomics; no gather / scatter pass in the new step."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    v_np, tri_np = synthetic.grid_mesh(24)
+    B = 3
+    eyes = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    base = torch.from_numpy(v_np).float().cuda()[None]
+    if per_view_mesh:
+        base = base.repeat(B, 1, 1) * torch.linspace(0.9, 1.1, B, device="cuda")[:, None, None]
+        tri = tri.repeat(B, 1, 1)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    out = {}
+    for on in (True, False):
+        r = nr.Renderer(image_size=64, anti_aliasing=aa, camera_mode="look_at", fill_back=True)
+        r.eye, r.mesh_modes = eyes, on
+        v = base.clone().requires_grad_(True)
+        with kernels_launched() as k:
+            image = getattr(r, "render_" + mode)(v, tri)
+            if on:
+                w = torch.rand(image.shape, device="cuda", generator=gen) - 0.3
+            (image * w).sum().backward()
+        out[on] = (image.detach(), v.grad.clone(), set(k.names))
+    assert out[True][0].shape == (B, 64, 64) and torch.equal(out[True][0], out[False][0])
+    assert 0.05 < float((out[True][0] > 0).float().mean()) < 1.0 if mode == "silhouettes" else True
+    g1, g0 = out[True][1], out[False][1]
+    assert float(g0.abs().max()) > 0 and float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+    assert {"k_gather_faces", "k_scatter_face_grads", "k_mark_visible"} & out[False][2]
+    assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible", "k_output_epilogue_backward"} & out[True][2]) \
+        or mode == "depth", sorted(out[True][2])
+    assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible"} & out[True][2]), sorted(out[True][2])

@@ -16,6 +16,9 @@ run "64 views per GPU" --views-per-gpu 64
 run "config 3: gan2shape renderer block, batch 16" --workload gan2shape
 run "config 3 with flip3: batch 32" --workload gan2shape --flip
 run "face3d mesh_cython family" --workload mesh_family
+run "silhouettes mode (render_silhouettes + silhouette loss + backward), headline mesh and cameras" --workload silhouettes
+run "depth mode (render_depth + masked L1 + backward), headline mesh and cameras" --workload depth
+run "silhouettes mode with anti-aliasing (S = 1024)" --workload silhouettes --anti-aliasing
 run "config 4 at 1024x1024 (the same 100352 triangles, four times as large on screen), 8 views" --image-size 1024 --views-per-gpu 8
 # the N > 1 step on ONE rank through RCCL (D3M_BENCH_FORCE_DIST: process group, the split exchange's two all-reduces per step)
 rccl() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; D3M_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --no-cpu-baseline --no-dropin "$@" 2>> $O/bench.err | grep "^{" | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
