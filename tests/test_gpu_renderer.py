@@ -1036,8 +1036,12 @@ def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mes
             image = getattr(r, "render_" + mode)(v, tri)
             if on:
                 w = torch.rand(image.shape, device="cuda", generator=gen) - 0.3
-            (image * w).sum().backward()
+            (image * w).sum().backward(retain_graph=on)
         out[on] = (image.detach(), v.grad.clone(), set(k.names))
+        if on:      # a second backward over the same graph (the first used the accumulator the forward pass had zeroed)
+            v.grad = None
+            (image * w).sum().backward()
+            assert float((v.grad - out[on][1]).abs().max()) <= 2e-5 * float(v.grad.abs().max())
     assert out[True][0].shape == (B, 64, 64) and torch.equal(out[True][0], out[False][0])
     assert 0.05 < float((out[True][0] > 0).float().mean()) < 1.0 if mode == "silhouettes" else True
     g1, g0 = out[True][1], out[False][1]
