@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 : > $O/${R}_bench_other_configs.jsonl
 run() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; timeout 600 python bench.py --no-cpu-baseline "$@" 2>> $O/bench.err | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
-run "config 2: 53138-triangle face mesh @256x256 with anti-aliasing (S = 512), 1 view (grid_mesh(164) = 53138 triangles)" --mesh-n 164 --image-size 256 --views-per-gpu 1 --anti-aliasing
+run "config 2: 53138-triangle mesh @256x256 with anti-aliasing (S = 512), 1 view" --mesh-n 164 --image-size 256 --views-per-gpu 1 --anti-aliasing
 run "config 2 without anti-aliasing" --mesh-n 164 --image-size 256 --views-per-gpu 1
 run "config 4 per-GPU shard at 4 GPUs: 8 of the 32 cameras" --views-per-gpu 8
 run "config 5: 1002528-triangle mesh @1024x1024, 8 views" --mesh-n 709 --image-size 1024 --views-per-gpu 8
@@ -16,16 +16,16 @@ run "64 views per GPU" --views-per-gpu 64
 run "config 3: gan2shape renderer block, batch 16" --workload gan2shape
 run "config 3 with flip3: batch 32" --workload gan2shape --flip
 run "face3d mesh_cython family" --workload mesh_family
-run "silhouettes mode (render_silhouettes + silhouette loss + backward), headline mesh and cameras" --workload silhouettes
-run "depth mode (render_depth + masked L1 + backward), headline mesh and cameras" --workload depth
-run "silhouettes mode with anti-aliasing (S = 1024)" --workload silhouettes --anti-aliasing
-run "config 4 at 1024x1024 (the same 100352 triangles, four times as large on screen), 8 views" --image-size 1024 --views-per-gpu 8
+run "silhouettes mode (render_silhouettes + loss + backward), 32 views" --workload silhouettes
+run "depth mode (render_depth + masked L1 + backward), 32 views" --workload depth
+run "silhouettes mode with anti-aliasing (S = 1024), 32 views" --workload silhouettes --anti-aliasing
+run "config 4's mesh @1024x1024, 8 views" --image-size 1024 --views-per-gpu 8
 # the N > 1 step on ONE rank through RCCL (D3M_BENCH_FORCE_DIST: process group, the split exchange's two all-reduces per step)
 rccl() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; D3M_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --no-cpu-baseline --no-dropin "$@" 2>> $O/bench.err | grep "^{" | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
 rccl "one rank through RCCL, split exchange (two graphs, two all-reduces): 32 views"
 rccl "one rank through RCCL, split exchange: config 4's 8-view shard" --views-per-gpu 8
-D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, ONE all-reduce behind the step: 32 views"
-D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, ONE all-reduce behind the step: config 4's 8-view shard" --views-per-gpu 8
+D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, one all-reduce behind the step: 32 views"
+D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, one all-reduce: config 4's 8-view shard" --views-per-gpu 8
 python3 - <<PY
 import json
 for l in open("$O/${R}_bench_other_configs.jsonl"):
