@@ -184,11 +184,26 @@ def look(vertices, eye, direction=[0, 1, 0], up=None, _perspective_angle=None):
         return _view_torch(vertices.float().expand(B, -1, -1), eye_t.expand(B, 3),
                            _frame_torch(eye_t.expand(B, 3), dir_t.expand(B, 3), up_t.expand(B, 3), False),
                            _perspective_angle)
-    rot = _basis(eye_t, dir_t, up_t, False, nb, device)
-    params = dict(mode=_lib.CAMERA_LOOK, batch=B, rot=rot, eye_or_t=eye_t,
-                  perspective=_perspective_angle is not None,
-                  width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
-    return _CameraFunction.apply(vertices, params)
+    return _CameraFunction.apply(vertices, look_params(vertices, eye, direction, up, _perspective_angle))
+
+
+def look_params(vertices, eye, direction=[0, 1, 0], up=None, _perspective_angle=None, defer_basis=False):
+    """look()'s parameter block (see look_at_params), or None when a camera parameter requires grad."""
+    if _learnable(eye, direction, up):
+        return None
+    device = vertices.device
+    eye_t, dir_t = _vec_param(eye, device), _vec_param(direction, device)
+    up_t = _vec_param([0, 1, 0] if up is None else up, device)
+    nb = max(eye_t.shape[0], dir_t.shape[0], up_t.shape[0])
+    p = dict(mode=_lib.CAMERA_LOOK, batch=max(vertices.shape[0], nb), eye_or_t=eye_t,
+             perspective=_perspective_angle is not None,
+             width=_tan_width(_perspective_angle) if _perspective_angle is not None else 1.0)
+    if defer_basis:
+        p["rot"] = torch.empty(nb, 3, 3, dtype=torch.float32, device=device)
+        p["basis"] = (eye_t, dir_t, up_t, False)
+    else:
+        p["rot"] = _basis(eye_t, dir_t, up_t, False, nb, device)
+    return p
 
 
 def perspective(vertices, angle=30.):
@@ -213,9 +228,19 @@ def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
     if _learnable(K, R, t, dist_coeffs) or eps != 1e-9:      # the fused kernel has the reference's default eps built in
         return _projection_torch(vertices.float().expand(batch, -1, -1), Kt.expand(batch, 3, 3), rot.expand(batch, 3, 3),
                                  tt.expand(batch, 3), dist.expand(batch, 5), float(orig_size), eps)
-    params = dict(mode=_lib.CAMERA_PROJECTION, batch=batch, rot=rot, eye_or_t=tt, K=Kt, dist=dist,
-                  orig_size=float(orig_size))
-    return _CameraFunction.apply(vertices, params)
+    return _CameraFunction.apply(vertices, projection_params(vertices, K, R, t, dist_coeffs, orig_size))
+
+
+def projection_params(vertices, K, R, t, dist_coeffs, orig_size):
+    """projection()'s parameter block (default eps), or None when a camera parameter requires grad."""
+    if _learnable(K, R, t, dist_coeffs):
+        return None
+    device = vertices.device
+    tt = as_device_f32(t, device).reshape(-1, 3).contiguous()
+    rot, Kt, dist = (as_device_f32(R, device).reshape(-1, 3, 3).contiguous(), as_device_f32(K, device).reshape(-1, 3, 3).contiguous(),
+                     as_device_f32(dist_coeffs, device).reshape(-1, 5).contiguous())
+    batch = max(vertices.shape[0], tt.shape[0], rot.shape[0], Kt.shape[0], dist.shape[0])
+    return dict(mode=_lib.CAMERA_PROJECTION, batch=batch, rot=rot, eye_or_t=tt, K=Kt, dist=dist, orig_size=float(orig_size))
 
 
 def get_points_from_angles(distance, elevation, azimuth, degrees=True):

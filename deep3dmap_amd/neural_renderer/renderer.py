@@ -125,7 +125,7 @@ class Renderer(nn.Module):
 
     # ---- public render methods ------------------------------------------------------------------------
     def render_silhouettes(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        cam = self._camera_in_node(vertices) if self.mesh_modes else None
+        cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size) if self.mesh_modes else None
         if cam is not None:     # the whole mode as one node over the indexed mesh (rasterize._RasterizeMeshModes)
             return rasterize_mesh_modes(vertices, faces, cam, self.fill_back, self.image_size, self.anti_aliasing, True, False)[0]
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
@@ -133,7 +133,7 @@ class Renderer(nn.Module):
         return rasterize_silhouettes(f, self.image_size, self.anti_aliasing)
 
     def render_depth(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
-        cam = self._camera_in_node(vertices) if self.mesh_modes else None
+        cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size) if self.mesh_modes else None
         if cam is not None:
             return rasterize_mesh_modes(vertices, faces, cam, self.fill_back, self.image_size, self.anti_aliasing, False, True)[1]
         f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
@@ -149,17 +149,28 @@ class Renderer(nn.Module):
         return self.lighting_on_the_fly and not mesh_ops.per_batch_light(
             self.light_color_ambient, self.light_color_directional, self.light_direction)
 
-    def _camera_in_node(self, vertices):
-        """look_at cameras with constant parameters run INSIDE the lit render node (its first launch projects, lights and
-        clears; one gradient for the mesh instead of the camera's plus the light's): their parameter block, else None."""
-        if self.camera_mode == 'look_at' and vertices.ndimension() == 3:
-            return cameras.look_at_params(vertices, self.eye, _perspective_angle=self.viewing_angle if self.perspective else None,
-                                          defer_basis=True)
+    def _camera_in_node(self, vertices, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        """Cameras with constant parameters run INSIDE the render node (its first launch projects, lights and clears; one
+        gradient for the mesh instead of the camera's plus the light's): their parameter block, else None (a parameter that
+        requires grad, or no camera_mode: _transform's torch composition / identity)."""
+        if vertices.ndimension() != 3:
+            return None
+        if self.camera_mode == 'look_at':
+            return cameras.look_at_params(vertices, self.eye, defer_basis=True,
+                                          _perspective_angle=self.viewing_angle if self.perspective else None)
+        if self.camera_mode == 'look':
+            return cameras.look_params(vertices, self.eye, self.camera_direction, defer_basis=True,
+                                       _perspective_angle=self.viewing_angle if self.perspective else None)
+        if self.camera_mode == 'projection':
+            return cameras.projection_params(vertices, self.K if K is None else K, self.R if R is None else R,
+                                             self.t if t is None else t,
+                                             self.dist_coeffs if dist_coeffs is None else dist_coeffs,
+                                             self.orig_size if orig_size is None else orig_size)
         return None
 
     def render_rgb(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
-            cam = self._camera_in_node(vertices)
+            cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size)
             sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             return rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                  self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
@@ -193,7 +204,7 @@ class Renderer(nn.Module):
             raise ValueError("render_fit_loss needs lighting_on_the_fly (one light for the batch)")
         # look_at cameras with constant parameters run INSIDE the node (one gradient for the mesh instead of the camera's
         # plus the light's; results straight into the caller's grad_sink buffers when it has set them)
-        cam = self._camera_in_node(vertices)
+        cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size)
         sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
         return rasterize_lit_fit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, targets,
                                  self.image_size, self.near, self.far, self.rasterizer_eps, self.background_color,
@@ -215,7 +226,7 @@ class Renderer(nn.Module):
 
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
-            cam = self._camera_in_node(vertices)
+            cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size)
             sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,

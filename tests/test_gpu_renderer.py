@@ -1050,3 +1050,66 @@ def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mes
     assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible", "k_output_epilogue_backward"} & out[True][2]) \
         or mode == "depth", sorted(out[True][2])
     assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible"} & out[True][2]), sorted(out[True][2])
+
+
+def _projection_camera(size, batch):
+    fx = 1.25 * size
+    K = torch.tensor([[fx, 0.0, size / 2.0], [0.0, fx, size / 2.0], [0.0, 0.0, 1.0]], device="cuda")[None]
+    ang = torch.linspace(-0.4, 0.4, batch)
+    R = torch.stack([torch.tensor([[float(torch.cos(a)), 0.0, float(torch.sin(a))], [0.0, 1.0, 0.0],
+                                   [-float(torch.sin(a)), 0.0, float(torch.cos(a))]]) for a in ang]).cuda()
+    t = torch.tensor([[0.05, -0.02, 2.8]], device="cuda").repeat(batch, 1)[:, None, :]
+    dist = torch.tensor([[0.05, 0.01, 0.001, -0.002, 0.0]], device="cuda")
+    return dict(K=K, R=R, t=t, dist_coeffs=dist, orig_size=size)
+
+
+@pytest.mark.parametrize("camera_mode", ["look", "projection"])
+def test_look_and_projection_cameras_run_inside_the_render_nodes(camera_mode):
+    """Round 5: not only look_at -- `look` and `projection` cameras with constant parameters also run inside the render
+    nodes (Renderer._camera_in_node: the lit node of render / render_rgb / render_fit_loss and the mesh node of
+    render_silhouettes / render_depth).  Against the same Renderer driven the reference's way (camera transform as a node of
+    its own, NR/renderer.py:88-112, then the rasterizer on the transformed vertices): images bit for bit, gradients to the
+    order of their float atomics."""
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    from deep3dmap_amd.neural_renderer.rasterize import rasterize_lit
+    v_np, tri_np = synthetic.grid_mesh(20)
+    B, size = 3, 64
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    tex = torch.from_numpy(synthetic.random_textures(tri_np.shape[0], 2)).float().cuda()[None]
+    r = nr.Renderer(image_size=size, anti_aliasing=False, camera_mode=camera_mode, fill_back=True)
+    kw = {}
+    if camera_mode == "look":
+        r.eye = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
+        r.camera_direction = (-r.eye / r.eye.norm(dim=1, keepdim=True)).contiguous()
+    else:
+        kw = _projection_camera(size, B)
+    assert r._camera_in_node(torch.zeros(1, 4, 3, device="cuda"), **kw) is not None
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    # silhouettes and depth: the mesh node against the operator sequence
+    for mode in ("silhouettes", "depth"):
+        res = []
+        for on in (True, False):
+            r.mesh_modes = on
+            v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+            image = getattr(r, "render_" + mode)(v, tri, **kw)
+            if on:
+                w = torch.rand(image.shape, device="cuda", generator=gen) - 0.3
+            (image * w).sum().backward()
+            res.append((image.detach(), v.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and float((res[0][0] != res[0][0][0, 0, 0]).float().mean()) > 0.02
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
+    # render(): the lit node with the camera inside against the lit node behind the camera's own node
+    v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+    t1 = tex.clone().requires_grad_(True)
+    rgb, depth, alpha = r.render(v, tri, t1, **kw)
+    w3 = torch.rand(rgb.shape, device="cuda", generator=gen)
+    (rgb * w3).sum().backward()
+    v2 = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+    t2 = tex.clone().requires_grad_(True)
+    sv = r._transform(v2, kw.get("K"), kw.get("R"), kw.get("t"), kw.get("dist_coeffs"), kw.get("orig_size"))
+    out = rasterize_lit(sv, v2, tri, t2, r._light_cfg(), r.fill_back, r.image_size, r.anti_aliasing, r.near, r.far,
+                        r.rasterizer_eps, r.background_color)
+    (out["rgb"] * w3).sum().backward()
+    assert torch.equal(rgb.detach(), out["rgb"].detach()) and torch.equal(depth.detach(), out["depth"].detach())
+    assert float((v.grad - v2.grad).abs().max()) <= 2e-5 * float(v2.grad.abs().max()) > 0
+    assert float((t1.grad - t2.grad).abs().max()) <= 2e-5 * float(t2.grad.abs().max())
