@@ -354,6 +354,12 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
     assert L.d3m_forward_face_index_map_mesh(*args(pi, 3, 16, 18)) == INVALID          # index batch 3 of 1
     tiny = (p, None, -4, 16, 18, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, 64, None, 0, 0, st)
     assert L.d3m_forward_face_index_map_mesh(*tiny) == WORKSPACE
+    # the mesh form of the depth backward: needs its vertex target, its visibility blob and its counter
+    vt0 = _lib.D3MVertexTarget(p, pi, 16, 18, 1, 1)
+    assert L.d3m_backward_depth_map_mesh(p, p, pi, p, p, 1, 36, 8, None, p, p, 0, st) == INVALID
+    assert L.d3m_backward_depth_map_mesh(p, p, pi, p, p, 1, 36, 8, ctypes.byref(vt0), None, p, 0, st) == INVALID
+    assert L.d3m_backward_depth_map_mesh(p, p, pi, p, p, 1, 36, 8, ctypes.byref(vt0), p, None, 0, st) == INVALID
+    assert L.d3m_backward_depth_map_mesh(p, p, pi, p, p, 0, 36, 8, ctypes.byref(vt0), p, p, 0, st) == INVALID
     # the camera's adjoint onto an existing gradient; the objective's scratch for small rasters
     cam = _lib.D3MCamera()
     assert L.d3m_camera_backward_add(p, 3, ctypes.byref(cam), p, p, 2, 4, st) == INVALID    # 3 meshes for 2 views
