@@ -1010,12 +1010,12 @@ def test_registered_objective_rides_in_the_render_pass(aa):
 @pytest.mark.parametrize("mode", ["silhouettes", "depth"])
 @pytest.mark.parametrize("aa", [False, True])
 @pytest.mark.parametrize("per_view_mesh", [False, True])
-def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mesh):
+def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mesh, coverage):
     """Renderer.render_silhouettes / render_depth (NR/renderer.py:114-183) with a look_at camera run as ONE node over the
     indexed mesh (rasterize._RasterizeMeshModes: camera inside, coverage through the index tensor, K4 / K6 straight into the
     vertices' gradient) -- against the reference's operator sequence, which the same Renderer runs with mesh_modes off
     (look_at -> vertices_to_faces -> rasterize_* -> scatter-add; itself pinned to the oracle by the tests above): images bit
-    for bit, vertex gradients to the order of their float atomics; no gather / scatter pass in the new step."""
+    for bit, vertex gradients to the order of their float atomics; no gather / scatter pass in the new step.  Both forms of coverage."""
     from conftest import kernels_launched
     from deep3dmap_amd import neural_renderer as nr, synthetic
     v_np, tri_np = synthetic.grid_mesh(24)
