@@ -475,3 +475,34 @@ def test_plan_capacity_follows_the_raster_size():
     assert torch.isfinite(loss) and torch.isfinite(gv).all()
     lines, gather = k.times["k_edge_lines"][1], k.times["k_edge_gather"][1]
     assert gather < lines, (lines, gather)       # (ms; the fallback takes 30x the line kernel's time when it runs, and the line kernel then none)
+
+
+@pytest.mark.parametrize("mode", ["silhouettes", "depth"])
+def test_modes_over_the_indexed_mesh_at_full_size(mode):
+    """The silhouette / depth modes as one node (rasterize._RasterizeMeshModes) on BASELINE config 4's mesh and raster -- eight
+    of its cameras, 100,352 triangles @512x512, the binned form of coverage as at 32 views -- against the operator sequence
+    of the reference (Renderer.mesh_modes off), which the reference-parity tests pin: images bit for bit; the vertex gradient
+    element-wise within the 1e-3 contract (|d| <= 1e-3 |ref| + 1e-5 max|ref| for all but a 1e-5 fraction: both sides add the
+    same terms with float atomics in another order)."""
+    from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
+    v_np, tri_np = synthetic.grid_mesh(225)
+    eyes = torch.from_numpy(synthetic.camera_ring(32)[::4].copy()).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    res = []
+    with _lib.coverage_form("binned"):
+        for on in (True, False):
+            r = nr.Renderer(image_size=512, anti_aliasing=False, camera_mode="look_at", fill_back=True)
+            r.eye, r.mesh_modes = eyes, on
+            v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+            image = getattr(r, "render_" + mode)(v, tri)
+            if on:
+                w = torch.rand(image.shape, device="cuda", generator=gen) - 0.4
+            (image * w).sum().backward()
+            res.append((image.detach(), v.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    g, ref = res[0][1], res[1][1]
+    scale = float(ref.abs().max())
+    bad = ((g - ref).abs() > 1e-3 * ref.abs() + 1e-5 * scale).float().mean()
+    assert scale > 0 and float(bad) <= 1e-5, float(bad)
+    assert float((g - ref).abs().max()) <= 1e-4 * scale
