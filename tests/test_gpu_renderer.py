@@ -1113,3 +1113,26 @@ def test_look_and_projection_cameras_run_inside_the_render_nodes(camera_mode):
     assert torch.equal(rgb.detach(), out["rgb"].detach()) and torch.equal(depth.detach(), out["depth"].detach())
     assert float((v.grad - v2.grad).abs().max()) <= 2e-5 * float(v2.grad.abs().max()) > 0
     assert float((t1.grad - t2.grad).abs().max()) <= 2e-5 * float(t2.grad.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["silhouettes", "depth"])
+def test_mesh_modes_without_fill_back_and_without_gradients(mode):
+    """The same node with fill_back off (front faces only) and under no_grad (no visibility list, no plan): images bit for
+    bit as the operator sequence's, gradients equal where they are asked for."""
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    v_np, tri_np = synthetic.grid_mesh(24)
+    eyes = torch.from_numpy(synthetic.camera_ring(3)).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    res = []
+    for on in (True, False):
+        r = nr.Renderer(image_size=48, anti_aliasing=True, camera_mode="look_at", fill_back=False)
+        r.eye, r.mesh_modes = eyes, on
+        v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+        with torch.no_grad():
+            plain = getattr(r, "render_" + mode)(v, tri)
+        image = getattr(r, "render_" + mode)(v, tri)
+        assert torch.equal(plain, image.detach())
+        (image * image).sum().backward()
+        res.append((image.detach(), v.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
