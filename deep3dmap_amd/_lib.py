@@ -55,6 +55,7 @@ CAMERA_NONE, CAMERA_LOOK_AT, CAMERA_LOOK, CAMERA_PROJECTION = 0, 1, 2, 3
 PRECLEARED = 1            # D3M_PRECLEARED: the caller has zeroed what the operator would clear (include/d3m_raster.h, "Clears")
 FIT_FINISH_DEFERRED = 2   # D3M_FIT_FINISH_DEFERRED: the fused objective's finish is left to d3m_backward_textures_lit
 FIT_POOLED = 4            # D3M_FIT_POOLED: records of an objective on the 2x2-pooled images (anti-aliasing)
+GRAD_OF_OUTPUT_IMAGE = 32   # D3M_GRAD_OF_OUTPUT_IMAGE (d3m_backward_depth_map_mesh)
 FRONT_RANGES = 10         # clears d3m_lit_front takes
 
 _SIGNATURES = {

@@ -55,7 +55,8 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
                                                           const float* __restrict__ weight_map,
                                                           const float* __restrict__ grad_depth_map,
                                                           float* __restrict__ grad_faces, int B, int S,
-                                                          const int* __restrict__ only_large, VertexTarget vt, GradScale gs) {
+                                                          const int* __restrict__ only_large, VertexTarget vt, GradScale gs,
+                                                          int flip_rows = 0) {
     // (a fixed grid striding over the pixels: see k_backward_textures_lit_pixels)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * blockDim.x) {
     const int fn = face_index_map[i];
@@ -75,7 +76,9 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
     const float depth2 = depth * depth;
     float s_rgb, s_alpha, s_depth;
     gs.get(s_rgb, s_alpha, s_depth);
-    const float g = grad_depth_map[i] * s_depth;
+    // (flip_rows: the gradient of the OUTPUT image -- its row S-1-y is the map's row y)
+    const long row = (i / S) % S;
+    const float g = grad_depth_map[flip_rows ? i + ((long)S - 1 - 2 * row) * S : i] * s_depth;
     float tmp[3] = {0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -103,10 +106,10 @@ __global__ void __launch_bounds__(256) k_backward_depth_map(FS fs, const float* 
                                                            float* __restrict__ grad_faces, int B, int S,
                                                            const int* __restrict__ only_large, VertexTarget vt,
                                                            GradScale gs = GradScale{nullptr, nullptr, 0.0f, 0, nullptr},
-                                                           const int* __restrict__ n_large = nullptr) {
+                                                           const int* __restrict__ n_large = nullptr, int flip_rows = 0) {
     if (n_large && *n_large == 0) return;          // no face was left to this kernel (uniform exit)
     backward_depth_map_pixels(fs, depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S,
-                              only_large, vt, gs);
+                              only_large, vt, gs, flip_rows);
 }
 
 }  // namespace d3m

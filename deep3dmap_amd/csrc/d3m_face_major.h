@@ -66,7 +66,7 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
                                                     const float* __restrict__ weight_map,
                                                     const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces,
                                                     int* __restrict__ flags, int S, long gi, int sub, int F,
-                                                    const VertexTarget& vt, int* __restrict__ n_large) {
+                                                    const VertexTarget& vt, int* __restrict__ n_large, int flip_rows) {
     const int bn = (int)(gi / F), fn = (int)(gi % F);
     float face[9], finv[9];
     fs.load(bn, fn, face);
@@ -92,7 +92,8 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
         const size_t p = base + (size_t)c.y * S + c.x;
         // the pixel's maps are requested together with its owner: one round trip per step of the scan, not two
         const bool own = face_index_map[p] == fn;
-        const float ld = depth_map[p], lg = grad_depth_map[p];
+        // (flip_rows: the gradient is that of the OUTPUT image, whose row S-1-y is the map's row y -- rasterize.py:311-317)
+        const float ld = depth_map[p], lg = grad_depth_map[flip_rows ? base + (size_t)(S - 1 - c.y) * S + c.x : p];
         const float lw[3] = {weight_map[3 * p], weight_map[3 * p + 1], weight_map[3 * p + 2]};
         if (!__builtin_amdgcn_ballot_w64(own)) continue;
         const float depth = own ? ld : 1.0f, g = own ? lg : 0.0f;     // selected, not multiplied away
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
                                                              float* __restrict__ grad_faces, int* __restrict__ flags, int B,
                                                              int S, const int* __restrict__ list,
                                                              const int* __restrict__ n_list, VertexTarget vt,
-                                                             int* __restrict__ n_large) {
+                                                             int* __restrict__ n_large, int flip_rows) {
     const int sub = threadIdx.x % FM_LANES;
     const int F = fs.num_faces();
     const long n_units = list ? (long)*n_list : (long)B * F;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
         const long gi = list ? (long)list[u] : u;
         if (!list && flags[gi] == FLAG_HIDDEN) continue;
         backward_depth_face(fs, depth_map, face_index_map, weight_map, grad_depth_map, grad_faces, flags, S, gi, sub, F, vt,
-                            n_large);
+                            n_large, flip_rows);
     }
 }
 

@@ -570,7 +570,7 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
         }
         LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S, (const int*)nullptr, (const int*)nullptr,
-               VertexTarget{nullptr, nullptr, 0, 0, 1}, (int*)nullptr);
+               VertexTarget{nullptr, nullptr, 0, 0, 1}, (int*)nullptr, 0);
     }
     LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags,
@@ -624,15 +624,16 @@ D3M_EXPORT int d3m_backward_depth_map_mesh(const float* faces, const float* dept
     const int B = batch_size, S = image_size;
     const long n = (long)B * S * S, nf = (long)B * num_faces;
     if (!(flags & D3M_PRECLEARED)) HIP_TRY(zero_async(large_counter, 256, st));
+    const int flip = (flags & D3M_GRAD_OF_OUTPUT_IMAGE) ? 1 : 0;
     const VisibilityView v = visibility_view(visibility, nf);
     DenseFaces fs{faces, num_faces};
     const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
     LAUNCH("k_backward_depth_faces", k_backward_depth_faces<DenseFaces>, dim3(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8),
            dim3(256), st, fs, depth_map, face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S,
-           (const int*)v.list, (const int*)v.count, vt, (int*)large_counter);
+           (const int*)v.list, (const int*)v.count, vt, (int*)large_counter, flip);
     LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S, (const int*)v.flags, vt,
-           GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter);
+           GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter, flip);
     return check_launch();
 }
 

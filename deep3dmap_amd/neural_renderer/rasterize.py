@@ -1042,7 +1042,7 @@ class _RasterizeMeshModes(torch.autograd.Function):
             _lib.zero_raw([_lib.tensor_range(acc)])
         grad_sv, counter = acc[:B * V * 3].view(B, V, 3), acc[B * V * 3:]
         target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
-        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if rd else None
+        g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if (rd and (ra or aa)) else None
         if ra:
             # the adjoint of the output epilogue writes the alpha gradient straight as the edge gradient's per-pixel records
             # (and the depth gradient as the map K6 reads)
@@ -1058,13 +1058,17 @@ class _RasterizeMeshModes(torch.autograd.Function):
                                           _lib.ptr(records[2][1]), 0)
             ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
                                    visibility=vis, unscaled=unscaled, edge_plan=plan)
-        elif rd:
-            _lib.check(L.d3m_output_epilogue_backward(None, None, _lib.ptr(f32c(g_depth)), None, None, _lib.ptr(g_depth_map),
-                                                      B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward")
+        k6_flags = _lib.PRECLEARED
+        if rd and not ra:
+            if aa:
+                _lib.check(L.d3m_output_epilogue_backward(None, None, _lib.ptr(f32c(g_depth)), None, None, _lib.ptr(g_depth_map),
+                                                          B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward")
+            else:   # the output image is the depth map with its rows reversed: K6 reads the gradient through the flip
+                g_depth_map, k6_flags = f32c(g_depth), k6_flags | _lib.GRAD_OF_OUTPUT_IMAGE
         if rd:
             _lib.check(L.d3m_backward_depth_map_mesh(_lib.ptr(faces), _lib.ptr(dm), _lib.ptr(fi), _lib.ptr(wm),
                                                      _lib.ptr(g_depth_map), B, Fp, S, ctypes.byref(target), _lib.ptr(vis),
-                                                     _lib.ptr(counter), _lib.PRECLEARED, _lib.stream_ptr()),
+                                                     _lib.ptr(counter), k6_flags, _lib.stream_ptr()),
                        "d3m_backward_depth_map_mesh")
         cam, _keep = cameras._camera_struct(ctx.camera, dev)
         grad_vertices = torch.empty_like(vertices)

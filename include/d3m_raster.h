@@ -221,7 +221,10 @@ int d3m_backward_depth_map(const float* faces, const float* depth_map, const int
 /* d3m_backward_depth_map for a mesh pipeline (faces = the dense copy d3m_forward_face_index_map_mesh left, visibility = the
  * blob it marked and d3m_visibility finished): runs over the listed faces only and ADDS its sums straight into
  * vertex_target->grad_vertices (float atomics) -- no dense grad_faces, no scatter-add pass behind it.  large_counter: 256
- * bytes, zero when the kernels start (cleared here unless flags & D3M_PRECLEARED). */
+ * bytes, zero when the kernels start (cleared here unless flags & D3M_PRECLEARED).  flags & D3M_GRAD_OF_OUTPUT_IMAGE:
+ * grad_depth_map is the gradient of the OUTPUT depth image [B,S,S] of a render without anti-aliasing (rows top to bottom,
+ * rasterize.py:311-317) -- read with the flip undone, so the adjoint of the output epilogue needs no pass of its own. */
+#define D3M_GRAD_OF_OUTPUT_IMAGE 32
 int d3m_backward_depth_map_mesh(const float* faces, const float* depth_map, const int32_t* face_index_map,
                                 const float* weight_map, const float* grad_depth_map, int batch_size, int num_faces,
                                 int image_size, const d3m_vertex_target* vertex_target, void* visibility,

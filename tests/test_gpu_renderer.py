@@ -1136,3 +1136,27 @@ def test_mesh_modes_without_fill_back_and_without_gradients(mode):
         res.append((image.detach(), v.grad.clone()))
     assert torch.equal(res[0][0], res[1][0])
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
+
+
+def test_mesh_depth_mode_with_large_faces():
+    """Faces whose pixel box exceeds the gathered pass's limit are left to the per-pixel pass (counted, so that it leaves at
+    once in the ordinary case): an 8-triangle mesh in a 384x384 image (boxes of ~7 000 pixels) takes that route in d3m_backward_depth_map_mesh --
+    with the output image's gradient read through the flip -- and must agree with the operator sequence."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    v_np, tri_np = synthetic.grid_mesh(3)
+    eyes = torch.from_numpy(synthetic.camera_ring(2)).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    res = []
+    for on in (True, False):
+        r = nr.Renderer(image_size=384, anti_aliasing=False, camera_mode="look_at", fill_back=True)
+        r.eye, r.mesh_modes = eyes, on
+        v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+        image = r.render_depth(v, tri)
+        w = torch.linspace(0.2, 1.3, 384, device="cuda")[None, :, None] * torch.linspace(1.0, 0.5, 384, device="cuda")[None, None, :]
+        (image.clamp(max=10) * w).sum().backward()
+        res.append((image.detach(), v.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    # the mean face owns more than 2 048 pixels, i.e. its box exceeds the limit of 4 096 (D3M_FM_MAX_BBOX_AREA)
+    assert float((res[0][0] < 50).float().sum(dim=(1, 2)).min()) / 8 > 2048
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
