@@ -1417,8 +1417,9 @@ D3M_EXPORT int d3m_output_epilogue_backward_records(const float* grad_rgb_out, c
     hipStream_t st = (hipStream_t)stream;
     const int S = image_size, B = batch_size;
     const size_t nz_bytes = (size_t)B * 2 * S * 4;
-    HIP_TRY(zero_async(edge_nz_lo_inv, nz_bytes, st));
-    HIP_TRY(zero_async(edge_nz_hi1, nz_bytes, st));
+    void* z_ptr[2] = {edge_nz_lo_inv, edge_nz_hi1};
+    size_t z_bytes[2] = {nz_bytes, nz_bytes};
+    HIP_TRY(zero_ranges_async(z_ptr, z_bytes, 2, st));       // (one launch)
     const ImageGrads img{grad_rgb_out, grad_alpha_out, grad_depth_out, grad_depth_map, anti_aliasing ? S / 2 : S,
                          anti_aliasing ? 1 : 0, 1};
     LAUNCH("k_pack_maps", k_pack_maps, dim3((S + 31) / 32, (S + 31) / 32, B), dim3(256), st, face_index_map,
