@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_bid_big(DenseFaces fs, unsigned long lo
 // k_bid_resolve: one lane per pixel: the winner's weights and depth recomputed (same arithmetic -> same bits), every
 // pixel of every map written (uncovered: the reference's initial values), the faces that own a pixel marked.
 __global__ void __launch_bounds__(256) k_bid_resolve(DenseFaces fs, const unsigned long long* __restrict__ zbuf, RasterOut out,
-                                                    int B, int S, float near, float far) {
+                                                    int B, int S, float near, float far, ModeOut mo) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const bool on = i < (long)B * S * S;
     const unsigned long long e = on ? zbuf[i] : 0ull;
@@ -297,11 +297,14 @@ __global__ void __launch_bounds__(256) k_bid_resolve(DenseFaces fs, const unsign
         out.depth_map[i] = zp;
         out.face_index_map[i] = fid;
         out.weight_map[3 * i + 0] = w[0]; out.weight_map[3 * i + 1] = w[1]; out.weight_map[3 * i + 2] = w[2];
+        mo.write((size_t)i, ((size_t)b * S + (S - 1 - pix / S)) * S + pix % S, true, zp);
         if (out.face_inv_map) {
 #pragma unroll
             for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
         }
     } else {
+        const long pix = i % ((long)S * S);
+        mo.write((size_t)i, (size_t)(i - pix) + (size_t)(S - 1 - pix / S) * S + pix % S, false, far);
         out.depth_map[i] = far;
         out.face_index_map[i] = -1;
         out.weight_map[3 * i + 0] = 0.0f; out.weight_map[3 * i + 1] = 0.0f; out.weight_map[3 * i + 2] = 0.0f;

@@ -311,6 +311,20 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The output images of the silhouette / depth modes, no anti-aliasing (any may be NULL): alpha_map [B,S,S] = covered (internal
+// layout, row 0 = bottom: what the edge gradient reads), alpha_out / depth_out [B,S,S] = the same and the depth map with
+// the rows reversed (rasterize.py:311-317).
+struct ModeOut {
+    float* alpha_map = nullptr;
+    float* alpha_out = nullptr;
+    float* depth_out = nullptr;
+    __device__ __forceinline__ void write(size_t i, size_t o, bool covered, float depth) const {
+        const float a = covered ? 1.0f : 0.0f;
+        if (alpha_map) alpha_map[i] = a;
+        if (alpha_out) alpha_out[o] = a;
+        if (depth_out) depth_out[o] = depth;
+    }
+};
 struct RasterOut {
     int32_t* face_index_map;
     float* weight_map;
@@ -332,8 +346,12 @@ struct RasterOut {
 #ifndef D3M_RT_STREAM_WAVES
 #define D3M_RT_STREAM_WAVES 5      // waves per SIMD the streaming form is held to (its LDS leaves room for 5.5)
 #endif
-template <class FS, int W, bool STREAM = false>
-__global__ void __launch_bounds__(64 * W, STREAM ? D3M_RT_STREAM_WAVES : 1) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far) {
+// MODE: the pass also writes the OUTPUT images of the renderer's silhouette / depth modes without anti-aliasing (ModeOut:
+// what d3m_output_epilogue would make of its maps in a pass of its own) -- an instantiation of its own, so that the ordinary
+// one (106 SGPRs in the streaming form) does not carry the pointers.
+template <class FS, int W, bool STREAM = false, bool MODE = false>
+__global__ void __launch_bounds__(64 * W, STREAM ? D3M_RT_STREAM_WAVES : 1) k_raster_tiles(FS fs, BinBuffers bb, RasterOut out, float near, float far,
+                                                                                          ModeOut mo) {
     static_assert(!STREAM || W == 1, "the streaming form is the one-wave form");
     __shared__ float s_face_all[W][9][WAVE];
     __shared__ float s_finv_all[W][9][WAVE];
@@ -553,17 +571,19 @@ __global__ void __launch_bounds__(64 * W, STREAM ? D3M_RT_STREAM_WAVES : 1) k_ra
             out.weight_map[3 * i + 0] = w[0];
             out.weight_map[3 * i + 1] = w[1];
             out.weight_map[3 * i + 2] = w[2];
-            if (out.face_inv_map) {
+            if constexpr (MODE) mo.write(i, ((size_t)b * S + (S - 1 - yi)) * S + xi, true, zp);
+            if (!MODE && out.face_inv_map) {        // (MODE: the mode outputs instead -- the entry point refuses both)
 #pragma unroll
                 for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = finv[k];
             }
         } else {
+            if constexpr (MODE) mo.write(i, ((size_t)b * S + (S - 1 - yi)) * S + xi, false, far);
             out.depth_map[i] = far;
             out.face_index_map[i] = -1;
             out.weight_map[3 * i + 0] = 0.0f;
             out.weight_map[3 * i + 1] = 0.0f;
             out.weight_map[3 * i + 2] = 0.0f;
-            if (out.face_inv_map) {
+            if (!MODE && out.face_inv_map) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) out.face_inv_map[9 * i + k] = 0.0f;
             }

@@ -260,7 +260,7 @@ D3M_EXPORT int d3m_forward_coverage_form(int batch_size, int num_triangles, int 
 // FS: the faces as the caller has them (indexed mesh: faces_dense receives the dense copy; dense: faces_dense IS the input)
 template <class FS, bool PAIRED>
 static int run_bidding(FS fs, float* faces_dense, float* faces_dense_out, float* faces_inv, int B, int F, int S, float near,
-                       float far, RasterOut out, void* ws, hipStream_t st, bool cleared = false) {
+                       float far, RasterOut out, void* ws, hipStream_t st, bool cleared = false, ModeOut mo = ModeOut{}) {
     const size_t zbytes = align_up((size_t)B * S * S * 8, 256);
     unsigned long long* zbuf = (unsigned long long*)ws;
     int* big_count = (int*)((char*)ws + zbytes);
@@ -273,7 +273,7 @@ static int run_bidding(FS fs, float* faces_dense, float* faces_dense_out, float*
     LAUNCH("k_bid_big", k_bid_big, dim3(128, (unsigned)((S + 255) / 256)), dim3(256), st, DenseFaces{faces_dense, F}, zbuf,
            (const int*)big_list, (const int*)big_count, S, near, far);
     LAUNCH("k_bid_resolve", k_bid_resolve, dim3(blocks_for((long)B * S * S, 256)), dim3(256), st, DenseFaces{faces_dense, F},
-           (const unsigned long long*)zbuf, out, B, S, near, far);
+           (const unsigned long long*)zbuf, out, B, S, near, far, mo);
     return check_launch();
 }
 
@@ -295,9 +295,9 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     if (n_tiles <= RASTER_SMALL_GRID)
-        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
+        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far, ModeOut{});
     else
-        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 1, true>), dim3(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8), dim3(64), st, fs, bb, out, near, far);
+        LAUNCH("k_raster_tiles", (k_raster_tiles<FS, 1, true>), dim3(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8), dim3(64), st, fs, bb, out, near, far, ModeOut{});
     return check_launch();
 }
 
@@ -305,13 +305,13 @@ static int run_forward(FS fs, int B, int F, int S, float near, float far, Raster
 // copy (front-facing faces only) that the tile pass and every later operator use.
 // cleared: the caller has zeroed the workspace's first d3m_forward_clear_bytes() bytes (of the form this launch takes)
 static int run_forward_mesh(IndexedFaces ifs, float* faces_out, int B, int S, float near, float far, RasterOut out, void* ws,
-                            size_t ws_bytes, hipStream_t st, bool cleared = false) {
+                            size_t ws_bytes, hipStream_t st, bool cleared = false, ModeOut mo = ModeOut{}) {
     // out.marks (optional): zeroed by the first pass, set by the tile pass
     if (S > 8 * 65535) return D3M_ERR_INVALID;
     const int F = ifs.num_faces();
     if (bidding_wanted(B, ifs.Ft, S, ws, ws_bytes, F)) {
-        if (ifs.fill_back) return run_bidding<IndexedFaces, true>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared);
-        return run_bidding<IndexedFaces, false>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared);
+        if (ifs.fill_back) return run_bidding<IndexedFaces, true>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared, mo);
+        return run_bidding<IndexedFaces, false>(ifs, faces_out, faces_out, nullptr, B, F, S, near, far, out, ws, st, cleared, mo);
     }
     BinBuffers bb;
     int rc = make_bins(bb, B, F, S, ws, ws_bytes);
@@ -342,10 +342,15 @@ counted:
     const int n_tiles = B * bb.T;
     const int per = (n_tiles + 7) / 8;
     DenseFaces fs{faces_out, F};
-    if (n_tiles <= RASTER_SMALL_GRID)
-        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far);
-    else
-        LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1, true>), dim3(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8), dim3(64), st, fs, bb, out, near, far);
+    const bool mode = mo.alpha_map || mo.alpha_out || mo.depth_out;
+    if (n_tiles <= RASTER_SMALL_GRID) {
+        if (mode) LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 4, false, true>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far, mo);
+        else LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 4>), dim3(per * 8), dim3(256), st, fs, bb, out, near, far, mo);
+    } else {
+        const dim3 grid(raster_stream_waves(per, bb.tiles_x, bb.tiles_y) * 8);
+        if (mode) LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1, true, true>), grid, dim3(64), st, fs, bb, out, near, far, mo);
+        else LAUNCH("k_raster_tiles", (k_raster_tiles<DenseFaces, 1, true>), grid, dim3(64), st, fs, bb, out, near, far, mo);
+    }
     return check_launch();
 }
 
@@ -410,6 +415,21 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
                                                int image_size, float near, float far, void* workspace,
                                                size_t workspace_bytes, void* visibility, size_t visibility_size,
                                                int flags, d3m_stream_t stream) {
+    return d3m_forward_face_index_map_mesh_modes(vertices, tri, tri_batch, num_vertices, num_tri, fill_back, faces_out,
+                                                 face_index_map, weight_map, depth_map, face_inv_map, batch_size, image_size,
+                                                 near, far, workspace, workspace_bytes, visibility, visibility_size, nullptr,
+                                                 nullptr, nullptr, flags, stream);
+}
+// ... which can also write, in its last pass, the output images of the renderer's silhouette / depth modes without
+// anti-aliasing (d3m_output_epilogue's work for those modes: alpha_map [B,S,S] internal layout, alpha_out / depth_out
+// [B,S,S] with the rows reversed; any may be NULL)
+D3M_EXPORT int d3m_forward_face_index_map_mesh_modes(const float* vertices, const int32_t* tri, int tri_batch, int num_vertices,
+                                                     int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
+                                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
+                                                     int image_size, float near, float far, void* workspace,
+                                                     size_t workspace_bytes, void* visibility, size_t visibility_size,
+                                                     float* alpha_map, float* alpha_out, float* depth_out, int flags,
+                                                     d3m_stream_t stream) {
     if (!vertices || !faces_out || !face_index_map || !weight_map || !depth_map || batch_size <= 0 ||
         num_vertices <= 0 || num_tri <= 0 || image_size <= 0)
         return D3M_ERR_INVALID;
@@ -423,8 +443,11 @@ D3M_EXPORT int d3m_forward_face_index_map_mesh(const float* vertices, const int3
         out.marks = visibility_view(visibility, nf).marks;
         out.marks_count = visibility_view(visibility, nf).count;
     }
+    if (face_inv_map && (alpha_map || alpha_out || depth_out)) return D3M_ERR_INVALID;      // one or the other
+    ModeOut mo;
+    mo.alpha_map = alpha_map; mo.alpha_out = alpha_out; mo.depth_out = depth_out;
     return run_forward_mesh(ifs, faces_out, batch_size, image_size, near, far, out, workspace, workspace_bytes,
-                            (hipStream_t)stream, (flags & D3M_PRECLEARED) != 0);
+                            (hipStream_t)stream, (flags & D3M_PRECLEARED) != 0, mo);
 }
 // The leading bytes of the forward workspace that d3m_forward_face_index_map_mesh zeroes in front of its kernels -- for the
 // form of coverage THAT launch takes (it depends on the workspace's size too) --, or 0 for an invalid / too small workspace.

@@ -1007,13 +1007,19 @@ class _RasterizeMeshModes(torch.autograd.Function):
                                    ctypes.byref(basis) if basis is not None else None, _lib.ptr(sv), B, V, _lib.ptr(tri),
                                    tri.shape[0], Ft, int(bool(fill_back)), None, 0, 0.0, 0.0, zero3, zero3, zero3, zp, zb,
                                    len(clears), _lib.stream_ptr()), "d3m_lit_front")
-        _lib.check(L.d3m_forward_face_index_map_mesh(
+        # without anti-aliasing the output images are the maps with their rows reversed: coverage's last pass writes them too
+        # (no epilogue pass); with it, the 2x2 pooling is a pass of its own
+        in_pass = not anti_aliasing
+        _lib.check(L.d3m_forward_face_index_map_mesh_modes(
             _lib.ptr(sv), _lib.ptr(tri), tri.shape[0], V, Ft, int(bool(fill_back)), _lib.ptr(faces), _lib.ptr(fi), _lib.ptr(wm),
             _lib.ptr(dm), None, B, S, float(near), float(far), _lib.ptr(ws), ws.numel(), _lib.ptr(vis),
-            vis.numel() if vis is not None else 0, flags_fwd, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
-        _lib.check(L.d3m_output_epilogue(_lib.ptr(fi), None, _lib.ptr(dm if return_depth else None), None, 1, None,
-                                         _lib.ptr(alpha_map), None, _lib.ptr(alpha), _lib.ptr(depth), B, S,
-                                         int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_output_epilogue")
+            vis.numel() if vis is not None else 0, _lib.ptr(alpha_map if in_pass else None),
+            _lib.ptr(alpha if in_pass else None), _lib.ptr(depth if in_pass else None), flags_fwd, _lib.stream_ptr()),
+            "d3m_forward_face_index_map_mesh_modes")
+        if not in_pass:
+            _lib.check(L.d3m_output_epilogue(_lib.ptr(fi), None, _lib.ptr(dm if return_depth else None), None, 1, None,
+                                             _lib.ptr(alpha_map), None, _lib.ptr(alpha), _lib.ptr(depth), B, S,
+                                             int(bool(anti_aliasing)), _lib.stream_ptr()), "d3m_output_epilogue")
         if need_grad:
             # (the first step of the visibility list -- which faces own a pixel -- was left by the coverage pass)
             _lib.check(L.d3m_visibility(None, _lib.ptr(vis), vis.numel(), B, Fp, S, _lib.stream_ptr()), "d3m_visibility")

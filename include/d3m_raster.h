@@ -115,6 +115,17 @@ int d3m_forward_face_index_map_mesh(const float* vertices, const int32_t* tri, i
                                     float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
                                     int image_size, float near, float far, void* workspace, size_t workspace_bytes,
                                     void* visibility, size_t visibility_size, int flags, d3m_stream_t stream);
+/* The same, also writing -- in its last pass -- the output images of the renderer's silhouette / depth modes WITHOUT
+ * anti-aliasing (NR/renderer.py:114-183; what d3m_output_epilogue makes of the maps in a pass of its own): alpha_map [B,S,S]
+ * (1 where covered; internal layout, row 0 = bottom: what the edge gradient reads), alpha_out and depth_out [B,S,S] (the
+ * same and depth_map with the rows reversed, rasterize.py:311-317).  Any of the three may be NULL; face_inv_map must be
+ * NULL when one is given (D3M_ERR_INVALID otherwise). */
+int d3m_forward_face_index_map_mesh_modes(const float* vertices, const int32_t* tri, int tri_batch, int num_vertices,
+                                          int num_tri, int fill_back, float* faces_out, int32_t* face_index_map,
+                                          float* weight_map, float* depth_map, float* face_inv_map, int batch_size,
+                                          int image_size, float near, float far, void* workspace, size_t workspace_bytes,
+                                          void* visibility, size_t visibility_size, float* alpha_map, float* alpha_out,
+                                          float* depth_out, int flags, d3m_stream_t stream);
 /* flags: D3M_PRECLEARED -- the caller has zeroed the first d3m_forward_clear_bytes(...) bytes of `workspace` (the tile
  * counters and arrival tickets of the per-tile lists, or the z-buffer of the bidding form: whichever form a launch with
  * THIS workspace size takes); 0: the operator clears them itself. */
