@@ -354,6 +354,9 @@ def test_c_entry_points_reject_bad_arguments_before_any_launch():
     assert L.d3m_forward_face_index_map_mesh(*args(pi, 3, 16, 18)) == INVALID          # index batch 3 of 1
     tiny = (p, None, -4, 16, 18, 1, p, pi, p, p, None, 1, 8, 0.1, 100.0, p, 64, None, 0, 0, st)
     assert L.d3m_forward_face_index_map_mesh(*tiny) == WORKSPACE
+    # the mode outputs of its last pass and the reference's face_inv_map exclude each other
+    assert L.d3m_forward_face_index_map_mesh_modes(p, None, -4, 16, 18, 1, p, pi, p, p, p, 1, 8, 0.1, 100.0, p, z.numel() * 4,
+                                                   None, 0, p, None, None, 0, st) == INVALID
     # the mesh form of the depth backward: needs its vertex target, its visibility blob and its counter
     vt0 = _lib.D3MVertexTarget(p, pi, 16, 18, 1, 1)
     assert L.d3m_backward_depth_map_mesh(p, p, pi, p, p, 1, 36, 8, None, p, p, 0, st) == INVALID
