@@ -399,6 +399,7 @@ def modes_workload(args):
     v_np, tri_np = synthetic.grid_mesh(args.mesh_n)
     r = nr.Renderer(image_size=s, anti_aliasing=args.anti_aliasing, camera_mode="look_at", fill_back=True)
     r.eye = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
+    r.mesh_modes = os.environ.get("D3M_MESH_MODES", "1") != "0"      # (0: the reference's operator sequence, for A/B)
     tri = torch.from_numpy(tri_np).int().cuda()[None]
     render = r.render_silhouettes if mode == "silhouettes" else r.render_depth
     with torch.no_grad():
@@ -452,7 +453,7 @@ def modes_workload(args):
         "config": {"workload": f"{F}-triangle mesh @{s}x{s}{' with anti-aliasing' if args.anti_aliasing else ''}, {B} views, "
                                f"{mode} only: Renderer.render_{mode} + loss + backward (vertex gradient)",
                    "api": f"Renderer.render_{mode} + {'silhouette_loss' if mode == 'silhouettes' else 'photometric_loss'} + backward",
-                   "views": B, "hip_graph": not args.no_graph},
+                   "views": B, "hip_graph": not args.no_graph, "one_node_over_the_indexed_mesh": bool(r.mesh_modes)},
         "launches_per_step": sum(c for c, _ in ktimes.values()) / n_inst,
         "hbm_roofline_frac_step": round(step_bytes / step_s / 8e12, 5), "algorithmic_bytes_per_step": step_bytes,
         "d3m_kernel_ms_per_step": round(sum(m for _, m in ktimes.values()) / n_inst, 4),
@@ -553,8 +554,14 @@ def main():
                          "min and max ride in the line (box-to-box and run-to-run spread is 1-2 %%)")
     ap.add_argument("--allow-dev", action="store_true",
                     help="accept D3M_LIB_PATH / D3M_BENCH_TIMING_EXPERIMENT (developer builds and timing experiments)")
+    ap.add_argument("--coverage-form", default="auto", choices=["auto", "binned", "bidding"],
+                    help="force one form of the forward's coverage (d3m_set_coverage_form; measurements)")
     args = ap.parse_args()
     dev_switches = args.dev_switches = refuse_dev_switches(args.allow_dev)
+    if args.coverage_form != "auto":
+        from deep3dmap_amd import _lib as _l
+        _l.check(_l.lib().d3m_set_coverage_form({"binned": 0, "bidding": 1}[args.coverage_form]), "d3m_set_coverage_form")
+        dev_switches = args.dev_switches = list(dev_switches) + [f"--coverage-form {args.coverage_form}"]
     if args.workload == "gan2shape":
         return gan2shape_workload(args)
     if args.workload == "mesh_family":

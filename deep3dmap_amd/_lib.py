@@ -70,6 +70,7 @@ _SIGNATURES = {
     "d3m_set_coverage_form": (_I, [_I]),
     "d3m_get_coverage_form": (_I, []),
     "d3m_forward_coverage_form": (_I, [_I, _I, _I]),
+    "d3m_forward_big_batch": (_I, [_I, _I, _I]),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
     "d3m_forward_face_index_map_mesh": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ, _I, _P]),
     "d3m_forward_face_index_map_mesh_modes": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _SZ, _P, _SZ,

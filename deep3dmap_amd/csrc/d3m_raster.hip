@@ -245,10 +245,29 @@ D3M_EXPORT int d3m_set_coverage_form(int form) {
     return D3M_OK;
 }
 D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
+// Which form of coverage a launch takes (d3m_set_coverage_form: forced).  Sub-pixel triangles (more than two per three
+// raster pixels: BASELINE config 5) bid whatever the batch; big batches of ordinary meshes (more than BID_MAX_TILES blocks
+// of 8 x 8 pixels: the headline's 32 views) go through per-tile lists; small batches bid -- UNLESS the mesh is coarse (round
+// 5): bidding hands a face's rows to the lanes of ONE wave, and a few thousand triangles of a hundred pixels each are a
+// few dozen waves with everything to do (a 2 450-triangle mesh @512^2: k_bid_faces 237 us, the whole binned forward 95;
+// 722 triangles: 341 against 175), where a tile's wave takes a tile-filling face in one step.  Measured crossover: ~8 raster
+// pixels per input triangle (19 602 triangles @512^2, 13 px each: lists 15 us ahead; 32 258, 8 px: equal; 53 138, 5 px:
+// bidding 10 us ahead).
+static bool big_batch(int B, long triangles, int S) {
+    const int blocks_x = (S + 7) / 8;            // (the threshold is in blocks of 8 x 8 pixels, whatever the tile pass's tiles)
+    return !((double)S * S < 1.5 * (double)triangles) && (long)B * blocks_x * blocks_x > BID_MAX_TILES;
+}
 static bool bidding_preferred(int B, long triangles, int S) {
     const int form = coverage_form();
-    const int blocks_x = (S + 7) / 8;            // (the threshold is in blocks of 8 x 8 pixels, whatever the tile pass's tiles)
-    return form >= 0 ? form == 1 : ((double)S * S < 1.5 * (double)triangles || (long)B * blocks_x * blocks_x <= BID_MAX_TILES);
+    if (form >= 0) return form == 1;
+    if ((double)S * S < 1.5 * (double)triangles) return true;
+    return !big_batch(B, triangles, S) && (double)S * S <= 10.0 * (double)triangles;
+}
+// Whether a launch is a "big batch" in that sense -- what the lit render node takes for "every kernel fills the chip by
+// itself: run on one stream" (rasterize._serial_branches), independent of the form of coverage a coarse mesh takes.
+D3M_EXPORT int d3m_forward_big_batch(int batch_size, int num_triangles, int image_size) {
+    if (batch_size <= 0 || num_triangles <= 0 || image_size <= 0) return -1;
+    return big_batch(batch_size, num_triangles, image_size) ? 1 : 0;
 }
 static bool bidding_wanted(int B, long triangles, int S, const void* ws, size_t ws_bytes, int F) {
     return bidding_preferred(B, triangles, S) && S <= 8192 && ws && ws_bytes >= bid_workspace_bytes(B, F, S);

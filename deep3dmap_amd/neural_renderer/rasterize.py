@@ -227,14 +227,14 @@ _side_streams = {}
 def _serial_branches(batch, num_tri, image_size):
     """Whether a lit render node runs its side branches (visibility list + edge plan beside the sampling pass; the
     gathered texture / depth pass beside the line walk) on the forking stream instead.  Measured: once
-    every kernel of the step fills the chip by itself -- the big batches of ordinary meshes, i.e. exactly the launches
-    whose coverage runs on per-tile lists -- the cross-queue waits of the branches cost more than the tails they fill
+    every kernel of the step fills the chip by itself -- the big batches of ordinary meshes (d3m_forward_big_batch; a coarse
+    mesh's small batch also takes the per-tile lists since round 5, and keeps its branches) -- the cross-queue waits of the branches cost more than the tails they fill
     (32 views of the headline mesh: -1.5 %), while small batches and dense meshes gain 3-6 % from them.
     D3M_SERIAL_BRANCHES=1 / 0 forces / forbids (measurements)."""
     env = os.environ.get("D3M_SERIAL_BRANCHES")
     if env is not None and env != "":
         return env != "0"
-    return _lib.lib().d3m_forward_coverage_form(int(batch), int(num_tri), int(image_size)) == 0
+    return _lib.lib().d3m_forward_big_batch(int(batch), int(num_tri), int(image_size)) == 1
 
 
 def _side_stream(device, which=0, serial=False):

@@ -85,6 +85,9 @@ int d3m_get_coverage_form(void);
  * (before fill_back) at `image_size` takes with a workspace of d3m_forward_workspace_bytes(); -1 for invalid sizes.  Callers
  * that shape the work AROUND the coverage pass by its form (the lit render node: side branches or one stream) ask here. */
 int d3m_forward_coverage_form(int batch_size, int num_triangles, int image_size);
+/* 1 when the launch is a BIG BATCH of an ordinary mesh (more than 65 536 blocks of 8 x 8 pixels, triangles not sub-pixel):
+ * every kernel of a step fills the chip by itself, and a caller's side branches cost more than they hide. */
+int d3m_forward_big_batch(int batch_size, int num_triangles, int image_size);
 
 /* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
  *   faces          [B,F,3,3] f32 in   NDC x,y in [-1,1] (+y up), z = depth
