@@ -749,15 +749,21 @@ __global__ void __launch_bounds__(256) k_alloc_plan(int* __restrict__ lane_block
 // ---- 3. the crossings' records, written in line order -------------------------------------------------------
 // Same flattening as the count pass.  The lanes of a wave that share a line take consecutive places under that
 // line's cursor with ONE atomic per distinct line.
+// `parts` (>= 1): the rounds of one block of faces are dealt to that many workgroups -- a coarse mesh has few blocks (722
+// triangles: 35) of faces with dozens of crossings per edge, i.e. a few workgroups with thirty rounds of dependent look-ups
+// each while the rest of the chip idles (125 us); the host sets it from the batch's face count (1 for ordinary meshes).
 template <class FS>
-__global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __restrict__ face_index_map, int is, EdgePlan w) {
+__global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __restrict__ face_index_map, int is, EdgePlan w,
+                                                     int parts) {
     __shared__ LaneTable t;
     __shared__ float s_slope[3][256];
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    const XcdOrder xo(n_blocks);
+    const int n_units = n_blocks * parts;
+    const XcdOrder xo(n_units);
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
-        const int blk = xo.unit(i);
-        if (blk >= n_blocks) continue;
+        const int unit = xo.unit(i);
+        if (unit >= n_units) continue;
+        const int blk = unit / parts, part = unit - blk * parts;
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
@@ -768,7 +774,7 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
             s_slope[0][l] = sl.s01; s_slope[1][l] = sl.s02; s_slope[2][l] = sl.s12;
         }
         __syncthreads();
-        for (int c0 = 0; c0 < total; c0 += 256) {
+        for (int c0 = part * 256; c0 < total; c0 += parts * 256) {
             const int c = c0 + threadIdx.x;
             const bool active = c < total;
             int l = 0;
@@ -1569,7 +1575,10 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
     LAUNCH("k_alloc_plan", k_alloc_plan, dim3((unsigned)(blocks_a + (nl + 255) / 256)), dim3(256), st, w.lane_block,
            (const int*)w.n_visible, EG_FACES_PER_BLOCK, w.alloc, blocks_a, (const int*)w.line_count, w.line_slice, w.alloc + 1, nl);
     // (the scatter pass keeps the by-key form: with the ranks taken from LDS cursors it was slower, 0.173 vs 0.150 ms)
-    LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g6, dim3(256), st, fs, face_index_map, S, w);
+    // (few blocks of faces: their rounds dealt to several workgroups each -- see the kernel)
+    const int parts = g6_full >= 2048 ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const dim3 g_scatter((unsigned)std::min<long>(8192, (g6_full * parts + 7) / 8 * 8));
+    LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g_scatter, dim3(256), st, fs, face_index_map, S, w, parts);
     return hipGetLastError();
 }
 

@@ -103,6 +103,7 @@ constexpr int BIN_THREADS_SMALL = 256;            // ... when 1024 per workgroup
 constexpr int TA_BITS = BIN_THREADS >= 1024 ? 11 : BIN_THREADS >= 512 ? 10 : 9;
 constexpr int TA_SLOTS = 1 << TA_BITS;   // a workgroup touches far fewer distinct tiles
 constexpr int TA_PROBES = 12;
+constexpr int BIN_TABLE_TILES = 4;       // tiles of one face that are counted / ranked through the workgroup's table
 // the part of the table a launch uses: two slots per lane (a 256-lane workgroup sweeps 512 slots, not 2048)
 __device__ __forceinline__ int ta_bits() { return blockDim.x >= 1024 ? TA_BITS : blockDim.x >= 512 ? TA_BITS - 1 : TA_BITS - 2; }
 struct TileAgg {
@@ -190,10 +191,13 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_count(FS fs, BinBuffers bb,
         }
         // count the (at most kcap) tiles of every small face in the workgroup's table, then one atomic per distinct tile
         const int w = small ? tx1 - tx0 + 1 : 0, nt = small ? w * (ty1 - ty0 + 1) : 0;
+        // (only a face's first BIN_TABLE_TILES tiles go through the table, as in k_bin_fill: the table is for the many small
+        //  faces that share a tile; a coarse mesh's faces of 16-64 tiles each overflowed it and spent the pass probing --
+        //  722 triangles @512^2: 109 us for three workgroups -- where plain atomics on their own tiles cost nothing)
         for (int s = 0; s < nt; s++) {
             const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
             int rank;
-            if (ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
+            if (s >= BIN_TABLE_TILES || ta_add(agg, tile, rank) < 0) atomicAdd(&bb.tile_count[tile], 1);
         }
     }
     __syncthreads();
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
     __shared__ TileAgg agg;
     ta_clear(agg);
     const int Fl = PAIRED ? bb.F / 2 : bb.F;
-    constexpr int TA_LOCAL = 4;
+    constexpr int TA_LOCAL = BIN_TABLE_TILES;
     int packed[FPT][TA_LOCAL], face_of[FPT];
 #pragma unroll
     for (int it = 0; it < FPT; it++) {
@@ -270,10 +274,10 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
         face_of[it] = f;
 #pragma unroll
         for (int s = 0; s < TA_LOCAL; s++) packed[it][s] = -1;
-        for (int s = 0; s < nt; s++) {
+        for (int s = 0; s < nt && s < TA_LOCAL; s++) {
             const int tile = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
-            int rank = 0, slot = -1;
-            if (s < TA_LOCAL) slot = ta_add(agg, tile, rank);
+            int rank = 0;
+            const int slot = ta_add(agg, tile, rank);
             if (slot >= 0) {
 #pragma unroll
                 for (int q = 0; q < TA_LOCAL; q++) if (q == s) packed[it][q] = (slot << 16) | rank;
@@ -281,6 +285,23 @@ __global__ void __launch_bounds__(BIN_THREADS) k_bin_fill(BinBuffers bb) {
                 const int pos = atomicAdd(&bb.tile_cursor[tile], 1);
                 bb.pairs[(size_t)bb.tile_offset[tile] + pos] = f;
             }
+        }
+        // a coarse face's further tiles (up to kcap - TA_LOCAL): four cursor atomics in flight at a time -- one after the
+        // other they are a chain of up to sixty round trips per lane (722 triangles @512^2: 41 us for three workgroups)
+        for (int s0 = TA_LOCAL; s0 < nt; s0 += 4) {
+            int tile[4], pos[4], off[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int s = min(s0 + j, nt - 1);
+                tile[j] = b * bb.T + (ty0 + s / w) * bb.tiles_x + tx0 + s % w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (s0 + j < nt) { pos[j] = atomicAdd(&bb.tile_cursor[tile[j]], 1); off[j] = bb.tile_offset[tile[j]]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (s0 + j < nt) bb.pairs[(size_t)off[j] + pos[j]] = f;
         }
     }
     __syncthreads();
