@@ -60,7 +60,9 @@ __global__ void __launch_bounds__(256) k_mark_visible(const int32_t* __restrict_
 
 // Depth backward, gathered: KCU:543-592 summed over the pixels a face owns.  The sums go to grad_faces (+=) or, with a
 // vertex target, straight into the gradient of the vertices the faces were gathered from (float atomics).
-template <class FS>
+// LANES adjacent lanes share a face: FM_LANES (8) for ordinary meshes, a whole wave (64) for coarse ones, whose faces of
+// hundreds of pixels were ninety steps of dependent loads for each of eight lanes (722 triangles @512^2: 234 us).
+template <class FS, int LANES>
 __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restrict__ depth_map,
                                                     const int32_t* __restrict__ face_index_map,
                                                     const float* __restrict__ weight_map,
@@ -87,8 +89,8 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
     }
     float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const size_t base = (size_t)bn * S * S;
-    BoxCursor c(x0, x1, y0, sub);
-    for (int i = sub; i < area; i += FM_LANES, c.advance()) {
+    BoxCursorN<LANES> c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
         // the pixel's maps are requested together with its owner: one round trip per step of the scan, not two
         const bool own = face_index_map[p] == fn;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
         }
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc[k] = quad_sum(acc[k]);
+    for (int k = 0; k < 9; k++) acc[k] = LANES == 64 ? wave_sum(acc[k]) : quad_sum(acc[k]);
     if (sub == 0) {
         if (vt.gv) {
 #pragma unroll
@@ -126,7 +128,7 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
 
 // Over every face of the batch (flags decide), or -- `list`, the compacted list of d3m_visibility -- over the faces that own
 // a pixel: a fixed grid striding either way (the FM_LANES lanes of a face stay together).
-template <class FS>
+template <class FS, int LANES = FM_LANES>
 __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float* __restrict__ depth_map,
                                                              const int32_t* __restrict__ face_index_map,
                                                              const float* __restrict__ weight_map,
@@ -135,14 +137,14 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
                                                              int S, const int* __restrict__ list,
                                                              const int* __restrict__ n_list, VertexTarget vt,
                                                              int* __restrict__ n_large, int flip_rows) {
-    const int sub = threadIdx.x % FM_LANES;
+    static_assert(LANES == FM_LANES || LANES == 64, "eight lanes per face, or a wave");
+    const int sub = threadIdx.x % LANES;
     const int F = fs.num_faces();
     const long n_units = list ? (long)*n_list : (long)B * F;
-    for (long u = (long)blockIdx.x * FM_FACES_PER_BLOCK + threadIdx.x / FM_LANES; u < n_units;
-         u += (long)gridDim.x * FM_FACES_PER_BLOCK) {
+    for (long u = (long)blockIdx.x * (256 / LANES) + threadIdx.x / LANES; u < n_units; u += (long)gridDim.x * (256 / LANES)) {
         const long gi = list ? (long)list[u] : u;
         if (!list && flags[gi] == FLAG_HIDDEN) continue;
-        backward_depth_face(fs, depth_map, face_index_map, weight_map, grad_depth_map, grad_faces, flags, S, gi, sub, F, vt,
+        backward_depth_face<FS, LANES>(fs, depth_map, face_index_map, weight_map, grad_depth_map, grad_faces, flags, S, gi, sub, F, vt,
                             n_large, flip_rows);
     }
 }

@@ -669,10 +669,18 @@ D3M_EXPORT int d3m_backward_depth_map_mesh(const float* faces, const float* dept
     const int flip = (flags & D3M_GRAD_OF_OUTPUT_IMAGE) ? 1 : 0;
     const VisibilityView v = visibility_view(visibility, nf);
     DenseFaces fs{faces, num_faces};
-    const unsigned all_blocks = blocks_for(nf, FM_FACES_PER_BLOCK);
-    LAUNCH("k_backward_depth_faces", k_backward_depth_faces<DenseFaces>, dim3(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8),
-           dim3(256), st, fs, depth_map, face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S,
-           (const int*)v.list, (const int*)v.count, vt, (int*)large_counter, flip);
+    // (a coarse mesh -- more than 48 raster pixels per triangle -- gives a face a whole wave instead of eight lanes)
+    const bool coarse = (double)S * S > 48.0 * ((double)num_faces / (vt.Ft && num_faces == 2 * vt.Ft ? 2.0 : 1.0));
+    const unsigned all_blocks = blocks_for(nf, coarse ? 4 : FM_FACES_PER_BLOCK);
+    const dim3 g_faces(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8);
+    if (coarse)
+        LAUNCH("k_backward_depth_faces", (k_backward_depth_faces<DenseFaces, 64>), g_faces, dim3(256), st, fs, depth_map,
+               face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S, (const int*)v.list,
+               (const int*)v.count, vt, (int*)large_counter, flip);
+    else
+        LAUNCH("k_backward_depth_faces", (k_backward_depth_faces<DenseFaces>), g_faces, dim3(256), st, fs, depth_map,
+               face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S, (const int*)v.list,
+               (const int*)v.count, vt, (int*)large_counter, flip);
     LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S, (const int*)v.flags, vt,
            GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter, flip);
