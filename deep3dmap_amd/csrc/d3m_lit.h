@@ -708,6 +708,12 @@ struct LitFaceArgs {
     int* n_large;                  // [1] zeroed: faces handed to the per-pixel kernels (which leave at once when it stays 0)
 };
 
+// LANES adjacent lanes share a face: LIT_LANES (8) for ordinary meshes, a whole wave (64) for coarse ones, whose faces of
+// hundreds of pixels were ninety steps of dependent loads for each of eight lanes (722 triangles @512^2: 210 us of a 337 us
+// step).  The arithmetic per pixel and the order of a lane's sums are the same; the sum over the lanes is a tree either way.
+template <int LANES>
+__device__ __forceinline__ float lit_lanes_sum(float v) { return LANES == 64 ? wave_sum(v) : lit_sum(v); }
+template <int LANES>
 __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi, int sub) {
     const float* __restrict__ faces = a.faces;
     const LitTextures& lt = a.lt;
@@ -741,7 +747,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
         flags[gi] = FLAG_LARGE;
         if (sub == 0) atomicAdd(a.n_large, 1);
-        for (int t = sub; t < 24; t += LIT_LANES) gt[t] = 0.0f;
+        for (int t = sub; t < 24; t += LANES) gt[t] = 0.0f;
         return;
     }
     // ts == 2: the sample position is clamped below 1 (KCU:222-223), so its integer part is 0 and corner pn of the
@@ -773,19 +779,19 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     // what the epilogue needs, requested now: this lane's texel (sub) of the face's cube and the face's light
     const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
     const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
-    constexpr int TPL = 8 / LIT_LANES;                    // texels per lane in the epilogue: sub, sub + LIT_LANES
+    constexpr int TPL = LANES >= 8 ? 1 : 8 / LANES;       // texels per lane in the epilogue: sub, sub + LANES (lanes >= 8: none)
     const float* tex_face = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * 24;
     int to[TPL];
     float tx[TPL][3];
 #pragma unroll
     for (int j = 0; j < TPL; j++) {
-        const int t = sub + j * LIT_LANES;
+        const int t = (sub + j * LANES) & 7;               // (lanes 8 .. 63 of a wave-wide face: unused copies)
         to[j] = fn >= lt.F ? ((t & 1) << 2) | (t & 2) | ((t >> 2) & 1) : t;   // (a,b,c) -> (c,b,a) for ts = 2
 #pragma unroll
         for (int c3 = 0; c3 < 3; c3++) tx[j][c3] = tex_face[to[j] * 3 + c3];
     }
-    BoxCursorN<LIT_LANES> c(x0, x1, y0, sub);
-    for (int i = sub; i < area; i += LIT_LANES, c.advance()) {
+    BoxCursorN<LANES> c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
         // Everything the pixel could contribute is requested together with its owner (ONE round trip per step of
         // the scan instead of two); a pixel of another face then computes on stand-in values with zero gradients
@@ -825,10 +831,10 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
         }
     }
 #pragma unroll
-    for (int t = 0; t < 24; t++) acc[t] = lit_sum(acc[t]);
+    for (int t = 0; t < 24; t++) acc[t] = lit_lanes_sum<LANES>(acc[t]);
     if (grad_depth_map) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) dacc[k] = lit_sum(dacc[k]);
+        for (int k = 0; k < 9; k++) dacc[k] = lit_lanes_sum<LANES>(dacc[k]);
         if (sub == 0) {
             if (vt.gv) {
 #pragma unroll
@@ -852,16 +858,18 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
         float mine[3] = {0, 0, 0};
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-            if (sub + j * LIT_LANES == t) { mine[0] = acc[3 * t]; mine[1] = acc[3 * t + 1]; mine[2] = acc[3 * t + 2]; }
+            if (sub + j * LANES == t) { mine[0] = acc[3 * t]; mine[1] = acc[3 * t + 1]; mine[2] = acc[3 * t + 2]; }
         }
+        if (sub + j * LANES < 8) {
 #pragma unroll
-        for (int c3 = 0; c3 < 3; c3++) {
-            gt[to[j] * 3 + c3] = mine[c3] * li[c3];          // plain store: see the kernel comment
-            gl[c3] += mine[c3] * tx[j][c3];
+            for (int c3 = 0; c3 < 3; c3++) {
+                gt[to[j] * 3 + c3] = mine[c3] * li[c3];      // plain store: see the kernel comment
+                gl[c3] += mine[c3] * tx[j][c3];
+            }
         }
     }
 #pragma unroll
-    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_sum(gl[c3]);
+    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_lanes_sum<LANES>(gl[c3]);
     if (grad_light && sub == 0) {
         atomicAdd(&grad_light[3 * (size_t)lrow + 0], gl[0]);
         atomicAdd(&grad_light[3 * (size_t)lrow + 1], gl[1]);
@@ -873,18 +881,21 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
 // a fill_back mesh, i.e. mostly idle waves); with the compacted list of a d3m_visibility only faces that own a pixel
 // do, on a fixed grid that strides over the list.
 // (111 registers, 4 waves per SIMD; held to 5 or 6 waves it spills and loses: 0.26 / 0.34 ms against 0.22)
+template <int LANES = LIT_LANES>
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs a) {
-    const int sub = threadIdx.x % LIT_LANES, slot = threadIdx.x / LIT_LANES;
+    static_assert(LANES == LIT_LANES || LANES == 64, "LIT_LANES lanes per face, or a wave");
+    constexpr int PER_BLOCK = 256 / LANES;
+    const int sub = threadIdx.x % LANES, slot = threadIdx.x / LANES;
     if (a.list) {
         const int n = *a.n_list;
-        const XcdOrder xo((n + LIT_FACES_PER_BLOCK - 1) / LIT_FACES_PER_BLOCK);     // neighbouring faces share map lines
+        const XcdOrder xo((n + PER_BLOCK - 1) / PER_BLOCK);     // neighbouring faces share map lines
         for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
-            const long base = (long)xo.unit(i) * LIT_FACES_PER_BLOCK;
-            if (base + slot < n) lit_face_backward(a, a.list[base + slot], sub);
+            const long base = (long)xo.unit(i) * PER_BLOCK;
+            if (base + slot < n) lit_face_backward<LANES>(a, a.list[base + slot], sub);
         }
     } else {
-        const long gi = (long)blockIdx.x * LIT_FACES_PER_BLOCK + slot;
-        if (gi < (long)a.B * a.lt.Fp) lit_face_backward(a, gi, sub);
+        const long gi = (long)blockIdx.x * PER_BLOCK + slot;
+        if (gi < (long)a.B * a.lt.Fp) lit_face_backward<LANES>(a, gi, sub);
     }
 }
 

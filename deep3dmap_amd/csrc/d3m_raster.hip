@@ -1375,9 +1375,12 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
-        const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
-        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces, dim3(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks),
-               dim3(256), st, fa);
+        // (a coarse mesh -- more than 48 raster pixels per triangle -- gives a face a whole wave instead of eight lanes)
+        const bool coarse = list && (double)S * S > 48.0 * (double)num_tri;
+        const unsigned all_blocks = blocks_for(nf, coarse ? 4 : LIT_FACES_PER_BLOCK);
+        const dim3 g_faces(list ? (all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8) : all_blocks);
+        if (coarse) LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces<64>, g_faces, dim3(256), st, fa);
+        else LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces<>, g_faces, dim3(256), st, fa);
         // the texel and depth gradients of the faces the gathered pass marked LARGE (normally none: leaves at once) -- and, for
         // a fused objective whose forward pass deferred it (D3M_FIT_FINISH_DEFERRED), the objective's finish
         FitFin fin;

@@ -1183,3 +1183,34 @@ def test_mesh_depth_mode_on_a_coarse_mesh(n, size):
         res.append((image.detach(), v.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and float((res[0][0] < 50).float().mean()) > 0.05
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_renderer_end_to_end_on_a_coarse_mesh_against_oracle(aa):
+    """More than 48 raster pixels per triangle (72 triangles @48^2, or @96^2 with anti-aliasing): the gathered texture /
+    depth pass gives a face a whole wave instead of eight lanes (k_backward_textures_lit_faces<64>), and small batches of
+    such meshes take the per-tile lists.  Images, loss and both gradients against the oracle, as the test above."""
+    nr = _nr()
+    from oracle import nr_oracle as O
+    v, tri, tex = _scene(n=7)
+    assert 48 * 48 > 24 * tri.shape[1]
+    kw = dict(image_size=48, anti_aliasing=aa, camera_mode="look_at", background_color=[0.2, 0.3, 0.4],
+              light_direction=[0.3, 0.8, -0.5])
+    ro, rg = O.Renderer(**kw), nr.Renderer(**kw)
+    ro.eye = rg.eye = [0.6, 0.9, -2.3]
+    gen = torch.Generator().manual_seed(5)
+    targets = (torch.rand(2, 3, 48, 48, generator=gen), torch.rand(2, 48, 48, generator=gen), torch.rand(2, 48, 48, generator=gen))
+
+    def run(renderer, dev):
+        vv = v.detach().clone().to(dev).requires_grad_(True)
+        tt = tex.detach().clone().to(dev).requires_grad_(True)
+        rgb, depth, alpha = renderer(vv, tri.to(dev), tt)
+        loss = ((rgb - targets[0].to(dev)) ** 2).sum() + ((alpha - targets[1].to(dev)) ** 2).sum() + \
+               (depth.clamp(max=5.0) - targets[2].to(dev)).abs().sum() * 0.1
+        loss.backward()
+        return [x.detach().cpu() for x in (rgb, depth, alpha, loss, vv.grad, tt.grad)]
+
+    with _association("product"):
+        ref = run(ro, "cpu")
+    got = run(rg, "cuda")
+    _compare_end_to_end(ref, got, "product", f"coarse[aa={int(aa)}]")
