@@ -57,42 +57,82 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
                                                           float* __restrict__ grad_faces, int B, int S,
                                                           const int* __restrict__ only_large, VertexTarget vt, GradScale gs,
                                                           int flip_rows = 0) {
-    // (a fixed grid striding over the pixels: see k_backward_textures_lit_pixels)
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * blockDim.x) {
-    const int fn = face_index_map[i];
-    if (fn < 0) continue;
-    const int bn = (int)(i / ((long)S * S));
+    // (a fixed grid striding over the pixels, a wave at a time; a wave whose pixels all belong to ONE face -- the ordinary case
+    //  where this pass runs at all: faces too large for the gathered pass -- sums its nine values over the wave and adds them
+    //  once: see backward_textures_lit_pixels, d3m_lit.h)
+    const long n = (long)B * S * S;
     const int F = fs.num_faces();
-    if (only_large && only_large[(size_t)bn * F + fn] != 2) continue;   // the rest was gathered per face
-    float face[9], finv[9];
-    fs.load(bn, fn, face);
-    if (face_inv_map) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) finv[k] = face_inv_map[i * 9 + k];
-    } else {
-        face_inverse(face, S, finv);
+    const int lane = (int)(threadIdx.x & 63);
+    for (long i0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += (long)gridDim.x * blockDim.x) {
+    const long i = i0 + lane;
+    int fn = -1, bn = 0;
+    bool active = i < n;
+    if (active) { fn = face_index_map[i]; active = fn >= 0; }
+    if (active) {
+        bn = (int)(i / ((long)S * S));
+        if (only_large && only_large[(size_t)bn * F + fn] != 2) active = false;   // the rest was gathered per face
     }
-    const float depth = depth_map[i];
-    const float depth2 = depth * depth;
-    float s_rgb, s_alpha, s_depth;
-    gs.get(s_rgb, s_alpha, s_depth);
-    // (flip_rows: the gradient of the OUTPUT image -- its row S-1-y is the map's row y)
-    const long row = (i / S) % S;
-    const float g = grad_depth_map[flip_rows ? i + ((long)S - 1 - 2 * row) * S : i] * s_depth;
-    float tmp[3] = {0, 0, 0};
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    if (!act) continue;                                             // (wave-uniform)
+    const int key = active ? bn * F + fn : -1;
+    float v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        float face[9], finv[9];
+        fs.load(bn, fn, face);
+        if (face_inv_map) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < 9; k++) finv[k] = face_inv_map[i * 9 + k];
+        } else {
+            face_inverse(face, S, finv);
+        }
+        const float depth = depth_map[i];
+        const float depth2 = depth * depth;
+        float s_rgb, s_alpha, s_depth;
+        gs.get(s_rgb, s_alpha, s_depth);
+        // (flip_rows: the gradient of the OUTPUT image -- its row S-1-y is the map's row y)
+        const long row = (i / S) % S;
+        const float g = grad_depth_map[flip_rows ? i + ((long)S - 1 - 2 * row) * S : i] * s_depth;
+        float tmp[3] = {0, 0, 0};
 #pragma unroll
-        for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / face[3 * l + 2];
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) tmp[k] += -finv[3 * l + k] / face[3 * l + 2];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float wk = weight_map[3 * i + k];
+            const float z_k = face[3 * k + 2];
+            v[3 * k + 0] = -g * tmp[0] * wk * depth2 * (float)S / 2.0f;
+            v[3 * k + 1] = -g * tmp[1] * wk * depth2 * (float)S / 2.0f;
+            v[3 * k + 2] = g * wk * depth2 / (z_k * z_k);
+        }
     }
+    // one face of the wave at a time (a wave of 64 consecutive pixels of a row holds one to three), every lane in step
+    // (up to four: a wave over micro-triangles holds dozens of faces, and those pixels add for themselves as they always did)
+    unsigned long long todo = act;
+    for (int round = 0; round < 4 && todo; round++) {               // (wave-uniform)
+        const int lead = __builtin_ctzll(todo);
+        const int key0 = __builtin_amdgcn_readlane(key, lead);
+        const bool mine = active && key == key0;
+        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        const int bn_a = key0 / F, fn_a = key0 % F;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float wk = weight_map[3 * i + k];
-        const float z_k = face[3 * k + 2];
-        float* gk = vt.gv ? vt.vertex(bn, fn, k) : grad_faces + ((size_t)bn * F + fn) * 9 + 3 * k;
-        atomicAdd(&gk[0], -g * tmp[0] * wk * depth2 * (float)S / 2.0f);
-        atomicAdd(&gk[1], -g * tmp[1] * wk * depth2 * (float)S / 2.0f);
-        atomicAdd(&gk[2], g * wk * depth2 / (z_k * z_k));
+        for (int k = 0; k < 3; k++) {
+            float* gk = vt.gv ? vt.vertex(bn_a, fn_a, k) : grad_faces + ((size_t)bn_a * F + fn_a) * 9 + 3 * k;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float sv = wave_sum(mine ? v[3 * k + c] : 0.0f);
+                if (lane == lead) atomicAdd(&gk[c], sv);
+            }
+        }
+    }
+    if ((todo >> lane) & 1ull) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float* gk = vt.gv ? vt.vertex(bn, fn, k) : grad_faces + ((size_t)bn * F + fn) * 9 + 3 * k;
+#pragma unroll
+            for (int c = 0; c < 3; c++) atomicAdd(&gk[c], v[3 * k + c]);
+        }
     }
     }
 }

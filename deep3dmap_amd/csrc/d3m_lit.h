@@ -909,36 +909,109 @@ __device__ __forceinline__ void backward_textures_lit_pixels(const float* __rest
                                                              const int* __restrict__ only_large, int B, int S, float eps,
                                                              GradScale gs) {
     // a fixed grid striding over the pixels: in only_large mode the launch normally has nothing to do, and 32 k
-    // workgroups that leave at once still cost 12 us of dispatch
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)B * S * S; i += (long)gridDim.x * 256) {
-    const int fi = face_index_map[i];
-    if (fi < 0) continue;
-    const int bn = (int)(i / ((long)S * S));
-    if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) continue;
-    const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
-    const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
-    float s_rgb, s_alpha, s_depth;
-    gs.get(s_rgb, s_alpha, s_depth);
-    const float g[3] = {grad_rgb.get(i, 0) * s_rgb, grad_rgb.get(i, 1) * s_rgb, grad_rgb.get(i, 2) * s_rgb};
-    int fl[3];
-    float fr[3];
-    sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);
+    // workgroups that leave at once still cost 12 us of dispatch.
+    // WAVE AGGREGATION (round 5): the pixels of a wave normally belong to ONE face here -- this is the pass of faces whose
+    // box exceeds the gathered pass's limit -- so for ts = 2 (where a corner's texel is the same for every pixel of the
+    // face) the 24 + 3 sums are taken over the wave first and its first lane adds them: 27 atomics per wave instead of
+    // 27 x 64 on the same few addresses (an 8-triangle mesh filling a 512^2 image: 14.75 ms -> see EXPERIMENTS).  A wave with
+    // pixels of several faces, and any other ts, adds per pixel as before.
+    const long n = (long)B * S * S;
+    for (long i0 = (long)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += (long)gridDim.x * 256) {
+    const long i = i0 + (threadIdx.x & 63);
+    int fi = -1, bn = 0;
+    bool active = i < n;
+    if (active) { fi = face_index_map[i]; active = fi >= 0; }
+    if (active) {
+        bn = (int)(i / ((long)S * S));
+        if (only_large && only_large[(size_t)bn * lt.Fp + fi] != FLAG_LARGE) active = false;
+    }
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    if (!act) continue;                                             // (wave-uniform)
+    const int key = active ? bn * lt.Fp + fi : -1;
+    const int lane = (int)(threadIdx.x & 63);
+    float g[3] = {0, 0, 0};
+    int fl[3] = {0, 0, 0};
+    float fr[3] = {0, 0, 0};
+    if (active) {
+        const float* face = faces + ((size_t)bn * lt.Fp + fi) * 9;
+        const float weight[3] = {weight_map[3 * i], weight_map[3 * i + 1], weight_map[3 * i + 2]};
+        float s_rgb, s_alpha, s_depth;
+        gs.get(s_rgb, s_alpha, s_depth);
+        g[0] = grad_rgb.get(i, 0) * s_rgb; g[1] = grad_rgb.get(i, 1) * s_rgb; g[2] = grad_rgb.get(i, 2) * s_rgb;
+        sample_setup(face, weight, depth_map[i], lt.ts, eps, fl, fr);
+    }
     const int ts3 = lt.ts * lt.ts * lt.ts;
+    if (lt.ts != 2) {                       // a corner's texel depends on the pixel: per-pixel atomics
+        if (!active) continue;
 #pragma unroll
-    for (int pn = 0; pn < 8; pn++) {
-        float w;
-        int isc, lrow = 0;
-        sample_corner(pn, lt.ts, fl, fr, w, isc);
-        const long off = lit_texel(lt, B, bn, fi, isc, &lrow);
-        if (off < 0) continue;
-        // off addresses `textures`; the per-view gradient buffer has the same [.., F, ts^3, 3] tail but batch B
-        const long in_batch = off % ((long)lt.F * ts3 * 3);
-        long vb = ((long)bn * lt.Fp + fi + isc / ts3) / lt.Fp;       // view of the face actually reached
-        float* gt = gtex_view + (size_t)vb * lt.F * ts3 * 3 + in_batch;
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc, lrow = 0;
+            sample_corner(pn, lt.ts, fl, fr, w, isc);
+            const long off = lit_texel(lt, B, bn, fi, isc, &lrow);
+            if (off < 0) continue;
+            // off addresses `textures`; the per-view gradient buffer has the same [.., F, ts^3, 3] tail but batch B
+            const long in_batch = off % ((long)lt.F * ts3 * 3);
+            long vb = ((long)bn * lt.Fp + fi + isc / ts3) / lt.Fp;       // view of the face actually reached
+            float* gt = gtex_view + (size_t)vb * lt.F * ts3 * 3 + in_batch;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            atomicAdd(&gt[k], w * g[k] * lt.light[3 * (size_t)lrow + k]);
-            if (grad_light) atomicAdd(&grad_light[3 * (size_t)lrow + k], w * g[k] * lt.textures[off + k]);
+            for (int k = 0; k < 3; k++) {
+                atomicAdd(&gt[k], w * g[k] * lt.light[3 * (size_t)lrow + k]);
+                if (grad_light) atomicAdd(&grad_light[3 * (size_t)lrow + k], w * g[k] * lt.textures[off + k]);
+            }
+        }
+        continue;
+    }
+    // ts = 2: one face of the wave at a time (a wave of 64 consecutive pixels of a row holds one to three), every lane in step
+    // (up to four; a wave with more -- small faces beside a large one -- lets the remaining pixels add for themselves)
+    unsigned long long todo = act;
+    for (int round = 0; round < 4 && todo; round++) {               // (wave-uniform)
+        const int lead = __builtin_ctzll(todo);
+        const int key0 = __builtin_amdgcn_readlane(key, lead);
+        const bool mine = active && key == key0;
+        todo &= ~__builtin_amdgcn_ballot_w64(mine);
+        const int bn_a = key0 / lt.Fp, fi_a = key0 % lt.Fp;
+        float gl_sum[3] = {0, 0, 0};
+        int lrow_a = 0;
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc, lrow = 0;
+            sample_corner(pn, 2, fl, fr, w, isc);                   // (fl = 0: isc does not depend on the pixel)
+            isc = ((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1);
+            if (!mine) w = 0.0f;
+            const long off = lit_texel(lt, B, bn_a, fi_a, isc, &lrow);
+            const long in_batch = off % ((long)lt.F * ts3 * 3);
+            float* gt = gtex_view + (size_t)bn_a * lt.F * ts3 * 3 + in_batch;
+            lrow_a = lrow;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float st = wave_sum(w * g[k] * lt.light[3 * (size_t)lrow + k]);
+                if (lane == lead) atomicAdd(&gt[k], st);
+                gl_sum[k] += w * g[k] * lt.textures[off + k];
+            }
+        }
+        if (grad_light) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float sl = wave_sum(gl_sum[k]);
+                if (lane == lead) atomicAdd(&grad_light[3 * (size_t)lrow_a + k], sl);
+            }
+        }
+    }
+    if ((todo >> lane) & 1ull) {
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc, lrow = 0;
+            sample_corner(pn, 2, fl, fr, w, isc);
+            const long off = lit_texel(lt, B, bn, fi, isc, &lrow);
+            float* gt = gtex_view + (size_t)bn * lt.F * ts3 * 3 + off % ((long)lt.F * ts3 * 3);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicAdd(&gt[k], w * g[k] * lt.light[3 * (size_t)lrow + k]);
+                if (grad_light) atomicAdd(&grad_light[3 * (size_t)lrow + k], w * g[k] * lt.textures[off + k]);
+            }
         }
     }
     }
