@@ -63,10 +63,15 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
     const long n = (long)B * S * S;
     const int F = fs.num_faces();
     const int lane = (int)(threadIdx.x & 63);
-    for (long i0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += (long)gridDim.x * blockDim.x) {
+    __shared__ WgSums<9> wg;                // (per face: the workgroup's sums, flushed once -- see WgSums)
+    wg.init();
+    // (a contiguous run of pixels per workgroup -- a few image rows, i.e. few faces -- in steps of one workgroup)
+    const long chunk = ((n + gridDim.x - 1) / gridDim.x + blockDim.x - 1) / blockDim.x * blockDim.x;
+    const long run_end = min(n, (long)(blockIdx.x + 1) * chunk);
+    for (long i0 = (long)blockIdx.x * chunk + (threadIdx.x & ~63u); i0 < run_end; i0 += blockDim.x) {
     const long i = i0 + lane;
     int fn = -1, bn = 0;
-    bool active = i < n;
+    bool active = i < run_end;
     if (active) { fn = face_index_map[i]; active = fn >= 0; }
     if (active) {
         bn = (int)(i / ((long)S * S));
@@ -116,13 +121,15 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
         const bool mine = active && key == key0;
         todo &= ~__builtin_amdgcn_ballot_w64(mine);
         const int bn_a = key0 / F, fn_a = key0 % F;
+        float sv[9];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float* gk = vt.gv ? vt.vertex(bn_a, fn_a, k) : grad_faces + ((size_t)bn_a * F + fn_a) * 9 + 3 * k;
+        for (int q = 0; q < 9; q++) sv[q] = wave_sum(mine ? v[q] : 0.0f);
+        if (lane == lead && !wg.add(key0, sv)) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float sv = wave_sum(mine ? v[3 * k + c] : 0.0f);
-                if (lane == lead) atomicAdd(&gk[c], sv);
+            for (int k = 0; k < 3; k++) {
+                float* gk = vt.gv ? vt.vertex(bn_a, fn_a, k) : grad_faces + ((size_t)bn_a * F + fn_a) * 9 + 3 * k;
+#pragma unroll
+                for (int c = 0; c < 3; c++) atomicAdd(&gk[c], sv[3 * k + c]);
             }
         }
     }
@@ -135,6 +142,15 @@ __device__ __forceinline__ void backward_depth_map_pixels(FS fs, const float* __
         }
     }
     }
+    __syncthreads();
+    for (int t = threadIdx.x; t < wg.slots * 9; t += blockDim.x) {  // the workgroup's sums: one atomic per face and value
+        const int slot = t / 9, q = t % 9, key = wg.key[slot];
+        if (key < 0) continue;
+        const int bn = key / F, fn = key % F;
+        float* gk = vt.gv ? vt.vertex(bn, fn, q / 3) : grad_faces + ((size_t)bn * F + fn) * 9 + 3 * (q / 3);
+        atomicAdd(&gk[q % 3], wg.v[slot][q]);
+    }
+    __syncthreads();                        // (the table may be initialised again by a caller's next pass)
 }
 
 template <class FS>

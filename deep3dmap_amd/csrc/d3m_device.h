@@ -252,6 +252,40 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Sums a workgroup collects per KEY before they go to global memory with one atomic each: the per-pixel fallbacks of the
+// gathered backward passes add, for every (large) face, the same few values from every wave that holds pixels of it, and
+// float atomics on ONE address from all over the chip take turns at the memory side (~150 ns each across the XCDs: eight
+// views of an 8-triangle mesh @1024^2 spent 1.2 ms in 9 x 170 000 of them).  A table of SLOTS keys in LDS: the wave's
+// leading lane adds its wave's sums under the face's key (LDS atomics), and the workgroup flushes once at its end.  The
+// callers give a workgroup a CONTIGUOUS run of pixels (a few image rows), so that it meets few faces.
+template <int NV, int SLOTS = 64>
+struct WgSums {
+    static constexpr int slots = SLOTS;
+    int key[SLOTS];
+    float v[SLOTS][NV];
+    __device__ __forceinline__ void init() {                        // (all threads of the workgroup)
+        for (int t = threadIdx.x; t < SLOTS; t += blockDim.x) key[t] = -1;
+        for (int t = threadIdx.x; t < SLOTS * NV; t += blockDim.x) (&v[0][0])[t] = 0.0f;
+        __syncthreads();
+    }
+    // one lane: false = the table is full (the caller adds to global memory itself)
+    __device__ __forceinline__ bool add(int k, const float* vals) {
+        static_assert((SLOTS & (SLOTS - 1)) == 0, "a power of two");
+        unsigned s = ((unsigned)k * 2654435761u) >> 16;
+        for (int p = 0; p < 8; p++, s++) {                          // (eight probes, then the caller's own atomics)
+            s &= SLOTS - 1;
+            int cur = key[s];
+            if (cur == -1) cur = atomicCAS(&key[s], -1, k);
+            if (cur == -1 || cur == k) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) atomicAdd(&v[s][j], vals[j]);
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
 // Inclusive running maximum over the 64 lanes (unsigned; 0 is the identity): four row_shr steps inside each 16-lane
 // row, then the two row broadcasts -- six DPP moves, no LDS crossbar.
 template <int CTRL, int ROW_MASK>

@@ -899,6 +899,25 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
     }
 }
 
+// ts = 2: the 24 + 3 sums of one face (corner pn's channels at 3 * pn, the light's at 24) into the per-view texel
+// gradients and the light's gradient
+__device__ __forceinline__ void lit_large_flush(const LitTextures& lt, int B, float* __restrict__ gtex_view,
+                                                float* __restrict__ grad_light, int bn, int fi, int lrow, const float* sums) {
+#pragma unroll
+    for (int pn = 0; pn < 8; pn++) {
+        const int isc = ((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1);
+        int lr = 0;
+        const long off = lit_texel(lt, B, bn, fi, isc, &lr);
+        float* gt = gtex_view + (size_t)bn * lt.F * 24 + off % ((long)lt.F * 24);
+#pragma unroll
+        for (int k = 0; k < 3; k++) atomicAdd(&gt[k], sums[3 * pn + k]);
+    }
+    if (grad_light) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) atomicAdd(&grad_light[3 * (size_t)lrow + k], sums[24 + k]);
+    }
+}
+
 // backward, per pixel with float atomics: any ts, and the faces the gathered form marked LARGE
 __device__ __forceinline__ void backward_textures_lit_pixels(const float* __restrict__ faces, const LitTextures& lt,
                                                              const int32_t* __restrict__ face_index_map,
@@ -916,10 +935,15 @@ __device__ __forceinline__ void backward_textures_lit_pixels(const float* __rest
     // 27 x 64 on the same few addresses (an 8-triangle mesh filling a 512^2 image: 14.75 ms -> see EXPERIMENTS).  A wave with
     // pixels of several faces, and any other ts, adds per pixel as before.
     const long n = (long)B * S * S;
-    for (long i0 = (long)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += (long)gridDim.x * 256) {
+    __shared__ WgSums<27> wg;               // (per face: the workgroup's 24 texel + 3 light sums, flushed once -- see WgSums)
+    wg.init();
+    // (a contiguous run of pixels per workgroup -- a few image rows, i.e. few faces -- in steps of one workgroup)
+    const long chunk = ((n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const long run_end = min(n, (long)(blockIdx.x + 1) * chunk);
+    for (long i0 = (long)blockIdx.x * chunk + (threadIdx.x & ~63); i0 < run_end; i0 += 256) {
     const long i = i0 + (threadIdx.x & 63);
     int fi = -1, bn = 0;
-    bool active = i < n;
+    bool active = i < run_end;
     if (active) { fi = face_index_map[i]; active = fi >= 0; }
     if (active) {
         bn = (int)(i / ((long)S * S));
@@ -970,34 +994,31 @@ __device__ __forceinline__ void backward_textures_lit_pixels(const float* __rest
         const int key0 = __builtin_amdgcn_readlane(key, lead);
         const bool mine = active && key == key0;
         todo &= ~__builtin_amdgcn_ballot_w64(mine);
-        const int bn_a = key0 / lt.Fp, fi_a = key0 % lt.Fp;
-        float gl_sum[3] = {0, 0, 0};
-        int lrow_a = 0;
+        // (the face's texels and light addressed once, without lit_texel's 64-bit quotients: ts = 2 stays inside the face)
+        const int bn_a = key0 / lt.Fp, fi_a = key0 - bn_a * lt.Fp;
+        const bool back = fi_a >= lt.F;
+        const float* tex_face = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn_a : 0) * lt.F + (back ? fi_a - lt.F : fi_a)) * 24;
+        const int lrow_a = (lt.light_batch > 1 ? bn_a : 0) * lt.Fp + fi_a;
+        const float li[3] = {lt.light[3 * (size_t)lrow_a], lt.light[3 * (size_t)lrow_a + 1], lt.light[3 * (size_t)lrow_a + 2]};
+        float gl_sum[3] = {0, 0, 0}, sums[27];      // sums: corner pn's three channels at 3 * pn, the light's at 24
 #pragma unroll
         for (int pn = 0; pn < 8; pn++) {
             float w;
-            int isc, lrow = 0;
+            int isc;
             sample_corner(pn, 2, fl, fr, w, isc);                   // (fl = 0: isc does not depend on the pixel)
             isc = ((pn & 1) << 2) | (pn & 2) | ((pn >> 2) & 1);
             if (!mine) w = 0.0f;
-            const long off = lit_texel(lt, B, bn_a, fi_a, isc, &lrow);
-            const long in_batch = off % ((long)lt.F * ts3 * 3);
-            float* gt = gtex_view + (size_t)bn_a * lt.F * ts3 * 3 + in_batch;
-            lrow_a = lrow;
+            const int idx = back ? ((isc & 1) << 2) | (isc & 2) | ((isc >> 2) & 1) : isc;   // back copy: texel (c,b,a)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float st = wave_sum(w * g[k] * lt.light[3 * (size_t)lrow + k]);
-                if (lane == lead) atomicAdd(&gt[k], st);
-                gl_sum[k] += w * g[k] * lt.textures[off + k];
+                sums[3 * pn + k] = wave_sum(w * g[k]) * li[k];
+                gl_sum[k] += w * g[k] * tex_face[idx * 3 + k];
             }
         }
-        if (grad_light) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float sl = wave_sum(gl_sum[k]);
-                if (lane == lead) atomicAdd(&grad_light[3 * (size_t)lrow_a + k], sl);
-            }
-        }
+        for (int k = 0; k < 3; k++) sums[24 + k] = grad_light ? wave_sum(gl_sum[k]) : 0.0f;
+        if (lane == lead && !wg.add(key0, sums))
+            lit_large_flush(lt, B, gtex_view, grad_light, bn_a, fi_a, lrow_a, sums);
     }
     if ((todo >> lane) & 1ull) {
 #pragma unroll
@@ -1015,6 +1036,17 @@ __device__ __forceinline__ void backward_textures_lit_pixels(const float* __rest
         }
     }
     }
+    __syncthreads();
+    if (lt.ts == 2) {
+        for (int slot = threadIdx.x; slot < wg.slots; slot += blockDim.x) {    // the workgroup's sums: 27 atomics per face
+            const int key = wg.key[slot];
+            if (key < 0) continue;
+            int lrow = 0;
+            lit_texel(lt, B, key / lt.Fp, key % lt.Fp, 0, &lrow);
+            lit_large_flush(lt, B, gtex_view, grad_light, key / lt.Fp, key % lt.Fp, lrow, wg.v[slot]);
+        }
+    }
+    __syncthreads();                        // (the table may be initialised again by a caller's next pass)
 }
 
 __global__ void __launch_bounds__(256) k_backward_textures_lit_pixels(const float* __restrict__ faces, LitTextures lt,

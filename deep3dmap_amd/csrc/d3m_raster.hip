@@ -681,7 +681,7 @@ D3M_EXPORT int d3m_backward_depth_map_mesh(const float* faces, const float* dept
         LAUNCH("k_backward_depth_faces", (k_backward_depth_faces<DenseFaces>), g_faces, dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S, (const int*)v.list,
                (const int*)v.count, vt, (int*)large_counter, flip);
-    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
+    LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, true)), dim3(256), st, fs, depth_map,
            face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S, (const int*)v.flags, vt,
            GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter, flip);
     return check_launch();
