@@ -1296,31 +1296,36 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
 }
 
 // ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
+// `parts` (> 1 only with a vertex target, whose sums are ADDED): a block's lanes are dealt to that many workgroups, each
+// taking every parts-th group of four crossings of every lane -- a coarse mesh's lane has hundreds of crossings to add up, one
+// dependent round trip per four (8 triangles @1024^2: 165 us for one workgroup's six-times-eight lanes).
 template <class FS>
 __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const float2* __restrict__ lane_partial,
                                                     const float* __restrict__ go, float* __restrict__ grad_faces,
-                                                    VertexTarget vt) {
+                                                    VertexTarget vt, int parts) {
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    const XcdOrder xo(n_blocks);
+    const int n_units = n_blocks * parts;
+    const XcdOrder xo(n_units);
     const bool complete = plan_complete(w);      // results in record order (found through xpos), else in crossing order
     const float go_abs = go ? fabsf(*go) : 1.0f; // the magnitude of the factor the records lacked (EdgeGradArgs::go)
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
-        const int blk = xo.unit(i);
-        if (blk >= n_blocks) continue;
+        const int unit = xo.unit(i);
+        if (unit >= n_units) continue;
+        const int blk = unit / parts, part = unit - blk * parts;
         const int t = threadIdx.x;
         const int pos = blk * EG_FACES_PER_BLOCK + t / 6, ea = t % 6;
         const bool on = t < EG_FACES_PER_BLOCK * 6 && pos < n_vis;
         float2 g = make_float2(0.0f, 0.0f);
         if (on) {
             const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
-            if (!complete) g = lane_partial[(size_t)pos * 6 + ea];
+            if (!complete && part == 0) g = lane_partial[(size_t)pos * 6 + ea];
             // slots (2c, 2c+1) of the lane's crossings c, contiguous and 16-byte aligned: one float4 per crossing, four
             // crossings requested per round, added in slot order; crossings past cap were folded into lane_partial
             const long c_first = (long)w.lane_block[blk] + lc.x, c_last = min(c_first + (long)lc.y, (long)w.cap);
             const float4* res4 = (const float4*)w.results;
-            for (long c = c_first; c < c_last; c += 4) {
+            for (long c = c_first + 4 * part; c < c_last; c += 4 * parts) {
                 long at[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) at[j] = (complete && c + j < c_last) ? (long)w.xpos[c + j] : c + j;
@@ -1715,7 +1720,11 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
     // (normally leaves at once: a small grid keeps that cheap; with an undersized workspace its workgroups stride)
     LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 512u)), dim3(256), st, fs, a, w, lane_partial);
-    LAUNCH("k_edge_gather", k_edge_gather<FS>, g6, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt);
+    // (few blocks of faces, sums added into a vertex target: a block's lanes dealt to several workgroups -- see the kernel)
+    const int gparts = (!vt.gv || g6_full >= 2048) ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const dim3 g_gather((unsigned)std::min<long>(8192, (g6_full * gparts + 7) / 8 * 8));
+    LAUNCH("k_edge_gather", k_edge_gather<FS>, g_gather, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt,
+           gparts);
     e = hipGetLastError();
     if (e != hipSuccess) { *last_err = (int)e; return 3; }
     return 0;
