@@ -250,9 +250,9 @@ D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
 // of 8 x 8 pixels: the headline's 32 views) go through per-tile lists; small batches bid -- UNLESS the mesh is coarse (round
 // 5): bidding hands a face's rows to the lanes of ONE wave, and a few thousand triangles of a hundred pixels each are a
 // few dozen waves with everything to do (a 2 450-triangle mesh @512^2: k_bid_faces 237 us, the whole binned forward 95;
-// 722 triangles: 341 against 175), where a tile's wave takes a tile-filling face in one step.  Measured crossover: ~8 raster
-// pixels per input triangle (19 602 triangles @512^2, 13 px each: lists 15 us ahead; 32 258, 8 px: equal; 53 138, 5 px:
-// bidding 10 us ahead).
+// 722 triangles: 341 against 175), where a tile's wave takes a tile-filling face in one step.  Measured crossover at ONE
+// view: ~8 raster pixels per input triangle (19 602 triangles @512^2, 13 px each: lists 15 us ahead; 32 258, 8 px: equal;
+// 53 138, 5 px: bidding 10 us ahead).
 static bool big_batch(int B, long triangles, int S) {
     const int blocks_x = (S + 7) / 8;            // (the threshold is in blocks of 8 x 8 pixels, whatever the tile pass's tiles)
     return !((double)S * S < 1.5 * (double)triangles) && (long)B * blocks_x * blocks_x > BID_MAX_TILES;
@@ -261,7 +261,10 @@ static bool bidding_preferred(int B, long triangles, int S) {
     const int form = coverage_form();
     if (form >= 0) return form == 1;
     if ((double)S * S < 1.5 * (double)triangles) return true;
-    return !big_batch(B, triangles, S) && (double)S * S <= 10.0 * (double)triangles;
+    // (the more views, the more waves bidding has to work with: the crossover moves from ~10 raster pixels per triangle at
+    //  one view to ~25 at eight -- 19 602 triangles @512^2: lists 15 us ahead at one view, bidding 22 us ahead at eight)
+    const double px_per_tri = std::min(10.0 + 2.0 * (B - 1), 32.0);
+    return !big_batch(B, triangles, S) && (double)S * S <= px_per_tri * (double)triangles;
 }
 // Whether a launch is a "big batch" in that sense -- what the lit render node takes for "every kernel fills the chip by
 // itself: run on one stream" (rasterize._serial_branches), independent of the form of coverage a coarse mesh takes.
