@@ -899,6 +899,136 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
     }
 }
 
+// ---- the gathered pass for texture cubes of 3^3 and 4^3 texels (round 5) ----------------------------------------------
+// neural_renderer's own default is texture_size 4 (NR/load_obj.py), and only ts = 2 had a gathered backward: every other
+// size took the per-pixel atomic passes -- 24 float atomics per covered pixel into a zero-filled [B,F,ts^3,3] buffer, nine
+// more for the depth gradient, a sum over ALL views behind them: 8 views of the headline mesh 2.8 ms against 0.49 at ts = 2,
+// a 2 450-triangle mesh 4.1 against 0.32.  Same structure as lit_face_backward -- eight lanes per listed face share the scan
+// of its box, the depth gradient rides along, one plain store per texel at the end -- with the face's ts^3 x 3 texel sums in
+// LDS (192 floats at ts = 4, thirty-two faces per workgroup) instead of registers: a corner's texel depends on the pixel.
+// (ts = 1 keeps the per-pixel pass: its corners reach into the FOLLOWING faces' texels, KCU:229-233.)
+constexpr int LIT_ANY_MAX_TEXELS = 64;
+__device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long gi, int sub, float* __restrict__ acc_lds) {
+    const LitTextures& lt = a.lt;
+    const int S = a.S, Fp = lt.Fp, ts = lt.ts, ts3 = ts * ts * ts;
+    float s_rgb, s_alpha, s_depth;
+    a.gs.get(s_rgb, s_alpha, s_depth);
+    const int bn = (int)(gi / Fp), fn = (int)(gi % Fp);
+    float fc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) fc[k] = a.faces[(size_t)gi * 9 + k];
+    int x0, x1, y0, y1;
+    if (!pixel_bbox(fc, S, x0, x1, y0, y1)) return;
+    const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+    const bool back = fn >= lt.F;
+    const int fo = back ? fn - lt.F : fn;
+    float* gt = a.gtex_view + ((size_t)bn * lt.F + fo) * ts3 * 3;
+    if (sub == 0 && a.view_mask) atomicOr(&a.view_mask[(size_t)fo * ((a.B + 31) >> 5) + (bn >> 5)], 1u << (bn & 31));
+    if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
+        a.flags[gi] = FLAG_LARGE;
+        if (sub == 0) atomicAdd(a.n_large, 1);
+        for (int t = sub; t < ts3 * 3; t += LIT_LANES) gt[t] = 0.0f;
+        return;
+    }
+    for (int t = sub; t < ts3 * 3; t += LIT_LANES) acc_lds[t] = 0.0f;
+    float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
+    if (a.grad_depth_map) {
+        float finv[9];
+        face_inverse(fc, S, finv);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) dtmp[k] += -finv[3 * l + k] / fc[3 * l + 2];     // KCU:582
+        }
+    }
+    const int lrow = (lt.light_batch > 1 ? bn : 0) * Fp + fn;
+    const float li[3] = {lt.light[3 * (size_t)lrow], lt.light[3 * (size_t)lrow + 1], lt.light[3 * (size_t)lrow + 2]};
+    const float* tex_face = lt.textures + ((size_t)(lt.tex_batch > 1 ? bn : 0) * lt.F + fo) * ts3 * 3;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the zeroes before the first sums: one wave, in order)
+    __builtin_amdgcn_wave_barrier();
+    const size_t base = (size_t)bn * S * S;
+    BoxCursorN<LIT_LANES> c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += LIT_LANES, c.advance()) {
+        const size_t p = base + (size_t)c.y * S + c.x;
+        // (the pixel's maps are requested together with its owner: one round trip per step of the scan)
+        const bool own = a.face_index_map[p] == fn;
+        const float lw[3] = {a.weight_map[3 * p], a.weight_map[3 * p + 1], a.weight_map[3 * p + 2]};
+        const float lg[3] = {a.grad_rgb.get(p, 0) * s_rgb, a.grad_rgb.get(p, 1) * s_rgb, a.grad_rgb.get(p, 2) * s_rgb};
+        const float ld = a.depth_map[p], lgd = a.grad_depth_map ? a.grad_depth_map[p] * s_depth : 0.0f;
+        if (!own) continue;
+        if (a.grad_depth_map) {
+            const float depth2 = ld * ld;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float z_k = fc[3 * k + 2];
+                dacc[3 * k + 0] += -lgd * dtmp[0] * lw[k] * depth2 * (float)S / 2.0f;      // KCU:588
+                dacc[3 * k + 1] += -lgd * dtmp[1] * lw[k] * depth2 * (float)S / 2.0f;
+                dacc[3 * k + 2] += lgd * lw[k] * depth2 / (z_k * z_k);                     // KCU:575
+            }
+        }
+        int fl[3];
+        float fr[3];
+        sample_setup(fc, lw, ld, ts, a.eps, fl, fr);
+#pragma unroll
+        for (int pn = 0; pn < 8; pn++) {
+            float w;
+            int isc;
+            sample_corner(pn, ts, fl, fr, w, isc);                  // (ts >= 2: the position is clamped below ts - 1: isc < ts^3)
+#pragma unroll
+            for (int k = 0; k < 3; k++) atomicAdd(&acc_lds[isc * 3 + k], w * lg[k]);
+        }
+    }
+    if (a.grad_depth_map) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) dacc[k] = lit_sum(dacc[k]);
+        if (sub == 0) {
+            if (a.vt.gv) {
+#pragma unroll
+                for (int n = 0; n < 3; n++) {
+                    float* g = a.vt.vertex(bn, fn, n);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) atomicAdd(&g[k], dacc[3 * n + k]);
+                }
+            } else {
+                float* gf = a.grad_faces + (size_t)gi * 9;
+#pragma unroll
+                for (int k = 0; k < 9; k++) gf[k] += dacc[k];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (every lane's sums before any lane reads them)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float gl[3] = {0, 0, 0};
+    for (int t = sub; t < ts3; t += LIT_LANES) {
+        // texel t = (a,b,c) of the virtual face is texel (c,b,a) of the original one for the back copy (NR/renderer.py:156)
+        const int to = back ? (t % ts) * ts * ts + ((t / ts) % ts) * ts + t / (ts * ts) : t;
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) {
+            const float m = acc_lds[t * 3 + c3];
+            gt[to * 3 + c3] = m * li[c3];                           // plain store (see k_backward_textures_lit_faces)
+            gl[c3] += m * tex_face[to * 3 + c3];
+        }
+    }
+#pragma unroll
+    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_sum(gl[c3]);
+    if (a.grad_light && sub == 0) {
+#pragma unroll
+        for (int c3 = 0; c3 < 3; c3++) atomicAdd(&a.grad_light[3 * (size_t)lrow + c3], gl[c3]);
+    }
+}
+// over the compacted visibility list only (a fixed grid striding, as k_backward_textures_lit_faces with a list)
+__global__ void __launch_bounds__(256) k_backward_textures_lit_faces_any(LitFaceArgs a) {
+    __shared__ float s_acc[LIT_FACES_PER_BLOCK][LIT_ANY_MAX_TEXELS * 3];
+    const int sub = threadIdx.x % LIT_LANES, slot = threadIdx.x / LIT_LANES;
+    const int n = *a.n_list;
+    const XcdOrder xo((n + LIT_FACES_PER_BLOCK - 1) / LIT_FACES_PER_BLOCK);
+    for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
+        const long base = (long)xo.unit(i) * LIT_FACES_PER_BLOCK;
+        if (base + slot < n) lit_face_backward_any(a, a.list[base + slot], sub, s_acc[slot]);
+    }
+}
+
 // ts = 2: the 24 + 3 sums of one face (corner pn's channels at 3 * pn, the light's at 24) into the per-view texel
 // gradients and the light's gradient
 __device__ __forceinline__ void lit_large_flush(const LitTextures& lt, int B, float* __restrict__ gtex_view,
@@ -1107,11 +1237,12 @@ __global__ void __launch_bounds__(256) k_sum_over_views(const float* __restrict_
 // The ts == 2 form of the above: one lane per 4 consecutive floats of a face's 24 (six lanes per face), 16-byte loads.
 // view_mask (written by k_backward_textures_lit_faces) names the views that wrote this face's entry, in view order:
 // typically 4 of 32, found with ffs instead of 2 x B flag loads.
+// (per_face4 float4s per face: 6 at ts = 2, 48 at ts = 4 -- 3^3 x 3 floats are no multiple of four: the form above)
 __global__ void __launch_bounds__(256) k_sum_over_views_ts2(const float4* __restrict__ in, float4* __restrict__ out, long n4,
-                                                           int B, const unsigned* __restrict__ view_mask) {
+                                                           int B, const unsigned* __restrict__ view_mask, int per_face4) {
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     if (j >= n4) return;
-    const int f = (int)(j / 6), words = (B + 31) >> 5;
+    const int f = (int)(j / per_face4), words = (B + 31) >> 5;
     float4 acc = make_float4(0, 0, 0, 0);
     for (int wd = 0; wd < words; wd++) {
         unsigned m = view_mask[(size_t)f * words + wd];

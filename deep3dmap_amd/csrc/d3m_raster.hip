@@ -1300,11 +1300,13 @@ static int lit_clear_ranges(const LitWorkspace& W, float* grad_textures, int tex
                             int B, int num_tri, int fill_back, int texture_size, bool has_visibility, void** ptr, size_t* bytes) {
     const size_t ts3 = (size_t)texture_size * texture_size * texture_size, view_elems = (size_t)num_tri * ts3 * 3;
     const int Fp = (fill_back ? 2 : 1) * num_tri;
-    const bool skip_zero = texture_size == 2 && textures_batch == 1;
+    // (gathered: texture sizes 2 -- and, over a visibility list, 3 and 4 -- store per-view sums instead of adding into zeros)
+    const bool gathered = texture_size == 2 || (has_visibility && texture_size >= 3 && texture_size <= 4);
+    const bool skip_zero = gathered && textures_batch == 1;
     int n = 0;
     if (!skip_zero) { ptr[n] = textures_batch > 1 ? grad_textures : W.gview; bytes[n++] = (size_t)B * view_elems * 4; }
     if (grad_light) { ptr[n] = grad_light; bytes[n++] = (size_t)light_batch * Fp * 12; }
-    if (texture_size == 2) {
+    if (gathered) {
         // shared textures: the view masks (the sum over views reads only what was written) | counter, adjacent
         if (skip_zero) { ptr[n] = W.view_mask; bytes[n++] = W.mask_bytes + 256; }
         else { ptr[n] = W.n_large; bytes[n++] = 256; }
@@ -1356,7 +1358,8 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     const long n = (long)B * S * S, nf = (long)B * lt.Fp;
     unsigned* view_mask = W.view_mask;
     // the gathered pass stores (does not add) and the shared-texture sum skips unwritten entries by the flags
-    const bool skip_zero = texture_size == 2 && textures_batch == 1;
+    const bool gathered_any = visibility && texture_size >= 3 && texture_size <= 4;      // (the LDS form: k_backward_textures_lit_faces_any)
+    const bool skip_zero = (texture_size == 2 || gathered_any) && textures_batch == 1;
     // every clear of this entry point in one launch -- or none: a caller that zeroed the ranges of
     // d3m_backward_textures_lit_clear_ranges itself says so (D3M_PRECLEARED)
     if (!(flags_in & D3M_PRECLEARED)) {
@@ -1393,6 +1396,20 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         LAUNCH("k_lit_large_faces", k_lit_large_faces, dim3(px_grid(n, true)), dim3(256), st, faces, lt, face_index_map,
                weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)W.n_large,
                grad_depth_map, grad_faces, vt, fin);
+    } else if (gathered_any) {
+        // texture cubes of 3^3 / 4^3 texels over the visibility list: the same three launches as ts = 2, the face's sums in LDS
+        LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
+                       grad_faces, vt, flags, skip_zero ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
+        const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
+        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces_any,
+               dim3(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8), dim3(256), st, fa);
+        FitFin fin;
+        memset(&fin, 0, sizeof(fin));
+        if (records && unscaled->scratch && unscaled->loss && (unscaled->flags & D3M_FIT_FINISH_DEFERRED))
+            fin = fit_fin_of_tiles(unscaled, B, S);
+        LAUNCH("k_lit_large_faces", k_lit_large_faces, dim3(px_grid(n, true)), dim3(256), st, faces, lt, face_index_map,
+               weight_map, depth_map, grad_rgb, gview, grad_light, (const int*)flags, B, S, eps, gs, (const int*)W.n_large,
+               grad_depth_map, grad_faces, vt, fin);
     } else {
         // (no kernel here for a deferred finish to ride in: a launch of its own)
         if (records && unscaled->scratch && unscaled->loss && (unscaled->flags & D3M_FIT_FINISH_DEFERRED)) {
@@ -1417,9 +1434,10 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         }
     }
     if (textures_batch == 1) {
-        if (skip_zero && (((uintptr_t)gview | (uintptr_t)grad_textures) & 15) == 0)
+        if ((texture_size == 2 || texture_size == 4) && skip_zero && (((uintptr_t)gview | (uintptr_t)grad_textures) & 15) == 0)
             LAUNCH("k_sum_over_views", k_sum_over_views_ts2, dim3(blocks_for((long)view_elems / 4, 256)), dim3(256), st,
-                   (const float4*)gview, (float4*)grad_textures, (long)view_elems / 4, B, (const unsigned*)view_mask);
+                   (const float4*)gview, (float4*)grad_textures, (long)view_elems / 4, B, (const unsigned*)view_mask,
+                   (int)(ts3 * 3 / 4));
         else
             LAUNCH("k_sum_over_views", k_sum_over_views, dim3(blocks_for((long)view_elems, 256)), dim3(256), st,
                    (const float*)gview, grad_textures, (long)view_elems, B,

@@ -644,7 +644,7 @@ def test_fit_objective_inside_the_rendering_node_large_faces():
         assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
 
 
-@pytest.mark.parametrize("ts", [1, 2, 4])
+@pytest.mark.parametrize("ts", [1, 2, 3, 4])
 @pytest.mark.parametrize("shared", [False, True])
 def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
     """render() with fill_back + lighting applied inside the sampler (shared or per-view mesh/textures) against the
