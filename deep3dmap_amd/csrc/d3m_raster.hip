@@ -213,7 +213,7 @@ static inline void launch_bin_count(const BinBuffers& bb, long lanes, hipStream_
 // grid of the per-pixel backward kernels (they stride): `sparse` = only the pixels of a few large faces have work, and
 // normally there are none
 static inline unsigned px_grid(long n, bool sparse) {
-    const long b = (n + 255) / 256, cap = sparse ? 1024 : 16384;
+    const long b = (n + 255) / 256, cap = sparse ? 2048 : 16384;
     return (unsigned)(b < cap ? b : cap);
 }
 
