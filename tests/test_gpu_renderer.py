@@ -1214,3 +1214,54 @@ def test_renderer_end_to_end_on_a_coarse_mesh_against_oracle(aa):
         ref = run(ro, "cpu")
     got = run(rg, "cuda")
     _compare_end_to_end(ref, got, "product", f"coarse[aa={int(aa)}]")
+
+
+def _needles(count):
+    """`count` thin triangles, each the height of the image, side by side: at 1024^2 every one's pixel box exceeds the gathered
+    passes' limit (5 x 1024 pixels), and half an image row crosses a hundred of them."""
+    xs = np.linspace(-0.9, 0.9, count + 1).astype(np.float32)
+    v = np.zeros((3 * count, 3), np.float32)
+    for i in range(count):
+        v[3 * i] = (xs[i], -0.9, 0.02 * (i % 5))
+        v[3 * i + 1] = (xs[i + 1], -0.9, 0.02 * (i % 3))
+        v[3 * i + 2] = (xs[i], 0.9, 0.01 * (i % 7))
+    tri = np.arange(3 * count, dtype=np.int32).reshape(count, 3)
+    return v, tri
+
+
+def test_large_face_fallbacks_with_more_faces_than_a_workgroup_table_holds():
+    """The per-pixel fallbacks of the gathered passes collect a workgroup's sums per face in a 64-slot LDS table (WgSums) and
+    add the rest directly: 200 needle triangles @1024^2 are all over the box limit, and a workgroup's run of pixels crosses a
+    hundred of them -- the table overflows in every workgroup (150 needles, each owning ~2 300 pixels in a box of ~5 000).  Depth mode against the operator sequence, and the lit
+    render (textures, light, depth) against the materialised sequence."""
+    nr = _nr()
+    v_np, tri_np = _needles(150)
+    tri = torch.from_numpy(tri_np).cuda()[None]
+    eye = [0.0, 0.0, -1.9]
+    res = []
+    for on in (True, False):
+        r = nr.Renderer(image_size=1024, anti_aliasing=False, camera_mode="look_at", fill_back=True)
+        r.eye, r.mesh_modes = eye, on
+        v = torch.from_numpy(v_np).cuda()[None].requires_grad_(True)
+        image = r.render_depth(v, tri)
+        w = torch.linspace(0.3, 1.2, 1024, device="cuda")[None, :, None] * torch.linspace(1.0, 0.5, 1024, device="cuda")[None, None, :]
+        (image.clamp(max=10) * w).sum().backward()
+        res.append((image.detach(), v.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    covered = float((res[0][0] < 50).float().sum())
+    assert 2 * covered / 150 > 4096, covered          # (a needle's box = twice its area: over the limit of 4 096 pixels)
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 5e-5 * float(res[1][1].abs().max()) > 0
+    tex = torch.rand(1, tri_np.shape[0], 2, 2, 2, 3, device="cuda")
+    out = []
+    for fly in (True, False):
+        r = nr.Renderer(image_size=1024, anti_aliasing=False, camera_mode="look_at", light_direction=[0.3, 0.8, -0.5])
+        r.eye, r.lighting_on_the_fly = eye, fly
+        vv = torch.from_numpy(v_np).cuda()[None].requires_grad_(True)
+        tt = tex.clone().requires_grad_(True)
+        rgb, depth, alpha = r(vv, tri, tt)
+        w3 = torch.linspace(0.5, 1.5, 1024, device="cuda")[None, None, :, None]
+        ((rgb * w3).sum() + depth.clamp(max=5).sum()).backward()
+        out.append((rgb.detach(), vv.grad.clone(), tt.grad.clone()))
+    assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6)
+    for k in (1, 2):
+        assert float((out[0][k] - out[1][k]).abs().max()) <= 1e-3 * float(out[1][k].abs().max()) > 0
