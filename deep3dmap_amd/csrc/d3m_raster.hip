@@ -263,7 +263,8 @@ static bool bidding_preferred(int B, long triangles, int S) {
     if ((double)S * S < 1.5 * (double)triangles) return true;
     // (the more views, the more waves bidding has to work with: the crossover moves from ~10 raster pixels per triangle at
     //  one view to ~25 at eight -- 19 602 triangles @512^2: lists 15 us ahead at one view, bidding 22 us ahead at eight)
-    const double px_per_tri = std::min(10.0 + 2.0 * (B - 1), 32.0);
+    //  -- provided the batch has the faces for it: 8 views of 722 triangles @128^2 are 90 waves, 0.169 ms bidding, 0.12 binned)
+    const double px_per_tri = (double)B * (double)triangles < 65536.0 ? 10.0 : std::min(10.0 + 2.0 * (B - 1), 32.0);
     return !big_batch(B, triangles, S) && (double)S * S <= px_per_tri * (double)triangles;
 }
 // Whether a launch is a "big batch" in that sense -- what the lit render node takes for "every kernel fills the chip by

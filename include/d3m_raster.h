@@ -84,8 +84,8 @@ int d3m_get_coverage_form(void);
 /* The form (0 | 1) a launch of d3m_forward_face_index_map_mesh on `batch_size` views of a mesh of `num_triangles` triangles
  * (before fill_back) at `image_size` takes with a workspace of d3m_forward_workspace_bytes(); -1 for invalid sizes.  The
  * automatic choice: bidding for sub-pixel triangles (more than two per three raster pixels) whatever the batch; per-tile
- * lists for big batches (d3m_forward_big_batch) and for coarse meshes (more than 10 + 2 (views - 1), at most 32, raster
- * pixels per triangle); bidding otherwise. */
+ * lists for big batches (d3m_forward_big_batch) and for coarse meshes (more than 10 raster pixels per triangle; with at
+ * least 65 536 (view, triangle) pairs in the batch more than 10 + 2 (views - 1), at most 32); bidding otherwise. */
 int d3m_forward_coverage_form(int batch_size, int num_triangles, int image_size);
 /* 1 when the launch is a BIG BATCH of an ordinary mesh (more than 65 536 blocks of 8 x 8 pixels, triangles not sub-pixel):
  * every kernel of a step fills the chip by itself, and a caller's side branches cost more than they hide. */
