@@ -16,4 +16,10 @@ done <<'L'
 --views-per-gpu 16 --image-size 2048 --mesh-n 225
 --views-per-gpu 2 --image-size 2048 --mesh-n 36
 --views-per-gpu 64 --image-size 256 --mesh-n 164 --anti-aliasing
+--views-per-gpu 256 --image-size 128 --mesh-n 100
+--views-per-gpu 4 --image-size 512 --mesh-n 20 --anti-aliasing
+--views-per-gpu 1 --image-size 1500 --mesh-n 100
+--views-per-gpu 3 --image-size 333 --mesh-n 77
+--views-per-gpu 32 --image-size 512 --mesh-n 36
+--views-per-gpu 32 --image-size 512 --mesh-n 64 --texture-size 4
 L
