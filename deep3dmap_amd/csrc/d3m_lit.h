@@ -908,6 +908,8 @@ __global__ void __launch_bounds__(256) k_backward_textures_lit_faces(LitFaceArgs
 // LDS (192 floats at ts = 4, thirty-two faces per workgroup) instead of registers: a corner's texel depends on the pixel.
 // (ts = 1 keeps the per-pixel pass: its corners reach into the FOLLOWING faces' texels, KCU:229-233.)
 constexpr int LIT_ANY_MAX_TEXELS = 64;
+// (LANES: LIT_LANES, or a whole wave per face on coarse meshes -- as lit_face_backward)
+template <int LANES>
 __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long gi, int sub, float* __restrict__ acc_lds) {
     const LitTextures& lt = a.lt;
     const int S = a.S, Fp = lt.Fp, ts = lt.ts, ts3 = ts * ts * ts;
@@ -927,10 +929,10 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
     if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
         a.flags[gi] = FLAG_LARGE;
         if (sub == 0) atomicAdd(a.n_large, 1);
-        for (int t = sub; t < ts3 * 3; t += LIT_LANES) gt[t] = 0.0f;
+        for (int t = sub; t < ts3 * 3; t += LANES) gt[t] = 0.0f;
         return;
     }
-    for (int t = sub; t < ts3 * 3; t += LIT_LANES) acc_lds[t] = 0.0f;
+    for (int t = sub; t < ts3 * 3; t += LANES) acc_lds[t] = 0.0f;
     float dacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dtmp[3] = {0, 0, 0};
     if (a.grad_depth_map) {
         float finv[9];
@@ -947,8 +949,8 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // (the zeroes before the first sums: one wave, in order)
     __builtin_amdgcn_wave_barrier();
     const size_t base = (size_t)bn * S * S;
-    BoxCursorN<LIT_LANES> c(x0, x1, y0, sub);
-    for (int i = sub; i < area; i += LIT_LANES, c.advance()) {
+    BoxCursorN<LANES> c(x0, x1, y0, sub);
+    for (int i = sub; i < area; i += LANES, c.advance()) {
         const size_t p = base + (size_t)c.y * S + c.x;
         // (the pixel's maps are requested together with its owner: one round trip per step of the scan)
         const bool own = a.face_index_map[p] == fn;
@@ -980,7 +982,7 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
     }
     if (a.grad_depth_map) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) dacc[k] = lit_sum(dacc[k]);
+        for (int k = 0; k < 9; k++) dacc[k] = lit_lanes_sum<LANES>(dacc[k]);
         if (sub == 0) {
             if (a.vt.gv) {
 #pragma unroll
@@ -1000,7 +1002,7 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float gl[3] = {0, 0, 0};
-    for (int t = sub; t < ts3; t += LIT_LANES) {
+    for (int t = sub; t < ts3; t += LANES) {
         // texel t = (a,b,c) of the virtual face is texel (c,b,a) of the original one for the back copy (NR/renderer.py:156)
         const int to = back ? (t % ts) * ts * ts + ((t / ts) % ts) * ts + t / (ts * ts) : t;
 #pragma unroll
@@ -1011,21 +1013,23 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
         }
     }
 #pragma unroll
-    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_sum(gl[c3]);
+    for (int c3 = 0; c3 < 3; c3++) gl[c3] = lit_lanes_sum<LANES>(gl[c3]);
     if (a.grad_light && sub == 0) {
 #pragma unroll
         for (int c3 = 0; c3 < 3; c3++) atomicAdd(&a.grad_light[3 * (size_t)lrow + c3], gl[c3]);
     }
 }
 // over the compacted visibility list only (a fixed grid striding, as k_backward_textures_lit_faces with a list)
+template <int LANES = LIT_LANES>
 __global__ void __launch_bounds__(256) k_backward_textures_lit_faces_any(LitFaceArgs a) {
-    __shared__ float s_acc[LIT_FACES_PER_BLOCK][LIT_ANY_MAX_TEXELS * 3];
-    const int sub = threadIdx.x % LIT_LANES, slot = threadIdx.x / LIT_LANES;
+    constexpr int PER_BLOCK = 256 / LANES;
+    __shared__ float s_acc[PER_BLOCK][LIT_ANY_MAX_TEXELS * 3];
+    const int sub = threadIdx.x % LANES, slot = threadIdx.x / LANES;
     const int n = *a.n_list;
-    const XcdOrder xo((n + LIT_FACES_PER_BLOCK - 1) / LIT_FACES_PER_BLOCK);
+    const XcdOrder xo((n + PER_BLOCK - 1) / PER_BLOCK);
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
-        const long base = (long)xo.unit(i) * LIT_FACES_PER_BLOCK;
-        if (base + slot < n) lit_face_backward_any(a, a.list[base + slot], sub, s_acc[slot]);
+        const long base = (long)xo.unit(i) * PER_BLOCK;
+        if (base + slot < n) lit_face_backward_any<LANES>(a, a.list[base + slot], sub, s_acc[slot]);
     }
 }
 

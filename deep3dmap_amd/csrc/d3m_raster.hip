@@ -1401,9 +1401,11 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         // texture cubes of 3^3 / 4^3 texels over the visibility list: the same three launches as ts = 2, the face's sums in LDS
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
                        grad_faces, vt, flags, skip_zero ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
-        const unsigned all_blocks = blocks_for(nf, LIT_FACES_PER_BLOCK);
-        LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces_any,
-               dim3(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8), dim3(256), st, fa);
+        const bool coarse = (double)S * S > 48.0 * (double)num_tri;          // (a wave per face: as at ts = 2)
+        const unsigned all_blocks = blocks_for(nf, coarse ? 4 : LIT_FACES_PER_BLOCK);
+        const dim3 g_faces(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8);
+        if (coarse) LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces_any<64>, g_faces, dim3(256), st, fa);
+        else LAUNCH("k_backward_textures_lit_faces", k_backward_textures_lit_faces_any<>, g_faces, dim3(256), st, fa);
         FitFin fin;
         memset(&fin, 0, sizeof(fin));
         if (records && unscaled->scratch && unscaled->loss && (unscaled->flags & D3M_FIT_FINISH_DEFERRED))

@@ -644,11 +644,14 @@ def test_fit_objective_inside_the_rendering_node_large_faces():
         assert float((ga - gb).abs().max()) <= 2e-5 * float(gb.abs().max())
 
 
+@pytest.mark.parametrize("size", [40, 160])
 @pytest.mark.parametrize("ts", [1, 2, 3, 4])
 @pytest.mark.parametrize("shared", [False, True])
-def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
+def test_on_the_fly_lighting_matches_materialised_path(ts, shared, size):
     """render() with fill_back + lighting applied inside the sampler (shared or per-view mesh/textures) against the
-    reference's sequence cat -> lighting -> rasterize on materialised arrays: same images, same gradients."""
+    reference's sequence cat -> lighting -> rasterize on materialised arrays: same images, same gradients.  At 160^2 the
+    242-triangle mesh is COARSE (more than 48 raster pixels per triangle): a wave per face in the gathered passes of
+    every texture size (k_backward_textures_lit_faces<64>, k_backward_textures_lit_faces_any<64>)."""
     nr = _nr()
     from deep3dmap_amd import synthetic
     v, tri = synthetic.grid_mesh(12)
@@ -657,7 +660,7 @@ def test_on_the_fly_lighting_matches_materialised_path(ts, shared):
     B = 3
     res = []
     for fly in (False, True):
-        r = nr.Renderer(image_size=40, anti_aliasing=False, camera_mode="look_at", light_direction=[0.3, 0.8, -0.5],
+        r = nr.Renderer(image_size=size, anti_aliasing=False, camera_mode="look_at", light_direction=[0.3, 0.8, -0.5],
                         background_color=[0.1, 0.2, 0.3])
         r.eye = eyes
         r.lighting_on_the_fly = fly
