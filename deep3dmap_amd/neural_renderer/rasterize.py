@@ -953,8 +953,9 @@ class _RasterizeMeshModes(torch.autograd.Function):
     index tensor and leaves the dense copy, the visibility list and the edge plan behind, and backward adds the edge
     gradient (K4, alpha) and the depth gradient (K6, over the listed faces) straight into the screen-space gradient of
     the VERTICES (d3m_vertex_target), which the camera's adjoint takes to the mesh.  No [B,F',3,3] gather, no dense
-    grad_faces, no scatter-add pass, no pass over face_index_map for the visibility flags: the 32-view silhouette step
-    1.57 -> see profiles/, same images bit for bit (tests/test_gpu_renderer.py)."""
+    grad_faces, no scatter-add pass, no pass over face_index_map for the visibility flags, no epilogue pass without
+    anti-aliasing: the 32-view silhouette step 1.57 -> 1.21 ms, the depth step 1.12 -> 0.66, same images bit for bit
+    (tests/test_gpu_renderer.py; docs/EXPERIMENTS.md C)."""
 
     @staticmethod
     def forward(ctx, vertices, tri, camera, fill_back, image_size, anti_aliasing, near, far, eps, return_alpha, return_depth):
