@@ -10,8 +10,15 @@ LIB_PATH = os.path.join(LIB_DIR, "libd3m_raster.so")
 # product library; build_library() ignores it.
 LOAD_PATH = os.environ.get("D3M_LIB_PATH", LIB_PATH)
 SOURCES = ["d3m_raster.hip"]
-HEADERS = ["d3m_launch.h", "d3m_device.h", "d3m_forward.h", "d3m_backward.h", "d3m_edge_grad.h", "d3m_face_major.h", "d3m_lit.h", "d3m_aux.h", "d3m_textures.h", "d3m_mesh.h", "d3m_uv.h", "d3m_g2s.h", "d3m_bid.h",
-           os.path.join("..", "..", "include", "d3m_raster.h")]
+
+
+def _headers():
+    """Every header the one translation unit can include: all of csrc/*.h (listed by hand up to round 5, and two were
+    forgotten: an edit to the step's first / last launch did not mark the library stale) and the C ABI's header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(_PKG, "..", "include", "d3m_raster.h")]
+
+
 # -ffp-contract=off: every f32 operation rounds once, so coverage decisions are bit-identical to the
 # reference algorithm evaluated without FMA contraction (DESIGN.md, "Arithmetic contract").
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -22,7 +29,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in [os.path.join(CSRC, s) for s in SOURCES] + _headers())
 
 
 def build_library(force=False, verbose=False):

@@ -39,6 +39,43 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.d3m_error_string(2) == b"workspace missing or too small"
 
 
+def test_any_header_edit_marks_the_library_stale(tmp_path, monkeypatch):
+    """build._stale(): the library is rebuilt when ANY file the translation unit includes is newer than it -- the list is
+    derived from csrc/*.h (round 5's hand-written one had lost d3m_front.h and d3m_tail.h) -- and every quoted #include of
+    the sources resolves to a file of that list."""
+    import shutil
+    from deep3dmap_amd import build
+    headers = build._headers()
+    names = {os.path.basename(h) for h in headers}
+    assert {"d3m_front.h", "d3m_tail.h", "d3m_edge_grad.h", "d3m_raster.h"} <= names
+    for f in headers + [os.path.join(build.CSRC, s) for s in build.SOURCES]:
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(f).read()):
+            assert os.path.basename(inc) in names, (f, inc)
+    # a copy of the tree's layout with controlled time stamps: the library newer than everything, then one file touched
+    pkg = tmp_path / "pkg"
+    (pkg / "csrc").mkdir(parents=True)
+    (pkg / "lib").mkdir()
+    (tmp_path / "include").mkdir()
+    for f in headers + [os.path.join(build.CSRC, s) for s in build.SOURCES]:
+        dst = (tmp_path / "include" if os.path.basename(f) == "d3m_raster.h" else pkg / "csrc") / os.path.basename(f)
+        shutil.copy(f, dst)
+        os.utime(dst, (1000, 1000))
+    lib = pkg / "lib" / "libd3m_raster.so"
+    lib.write_bytes(b"")
+    os.utime(lib, (2000, 2000))
+    monkeypatch.setattr(build, "_PKG", str(pkg))
+    monkeypatch.setattr(build, "CSRC", str(pkg / "csrc"))
+    monkeypatch.setattr(build, "LIB_PATH", str(lib))
+    assert not build._stale()
+    touched = [os.path.join(build.CSRC, s) for s in build.SOURCES] + build._headers()
+    assert len(touched) == len(headers) + len(build.SOURCES)
+    for f in touched:
+        os.utime(f, (3000, 3000))
+        assert build._stale(), f
+        os.utime(f, (1000, 1000))
+        assert not build._stale()
+
+
 def test_coverage_form_switch_is_host_state():
     """d3m_set_coverage_form: -1 / 0 / 1 accepted and read back, anything else D3M_ERR_INVALID and no change; the
     context manager restores the previous form (no launch involved: runs without a GPU)."""
