@@ -69,6 +69,8 @@ _SIGNATURES = {
     "d3m_forward_workspace_min_bytes": (_SZ, [_I, _I, _I]),
     "d3m_set_coverage_form": (_I, [_I]),
     "d3m_get_coverage_form": (_I, []),
+    "d3m_set_deterministic": (_I, [_I]),
+    "d3m_get_deterministic": (_I, []),
     "d3m_forward_coverage_form": (_I, [_I, _I, _I]),
     "d3m_forward_big_batch": (_I, [_I, _I, _I]),
     "d3m_forward_face_index_map": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _SZ, _P]),
@@ -235,6 +237,22 @@ class coverage_form:
 
     def __exit__(self, *exc):
         lib().d3m_set_coverage_form(self.previous)
+        return False
+
+
+class deterministic:
+    """Context manager: the visibility list in ascending face order (d3m_set_deterministic) inside the block."""
+
+    def __init__(self, on=True):
+        self.on = int(bool(on))
+
+    def __enter__(self):
+        self.previous = lib().d3m_get_deterministic()
+        check(lib().d3m_set_deterministic(self.on), "d3m_set_deterministic")
+        return self
+
+    def __exit__(self, *exc):
+        lib().d3m_set_deterministic(self.previous)
         return False
 
 

@@ -220,8 +220,13 @@ def multiview_fit_loss(rgb, depth, alpha, rgb_target, depth_target, alpha_target
                 tuple(x.shape) == (B,) + tuple(rgb.shape[2:]) for x in (depth, alpha, depth_target, alpha_target, mask)) \
                 and tuple(rgb_target.shape) == tuple(rgb.shape):
             hs = getattr(lit, "hint_state", None)
+            # ... and the same NORMALISER: a registered objective that carried a (global) mask_sum is only this call's when
+            # this call passes that very tensor, one that did not only when this call does not either (sum(mask) both times)
+            given = getattr(lit, "hint_mask_sum_given", False)
+            same_norm = (mask_sum is None and not given) or \
+                (mask_sum is not None and given and hs is not None and _same(hs[7], mask_sum.reshape(1)))
             if hs is not None and _same(hs[0], rgb_target) and _same(hs[1], depth_target) and _same(hs[2], alpha_target) \
-                    and _same(hs[3], mask) and (mask_sum is None or _same(hs[7], mask_sum.reshape(1))):
+                    and _same(hs[3], mask) and same_norm:
                 return _FitLossFromRenderNode.apply(rgb, depth, alpha, lit)
             if not lit.cfg[2]:      # (the objective on FINISHED images takes them at the internal size: no anti-aliasing)
                 return _FitLossOnLitImages.apply(rgb, depth, alpha, rgb_target, depth_target, alpha_target, mask, mask_sum, lit)

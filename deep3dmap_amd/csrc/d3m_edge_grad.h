@@ -40,6 +40,7 @@
 // inside the 1e-3 gradient tolerance.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include "d3m_backward.h"
 #include "d3m_face_major.h"
@@ -758,6 +759,9 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
     __shared__ LaneTable t;
     __shared__ float s_slope[3][256];
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    // parts < 0: up to -parts, as many as the grid has workgroups for (the number of listed faces is only known here: of a
+    // fill_back mesh a tenth of the faces own a pixel, and a small batch leaves most of a grid sized by ALL faces idle)
+    if (parts < 0) parts = max(1, min(-parts, (int)gridDim.x / max(n_blocks, 1)));
     const int n_units = n_blocks * parts;
     const XcdOrder xo(n_units);
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
@@ -1306,6 +1310,7 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
+    if (parts < 0) parts = max(1, min(-parts, (int)gridDim.x / max(n_blocks, 1)));      // (as k_edge_scatter)
     const int n_units = n_blocks * parts;
     const XcdOrder xo(n_units);
     const bool complete = plan_complete(w);      // results in record order (found through xpos), else in crossing order
@@ -1483,6 +1488,20 @@ inline VisibilityView visibility_view(void* blob, long nf) {
     return v;
 }
 
+// D3M_DETERMINISTIC (d3m_set_deterministic): the list in ASCENDING face order -- count, scan, compact: three launches
+// instead of one -- instead of chunks in arrival order.  Every pass over the list then adds its float atomics from the same
+// workgroups in every run (see DESIGN.md section 6 for what that does and does not guarantee).
+inline std::atomic<int> g_deterministic{-1};        // -1: not yet read from the environment
+inline bool deterministic_mode() {
+    int d = g_deterministic.load(std::memory_order_relaxed);
+    if (d < 0) {
+        const char* e = getenv("D3M_DETERMINISTIC");
+        d = (e && e[0] == '1') ? 1 : 0;
+        int expected = -1;
+        if (!g_deterministic.compare_exchange_strong(expected, d)) d = expected;
+    }
+    return d == 1;
+}
 inline hipError_t run_visibility(const int32_t* face_index_map, const VisibilityView& v, int B, int F, int S, hipStream_t st) {
     const long nf = (long)B * F;
     if (face_index_map) {       // NULL: the marks were left (and the count cleared) by d3m_forward_face_index_map_mesh
@@ -1491,6 +1510,14 @@ inline hipError_t run_visibility(const int32_t* face_index_map, const Visibility
         const long px_blocks = ((long)B * S * S + 255) / 256;
         LAUNCH("k_mark_visible", k_mark_visible_bytes, dim3((unsigned)std::min(px_blocks, 4096l)), dim3(256), st,
                face_index_map, v.marks, B, F, S);
+    }
+    if (deterministic_mode()) {
+        const int n_blocks = (int)((nf + EG_COMPACT_CHUNK - 1) / EG_COMPACT_CHUNK);
+        LAUNCH("k_count_visible", k_count_visible, dim3(n_blocks), dim3(256), st, (const unsigned char*)v.marks, v.vis_block, nf);
+        LAUNCH("k_scan_small", k_scan_small, dim3(1), dim3(1024), st, v.vis_block, n_blocks, (const int*)nullptr, 1, v.count);
+        LAUNCH("k_compact_visible", k_compact_visible, dim3(n_blocks), dim3(256), st, (const unsigned char*)v.marks, v.flags,
+               v.list, (const int*)v.vis_block, nf);
+        return hipGetLastError();
     }
     const int n_chunks = (int)((nf + EG_COMPACT1_FACES - 1) / EG_COMPACT1_FACES);
     LAUNCH("k_compact_visible", k_compact_visible_atomic, dim3(n_chunks), dim3(1024), st, (const unsigned char*)v.marks, v.flags,
@@ -1581,8 +1608,10 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
            (const int*)w.n_visible, EG_FACES_PER_BLOCK, w.alloc, blocks_a, (const int*)w.line_count, w.line_slice, w.alloc + 1, nl);
     // (the scatter pass keeps the by-key form: with the ranks taken from LDS cursors it was slower, 0.173 vs 0.150 ms)
     // (few blocks of faces: their rounds dealt to several workgroups each -- see the kernel)
-    const int parts = g6_full >= 2048 ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
-    const dim3 g_scatter((unsigned)std::min<long>(8192, (g6_full * parts + 7) / 8 * 8));
+    int parts = g6_full >= 2048 ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const int dev_parts = d3m_env_int("D3M_SCATTER_PARTS", 1);      // > 1: decided on the device, at most this many
+    if (parts == 1 && dev_parts > 1) parts = -dev_parts;
+    const dim3 g_scatter((unsigned)std::min<long>(8192, (g6_full * std::abs(parts) + 7) / 8 * 8));
     LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g_scatter, dim3(256), st, fs, face_index_map, S, w, parts);
     return hipGetLastError();
 }
@@ -1719,10 +1748,12 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
     // (normally leaves at once: a small grid keeps that cheap; with an undersized workspace its workgroups stride)
-    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 512u)), dim3(256), st, fs, a, w, lane_partial);
+    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, (unsigned)d3m_env_int("D3M_OVERFLOW_GRID", 512))), dim3(256), st, fs, a, w, lane_partial);
     // (few blocks of faces, sums added into a vertex target: a block's lanes dealt to several workgroups -- see the kernel)
-    const int gparts = (!vt.gv || g6_full >= 2048) ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
-    const dim3 g_gather((unsigned)std::min<long>(8192, (g6_full * gparts + 7) / 8 * 8));
+    int gparts = (!vt.gv || g6_full >= 2048) ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const int dev_gparts = d3m_env_int("D3M_GATHER_PARTS", 1);
+    if (gparts == 1 && vt.gv && dev_gparts > 1) gparts = -dev_gparts;
+    const dim3 g_gather((unsigned)std::min<long>(8192, (g6_full * std::abs(gparts) + 7) / 8 * 8));
     LAUNCH("k_edge_gather", k_edge_gather<FS>, g_gather, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt,
            gparts);
     e = hipGetLastError();

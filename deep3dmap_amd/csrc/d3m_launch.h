@@ -40,9 +40,9 @@ inline bool d3m_dev_skip(const char* name) {
 #else
 inline bool d3m_dev_skip(const char*) { return false; }
 #endif
-// D3M_TRACE_LAUNCHES=1 in the environment (debugging a hang; eager launches only, never inside a capture): every launch is
-// announced on stderr, the stream synchronised behind it and the result reported -- the last line names the kernel that
-// does not come back.
+// D3M_TRACE_LAUNCHES=1 in the environment (debugging a hang): every launch is announced on stderr, the stream synchronised
+// behind it (eager launches; inside a capture only announced) and the result reported -- the last line names the kernel that
+// does not come back.  The switch is read ONCE, at the first launch of the process: set it before anything is launched.
 #include <cstdio>
 #include <cstdlib>
 inline bool d3m_trace_launches() {
@@ -60,11 +60,23 @@ inline void d3m_trace_begin(const char* name, dim3 g, dim3 b) {
 }
 inline void d3m_trace_end(hipStream_t st) {
     if (d3m_trace_launches()) {
+        // (a stream that is being captured must not be synchronised: that invalidates the capture -- announce only)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            fprintf(stderr, "recorded (stream is capturing)\n");
+            fflush(stderr);
+            return;
+        }
         hipError_t e = hipStreamSynchronize(st);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_t0).count();
         fprintf(stderr, "%s (%.3f ms incl. the host round trip)\n", e == hipSuccess ? "done" : hipGetErrorString(e), ms);
         fflush(stderr);
     }
+}
+// integer tuning switch from the environment (developer A/B runs; the defaults are the measured choices)
+inline int d3m_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
 }
 #define LAUNCH(name, kernel, grid, block, stream, ...)                          \
     do {                                                                        \

@@ -375,6 +375,12 @@ __global__ void __launch_bounds__(256, D3M_EPI_MINWAVES) k_render_lit_epilogue(c
 // plus each line's non-zero extent.  k_pack_maps and the unscaled g_rgb / g_alpha maps (16 B per pixel written here,
 // 36 B read there) disappear from the step; the gathered texture pass reads grad.yzw (one 16-byte load instead of three
 // dwords).  A 32x32 tile per workgroup, so that the column extents are merged in LDS (one atomic per column and tile).
+// the lanes of this thread's tile row (TILE consecutive lanes of the wave) out of a wave ballot
+template <int TILE>
+__device__ __forceinline__ unsigned tile_row_mask(unsigned long long ball) {
+    const int sub = (int)(threadIdx.x & 63) / TILE;
+    return (unsigned)(ball >> (sub * TILE)) & (TILE == 32 ? 0xFFFFFFFFu : (1u << (TILE & 31)) - 1u);
+}
 struct FitRecords {
     float4* grad;          // [B,S,S]
     float2* dot;           // [B,S,S]
@@ -389,6 +395,10 @@ struct FitRecords {
 #ifndef D3M_FIT_MINWAVES
 #define D3M_FIT_MINWAVES 4
 #endif
+// TILE: 32 (four pixels per thread, eight rows apart) for big batches; 16 (one pixel per thread) for small ones -- one view
+// at 512^2 is 256 tiles of 32 x 32, ONE wave per SIMD with four dependent pixels each: 25-31 us whatever the mesh (round 5's
+// floor of every small configuration); as 1024 tiles of 16 x 16 the same pixels are four waves per SIMD with one pixel each.
+template <int TILE>
 __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_records(const float* __restrict__ faces, LitTextures lt,
                                                                const int32_t* __restrict__ face_index_map,
                                                                const float* __restrict__ weight_map,
@@ -398,17 +408,19 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
                                                                float* __restrict__ rgb_out, float* __restrict__ alpha_out,
                                                                float* __restrict__ depth_out,
                                                                int B, int S, float eps, FitTargets fit, FitRecords rec) {
+    static_assert(TILE == 32 || TILE == 16, "tile of 32 x 32 or 16 x 16 pixels");
+    constexpr int ROWS = 256 / TILE;                          // rows of the tile per step of the workgroup
     __shared__ float4 s_part[4];
-    __shared__ int s_col_lo_inv[32], s_col_hi1[32];
-    if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
+    __shared__ int s_col_lo_inv[TILE], s_col_hi1[TILE];
+    if (threadIdx.x < TILE) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
-    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int b = blockIdx.z, x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
     const float* bg = background + (size_t)(bg_b > 1 ? b : 0) * 3;
     const float inv_pixels = 1.0f / (float)((long)S * S), inv_3den = 1.0f / (3.0f * *rec.mask_sum);
     float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
     auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
-    for (int r = ty; r < 32; r += 8) {
+    for (int r = ty; r < TILE; r += ROWS) {
         const int yi = y0 + r, xi = x0 + tx;                  // internal pixel; row 0 = bottom (rasterize.py:311-317)
         bool nz = false;
         if (yi < S && xi < S) {
@@ -458,9 +470,8 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
                 nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
             }
         }
-        if (rec.grad) {     // non-zero extents: this tile's share of row yi (one half-wave = one tile row) and of its 32 columns
-            const unsigned long long ball = __ballot(nz);
-            const unsigned half = (threadIdx.x & 32) ? (unsigned)(ball >> 32) : (unsigned)ball;
+        if (rec.grad) {     // non-zero extents: this tile's share of row yi (TILE lanes of a wave = one tile row) and of its columns
+            const unsigned half = tile_row_mask<TILE>(__ballot(nz));
             if (half != 0 && tx == 0) {
                 const size_t line = ((size_t)b * 2 + 1) * S + (y0 + r);
                 atomicMax(&rec.nz_lo_inv[line], S - (x0 + (__ffs((int)half) - 1)));
@@ -473,7 +484,7 @@ __global__ void __launch_bounds__(256, D3M_FIT_MINWAVES) k_render_lit_fit_record
         }
     }
     __syncthreads();
-    if (rec.grad && threadIdx.x < 32 && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
+    if (rec.grad && threadIdx.x < TILE && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
         const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
         atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
         atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);
@@ -593,20 +604,22 @@ __global__ void __launch_bounds__(256, 3) k_render_lit_fit_records_pooled(
 // an output pixel is an internal pixel), so partial sums, records, extents and the depth gradient are bit-identical to
 // its own -- and backward takes the records route: no gradient images, no k_fit_loss_grad, no k_pack_maps.  Reads
 // 20 B (images) + 24 B (targets) + 4 B (owner) per pixel, writes 28 B.
+template <int TILE>
 __global__ void __launch_bounds__(256) k_fit_loss_records(const float* __restrict__ rgb_im, const float* __restrict__ depth_im,
                                                          const float* __restrict__ alpha_im,
                                                          const int32_t* __restrict__ face_index_map, int B, int S,
                                                          FitTargets fit, FitRecords rec) {
+    constexpr int ROWS = 256 / TILE;
     __shared__ float4 s_part[4];
-    __shared__ int s_col_lo_inv[32], s_col_hi1[32];
-    if (threadIdx.x < 32) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
+    __shared__ int s_col_lo_inv[TILE], s_col_hi1[TILE];
+    if (threadIdx.x < TILE) { s_col_lo_inv[threadIdx.x] = 0; s_col_hi1[threadIdx.x] = 0; }
     __syncthreads();
-    const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int b = blockIdx.z, x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int tx = threadIdx.x % TILE, ty = threadIdx.x / TILE;
     const float inv_pixels = 1.0f / (float)((long)S * S), inv_3den = 1.0f / (3.0f * *rec.mask_sum);
     float t_rgb = 0, t_d = 0, t_m = 0, t_sse = 0;
     auto sgn = [](float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); };
-    for (int r = ty; r < 32; r += 8) {
+    for (int r = ty; r < TILE; r += ROWS) {
         const int yi = y0 + r, xi = x0 + tx;                  // internal pixel; row 0 = bottom (rasterize.py:311-317)
         bool nz = false;
         if (yi < S && xi < S) {
@@ -641,8 +654,7 @@ __global__ void __launch_bounds__(256) k_fit_loss_records(const float* __restric
             rec.g_depth[p] = sgn(depth - tg[3]) * m;
             nz = g.x != 0 || g.y != 0 || g.z != 0 || g.w != 0 || dot != 0;
         }
-        const unsigned long long ball = __ballot(nz);
-        const unsigned half = (threadIdx.x & 32) ? (unsigned)(ball >> 32) : (unsigned)ball;
+        const unsigned half = tile_row_mask<TILE>(__ballot(nz));
         if (half != 0 && tx == 0) {
             const size_t line = ((size_t)b * 2 + 1) * S + (y0 + r);
             atomicMax(&rec.nz_lo_inv[line], S - (x0 + (__ffs((int)half) - 1)));
@@ -654,7 +666,7 @@ __global__ void __launch_bounds__(256) k_fit_loss_records(const float* __restric
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32 && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
+    if (threadIdx.x < TILE && s_col_hi1[threadIdx.x] != 0 && x0 + (int)threadIdx.x < S) {
         const size_t line = ((size_t)b * 2 + 0) * S + (x0 + threadIdx.x);
         atomicMax(&rec.nz_lo_inv[line], s_col_lo_inv[threadIdx.x]);
         atomicMax(&rec.nz_hi1[line], s_col_hi1[threadIdx.x]);

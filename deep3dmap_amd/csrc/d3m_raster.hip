@@ -245,6 +245,13 @@ D3M_EXPORT int d3m_set_coverage_form(int form) {
     return D3M_OK;
 }
 D3M_EXPORT int d3m_get_coverage_form(void) { return coverage_form(); }
+D3M_EXPORT int d3m_set_deterministic(int on) {
+    if (on != 0 && on != 1) return D3M_ERR_INVALID;
+    (void)deterministic_mode();
+    g_deterministic.store(on);
+    return D3M_OK;
+}
+D3M_EXPORT int d3m_get_deterministic(void) { return deterministic_mode() ? 1 : 0; }
 // Which form of coverage a launch takes (d3m_set_coverage_form: forced).  Sub-pixel triangles (more than two per three
 // raster pixels: BASELINE config 5) bid whatever the batch; big batches of ordinary meshes (more than BID_MAX_TILES blocks
 // of 8 x 8 pixels: the headline's 32 views) go through per-tile lists; small batches bid -- UNLESS the mesh is coarse (round
@@ -1124,9 +1131,20 @@ D3M_EXPORT int d3m_forward_texture_sampling_lit(const float* faces, const float*
 struct FitScratch {
     size_t off_partials, off_group_sums, off_tickets, ticket_words, floats;
 };
+// Tile edge of the records form of the objective's pass (k_render_lit_fit_records<TILE>, k_fit_loss_records<TILE>): 16 -- one
+// pixel per thread, four times the workgroups -- while the batch has at most FIT_TILE16_MAX_PIXELS pixels (a pass of a
+// few hundred 32 x 32 tiles is one wave per SIMD with four dependent pixels each: 25-31 us for ANY small batch, round 5),
+// 32 above.  A function of the launch's size alone: the objective's finish, which may run from another entry point, must
+// find the same partial sums.
+static const long FIT_TILE16_MAX_PIXELS = 4l << 20;
+static int fit_tile(int B, int S) {
+    const long limit = (long)d3m_env_int("D3M_FIT_TILE16_MAX_PIXELS", (int)FIT_TILE16_MAX_PIXELS);
+    return (long)B * S * S <= limit ? 16 : 32;
+}
 static FitScratch fit_scratch_layout(int B, int S) {
     const size_t per_pixels = blocks_for((long)B * S * S, 256);
-    const size_t tiles = (size_t)B * ((S + 31) / 32) * ((S + 31) / 32);
+    const size_t tiles32 = (size_t)B * ((S + 31) / 32) * ((S + 31) / 32), tiles16 = (size_t)B * ((S + 15) / 16) * ((S + 15) / 16);
+    const size_t tiles = tiles32 > tiles16 ? tiles32 : tiles16;       // (room for either tile size: see fit_tile)
     const size_t P = per_pixels > tiles ? per_pixels : tiles;
     const size_t G = std::max((size_t)B, (per_pixels + 255) / 256);
     FitScratch L;
@@ -1169,8 +1187,10 @@ static FitFin make_fit_fin(const d3m_fit_targets* fit, int B, int S, int s, int 
                   (unsigned*)(fit->scratch + L.off_tickets), n_partials, group_size, (n_partials + group_size - 1) / group_size,
                   (float)((long)s * s), fit->mask_sum, fit->scratch, fit->loss};
 }
-static FitFin fit_fin_of_tiles(const d3m_fit_targets* fit, int B, int S) {     // the records form: a view's 32x32 tiles
-    const int tiles = ((S + 31) / 32) * ((S + 31) / 32);
+static FitFin fit_fin_of_tiles(const d3m_fit_targets* fit, int B, int S) {     // the records form: a view's tiles
+    // (the pooled form -- anti-aliasing -- keeps 32 x 32 internal pixels per workgroup)
+    const int T = (fit->flags & D3M_FIT_POOLED) ? 32 : fit_tile(B, S);
+    const int tiles = ((S + T - 1) / T) * ((S + T - 1) / T);
     return make_fit_fin(fit, B, S, (fit->flags & D3M_FIT_POOLED) ? S / 2 : S, B * tiles, tiles);
 }
 static int clear_fit_tickets(const d3m_fit_targets* fit, int B, int S, hipStream_t st) {
@@ -1210,14 +1230,19 @@ D3M_EXPORT int d3m_render_lit_epilogue(const float* faces, const float* textures
         if (!fit->edge_dot || !fit->edge_nz_lo_inv || !fit->edge_nz_hi1 || !fit->mask_sum || !fit->grad_depth_map)
             return D3M_ERR_INVALID;
         const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
+        const dim3 tiles16((image_size + 15) / 16, (image_size + 15) / 16, batch_size);
         FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
                        fit->grad_depth_map};
         if (anti_aliasing)
             LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records_pooled, tiles, dim3(256), st, faces, lt,
                    face_index_map, weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out,
                    alpha_out, depth_out, batch_size, image_size, eps, ft, rec);
+        else if (fit_tile(batch_size, image_size) == 16)
+            LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records<16>, tiles16, dim3(256), st, faces, lt, face_index_map,
+                   weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
+                   depth_out, batch_size, image_size, eps, ft, rec);
         else
-            LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records, tiles, dim3(256), st, faces, lt, face_index_map,
+            LAUNCH("k_render_lit_fit_records", k_render_lit_fit_records<32>, tiles, dim3(256), st, faces, lt, face_index_map,
                    weight_map, depth_map, background, background_batch, rgb_blended, alpha_map, rgb_out, alpha_out,
                    depth_out, batch_size, image_size, eps, ft, rec);
         // *fit->loss: a launch of its own (k_fit_finish, two levels), or -- D3M_FIT_FINISH_DEFERRED -- left to the caller's
@@ -1261,11 +1286,14 @@ D3M_EXPORT int d3m_fit_loss_records(const float* rgb, const float* depth, const 
     if (fit->flags & (D3M_FIT_FINISH_DEFERRED | D3M_FIT_POOLED)) return D3M_ERR_INVALID;      // (finished images: no pooling here)
     hipStream_t st = (hipStream_t)stream;
     if (int rc = clear_fit_tickets(fit, batch_size, image_size, st)) return rc;
-    const dim3 tiles((image_size + 31) / 32, (image_size + 31) / 32, batch_size);
     FitRecords rec{(float4*)fit->edge_grad, (float2*)fit->edge_dot, fit->edge_nz_lo_inv, fit->edge_nz_hi1, fit->mask_sum,
                    fit->grad_depth_map};
-    LAUNCH("k_fit_loss_records", k_fit_loss_records, tiles, dim3(256), st, rgb, depth, alpha, face_index_map, batch_size,
-           image_size, ft, rec);
+    if (fit_tile(batch_size, image_size) == 16)
+        LAUNCH("k_fit_loss_records", k_fit_loss_records<16>, dim3((image_size + 15) / 16, (image_size + 15) / 16, batch_size),
+               dim3(256), st, rgb, depth, alpha, face_index_map, batch_size, image_size, ft, rec);
+    else
+        LAUNCH("k_fit_loss_records", k_fit_loss_records<32>, dim3((image_size + 31) / 32, (image_size + 31) / 32, batch_size),
+               dim3(256), st, rgb, depth, alpha, face_index_map, batch_size, image_size, ft, rec);
     const FitFin fin = fit_fin_of_tiles(fit, batch_size, image_size);
     LAUNCH("k_fit_finish", k_fit_finish, dim3(fin.n_groups), dim3(256), st, fin);
     return check_launch();

@@ -38,6 +38,7 @@ class CapturedStep:
         self.graph = None               # the parts' graphs once captured
         self._static_out = None
         self._last_eager_out = None
+        self._scratch_refs = None
 
     def _run_parts(self, run):
         out = None
@@ -100,6 +101,10 @@ class CapturedStep:
             if gc_was_on:
                 gc.enable()
         self.graph = graphs
+        # the library's cached scratch buffers this capture baked into the graphs live as long as the graphs do, whatever the
+        # (bounded) cache does with its entries meanwhile
+        from .neural_renderer import rasterize_ops
+        self._scratch_refs = rasterize_ops.take_captured_refs()
         cur.wait_stream(self.stream)
         return self
 
@@ -107,3 +112,4 @@ class CapturedStep:
         """Back to eager execution (still on the dedicated stream)."""
         self.graph = None
         self._static_out = None
+        self._scratch_refs = None

@@ -221,7 +221,7 @@ def _vec3_host(x):
     return np.ctypeslib.as_ctypes(a)
 
 
-_side_streams = {}
+_side_streams = ops.StreamKeyedCache(max_per_kind=64)     # ((device index, which), forking stream handle) -> torch.cuda.Stream
 
 
 def _serial_branches(batch, num_tri, image_size):
@@ -244,10 +244,12 @@ def _side_stream(device, which=0, serial=False):
     if serial:
         return torch.cuda.current_stream(device)
     index = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(device).cuda_stream, which)       # one set per stream that forks
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
+    key = ((index, which), torch.cuda.current_stream(device).cuda_stream)     # one set per stream that forks
+    stream = _side_streams.get(key)
+    if stream is None:
+        stream = torch.cuda.Stream(device=device)
+        _side_streams.put(key, stream)
+    return stream
 
 
 MAX_VIEW_GROUPS = 3       # every group brings two streams; a captured step with ten concurrent branches made hipGraphLaunch
@@ -423,6 +425,9 @@ class _RasterizeLit(torch.autograd.Function):
         light = torch.empty(Bl, Fp, 3, dtype=torch.float32, device=dev)        # (filled by the first launch, below)
         background = _background_tensor(background_color, dev)
         need_grad = any(ctx.needs_input_grad[:4])
+        # the GEOMETRY side of backward (edge gradient K4, depth gradient K6, the light's and the camera's adjoints) only
+        # exists for a mesh that wants a gradient: a texture-only optimisation builds no plan and walks no line
+        need_geom = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         groups = _group_bounds(B, view_groups)
         G = len(groups)
         # Everything the branches write is allocated here, on the current stream: no tensor changes its owning stream.
@@ -443,7 +448,7 @@ class _RasterizeLit(torch.autograd.Function):
         # ... and so is the edge gradient's plan (where the visible faces' edges cross the pixel grid, by image line):
         # geometry only, so it is built on the same branch and the backward pass starts with the line walk
         plan = [torch.empty(int(L.d3m_edge_plan_bytes(hi - lo, Fp, S)), dtype=torch.uint8, device=dev) for lo, hi in groups] \
-            if need_grad else None
+            if need_geom else None
         s_out = S // 2 if anti_aliasing else S
         rgb = alpha = depth = loss_g = None
         fit_state = None
@@ -537,7 +542,7 @@ class _RasterizeLit(torch.autograd.Function):
             os.environ.get("D3M_NO_PRECLEAR") != "1"
         if step_mode:
             pre = _RasterizeLit._backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera is not None,
-                                                  B, V, Ft, ts, Bl, fill_back, idr)
+                                                  B, V, Ft, ts, Bl, fill_back, idr, need_geom)
             if len(clears) + len(pre["clears"]) <= _lib.FRONT_RANGES:
                 clears += pre["clears"]
             else:
@@ -559,7 +564,7 @@ class _RasterizeLit(torch.autograd.Function):
         # on the same stream and (if captured) in the same capture, may leave that branch open at the end of forward
         # (defer_plan_join): backward waits for the plan where it first needs it and joins the branch, which runs on
         # under the loss and the first backward passes.  The outputs are then only valid after backward.
-        plan_ready = [] if (vis is not None and defer_plan_join and G == 1) else None   # (G > 1: capture crashes, as above)
+        plan_ready = [] if (plan is not None and defer_plan_join and G == 1) else None   # (G > 1: capture crashes, as above)
         vis_ready, vis_on_main = None, False
         for k in range(G):
             if mains[k] is not cur:
@@ -579,7 +584,12 @@ class _RasterizeLit(torch.autograd.Function):
                     _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), None, Bg, S, float(near), float(far), _lib.ptr(ws),
                     ws.numel(), _lib.ptr(vis[k]) if vis is not None else None, vis[k].numel() if vis is not None else 0,
                     flags_fwd, _lib.stream_ptr()), "d3m_forward_face_index_map_mesh")
-                if vis is not None:
+                if vis is not None and plan is None:
+                    # (texture-only: the list is all backward needs -- on this stream, no branch)
+                    _lib.check(L.d3m_visibility(None, _lib.ptr(vis[k]), vis[k].numel(), Bg, Fp, S, _lib.stream_ptr()),
+                               "d3m_visibility")
+                    vis_on_main = True
+                elif vis is not None:
                     # ONE FORK, BEHIND THE VISIBILITY LIST (round 5).  The list has two readers -- the plan (side branch) and
                     # backward's gathered pass (this stream) -- and the coverage pass two as well (the list, the sampling
                     # pass).  Forked behind coverage, a replayed graph's critical chain (coverage -> list -> plan -> line
@@ -636,6 +646,9 @@ class _RasterizeLit(torch.autograd.Function):
         ctx.maps = m
         ctx.fit = None if hinted else fit_state
         ctx.hint_state = fit_state if hinted else None
+        # (whether the registered objective brought its normaliser or the node took sum(mask): multiview_fit_loss only rides
+        #  on the node's result when it is asked for the same one)
+        ctx.hint_mask_sum_given = bool(hinted and len(fit_hint) > 4 and fit_hint[4] is not None)
         ctx.camera, ctx.cam_keep, ctx.grad_sink = camera, cam_keep, grad_sink
         ctx.save_for_backward(faces, vertices, tri, textures, light)
         if fit is not None and not hinted:
@@ -644,7 +657,8 @@ class _RasterizeLit(torch.autograd.Function):
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
 
     @staticmethod
-    def _backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera_inside, B, V, Ft, ts, Bl, fill_back, idr):
+    def _backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera_inside, B, V, Ft, ts, Bl, fill_back, idr,
+                          need_geom=True):
         """The backward pass's accumulators and the gathered pass's workspace, allocated in FORWARD for a caller that runs
         backward right behind it: the forward's first launch zeroes what they need zeroed (`clears`), so the backward
         pass starts without a clear of its own.  Mirrors the allocations of _backward_halves (one pipeline)."""
@@ -652,9 +666,10 @@ class _RasterizeLit(torch.autograd.Function):
         need_tex = ctx.needs_input_grad[3]
         need_vert = ctx.needs_input_grad[1] and idr != 0
         gathered = need_tex or need_vert
-        pre = {"clears": [], "gathered": gathered, "grad_vertices": None}
-        pre["grad_sv"] = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-        pre["clears"].append(_lib.tensor_range(pre["grad_sv"]))
+        pre = {"clears": [], "gathered": gathered, "grad_vertices": None, "grad_sv": None}
+        if need_geom:
+            pre["grad_sv"] = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+            pre["clears"].append(_lib.tensor_range(pre["grad_sv"]))
         if gathered and need_vert:
             gv = grad_sink[0] if (grad_sink is not None and camera_inside) else torch.empty_like(vertices)
             pre["grad_vertices"] = gv
@@ -713,7 +728,12 @@ class _RasterizeLit(torch.autograd.Function):
         # launch (ctx.pre: one use -- a second backward over the same graph allocates and clears its own)
         pre = getattr(ctx, "pre", None)
         ctx.pre = None
-        grad_sv = pre["grad_sv"] if pre is not None else torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+        # (no gradient for the mesh wanted -- a texture-only optimisation: no screen-space accumulator, no edge gradient, no
+        #  depth gradient, no camera adjoint; the node returns None for the vertices)
+        need_geom = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        grad_sv = None
+        if need_geom:
+            grad_sv = pre["grad_sv"] if pre is not None else torch.empty(B, V, 3, dtype=torch.float32, device=dev)
         grad_loss = scratch = mask_sum = None
         records = None
         # A fit objective evaluated on this node's finished images (core.losses.multiview_fit_loss -> LitImagesLink) has left
@@ -760,7 +780,8 @@ class _RasterizeLit(torch.autograd.Function):
         sink = ctx.grad_sink
         if pre is not None and (pre["gathered"] != gathered or G != 1):
             pre = None
-            _lib.zero_(grad_sv)                      # (cannot happen: the same inputs decide both; stay correct anyway)
+            if grad_sv is not None:
+                _lib.zero_(grad_sv)                  # (cannot happen: the same inputs decide both; stay correct anyway)
         if gathered and need_vert:
             grad_vertices = pre["grad_vertices"] if pre is not None else \
                 (sink[0] if (sink is not None and ctx.camera is not None) else torch.empty_like(vertices))
@@ -809,7 +830,7 @@ class _RasterizeLit(torch.autograd.Function):
             if gathered:
                 lit_ws, lit_flags = [pre["lit_ws"]], _lib.PRECLEARED
         else:
-            ranges = [_lib.tensor_range(grad_sv)]
+            ranges = [_lib.tensor_range(grad_sv)] if grad_sv is not None else []
             if grad_vertices is not None:
                 ranges.append(_lib.tensor_range(grad_vertices))
             if gathered and G == 1:
@@ -839,10 +860,16 @@ class _RasterizeLit(torch.autograd.Function):
             Bg = hi - lo
             tri_g, tex_g, light_g = (_bslice(t, lo, hi) for t in (tri, textures, light))
             fi_g, wm_g, dm_g = m["face_index_map"][lo:hi], m["weight_map"][lo:hi], m["depth_map"][lo:hi]
-            target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back))
+            target = _lib.D3MVertexTarget(_lib.ptr(grad_sv[lo:hi]), _lib.ptr(tri_g), V, Ft, tri_g.shape[0], int(fill_back)) \
+                if need_geom else None
+            rd_geom = rd and need_geom              # the depth gradient (K6) is the mesh's
             unscaled = None
             if fit is not None:
-                unscaled = _RasterizeLit._fit_struct(fit, k, lo, hi, grad_loss, flags=getattr(ctx, "fit_flags", 0))
+                # (the deferred finish belongs to the objective THIS node evaluated -- its own or the registered one -- not to
+                #  a foreign state a linked loss built on the finished images)
+                own_fit = fit is ctx.fit or fit is getattr(ctx, "hint_state", None)
+                unscaled = _RasterizeLit._fit_struct(fit, k, lo, hi, grad_loss,
+                                                     flags=getattr(ctx, "fit_flags", 0) if own_fit else 0)
             elif records is not None:           # final records: no scratch, no scalars to apply
                 unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, None, None, None, None,
                                               _lib.ptr(records[0][lo:hi]), _lib.ptr(records[1][lo:hi]),
@@ -856,18 +883,19 @@ class _RasterizeLit(torch.autograd.Function):
                         _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
                         _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(_bslice(g_rgb_map, lo, hi)), _lib.ptr(gt_g[k]),
                         _lib.ptr(gl_g[k]) if gl_g is not None else None,
-                        _lib.ptr(g_depth_map[lo:hi]) if rd else None, None, Bg, Ft, int(fill_back), S, ts, eps,
-                        _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd else None, _lib.ptr(vis[k]),
+                        _lib.ptr(g_depth_map[lo:hi]) if rd_geom else None, None, Bg, Ft, int(fill_back), S, ts, eps,
+                        _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd_geom else None, _lib.ptr(vis[k]),
                         ctypes.byref(unscaled) if unscaled is not None else None, lit_flags, _lib.stream_ptr()),
                         "d3m_backward_textures_lit")
             if G == 1:
                 yield "textures"        # (one pipeline: the texture side is complete in the order of its stream)
-            with torch.cuda.stream(s_edges[k]):
-                ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
-                                       _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S, eps,
-                                       True, ra,
-                                       vertex_target=target, visibility=vis[k], unscaled=unscaled,
-                                       edge_plan=m["edge_plan"][k])
+            if need_geom:
+                with torch.cuda.stream(s_edges[k]):
+                    ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
+                                           _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S,
+                                           eps, True, ra,
+                                           vertex_target=target, visibility=vis[k], unscaled=unscaled,
+                                           edge_plan=m["edge_plan"][k])
         if G > 1:
             yield "textures"
         def light_to_vertices(grad_light):
@@ -908,7 +936,7 @@ class _RasterizeLit(torch.autograd.Function):
                 light_to_vertices(grad_light)
             if not need_tex:
                 grad_textures = None
-        elif rd:                            # textures and lighting need no gradient: the depth term on its own
+        elif rd and need_geom:              # textures and lighting need no gradient: the depth term on its own
             if fit is not None:
                 # d3m_backward_depth_map takes final maps: the fused objective left sign(depth - target) * mask, which
                 # still lacks grad_loss / sum(mask) (GradScale::get, d3m_device.h); totals[2] of the scratch holds that
@@ -927,7 +955,7 @@ class _RasterizeLit(torch.autograd.Function):
                                       _lib.ptr(gl_g[0] if light_shared else grad_light), Bl, ia, idr, _vec3_host(ca),
                                       _vec3_host(cd), _vec3_host(direction), _lib.stream_ptr()), "d3m_lit_back")
             grad_sv = None
-        elif ctx.camera is not None:
+        elif ctx.camera is not None and need_geom:
             # the camera's adjoint joins the light's in the same buffer (or writes it, when there is none)
             from . import cameras
             cam, _keep = cameras._camera_struct(ctx.camera, dev)
@@ -942,7 +970,7 @@ class _RasterizeLit(torch.autograd.Function):
             grad_sv = None
         if tail_on_side:
             cur.wait_stream(auxs[0])
-        return (grad_sv, grad_vertices, None, grad_textures) + (None,) * 17
+        return (grad_sv if need_geom else None, grad_vertices if need_geom else None, None, grad_textures) + (None,) * 17
 
 
 class _RasterizeMeshModes(torch.autograd.Function):

@@ -9,26 +9,86 @@ import torch
 
 from .. import _lib
 
-_workspaces = {}
+class StreamKeyedCache:
+    """Per-stream objects (scratch buffers, side streams) keyed by (kind, ..., raw stream handle), BOUNDED: at most
+    `max_per_kind` entries per kind, least recently used first out.  A handle says nothing about the life of the stream
+    behind it -- torch.cuda.current_stream() returns a fresh wrapper object on every call, so there is nothing to hang a
+    weak reference on, and torch hands out its pooled streams' handles again and again -- so entries are not tied to stream
+    destruction; what is bounded is what a process that keeps switching streams can pile up (up to round 5: one scratch
+    buffer of up to gigabytes per (kind, stream) ever seen, for the life of the process).  Eviction only drops the cache's
+    reference: a buffer was allocated under the stream it is used on, so the caching allocator reuses its memory in that
+    stream's order.  Pure host logic (tests/test_host_logic.py)."""
+
+    def __init__(self, max_per_kind=8):
+        self.max_per_kind = int(max_per_kind)
+        self._items = {}            # key -> value, in order of last use (dicts keep insertion order)
+
+    def get(self, key):
+        v = self._items.pop(key, None)
+        if v is not None:
+            self._items[key] = v    # most recently used last
+        return v
+
+    def put(self, key, value):
+        self._items.pop(key, None)
+        self._items[key] = value
+        same = [k for k in self._items if k[0] == key[0]]
+        for k in same[:max(0, len(same) - self.max_per_kind)]:
+            del self._items[k]
+
+    def clear(self):
+        self._items.clear()
+
+    def __len__(self):
+        return len(self._items)
+
+
+_workspaces = StreamKeyedCache(max_per_kind=8)
+
+
+# Scratch handed out INSIDE a stream capture is baked into the captured graph as raw addresses: such a buffer must outlive
+# the graph whatever the cache does with its entry.  It is remembered here until the owner of the capture claims it
+# (graph.CapturedStep.capture -> take_captured_refs(): the buffers then live exactly as long as the step's graphs); a
+# capture nobody claims for keeps them for the life of the process, which is what every buffer did up to round 5.
+_captured_refs = {}
+
+
+def take_captured_refs():
+    """The scratch buffers handed out under a capture since the last call (and forget them here)."""
+    refs = list(_captured_refs.values())
+    _captured_refs.clear()
+    return refs
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (they are re-allocated on demand; buffers a captured graph uses stay alive
+    through _captured_refs / their CapturedStep)."""
+    _workspaces.clear()
 
 
 def _workspace(key, nbytes, device):
     """Scratch buffers are cached per (kind, device, stream) and only ever grow: operators that run concurrently on
-    different streams (view groups, the side branch of the lit backward) must not share scratch."""
-    k = (key, device, torch.cuda.current_stream(device).cuda_stream)
+    different streams (view groups, the side branch of the lit backward) must not share scratch.  At most eight streams
+    per kind and the least recently used goes (StreamKeyedCache)."""
+    k = (key, str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(k)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _workspaces[k] = buf
+        _workspaces.put(k, buf)
+    if torch.cuda.is_current_stream_capturing():
+        _captured_refs[id(buf)] = buf
     return buf
 
 
-def visibility(face_index_map, num_faces):
+def visibility(face_index_map, num_faces, out=None):
     """The flags + compacted list of the faces that own a pixel (d3m_visibility), shared by the backward operators
-    of one forward result.  Returns the (cached, reused) blob."""
+    of one forward result.  Returns the blob: `out` if given (at least d3m_visibility_bytes), else a FRESH buffer per
+    call -- up to round 5 this was one cached blob per stream, so that two live forward results on a stream aliased
+    (tests/test_gpu_ops.py::test_visibility_blobs_do_not_alias)."""
     L = _lib.lib()
     B, S = face_index_map.shape[0], face_index_map.shape[1]
-    blob = _workspace("visibility", L.d3m_visibility_bytes(B, num_faces), face_index_map.device)
+    blob = out if out is not None else torch.empty(int(L.d3m_visibility_bytes(B, num_faces)), dtype=torch.uint8,
+                                                   device=face_index_map.device)
     _lib.check(L.d3m_visibility(_lib.ptr(face_index_map), _lib.ptr(blob), blob.numel(), B, num_faces, S,
                                 _lib.stream_ptr()), "d3m_visibility")
     return blob

@@ -65,15 +65,19 @@ class Renderer(nn.Module):
         # The views of a batch are independent; the on-the-fly path may run them as this many concurrent pipelines
         # (rasterize._RasterizeLit, "VIEW GROUPS").  1 = one pipeline for the whole batch.
         self.view_groups = 1
-        # render_fit_loss only: leave the forward's side branch (visibility list, edge-gradient plan) open for backward
-        # to join.  ONLY for callers that run backward right behind forward on the same stream (MultiViewFit does).
+        # render_fit_loss AND render(): leave the forward's side branch (visibility list, edge-gradient plan) open for
+        # backward to join.  ONLY for callers that run backward right behind forward on the same stream (MultiViewFit does).
+        # With it the outputs of forward are valid only AFTER that backward pass: the value of a fused or registered
+        # objective (render_fit_loss / fit_targets + multiview_fit_loss) is finished by a kernel of the backward pass.
         self.defer_plan_join = False
         # A fit objective REGISTERED with the renderer: (rgb_target [B,3,s,s], depth_target, alpha_target, mask [B,s,s]
-        # [, mask_sum]).  render() (lit path, no anti-aliasing) then evaluates it in the pass that writes the images and
-        # leaves its gradient as the edge gradient's walk records; core.losses.multiview_fit_loss called on those images
-        # with these very tensors returns that value and back-propagates through the records -- the reference-shaped
+        # [, mask_sum]) at the OUTPUT size s = image_size.  render() (lit path; with anti-aliasing too: the objective of
+        # the pooled images, per-pixel records at the internal size) then evaluates it in the pass that writes the images
+        # and leaves its gradient as the edge gradient's walk records; core.losses.multiview_fit_loss called on those
+        # images with these very tensors returns that value and back-propagates through the records -- the reference-shaped
         # composition  loss(*renderer.render(...))  at the price of the fused objective plus the images' 20 B per pixel.
-        # Any other use of the images stays correct (they are ordinary differentiable outputs).  None: off.
+        # Any other use of the images stays correct (they are ordinary differentiable outputs).  The registration stays
+        # until it is taken back (None: off); a call whose batch or image size it does not fit ignores it (_fit_hint).
         self.fit_targets = None
         self.mesh_modes = True      # render_silhouettes / render_depth of look_at cameras as one node over the indexed mesh
 
@@ -224,13 +228,30 @@ class Renderer(nn.Module):
                               self.near, self.far, self.rasterizer_eps, self.background_color, cam, grad_sink=grad_sink,
                               images_out=images_out, anti_aliasing=self.anti_aliasing)
 
+    def _fit_hint(self, batch):
+        """The registered objective (fit_targets) if it fits THIS call -- `batch` views at the current image_size, float32
+        tensors on one device -- else None: the call is then a plain render() (the registration is sticky; a later call with
+        another batch or size must not fail on it)."""
+        hint = self.fit_targets
+        if hint is None:
+            return None
+        s = int(self.image_size)
+        try:
+            rgb_t, depth_t, alpha_t, mask = hint[:4]
+            ok = tuple(rgb_t.shape) == (batch, 3, s, s) and all(tuple(x.shape) == (batch, s, s) for x in (depth_t, alpha_t, mask)) \
+                and all(x.is_cuda and x.dtype == torch.float32 for x in (rgb_t, depth_t, alpha_t, mask))
+        except (TypeError, ValueError, AttributeError):
+            ok = False
+        return hint if ok else None
+
     def render(self, vertices, faces, textures, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
         if self._on_the_fly():
             cam = self._camera_in_node(vertices, K, R, t, dist_coeffs, orig_size)
             sv = None if cam is not None else self._transform(vertices, K, R, t, dist_coeffs, orig_size)
             out = rasterize_lit(sv, vertices, faces, textures, self._light_cfg(), self.fill_back, self.image_size,
                                 self.anti_aliasing, self.near, self.far, self.rasterizer_eps, self.background_color,
-                                view_groups=self.view_groups, camera=cam, fit_hint=self.fit_targets,
+                                view_groups=self.view_groups, camera=cam,
+                                fit_hint=self._fit_hint(cam["batch"] if cam is not None else sv.shape[0]),
                                 defer_plan_join=self.defer_plan_join)
         else:
             f = self._screen_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)

@@ -81,6 +81,14 @@ size_t d3m_forward_workspace_min_bytes(int batch_size, int num_faces, int image_
  * sets the initial value.  Returns D3M_ERR_INVALID for any other value. */
 int d3m_set_coverage_form(int form);
 int d3m_get_coverage_form(void);
+
+/* Run-to-run reproducibility (no reference counterpart: the reference's float atomics, KCU:533-538,586-589, are unordered
+ * too).  on = 1: d3m_visibility (and the list a forward launch leaves) is built in ASCENDING face order by three launches
+ * -- count, scan, compact -- instead of one whose chunks land in arrival order, so that every pass over the list issues its
+ * float atomics from the same workgroups, in the same list order, in every run.  Process-wide, read at every launch; the
+ * environment variable D3M_DETERMINISTIC=1 sets the initial value.  Returns D3M_ERR_INVALID for values other than 0 / 1. */
+int d3m_set_deterministic(int on);
+int d3m_get_deterministic(void);
 /* The form (0 | 1) a launch of d3m_forward_face_index_map_mesh on `batch_size` views of a mesh of `num_triangles` triangles
  * (before fill_back) at `image_size` takes with a workspace of d3m_forward_workspace_bytes(); -1 for invalid sizes.  The
  * automatic choice: bidding for sub-pixel triangles (more than two per three raster pixels) whatever the batch; per-tile

@@ -299,6 +299,61 @@ def test_backward_operators_differential_fuzz(seed, coverage):
     assert np.array_equal(wm2.cpu().numpy(), m["weight_map"])
 
 
+def test_visibility_blobs_do_not_alias():
+    """rasterize_ops.visibility() returns a blob of its own per call (round 5: one cached blob per stream, so a second
+    forward result on the stream overwrote the first one's list), or fills the caller's `out`."""
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    L = _lib.lib()
+    S, F = 32, 40
+    fi_a = torch.full((1, S, S), -1, dtype=torch.int32, device="cuda")
+    fi_b = fi_a.clone()
+    fi_a[0, 3:9, 4:20] = 7
+    fi_a[0, 20, 5] = 31
+    fi_b[0, 10:12, 10:12] = 2
+    blob_a = ops.visibility(fi_a, F)
+    keep = blob_a.clone()
+    blob_b = ops.visibility(fi_b, F)
+    assert blob_a.data_ptr() != blob_b.data_ptr()
+    assert torch.equal(blob_a, keep)                          # the second call left the first result alone
+    flags_a = blob_a[:4 * F].view(torch.int32).cpu().numpy()
+    flags_b = blob_b[:4 * F].view(torch.int32).cpu().numpy()
+    assert sorted(np.nonzero(flags_a)[0]) == [7, 31] and sorted(np.nonzero(flags_b)[0]) == [2]
+    out = torch.empty(int(L.d3m_visibility_bytes(1, F)), dtype=torch.uint8, device="cuda")
+    assert ops.visibility(fi_a, F, out=out) is out
+    assert sorted(np.nonzero(out[:4 * F].view(torch.int32).cpu().numpy())[0]) == [7, 31]
+
+
+def test_scratch_of_a_captured_step_outlives_the_cache():
+    """The library's scratch buffers are cached per stream in a BOUNDED cache; a buffer handed out inside a capture is baked
+    into the graph and is kept alive by the CapturedStep (rasterize_ops.take_captured_refs), so dropping the cache and
+    allocating over it does not touch what the replays write."""
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.graph import CapturedStep
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    import deep3dmap_amd.neural_renderer as nr
+    v, tri = synthetic.grid_mesh(14)
+    v, tri = torch.from_numpy(v)[None].cuda(), torch.from_numpy(tri)[None].cuda()
+    vv = v.clone().requires_grad_(True)
+    r = nr.Renderer(camera_mode="look_at", image_size=48, anti_aliasing=False)
+    r.eye = [0.3, 0.5, -2.5]
+
+    def step():
+        vv.grad = None
+        sil = r(vv, tri, mode="silhouettes")
+        (sil.sum()).backward()
+        return sil, vv.grad
+    cs = CapturedStep(step).capture()
+    assert cs._scratch_refs, "the capture handed out no scratch?"
+    sil0, g0 = [t.clone() for t in cs()]
+    ops.release_workspaces()
+    junk = [torch.full((1 << 22,), 255, dtype=torch.uint8, device="cuda") for _ in range(8)]     # would land in freed scratch
+    torch.cuda.synchronize()
+    sil1, g1 = [t.clone() for t in cs()]
+    assert torch.equal(sil0, sil1) and torch.allclose(g0, g1, rtol=0, atol=1e-6 * float(g0.abs().max()))
+    del junk
+
+
 def test_ops_reject_float64_like_the_reference_extension():
     """rasterize_cuda_kernel.cu:614 dispatches float and double, but every map is read with .data<scalar_t>(): a double
     `faces` with the float32 maps rasterize.py:50-69 allocates raises there.  Same error class here, before any launch."""

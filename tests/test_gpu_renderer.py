@@ -1268,3 +1268,83 @@ def test_large_face_fallbacks_with_more_faces_than_a_workgroup_table_holds():
     assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=1e-6)
     for k in (1, 2):
         assert float((out[0][k] - out[1][k]).abs().max()) <= 1e-3 * float(out[1][k].abs().max()) > 0
+
+
+@pytest.mark.parametrize("route", ["render", "fit_loss"])
+def test_texture_only_optimisation_skips_the_geometry_side(route):
+    """with the camera inside the node, a mesh that wants no gradient (texture-only optimisation) used to pay for
+    the whole geometry side -- screen-space accumulator, plan, line walk, K6, camera adjoint -- to produce a gradient
+    autograd throws away.  Now: no k_edge_* launch at all, grad_vertices None, and the texture gradient equal to the one the
+    full backward pass produces."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core.losses import multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(18)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(3), image_size=64, anti_aliasing=False)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    rgb_t, depth_t, alpha_t = fit.targets
+    r = fit.renderer
+
+    def run(vertices_grad):
+        vtx = fit.vertices.detach().clone().requires_grad_(vertices_grad)
+        txt = fit.textures.detach().clone().requires_grad_(True)
+        with kernels_launched() as k:
+            if route == "render":
+                rgb, depth, alpha = r(vtx[None], fit.triangles[None], txt[None])
+                loss = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t)
+            else:
+                loss = r.render_fit_loss(vtx[None], fit.triangles[None], txt[None], (rgb_t, depth_t, alpha_t, alpha_t))
+            loss.backward()
+        return float(loss.detach()), vtx.grad, txt.grad, k.names
+
+    loss_full, gv_full, gt_full, names_full = run(True)
+    loss_tex, gv_tex, gt_tex, names_tex = run(False)
+    assert gv_full is not None and gv_tex is None
+    assert loss_tex == loss_full
+    assert _rel_max(gt_tex, gt_full) < 1e-6
+    assert "k_edge_lines" in names_full and "k_edge_scatter" in names_full
+    geometry = {n for n in names_tex if n.startswith("k_edge_") or n.startswith("k_camera_backward") or n == "k_lit_back"}
+    assert not geometry, sorted(names_tex)
+
+
+def test_registered_objective_that_does_not_fit_the_call_is_ignored():
+    """Renderer.fit_targets is sticky; a later render() with another batch or image size must not raise on it --
+    the call is a plain render (and multiview_fit_loss on its images takes the ordinary routes).  And a registered objective
+    WITH a global mask_sum is not silently used for a call that asks for the local normaliser (mask_sum=None)."""
+    from conftest import kernels_launched
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.core.losses import multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    v, tri = synthetic.grid_mesh(16)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(2), image_size=48, anti_aliasing=False)
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    rgb_t, depth_t, alpha_t = fit.targets
+    r = fit.renderer
+    r.fit_targets = (rgb_t, depth_t, alpha_t, alpha_t, fit.mask_sum)
+    try:
+        with torch.no_grad():
+            want = [t.clone() for t in r(fit.vertices[None], fit.triangles[None], fit.textures[None])]
+        r.image_size = 32                                   # the registration no longer fits: ignored, not an error
+        with kernels_launched() as k:
+            small = r(fit.vertices[None], fit.triangles[None], fit.textures[None])
+        assert tuple(small[0].shape) == (2, 3, 32, 32) and "k_render_lit_fit_records" not in k.names
+        r.image_size = 48
+        # the registered objective carries the GLOBAL normaliser (here: twice the local one)
+        double = (fit.mask_sum * 2.0).reshape(1)
+        r.fit_targets = (rgb_t, depth_t, alpha_t, alpha_t, double)
+        fit.vertices.grad = fit.textures.grad = None
+        rgb, depth, alpha = r(fit.vertices[None], fit.triangles[None], fit.textures[None])
+        assert all(torch.equal(a.detach(), b) for a, b in zip((rgb, depth, alpha), want))
+        local = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t)         # mask_sum=None: sum(mask)
+        glob = multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, double)
+    finally:
+        r.fit_targets = None
+    rgb2, depth2, alpha2 = fit.render()
+    ref_local = multiview_fit_loss(rgb2, depth2, alpha2, rgb_t, depth_t, alpha_t, alpha_t, link=False)
+    ref_glob = multiview_fit_loss(rgb2, depth2, alpha2, rgb_t, depth_t, alpha_t, alpha_t, double, link=False)
+    assert abs(float(local) - float(ref_local)) <= 1e-6 * abs(float(ref_local))
+    assert abs(float(glob) - float(ref_glob)) <= 1e-6 * abs(float(ref_glob))
+    assert abs(float(ref_local) - float(ref_glob)) > 1e-3 * abs(float(ref_local))          # (the two really differ)

@@ -76,6 +76,29 @@ def test_any_header_edit_marks_the_library_stale(tmp_path, monkeypatch):
         assert not build._stale()
 
 
+def test_stream_keyed_cache_is_bounded_and_lru():
+    """rasterize_ops.StreamKeyedCache (scratch buffers / side streams per raw stream handle): at most max_per_kind entries
+    per kind, the least recently USED goes first, other kinds are untouched."""
+    from deep3dmap_amd.neural_renderer.rasterize_ops import StreamKeyedCache
+    c = StreamKeyedCache(max_per_kind=3)
+    for stream in range(3):
+        c.put(("fwd", "cuda:0", stream), f"fwd{stream}")
+    c.put(("edge", "cuda:0", 0), "edge0")
+    assert len(c) == 4
+    assert c.get(("fwd", "cuda:0", 0)) == "fwd0"            # 0 is now the most recently used of its kind
+    c.put(("fwd", "cuda:0", 3), "fwd3")                      # evicts stream 1, the least recently used
+    assert c.get(("fwd", "cuda:0", 1)) is None
+    assert [c.get(("fwd", "cuda:0", k)) for k in (0, 2, 3)] == ["fwd0", "fwd2", "fwd3"]
+    assert c.get(("edge", "cuda:0", 0)) == "edge0"
+    for stream in range(10, 30):
+        c.put(("fwd", "cuda:0", stream), stream)
+    assert len(c) == 4 and c.get(("edge", "cuda:0", 0)) == "edge0"
+    c.put(("fwd", "cuda:0", 29), "again")                    # replacing an entry does not evict
+    assert len(c) == 4 and c.get(("fwd", "cuda:0", 29)) == "again"
+    c.clear()
+    assert len(c) == 0
+
+
 def test_coverage_form_switch_is_host_state():
     """d3m_set_coverage_form: -1 / 0 / 1 accepted and read back, anything else D3M_ERR_INVALID and no change; the
     context manager restores the previous form (no launch involved: runs without a GPU)."""
@@ -111,7 +134,7 @@ def test_no_kernel_spills_to_scratch():
         assert got, prefix
         return got
     assert all(r["vgprs"] <= 64 and r["occupancy"] == 8 for r in rows("k_edge_lines<"))
-    assert all(r["vgprs"] <= 128 for r in rows("k_render_lit_fit_records(")) and all(r["vgprs"] <= 128 for r in rows("k_backward_textures_lit_faces"))
+    assert all(r["vgprs"] <= 128 for r in rows("k_render_lit_fit_records<")) and all(r["vgprs"] <= 128 for r in rows("k_backward_textures_lit_faces"))
     for name in ("k_raster_tiles<", "k_bid_faces<", "k_edge_scatter<", "k_edge_count_window<", "k_edge_gather<", "k_bin_count<"):
         assert all(r["scratch"] == 0 for r in rows(name))
 
