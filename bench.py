@@ -84,41 +84,74 @@ def algorithmic_bytes(V, F, S, s, ts, alpha=1, depth=1, rgb=1, tex_grad=1):
     return a_fwd, a_bwd
 
 
-# Per-kernel share of that byte count: the section-8(d) terms each kernel must touch, per view.
-def kernel_bytes(name, V, F, S, ts):
-    P = S * S
-    maps = P * (4 + 4 + 12)            # face_index + alpha + rgb values
-    grads = P * (4 + 12)               # their gradients
-    table = {
-        "k_raster_tiles": 12 * V + 12 * F + 20 * P,
-        # coverage by bidding (csrc/d3m_bid.h): the mesh in, the 8-byte z-buffer entry of every pixel written at least
-        # once; then that entry in and the three maps out
-        "k_bid_faces": 12 * V + 12 * F + 8 * P,
-        "k_bid_resolve": 8 * P + 20 * P,
-        "k_bin_count": 12 * V + 12 * F,
-        "k_bin_fill": 12 * F,
-        "k_texture_sampling": F * ts ** 3 * 12 + 20 * P + 12 * P,
-        # sampling inputs, blended maps out, then either the images (20 B) or the objective's targets in (24 B) and the
-        # unscaled gradient maps out (20 B)
-        "k_render_lit_epilogue": F * ts ** 3 * 12 + 20 * P + 12 * P + P * (4 + 4 + 12) + P * 24,
-        # the same pass when it also leaves the objective's gradient as the edge gradient's per-pixel records
-        # (16 + 8 B) and the depth gradient map (4 B) instead of images
-        "k_render_lit_fit_records": F * ts ** 3 * 12 + 20 * P + 12 * P + P * 24 + P * (16 + 8 + 4),
-        "k_pack_maps": maps + grads,
-        "k_edge_lines": maps + grads,
-        "k_edge_emit": 12 * V + 12 * F + maps + grads,
-        "k_edge_count": 12 * V + 12 * F,
-        "k_edge_scatter": 12 * V + 12 * F + 4 * P,
-        "k_edge_gather": 12 * F + 12 * V,
-        "k_backward_textures_lit_faces": 12 * V + 12 * F + P * (20 + 12 + 4) + F * ts ** 3 * 12 + 12 * V,
-        "k_backward_textures_faces": 12 * V + 12 * F + P * (4 + 12 + 12) + F * ts ** 3 * 12,
-        "k_backward_textures": P * (4 + 12) + F * ts ** 3 * 12,
-        "k_backward_depth_faces": 12 * V + 12 * F + P * (20 + 4) + 12 * V,
-        "k_backward_depth_map": P * (20 + 4) + 12 * V + 12 * F + 12 * V,
-        "k_lighting_forward": 12 * V + 12 * F + 2 * F * ts ** 3 * 12,
-        "k_lighting_backward": 12 * V + 12 * F + 2 * F * ts ** 3 * 12 + 12 * V,
-    }
-    return table.get(name)
+# Per-kernel shares of that byte count: a PARTITION of section 8(d) -- every term of A_fwd + A_bwd belongs to exactly one
+# kernel of the step (the first kernel of its owner list that the step launches), so the shares of a step's kernels add up
+# to algorithmic_bytes() (tests/test_host_logic.py holds that for both forms of coverage).  Up to round 5 this was a table of
+# what each kernel "must touch", which counted the shared textures and the saved maps in several kernels: the shares summed
+# to 2.5 GB against 1.56 GB per headline step, and the secondary kernels' fractions of the roofline were inflated by it.
+# What the kernels move BEYOND their share -- crossing records, per-view texel gradients, the dense face copy -- is the
+# formulation's own traffic: profiles/*pmc_traffic*.json has it.
+def byte_terms(V, F, S, s, ts):
+    P, Po, T = S * S, s * s, F * ts ** 3 * 12
+    return {"fwd_vertices": 12 * V, "fwd_indices": 12 * F, "fwd_textures": T, "fwd_saved_maps": 20 * P,
+            "fwd_outputs": 20 * Po,
+            "bwd_output_grads_alpha_rgb": 16 * Po, "bwd_output_grad_depth": 4 * Po,
+            "bwd_saved_face_index": 4 * P, "bwd_saved_weights_depth": 16 * P, "bwd_alpha_rgb_maps": 16 * P,
+            "bwd_vertices": 12 * V, "bwd_indices": 12 * F, "bwd_grad_vertices": 12 * V, "bwd_grad_textures": T}
+
+
+TERM_OWNERS = {
+    "fwd_vertices": ["k_lit_front", "k_camera_forward", "k_bin_count", "k_bid_faces"],
+    "fwd_indices": ["k_bin_count", "k_bid_faces", "k_gather_faces"],
+    "fwd_textures": ["k_render_lit_fit_records", "k_render_lit_epilogue", "k_texture_sampling"],
+    "fwd_saved_maps": ["k_raster_tiles", "k_bid_resolve"],
+    "fwd_outputs": ["k_render_lit_fit_records", "k_render_lit_epilogue", "k_output_epilogue"],
+    # the edge gradient's walk: the values (alpha 4 + rgb 12), the owner (4) and the gradients (alpha 4 + rgb 12) of every
+    # pixel -- 36 B per pixel, in whatever form the step hands them over (maps, or the fused objective's per-pixel records)
+    "bwd_output_grads_alpha_rgb": ["k_edge_lines"],
+    "bwd_saved_face_index": ["k_edge_lines"],
+    "bwd_alpha_rgb_maps": ["k_edge_lines"],
+    "bwd_output_grad_depth": ["k_backward_textures_lit_faces", "k_backward_depth_faces", "k_backward_depth_map"],
+    "bwd_saved_weights_depth": ["k_backward_textures_lit_faces", "k_backward_textures_faces", "k_backward_depth_faces",
+                                "k_backward_textures"],
+    "bwd_vertices": ["k_lit_back", "k_camera_backward"],
+    "bwd_indices": ["k_edge_scatter", "k_edge_gather"],
+    "bwd_grad_vertices": ["k_edge_gather", "k_scatter_face_grads"],
+    "bwd_grad_textures": ["k_backward_textures_lit_faces", "k_backward_textures_faces", "k_backward_textures"],
+}
+# the headline step, per-tile lists | bidding
+STEP_KERNELS = {
+    "binned": ["k_lit_front", "k_bin_count", "k_bin_alloc", "k_bin_fill", "k_raster_tiles", "k_compact_visible",
+               "k_edge_count", "k_alloc_plan", "k_edge_scatter", "k_render_lit_fit_records", "k_backward_textures_lit_faces",
+               "k_lit_large_faces", "k_sum_over_views_ts2", "k_edge_lines", "k_edge_overflow", "k_edge_gather", "k_lit_back"],
+    "bidding": ["k_lit_front", "k_bid_faces", "k_bid_big", "k_bid_resolve", "k_compact_visible", "k_edge_count",
+                "k_alloc_plan", "k_edge_scatter", "k_render_lit_fit_records", "k_backward_textures_lit_faces",
+                "k_lit_large_faces", "k_sum_over_views_ts2", "k_edge_lines", "k_edge_overflow", "k_edge_gather",
+                "k_face_light_backward", "k_camera_backward"],
+}
+
+
+def byte_partition(step_kernels, V, F, S, ts, s=None):
+    """{kernel: its share of section 8(d)'s bytes per view} over the kernels `step_kernels` of one step; the shares add
+    up to algorithmic_bytes() when every term finds an owner among them (None is returned for the key "unowned" otherwise)."""
+    terms = byte_terms(V, F, S, S if s is None else s, ts)
+    shares = {k: 0 for k in step_kernels}
+    for term, owners in TERM_OWNERS.items():
+        owner = next((k for k in owners if k in shares), None)
+        if owner is None:
+            shares["unowned"] = shares.get("unowned", 0) + terms[term]
+        else:
+            shares[owner] += terms[term]
+    return shares
+
+
+def kernel_bytes(name, V, F, S, ts, step_kernels=None, s=None):
+    """Kernel `name`'s share of section 8(d)'s bytes per view in a step that launches `step_kernels` (default: the headline
+    step in the form of coverage that launches `name`); None for a kernel that owns no term."""
+    if step_kernels is None:
+        step_kernels = STEP_KERNELS["bidding" if name.startswith("k_bid_") else "binned"]
+    share = byte_partition(list(step_kernels), V, F, S, ts, s).get(name)
+    return share if share else None
 
 
 def owed_bytes(V, F, S, s, ts, api):
@@ -536,8 +569,17 @@ def main():
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the second timed pass (the same step through Renderer.render + multiview_fit_loss)")
     ap.add_argument("--materialise-images", action="store_true",
-                    help="render() the output images and evaluate the objective on them (multiview_fit_loss) instead of "
-                         "inside the rendering node")
+                    help="time what an UNMODIFIED caller of the reference's surface runs: Renderer.render() with nothing "
+                         "registered on the renderer, the objective composed from the loss operators on the images "
+                         "(--loss-form torch: from plain torch operators), gradient images back through the epilogue's "
+                         "adjoint")
+    ap.add_argument("--loss-form", default="operators", choices=["operators", "torch"],
+                    help="--materialise-images: photometric_loss / silhouette_loss of deep3dmap_amd.core.losses, or the same "
+                         "formulas written in eager torch")
+    ap.add_argument("--strong-shrink", type=float, default=1.0,
+                    help="N > 1: scale the meshes and rasters of the strong-scaling lines (BASELINE configs 4 and 5) by "
+                         "this factor, camera counts unchanged, and run them whatever --mesh-n / --image-size are -- a "
+                         "pre-flight of the multi-rank line's code path on a small box (tests/test_gpu_multirank.py)")
     ap.add_argument("--fit-with-images", action="store_true",
                     help="the fused objective, and the same pass also writes the output images (Renderer.render_fit_loss "
                          "images_out): what keeping the images costs on top of the headline line")
@@ -557,6 +599,12 @@ def main():
     ap.add_argument("--coverage-form", default="auto", choices=["auto", "binned", "bidding"],
                     help="force one form of the forward's coverage (d3m_set_coverage_form; measurements)")
     args = ap.parse_args()
+    t_start = time.perf_counter()
+
+    def stage(what):
+        """wall time of the line's stages on stderr (rank 0): a run that hits the driver's limit says where it was"""
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"[bench] +{time.perf_counter() - t_start:7.1f} s  {what}", file=sys.stderr, flush=True)
     dev_switches = args.dev_switches = refuse_dev_switches(args.allow_dev)
     if args.coverage_form != "auto":
         from deep3dmap_amd import _lib as _l
@@ -613,6 +661,7 @@ def main():
         ranks_seen = [None] * world_seen
         dist.all_gather_object(ranks_seen, rank_identity(rank, local_rank))
         assert world_seen == world and sorted(r["rank"] for r in ranks_seen) == list(range(world)), ranks_seen
+    stage(f"process group up: {world_seen} rank(s), backend {backend_seen}")
 
     from deep3dmap_amd import _lib, synthetic, multiview
     from deep3dmap_amd.multiview import MultiViewFit, shard_views
@@ -631,7 +680,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return [float(x) for x in tmax.tolist()]
 
-    def measure(mesh_n, image_size, n_views, steps, warmup, repeats, objective_in_renderer=True, share=None, want_graph=True):
+    def measure(mesh_n, image_size, n_views, steps, warmup, repeats, objective_in_renderer=True, share=None, want_graph=True,
+                loss_form="linked"):
         """One camera-sharded fit of `n_views` cameras in all: eager step, capture, warm-up, `repeats` barrier-bracketed
         regions of `steps` steps (MAX over ranks, median).  Returns (fit, results dict); the fit is left in eager mode."""
         v, tri = synthetic.grid_mesh(mesh_n)
@@ -639,7 +689,7 @@ def main():
         eyes = synthetic.camera_ring(n_views)
         fit = MultiViewFit(v, tri, tex, eyes, image_size=image_size, anti_aliasing=args.anti_aliasing, rank=rank,
                            world_size=world, device=dev, objective_in_renderer=objective_in_renderer,
-                           view_groups=args.view_groups)
+                           view_groups=args.view_groups, loss_form=loss_form)
         if share is not None:       # the same targets as another fit of the same shard (the drop-in pass)
             fit.targets, fit.mask_sum, fit._mask_sum_local = share.targets, share.mask_sum, share._mask_sum_local
         else:
@@ -686,8 +736,10 @@ def main():
     else:
         n_views = args.views_per_gpu * world
     fit, res = measure(args.mesh_n, args.image_size, n_views, args.steps, args.warmup, args.repeats,
-                       objective_in_renderer=not args.materialise_images, want_graph=not args.no_graph)
+                       objective_in_renderer=not args.materialise_images, want_graph=not args.no_graph,
+                       loss_form=args.loss_form if args.materialise_images else "linked")
     graph_on, regions, elapsed_step = res["graph_on"], res["regions"], res["seconds_per_step"]
+    stage(f"headline measured: {n_views} views, {res['ms_per_step']:.3f} ms per step")
 
     # instrumented pass (not part of `value`), eager: per-kernel HIP-event durations on the launch stream
     _lib.kernel_timing(True)
@@ -705,11 +757,30 @@ def main():
                            objective_in_renderer=False, share=fit, want_graph=graph_on)
         rel2 = float(torch.linalg.norm(r2["gv_eager"] - res["gv_eager"]) / (torch.linalg.norm(res["gv_eager"]) + 1e-20))
         assert rel2 < 1e-3 and abs(r2["loss_eager"] - res["loss_eager"]) <= 1e-4 * abs(res["loss_eager"]), (rel2, r2["loss_eager"])
-        dropin = {"api": "Renderer.render + multiview_fit_loss + backward", "value": round(r2["value"], 2), "unit": "Mpix/s",
+        dropin = {"api": "Renderer.fit_targets registered; Renderer.render + multiview_fit_loss + backward",
+                  "value": round(r2["value"], 2), "unit": "Mpix/s",
                   "ms_per_step": round(r2["ms_per_step"], 4), "ms_per_step_min": round(r2["ms_per_step_min"], 4),
                   "ms_per_step_max": round(r2["ms_per_step_max"], 4),
                   "over_fused": round(r2["ms_per_step"] / res["ms_per_step"], 4)}
         del fit2, r2
+        stage("drop-in form (registered objective) measured")
+        # ... and what a caller gets who changes NOTHING: render() with nothing registered, deep3dmap's own losses on the
+        # images (the package's operators for them; then the same formulas in eager torch), gradient images back through
+        # the output epilogue's adjoint (d3m_output_epilogue_backward_records)
+        for form in ("operators", "torch"):
+            fit3, r3 = measure(args.mesh_n, args.image_size, n_views, args.steps, args.warmup, args.repeats,
+                               objective_in_renderer=False, share=fit, want_graph=graph_on, loss_form=form)
+            rel3 = float(torch.linalg.norm(r3["gv_eager"] - res["gv_eager"]) / (torch.linalg.norm(res["gv_eager"]) + 1e-20))
+            assert rel3 < 1e-3 and abs(r3["loss_eager"] - res["loss_eager"]) <= 1e-4 * abs(res["loss_eager"]), (form, rel3, r3["loss_eager"])
+            dropin["generic_" + form] = {
+                "api": "Renderer.render (nothing registered) + " +
+                       ("photometric_loss / silhouette_loss operators" if form == "operators" else "the losses in eager torch ops") +
+                       " + backward",
+                "value": round(r3["value"], 2), "unit": "Mpix/s", "ms_per_step": round(r3["ms_per_step"], 4),
+                "ms_per_step_min": round(r3["ms_per_step_min"], 4), "ms_per_step_max": round(r3["ms_per_step_max"], 4),
+                "over_fused": round(r3["ms_per_step"] / res["ms_per_step"], 4)}
+            del fit3, r3
+        stage("generic drop-in forms measured")
     split_exchange = res["split_exchange"]
     del fit
     torch.cuda.empty_cache()
@@ -719,10 +790,12 @@ def main():
     # 256 cameras of the 1M-triangle mesh @1024.  Fewer steps; per-GPU shards above 64 views of config 5 are not run (a
     # 128-view shard holds ~75 GB of per-view scratch: a memory sweep is not what a bench run is for).
     strong = None
-    if world > 1 and args.strong_lines and (args.mesh_n, args.image_size) == (225, 512):
+    shrink = min(1.0, max(0.01, args.strong_shrink))
+    if world > 1 and args.strong_lines and ((args.mesh_n, args.image_size) == (225, 512) or shrink < 1.0):
         strong = {}
-        todo = [("config4", 225, 512, 32, args.steps, args.warmup, args.repeats),
-                ("config5", 709, 1024, 256, max(2, args.steps // 4), 2, max(1, args.repeats // 2))]
+        small = lambda n, lo, step: max(lo, int(round(n * shrink / step)) * step)
+        todo = [("config4", small(225, 6, 1), small(512, 32, 8), 32, args.steps, args.warmup, args.repeats),
+                ("config5", small(709, 8, 1), small(1024, 32, 8), 256, max(2, args.steps // 4), 2, max(1, args.repeats // 2))]
         for name, mesh_n, size, total, k, w, reps in todo:
             per = shard_views(total, 0, world)[1]
             if args.scaling == "strong" and (mesh_n, size, total) == (args.mesh_n, args.image_size, n_views):
@@ -732,7 +805,9 @@ def main():
                 strong[name] = {"skipped": f"{per} cameras per GPU at {world} GPUs (run where a shard is <= 64 cameras)"}
                 continue
             try:
+                stage(f"strong-scaling line {name}: grid_mesh({mesh_n}) @{size}, {total} cameras, {per} per GPU ...")
                 f3, r3 = measure(mesh_n, size, total, k, w, reps)
+                stage(f"... {name} measured: {r3['ms_per_step']:.3f} ms per step")
                 strong[name] = {"scaling": "strong", "total_views": total, "views_per_gpu": r3["views_per_rank"],
                                 "triangles": r3["F"], "image_size": size, "steps": k, "warmup": w,
                                 "value": round(r3["value"], 2), "unit": "Mpix/s", "ms_per_step": round(r3["ms_per_step"], 4),
@@ -742,6 +817,9 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:          # never lose the headline line to a secondary one
                 strong[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                stage(f"... {name} FAILED: {type(e).__name__}")
+            if shrink < 1.0 and name in strong:
+                strong[name]["shrunk_by"] = shrink
 
     if rank == 0:
         lib_path, lib_sha = library_identity()
@@ -749,7 +827,7 @@ def main():
         ms_per_step = elapsed_step * 1e3
         value = res["value"]
         Si = 2 * S if args.anti_aliasing else S                       # internal raster size
-        api = ("render+loss" if args.materialise_images else
+        api = (f"render+loss ({args.loss_form}, nothing registered)" if args.materialise_images else
                ("render_fit_loss+images_out" if args.fit_with_images else "render_fit_loss"))
         a_fwd, a_bwd = algorithmic_bytes(V, F, Si, S, ts)
         o_fwd, o_bwd = owed_bytes(V, F, Si, S, ts, api)
@@ -761,7 +839,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         dom_count, dom_ms = per_kernel[dom]
         dom_avg_s = dom_ms / dom_count / 1e3
-        kb = kernel_bytes(dom, V, F, Si, ts)
+        kb = kernel_bytes(dom, V, F, Si, ts, step_kernels=list(per_kernel), s=S)
         roof = None
         if kb is not None:
             ach = kb * args.views_per_gpu / dom_avg_s / 1e9
@@ -835,7 +913,9 @@ def main():
         if strong is not None:
             out["strong_scaling"] = strong
         if world == 1 and not args.no_cpu_baseline:
+            stage("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(args.mesh_n, S, ts)
+        stage("done")
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

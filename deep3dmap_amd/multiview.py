@@ -100,7 +100,7 @@ class MultiViewFit:
 
     def __init__(self, vertices, triangles, textures, eyes, image_size=512, anti_aliasing=False, rank=0,
                  world_size=1, optimise_textures=True, device="cuda", objective_in_renderer=True, view_groups=1,
-                 split_exchange=None):
+                 split_exchange=None, loss_form="linked"):
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         lo, hi = shard_views(len(eyes), rank, world_size)
@@ -115,6 +115,18 @@ class MultiViewFit:
         self.renderer.view_groups = view_groups     # concurrent pipelines over this rank's views (rasterize.py)
         self.image_size = image_size
         self.objective_in_renderer = objective_in_renderer      # False: render() the images, then loss() on them
+        # ... and HOW, when the objective is not evaluated inside the renderer:
+        #   "linked"     Renderer.fit_targets registered + multiview_fit_loss on the images: value and walk records come out
+        #                of the render pass (the drop-in form with two added lines: DESIGN.md 4.4);
+        #   "operators"  what a caller of the REFERENCE's surface runs unmodified: Renderer.render() with nothing
+        #                registered, the objective composed from the package's drop-ins for deep3dmap's own loss functions
+        #                (photometric_loss, utils.py:105-114; silhouette_loss, examples/example2.py:46) -- three loss
+        #                nodes, gradient IMAGES back through the output epilogue's adjoint;
+        #   "torch"      the same composition in plain torch operators (as models/frameworks/gan2shape.py:469-497 and
+        #                examples/example2.py:43-47 write their losses).
+        if loss_form not in ("linked", "operators", "torch"):
+            raise ValueError("loss_form: 'linked', 'operators' or 'torch'")
+        self.loss_form = loss_form
         self.keep_images = False        # True: the fused objective's pass also writes this step's images to self.images
         self.images = None              # (rgb, depth, alpha)
         self.targets = None
@@ -170,7 +182,7 @@ class MultiViewFit:
         # the drop-in form (render, then the objective on the images): the objective is REGISTERED with the renderer, whose
         # pass then leaves value and walk records behind for multiview_fit_loss to find (Renderer.fit_targets)
         self.renderer.fit_targets = None
-        if not self.objective_in_renderer and self.targets is not None and vertices is None:
+        if not self.objective_in_renderer and self.loss_form == "linked" and self.targets is not None and vertices is None:
             rgb_t, depth_t, alpha_t = self.targets
             self.renderer.fit_targets = (rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum)
         # one mesh, one texture set, n_local cameras (renderer.eye is [n_local, 3]): batch-1 inputs are shared
@@ -190,12 +202,17 @@ class MultiViewFit:
         """The fit objective.  `fused=False` composes it from the three loss operators (the definition; the fused
         node computes the same value and gradients in 3 launches instead of ~11)."""
         rgb_t, depth_t, alpha_t = self.targets
-        if fused:
+        if fused and self.loss_form == "linked":
             return multiview_fit_loss(rgb, depth, alpha, rgb_t, depth_t, alpha_t, alpha_t, self.mask_sum)
         mask = alpha_t[:, None]
         pixels = float(self.image_size * self.image_size)
         # photometric_loss divides by the LOCAL sum(mask); as this rank's part of the global mean it weighs local/global
         share = 1.0 if self.mask_sum is None else (self._mask_sum_local / self.mask_sum)[0]
+        if self.loss_form == "torch":       # deep3dmap's own formulas, eager torch (utils.py:105-114; example2.py:46)
+            den = mask.sum()
+            l_rgb = ((rgb - rgb_t).abs() * mask.expand_as(rgb)).sum() / (3.0 * den)
+            l_depth = ((depth - depth_t).abs()[:, None] * mask).sum() / den
+            return l_rgb * share + ((alpha - alpha_t) ** 2).sum() / pixels + l_depth * share
         return (photometric_loss(rgb, rgb_t, mask=mask) * share + silhouette_loss(alpha, alpha_t) / pixels +
                 photometric_loss(depth[:, None], depth_t[:, None], mask=mask) * share)
 

@@ -60,15 +60,16 @@ def test_sharded_fit_equals_unsharded_with_graph_replay(tmp_path, world, materia
             assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max(), (r, k, np.abs(a - b).max(), np.abs(b).max())
 
 
-def _bench(world, scaling, extra=(), bare=False):
+def _bench(world, scaling, extra=(), bare=False, env_extra=None, steps=4):
     """bench.py exactly as the driver launches it -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` for N > 1 -- in FRESH child processes, with the two
     debug switches that let N ranks share this box's one GPU (every rank on device 0, gloo instead of RCCL)."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", D3M_BENCH_SINGLE_DEVICE="1", D3M_BENCH_BACKEND="gloo")
+    env.update(env_extra or {})
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", str(world), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-dropin", "--scaling", scaling,
+    args = ["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-dropin", "--scaling", scaling,
             *extra]
     if not bare and "--no-strong-lines" not in args:
         args.append("--no-strong-lines")
@@ -85,7 +86,9 @@ def _bench(world, scaling, extra=(), bare=False):
         f.write(f"--- {' '.join(cmd[1:])} (exit {p.returncode}) ---\n{p.stdout}\n{p.stderr[-2000:]}\n")
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, p.stdout                          # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_stderr"] = p.stderr
+    return d
 
 
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
@@ -150,3 +153,32 @@ def test_bench_one_rank_through_rccl():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0
+
+
+def test_bench_eight_ranks_preflight():
+    """the line the driver's SCALE run executes -- `bench.py --gpus 8`, weak scaling with the strong-scaling
+    figures of BASELINE configs 4 (4 cameras per GPU) and 5 (32 per GPU) riding in it -- had never run anywhere beyond two
+    ranks.  Here: eight ranks on this box's one GPU (gloo), meshes and rasters shrunk (--strong-shrink; camera counts and
+    therefore shard sizes as in the real run), the split exchange forced on (D3M_SERIAL_BRANCHES=1: two captured graphs and
+    two collectives per step on every rank), in the bare form (bench.py starts its ranks) and in the driver's form with an
+    odd camera count (30 over 8: shards of 4 and 3).  No rate is checked -- eight processes share one device --: one JSON
+    line, eight distinct ranks seen through the process group, finite figures, and the stages' wall times on stderr."""
+    import math
+    small = ("--mesh-n", "40", "--image-size", "128", "--views-per-gpu", "6", "--repeats", "2")
+    split_on = {"D3M_SERIAL_BRANCHES": "1"}
+    d = _bench(8, "weak", extra=small + ("--strong-shrink", "0.2"), bare=True, env_extra=split_on, steps=3)
+    assert d["n_gpus"] == 8 and d["world_size_seen"] == 8 and len(d["ranks"]) == 8
+    assert len({r["pid"] for r in d["ranks"]}) == 8 and sorted(r["rank"] for r in d["ranks"]) == list(range(8))
+    assert d["config"]["total_views"] == 48 and d["config"]["views_per_rank"] == [6] * 8
+    assert "two all-reduces" in d["config"]["exchange"], d["config"]["exchange"]
+    assert math.isfinite(d["value"]) and d["value"] > 0
+    st = d["strong_scaling"]
+    for name, per, total in (("config4", 4, 32), ("config5", 32, 256)):
+        assert "error" not in st[name] and "skipped" not in st[name], st[name]
+        assert st[name]["views_per_gpu"] == [per] * 8 and st[name]["total_views"] == total and st[name]["shrunk_by"] == 0.2
+        assert math.isfinite(st[name]["value"]) and st[name]["value"] > 0 and st[name]["split_exchange"] is True
+    for stage in ("process group up: 8 rank(s)", "headline measured", "strong-scaling line config4", "config5 measured", "done"):
+        assert stage in d["_stderr"], (stage, d["_stderr"][-1500:])
+    odd = _bench(8, "strong", extra=small + ("--total-views", "30", "--no-strong-lines"), env_extra=split_on, steps=3)
+    assert odd["world_size_seen"] == 8 and odd["config"]["views_per_rank"] == [4] * 6 + [3] * 2
+    assert odd["config"]["total_views"] == 30 and math.isfinite(odd["value"]) and odd["value"] > 0

@@ -234,6 +234,18 @@ def test_algorithmic_byte_model_matches_survey_worked_values():
     assert abs(a_fwd / 1e6 - 21.93) < 0.02 and abs(a_bwd / 1e6 - 26.73) < 0.02        # SURVEY.md 8(d), C4 headline
     a_fwd, a_bwd = bench.algorithmic_bytes(50625, 100352, 512, 512, 2, alpha=1, depth=0, rgb=0, tex_grad=0)
     assert abs((a_fwd + a_bwd) / 1e6 - 17.86) < 0.02                                      # silhouettes only
+    # the per-kernel shares PARTITION section 8(d): over the kernels of the headline step, in either form of coverage and
+    # with anti-aliasing (S = 2 s), they add up to A_fwd + A_bwd exactly, every term owned once
+    for V, F, S, s_out, ts in ((50625, 100352, 512, 512, 2), (26896, 53138, 512, 256, 2), (502681, 1002528, 1024, 1024, 4)):
+        a_fwd, a_bwd = bench.algorithmic_bytes(V, F, S, s_out, ts)
+        assert sum(bench.byte_terms(V, F, S, s_out, ts).values()) == a_fwd + a_bwd
+        for form, kernels in bench.STEP_KERNELS.items():
+            shares = bench.byte_partition(kernels, V, F, S, ts, s_out)
+            assert "unowned" not in shares and sum(shares.values()) == a_fwd + a_bwd, (form, shares)
+            assert all(bench.kernel_bytes(k, V, F, S, ts, kernels, s_out) == (shares[k] or None) for k in kernels)
+    # the dominant kernel's share: values + owner + gradients of every pixel
+    assert bench.kernel_bytes("k_edge_lines", 50625, 100352, 512, 2) == 36 * 512 * 512
+    assert bench.kernel_bytes("k_bin_fill", 50625, 100352, 512, 2) is None               # owns no term of 8(d)
 
 
 def test_committed_bench_line_and_profiles_are_consistent():
