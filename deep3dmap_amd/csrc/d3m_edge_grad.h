@@ -86,6 +86,8 @@ struct EdgeGradArgs {
     int S, use_rgb, use_alpha;
     float eps;
     unsigned n_lines;   // B*2*S
+    int sparse_max;     // alpha only: a line with at most this many pixels that can contribute to an OUTWARD walk takes the
+                        // sparse form of those walks (k_edge_lines, "SPARSE OUTWARD WALKS"); 0 = always the dense walk
 };
 
 struct SegRef {
@@ -245,6 +247,20 @@ __device__ __forceinline__ void visit_pixel(float diff, int d1, float d1_cross, 
     const bool skip = diff <= 0;
     g0 -= (skip || !f0) ? 0.0f : c0;
     g1 -= (skip || !f1) ? 0.0f : c1;
+}
+
+// the same with correctly rounded quotients (the sparse outward walks of the alpha-only mode: a handful of terms per walk,
+// so the exact division costs nothing and the sum carries the reference's own rounding, KCU:404-412)
+__device__ __forceinline__ void visit_pixel_div(float diff, int d1, float d1_cross, float q0, float q1, bool f0, bool f1,
+                                                float two_over_is, float eps, float& g0, float& g1) {
+    const float t = (float)d1 - d1_cross;
+    float dist0 = q0 * t * two_over_is;
+    dist0 = (0 < dist0) ? dist0 + eps : dist0 - eps;
+    float dist1 = q1 * t * two_over_is;
+    dist1 = (0 < dist1) ? dist1 + eps : dist1 - eps;
+    const bool skip = diff <= 0;
+    g0 -= (skip || !f0) ? 0.0f : diff / dist0;
+    g1 -= (skip || !f1) ? 0.0f : diff / dist1;
 }
 
 // reference values of a segment: pixel (line d0, position d1) of `axis` in the ORIGINAL maps
@@ -759,9 +775,6 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
     __shared__ LaneTable t;
     __shared__ float s_slope[3][256];
     const int n_blocks = (*w.n_visible + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    // parts < 0: up to -parts, as many as the grid has workgroups for (the number of listed faces is only known here: of a
-    // fill_back mesh a tenth of the faces own a pixel, and a small batch leaves most of a grid sized by ALL faces idle)
-    if (parts < 0) parts = max(1, min(-parts, (int)gridDim.x / max(n_blocks, 1)));
     const int n_units = n_blocks * parts;
     const XcdOrder xo(n_units);
     for (int i = blockIdx.x; xo.more(i); i += gridDim.x) {
@@ -934,6 +947,21 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     __shared__ int s_hist[33];
     __shared__ unsigned short s_order[EG_LINE_THREADS];
     __shared__ int s_nitems, s_pass[2];
+    // SPARSE OUTWARD WALKS (alpha only: render_silhouettes and every return_rgb == 0 call).  An outward walk only exists
+    // when its in-pixel is the face's own (KCU:354-355), i.e. covered: alpha_in = 1, and its terms are
+    //     diff_grad(d) = (alpha(d) - 1) * grad_alpha(d)                                          (KCU:385-387)
+    // -- independent of the crossing, and kept only where > 0 (KCU:401): at UNCOVERED pixels whose alpha gradient is
+    // negative, the band where the silhouette should grow.  So the line's pixels that can contribute to ANY outward walk
+    // are compacted once, in ascending order (s_nz: positions), and the thread that sets a crossing up adds its outward
+    // walk's few terms on the spot -- binary search for the segment's first entry, then entries up to its end -- instead of
+    // queueing a segment that visits every pixel between the crossing and the image border (a 32-view silhouette step walked
+    // 1.3 G pixels per launch to find the ~2 % of them that count).  Exact: the skipped pixels are exactly those the
+    // reference's `diff_grad <= 0` skips; the kept terms use its own expression with correctly rounded quotients
+    // (visit_pixel_div).  A line with more such pixels than a.sparse_max (or than the list holds), and a walk whose
+    // reference alpha is not exactly 1 (a caller's own alpha map), take the dense forms below.
+    constexpr int NZ_CAP = USE_RGB ? 1 : WAVES * 64;
+    __shared__ unsigned short s_nz[NZ_CAP];
+    __shared__ int s_wcnt[USE_RGB ? 1 : WAVES];
     const int is = a.S;
     // XCD-aware order: consecutive workgroups are dealt round-robin to the 8 XCDs, and neighbouring COLUMN lines share
     // their pixels' cache lines (a 64-byte line holds the records of 4 neighbouring columns, the pairs of 8, the alphas
@@ -1196,6 +1224,33 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         for (int k = 0; k < 33; k++) s_hist[k] = 0;
     }
     __syncthreads();                                          // the image is staged
+    int n_nz = -1;                                            // entries of s_nz; -1: this line walks densely
+    if constexpr (!USE_RGB) {
+        if (a.sparse_max > 0) {
+            const v2f one_ar = {-1.0f, 0.0f}, none_gb = {0.0f, 0.0f};
+            int run = 0;                                      // (uniform)
+            for (int p0 = p_lo; p0 <= p_hi; p0 += EG_LINE_THREADS) {
+                const int p = p0 + (int)threadIdx.x;
+                bool on = false;
+                if (p <= p_hi) on = !(diff_of(s_grd[p], s_df[p], one_ar, none_gb) <= 0);      // (NaN stays, as in the walk)
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(on);
+                if (lane_here() == 0) s_wcnt[wv] = __popcll(m);
+                __syncthreads();
+                int before = run, total = 0;
+#pragma unroll
+                for (int k = 0; k < WAVES; k++) {
+                    const int c = s_wcnt[k];
+                    before += k < wv ? c : 0;
+                    total += c;
+                }
+                const int at = before + mask_rank(m);
+                if (on && at < NZ_CAP) s_nz[at] = (unsigned short)p;
+                run = __builtin_amdgcn_readfirstlane(run + total);
+                __syncthreads();
+            }
+            n_nz = run <= min(a.sparse_max, NZ_CAP) ? run : -1;
+        }
+    }
     // the queue item of a long segment (see "Item" above); 1 / qc by v_rcp_f32 (1 ulp), like every quotient of the walk
     auto make_item = [&](const Segment& q, int fn, uint32_t slot, uint4& rec0, uint4& rec1) {
         const float qc0 = (q.f0 ? q.q0 : 1.0f) * two_over_is, qc1 = (q.f1 ? q.q1 : 1.0f) * two_over_is;
@@ -1237,7 +1292,26 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                 if (ci < n_x) {
                     Segment q;
                     queue_it = geometry_segment(geo, 0, axis, d0, is, p_lo, p_hi, q);
-                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci)] = make_float2(0.0f, 0.0f);
+                    float g0 = 0, g1 = 0;
+                    if constexpr (!USE_RGB) {
+                        if (queue_it && n_nz >= 0 && s_val[q.ref_pos].x == 1.0f) {      // the sparse form (see s_nz)
+                            queue_it = false;
+                            int lo = 0, hi = n_nz;
+                            while (lo < hi) {                         // first entry at or behind the segment's start
+                                const int mid = (lo + hi) >> 1;
+                                if ((int)s_nz[mid] < q.from) lo = mid + 1; else hi = mid;
+                            }
+                            const v2f one_ar = {-1.0f, 0.0f}, none_gb = {0.0f, 0.0f};
+                            const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
+                            for (int i = lo; i < n_nz; i++) {
+                                const int d1 = (int)s_nz[i];
+                                if (d1 > q.to) break;
+                                visit_pixel_div(diff_of(s_grd[d1], s_df[d1], one_ar, none_gb), d1, q.d1_cross, qq0, qq1, q.f0 != 0,
+                                                q.f1 != 0, two_over_is, a.eps, g0, g1);
+                            }
+                        }
+                    }
+                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci)] = make_float2(g0, g1);
                 }
                 qm[0] = __builtin_amdgcn_ballot_w64(queue_it);
             }
@@ -1310,7 +1384,6 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
     __shared__ float2 s_g[256];
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
-    if (parts < 0) parts = max(1, min(-parts, (int)gridDim.x / max(n_blocks, 1)));      // (as k_edge_scatter)
     const int n_units = n_blocks * parts;
     const XcdOrder xo(n_units);
     const bool complete = plan_complete(w);      // results in record order (found through xpos), else in crossing order
@@ -1608,10 +1681,11 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
            (const int*)w.n_visible, EG_FACES_PER_BLOCK, w.alloc, blocks_a, (const int*)w.line_count, w.line_slice, w.alloc + 1, nl);
     // (the scatter pass keeps the by-key form: with the ranks taken from LDS cursors it was slower, 0.173 vs 0.150 ms)
     // (few blocks of faces: their rounds dealt to several workgroups each -- see the kernel)
-    int parts = g6_full >= 2048 ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
-    const int dev_parts = d3m_env_int("D3M_SCATTER_PARTS", 1);      // > 1: decided on the device, at most this many
-    if (parts == 1 && dev_parts > 1) parts = -dev_parts;
-    const dim3 g_scatter((unsigned)std::min<long>(8192, (g6_full * std::abs(parts) + 7) / 8 * 8));
+    // (round 6: the same dealing decided on the DEVICE from the number of listed faces -- a small batch of a fine mesh leaves
+    //  most of this grid idle too -- bought nothing: 4 views of the headline mesh 31 -> 33 us with two parts, 38 with four;
+    //  the pass is a chain of dependent look-ups per round, and more workgroups only repeat its set-up.  docs/EXPERIMENTS.md E)
+    const int parts = g6_full >= 2048 ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const dim3 g_scatter((unsigned)std::min<long>(8192, (g6_full * parts + 7) / 8 * 8));
     LAUNCH("k_edge_scatter", k_edge_scatter<FS>, g_scatter, dim3(256), st, fs, face_index_map, S, w, parts);
     return hipGetLastError();
 }
@@ -1716,6 +1790,8 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     }
     a.alpha_map = m.alpha_map; a.rgb_map = m.rgb_map;
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
+    // (a quarter of the line: beyond that the list holds about as many entries as the dense walks would visit)
+    a.sparse_max = m.use_rgb ? 0 : d3m_env_int("D3M_EG_SPARSE_MAX", S / 4);
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
 #define D3M_LINES(RGB, ALPHA, WV)                                                                                    \
     do {                                                                                                             \
@@ -1748,12 +1824,10 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     const dim3 g6((unsigned)(g6_full < 8192 ? (g6_full + 7) / 8 * 8 : 8192));      // a multiple of 8: see XcdOrder
     // crossings without a record (workspace smaller than the scene needs): leaves at once otherwise
     // (normally leaves at once: a small grid keeps that cheap; with an undersized workspace its workgroups stride)
-    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, (unsigned)d3m_env_int("D3M_OVERFLOW_GRID", 512))), dim3(256), st, fs, a, w, lane_partial);
+    LAUNCH("k_edge_overflow", k_edge_overflow<FS>, dim3(std::min(g6.x, 512u)), dim3(256), st, fs, a, w, lane_partial);
     // (few blocks of faces, sums added into a vertex target: a block's lanes dealt to several workgroups -- see the kernel)
-    int gparts = (!vt.gv || g6_full >= 2048) ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
-    const int dev_gparts = d3m_env_int("D3M_GATHER_PARTS", 1);
-    if (gparts == 1 && vt.gv && dev_gparts > 1) gparts = -dev_gparts;
-    const dim3 g_gather((unsigned)std::min<long>(8192, (g6_full * std::abs(gparts) + 7) / 8 * 8));
+    const int gparts = (!vt.gv || g6_full >= 2048) ? 1 : (int)std::min<long>(8, 2048 / std::max<long>(1, g6_full));
+    const dim3 g_gather((unsigned)std::min<long>(8192, (g6_full * gparts + 7) / 8 * 8));
     LAUNCH("k_edge_gather", k_edge_gather<FS>, g_gather, dim3(256), st, fs, w, (const float2*)lane_partial, a.go, grad_faces, vt,
            gparts);
     e = hipGetLastError();

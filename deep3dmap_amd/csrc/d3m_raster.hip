@@ -1136,11 +1136,11 @@ struct FitScratch {
 // few hundred 32 x 32 tiles is one wave per SIMD with four dependent pixels each: 25-31 us for ANY small batch, round 5),
 // 32 above.  A function of the launch's size alone: the objective's finish, which may run from another entry point, must
 // find the same partial sums.
+// Measured (round 6, same box, committed tree | this): one view of the 53 k mesh @256 0.108 -> 0.102 ms (the pass itself
+// 24.4 -> 11 us), 8 views of the headline mesh 0.467 -> 0.458; 4 views 0.270 -> 0.273 (the pass is off that step's critical
+// chain); 32 views keep the 32 x 32 tiles (one atomic per column and tile instead of four).
 static const long FIT_TILE16_MAX_PIXELS = 4l << 20;
-static int fit_tile(int B, int S) {
-    const long limit = (long)d3m_env_int("D3M_FIT_TILE16_MAX_PIXELS", (int)FIT_TILE16_MAX_PIXELS);
-    return (long)B * S * S <= limit ? 16 : 32;
-}
+static int fit_tile(int B, int S) { return (long)B * S * S <= FIT_TILE16_MAX_PIXELS ? 16 : 32; }
 static FitScratch fit_scratch_layout(int B, int S) {
     const size_t per_pixels = blocks_for((long)B * S * S, 256);
     const size_t tiles32 = (size_t)B * ((S + 31) / 32) * ((S + 31) / 32), tiles16 = (size_t)B * ((S + 15) / 16) * ((S + 15) / 16);

@@ -22,6 +22,7 @@ _SIGS = {
     "refhipd_face_index_map": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I],
     "refhipd_texture_sampling": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F],
     "refhipd_backward_pixel_map": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I],
+    "refhipd_backward_pixel_map_f64": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_double, _I, _I],
     "refhipd_backward_textures": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "refhipd_backward_depth_map": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
 }
@@ -115,3 +116,27 @@ def backward(m, grad_rgb_map, grad_alpha_map, grad_depth_map, return_rgb, return
                                      _p(m["weight_map"]), _p(grad_depth_map), _p(grad_faces), B, Fn, S)
     torch.cuda.synchronize()
     return grad_faces, grad_textures
+
+
+def backward_pixel_map_f64(m, grad_rgb_map, grad_alpha_map, return_rgb=True, return_alpha=True):
+    """K4 alone through the reference kernel's DOUBLE instantiation (KCU:245-503 with scalar_t = double; the reference
+    dispatches on the faces' type, KCU:614) on the same inputs widened to f64: grad_faces [B,F,3,3] f64 -- the value both
+    f32 evaluations (the reference's own and the product's) approximate."""
+    L = lib("off")
+    faces = m["faces"]
+    dev = faces.device
+    B, Fn = faces.shape[:2]
+    S = m["image_size"]
+    dummy = torch.zeros(1, dtype=torch.float64, device=dev)
+    wide = lambda t, on: t.double().contiguous() if on else dummy
+    f64 = faces.double().contiguous()
+    rgb, alpha = wide(m.get("rgb_map"), return_rgb), wide(m.get("alpha_map"), return_alpha)
+    g_rgb, g_alpha = wide(grad_rgb_map, return_rgb), wide(grad_alpha_map, return_alpha)
+    grad_faces = torch.zeros_like(f64)
+    torch.cuda.synchronize()
+    # (eps as the f32 value the float instantiation receives, widened)
+    L.refhipd_backward_pixel_map_f64(_p(f64), _p(m["face_index_map"]), _p(rgb), _p(alpha), _p(g_rgb), _p(g_alpha),
+                                     _p(grad_faces), B, Fn, S, float(torch.tensor(m["eps"], dtype=torch.float32)),
+                                     int(bool(return_rgb)), int(bool(return_alpha)))
+    torch.cuda.synchronize()
+    return grad_faces

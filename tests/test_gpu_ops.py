@@ -211,6 +211,70 @@ def test_edge_gradient_pass_with_more_long_segments_than_the_queue_holds():
     assert np.abs(gf_ref).max() > 0 and _grad_close(gf.cpu().numpy(), gf_ref)
 
 
+@pytest.mark.parametrize("gradient", ["grow_band", "dense", "single_pixels", "nan"])
+def test_alpha_only_edge_gradient_sparse_and_dense_walks(gradient, monkeypatch):
+    """K4 with return_rgb == 0 (render_silhouettes): the outward walks' terms are (alpha(d) - 1) * grad_alpha(d), non-zero
+    only at uncovered pixels with a negative gradient, so k_edge_lines compacts those pixels per line and a crossing's
+    thread adds its few terms itself (SPARSE OUTWARD WALKS) -- unless the line holds more of them than D3M_EG_SPARSE_MAX
+    (default S / 4), which walks densely as the rgb modes do.  Both forms against the oracle's per-face walk
+    (KCU:245-503), and against each other far below the tolerance: a thin band of negative gradients outside the
+    silhouette (the shape a silhouette fit produces), dense random gradients (every line over the limit at the default;
+    forced sparse with the limit raised), isolated pixels, and a NaN gradient (kept by `diff_grad <= 0` being false,
+    KCU:401: it must poison the same faces in both forms)."""
+    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
+    from oracle import nr_oracle as O
+    S, n = 192, 300
+    rng = np.random.default_rng(77)
+    xy = rng.uniform(-0.55, 0.55, (2, n, 1, 2)) + rng.uniform(-1, 1, (2, n, 3, 2)) * rng.choice([0.02, 0.08, 0.3], (2, n, 1, 1))
+    faces = np.concatenate([xy, rng.uniform(1.0, 2.0, (2, n, 3, 1))], -1).astype(np.float32)
+    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
+    m = O.raster_forward(faces, None, S, 0.1, 100.0, 1e-3, None, False, True, False)
+    alpha = m["alpha_map"]
+    assert 0.15 < alpha.mean() < 0.85
+    if gradient == "grow_band":         # 2 (alpha - target) / P with a target that is the silhouette dilated by ~6 pixels
+        import scipy.ndimage as ndi
+        target = np.stack([ndi.binary_dilation(a > 0, iterations=6) for a in alpha]).astype(np.float32)
+        target[:, :, : S // 3] = alpha[:, :, : S // 3] * 0.0      # ... and shrunk away on the left third (positive gradients)
+        g_alpha = (2.0 * (alpha - target) / (S * S)).astype(np.float32)
+    elif gradient == "dense":
+        g_alpha = rng.normal(size=alpha.shape).astype(np.float32)
+    else:
+        g_alpha = np.zeros_like(alpha)
+        ys, xs = rng.integers(0, S, 40), rng.integers(0, S, 40)
+        g_alpha[rng.integers(0, 2, 40), ys, xs] = -rng.uniform(0.5, 2.0, 40).astype(np.float32)
+        if gradient == "nan":
+            unc = np.argwhere(alpha[0] == 0)
+            y, x = unc[len(unc) // 2]
+            g_alpha[0, y, x] = np.nan
+    gf_ref, _ = O.raster_backward(m, None, g_alpha, None, False, True, False)
+    fd, fi, am, ga = _dev(faces), _dev(m["face_index_map"]), _dev(alpha), _dev(g_alpha)
+    dummy = torch.zeros(1, device="cuda")
+    got = {}
+    for form, limit in (("default", None), ("dense", "0"), ("sparse", str(S))):
+        if limit is None:
+            monkeypatch.delenv("D3M_EG_SPARSE_MAX", raising=False)
+        else:
+            monkeypatch.setenv("D3M_EG_SPARSE_MAX", limit)
+        gf = torch.zeros_like(fd)
+        ops.backward_pixel_map(fd, fi, dummy, am, dummy, ga, gf, S, 1e-3, False, True)
+        got[form] = gf.cpu().numpy()
+    if gradient == "nan":
+        poisoned = np.isnan(gf_ref).any(axis=(2, 3))
+        assert poisoned.any()
+        for form, g in got.items():
+            assert np.array_equal(np.isnan(g).any(axis=(2, 3)), poisoned), form
+            ok = ~np.isnan(gf_ref)
+            assert np.abs(g[ok] - gf_ref[ok]).max() <= GRAD_RTOL * np.abs(gf_ref[ok]).max(), form
+        return
+    assert np.abs(gf_ref).max() > 0
+    for form, g in got.items():
+        assert _grad_close(g, gf_ref), (form, np.abs(g - gf_ref).max() / np.abs(gf_ref).max())
+    scale = np.abs(gf_ref).max()
+    assert np.abs(got["sparse"] - got["dense"]).max() <= 1e-4 * scale
+    # the sparse form's terms carry correctly rounded quotients: no further from the reference than the dense walk
+    assert np.abs(got["sparse"] - gf_ref).max() <= np.abs(got["dense"] - gf_ref).max() + 2e-6 * scale
+
+
 def test_edge_gradient_on_an_image_wider_than_the_line_window():
     """K4 at S = 2304: above 2048 pixels per line the plan's count pass merges its line counters by key instead of in
     the LDS line window, and the line kernel clamps instead of padding -- small and large faces, two views, against

@@ -29,7 +29,7 @@ def _rel_max(got, ref):
 
 
 ELEM_RTOL, ELEM_ATOL_OF_MAX = 1e-3, 1e-5     # element-wise: |d| <= 1e-3 |ref| + 1e-5 max|ref|
-ELEM_VIOLATING_FRAC = 1e-5                  # ... for all but this fraction of the entries
+ELEM_VIOLATING_FRAC = 7e-6                  # ... for all but this fraction of the entries (measured: 0.3 .. 2.1e-6, x 3)
 
 
 def _grad_stats(got, ref):
@@ -268,6 +268,17 @@ def _full_size_check(faces, S, ts, form, ran, seed, textures_batch=None):
     gf4_ref, _ = RH.backward(ref, g_rgb, g_alpha, None, True, True, False)
     gf4, _ = _raster_backward_parts(faces, tex, m, S, eps, g_rgb, g_alpha, None)
     dist["grad_faces_K4_alone"] = _grad_stats(gf4, gf4_ref)
+    # HOW MUCH OF THAT IS THE F32 WALK'S OWN ROUNDING.  The reference's kernel instantiated for double (its
+    # own second dispatch, KCU:614) on the same inputs is the value both f32 evaluations approximate.  Measured against
+    # it, the reference's float instantiation and the product are the same distance away (recorded per configuration): the
+    # ~9e-4 tail of product-vs-reference is two independent f32 roundings of sums whose terms cancel, not a drift of the
+    # product -- and the product must stay as close to the f64 value as the reference's own f32 evaluation is.
+    truth = RH.backward_pixel_map_f64(ref, g_rgb, g_alpha)
+    dist["K4_reference_f32_vs_reference_f64"] = _grad_stats(gf4_ref, truth)
+    dist["K4_product_vs_reference_f64"] = _grad_stats(gf4, truth)
+    noise, ours = dist["K4_reference_f32_vs_reference_f64"], dist["K4_product_vs_reference_f64"]
+    assert ours["rel_p999"] <= 1.5 * noise["rel_p999"] + 1e-4 and ours["rel_max"] <= 1.5 * noise["rel_max"] + 1e-4, (ours, noise)
+    del truth
     gf6_ref, _ = RH.backward(ref, None, None, g_depth, False, False, True)
     gf6, _ = _raster_backward_parts(faces, tex, m, S, eps, None, None, g_depth)
     dist["grad_faces_K6_alone"] = _grad_stats(gf6, gf6_ref)
