@@ -233,6 +233,41 @@ __global__ void __launch_bounds__(256) k_scatter_face_grads(IndexedFaces fs, con
     atomicAdd(&grad_vertices[((size_t)b * fs.V + ids[n]) * 3 + c], g);
 }
 
+// ---- the same sums GATHERED per vertex, in a fixed order (deterministic mode, d3m_set_deterministic) ----------------------
+// The scatter above (and the vertex targets of the backward operators) add with float atomics: which workgroup's term lands
+// first depends on timing, and a float sum depends on its order -- the vertex gradient differs by ~1e-7 of its largest entry
+// from run to run.  Here every (view, vertex) is ONE lane that walks the vertex's incident (triangle, corner) pairs in
+// ascending order -- a CSR adjacency of the index tensor, built once per topology on the host side -- and adds the entries
+// of up to two per-face gradient arrays (K4's and K6's: the reference's own layout [B,F',3,3]) for the front copy, then for
+// the fill_back copy (face F + f holds the triangle's vertices reversed: corner 2 - c).  Plain store: every run adds the
+// same floats in the same order.
+__global__ void __launch_bounds__(256) k_vertex_gather(const float* __restrict__ gf_a, const float* __restrict__ gf_b,
+                                                      const int32_t* __restrict__ adj_offsets,
+                                                      const int32_t* __restrict__ adj_items, float* __restrict__ grad_vertices,
+                                                      int B, int V, int Ft, int fill_back) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * V) return;
+    const int b = (int)(i / V), v = (int)(i % V);
+    const int Fp = fill_back ? 2 * Ft : Ft;
+    const size_t view = (size_t)b * Fp * 9;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int e = adj_offsets[v]; e < adj_offsets[v + 1]; e++) {
+        const int item = adj_items[e], f = item / 3, c = item - 3 * f;
+#pragma unroll
+        for (int copy = 0; copy < 2; copy++) {
+            if (copy == 1 && !fill_back) break;
+            const size_t at = view + (size_t)(copy ? Ft + f : f) * 9 + (size_t)(copy ? 2 - c : c) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (gf_a) acc[k] += gf_a[at + k];
+                if (gf_b) acc[k] += gf_b[at + k];
+            }
+        }
+    }
+    float* out = grad_vertices + (size_t)i * 3;
+    out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
+}
+
 // ---- lighting (neural_renderer/lighting.py:33-56) ---------------------------------------------------------
 // light[b,f,:] = ia*ca + id*cd*relu(normal . direction), normal = normalise(cross(v0-v1, v2-v1), eps 1e-5);
 // textures[b,f,...,:] *= light.  A block owns 256 consecutive faces: phase 1 one lane per face computes the

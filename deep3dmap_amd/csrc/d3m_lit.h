@@ -90,6 +90,52 @@ __global__ void __launch_bounds__(256) k_face_light_backward(IndexedFaces fs, Li
     }
 }
 
+// The same adjoint GATHERED per vertex in a fixed order (deterministic mode; see k_vertex_gather): one lane per vertex of
+// ONE shared mesh walks the vertex's incident (triangle, corner) pairs and adds what the front copy and the fill_back copy of
+// each triangle send to that corner -- the per-face expressions of k_face_light_backward, recomputed per incident face
+// (six per vertex on a grid mesh) instead of scattered with float atomics.  grad_vertices [V,3] is WRITTEN.
+__device__ __forceinline__ void face_light_corner_grad(const IndexedFaces& fs, const LightParams& lp,
+                                                       const float* __restrict__ g_light, int f, int corner, float* acc) {
+    const float gl[3] = {g_light[3 * (size_t)f], g_light[3 * (size_t)f + 1], g_light[3 * (size_t)f + 2]};
+    if (gl[0] == 0 && gl[1] == 0 && gl[2] == 0) return;
+    float fc[9], l[3], nrm[3], len, cs;
+    fs.load(0, f, fc);
+    face_light(fc, lp, l, nrm, &len, &cs);
+    if (!(cs > 0)) return;
+    const float g_cos = lp.id * (lp.cd[0] * gl[0] + lp.cd[1] * gl[1] + lp.cd[2] * gl[2]);
+    const float gn[3] = {g_cos * lp.dir[0], g_cos * lp.dir[1], g_cos * lp.dir[2]};
+    float gc[3];
+    if (len > 1e-5f) {
+        const float dot = nrm[0] * gn[0] + nrm[1] * gn[1] + nrm[2] * gn[2];
+        for (int k = 0; k < 3; k++) gc[k] = (gn[k] - nrm[k] * dot) / len;
+    } else {
+        for (int k = 0; k < 3; k++) gc[k] = gn[k] / 1e-5f;
+    }
+    const float a[3] = {fc[0] - fc[3], fc[1] - fc[4], fc[2] - fc[5]};
+    const float bb[3] = {fc[6] - fc[3], fc[7] - fc[4], fc[8] - fc[5]};
+    float ga[3], gb[3];
+    cross3(bb, gc, ga);
+    cross3(gc, a, gb);
+    for (int k = 0; k < 3; k++) acc[k] += corner == 0 ? ga[k] : (corner == 2 ? gb[k] : -(ga[k] + gb[k]));
+}
+__global__ void __launch_bounds__(256) k_face_light_backward_gather(IndexedFaces fs, LightParams lp,
+                                                                   const float* __restrict__ g_light,
+                                                                   const int32_t* __restrict__ adj_offsets,
+                                                                   const int32_t* __restrict__ adj_items,
+                                                                   float* __restrict__ grad_vertices) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= fs.V) return;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    if (lp.id != 0) {
+        for (int e = adj_offsets[v]; e < adj_offsets[v + 1]; e++) {
+            const int item = adj_items[e], f = item / 3, c = item - 3 * f;
+            face_light_corner_grad(fs, lp, g_light, f, c, acc);
+            if (fs.fill_back) face_light_corner_grad(fs, lp, g_light, fs.Ft + f, 2 - c, acc);
+        }
+    }
+    grad_vertices[3 * (size_t)v + 0] = acc[0]; grad_vertices[3 * (size_t)v + 1] = acc[1]; grad_vertices[3 * (size_t)v + 2] = acc[2];
+}
+
 // trilinear sample positions of one covered pixel: KCU:209-231 (shared by the sampler and its backward)
 __device__ __forceinline__ void sample_setup(const float* face, const float* weight, float depth, int ts, float eps,
                                              int* fl, float* fr) {
@@ -718,6 +764,8 @@ struct LitFaceArgs {
     float eps;
     GradScale gs;
     int* n_large;                  // [1] zeroed: faces handed to the per-pixel kernels (which leave at once when it stays 0)
+    int max_area = FM_MAX_BBOX_AREA;   // faces with a larger box go to the per-pixel kernels; INT_MAX in the deterministic mode
+                                       // (those add with float atomics in arrival order; here a face's lanes own its sums)
 };
 
 // LANES adjacent lanes share a face: LIT_LANES (8) for ordinary meshes, a whole wave (64) for coarse ones, whose faces of
@@ -756,7 +804,7 @@ __device__ __forceinline__ void lit_face_backward(const LitFaceArgs& a, long gi,
     const int fo = fn >= lt.F ? fn - lt.F : fn;
     float* gt = gtex_view + ((size_t)bn * lt.F + fo) * 24;
     if (sub == 0 && a.view_mask) atomicOr(&a.view_mask[(size_t)fo * ((a.B + 31) >> 5) + (bn >> 5)], 1u << (bn & 31));
-    if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
+    if (area > a.max_area) {              // left to the per-pixel atomic kernel, which adds: give it zeros
         flags[gi] = FLAG_LARGE;
         if (sub == 0) atomicAdd(a.n_large, 1);
         for (int t = sub; t < 24; t += LANES) gt[t] = 0.0f;
@@ -938,7 +986,7 @@ __device__ __forceinline__ void lit_face_backward_any(const LitFaceArgs& a, long
     const int fo = back ? fn - lt.F : fn;
     float* gt = a.gtex_view + ((size_t)bn * lt.F + fo) * ts3 * 3;
     if (sub == 0 && a.view_mask) atomicOr(&a.view_mask[(size_t)fo * ((a.B + 31) >> 5) + (bn >> 5)], 1u << (bn & 31));
-    if (area > FM_MAX_BBOX_AREA) {        // left to the per-pixel atomic kernel, which adds: give it zeros
+    if (area > a.max_area) {              // left to the per-pixel atomic kernel, which adds: give it zeros
         a.flags[gi] = FLAG_LARGE;
         if (sub == 0) atomicAdd(a.n_large, 1);
         for (int t = sub; t < ts3 * 3; t += LANES) gt[t] = 0.0f;

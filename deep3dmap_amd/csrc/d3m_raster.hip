@@ -20,6 +20,7 @@
 #include "d3m_g2s.h"
 #include "d3m_bid.h"
 #include "d3m_front.h"
+#include <climits>
 #include <cstdlib>
 #include <atomic>
 
@@ -1005,6 +1006,34 @@ D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch
     return check_launch();
 }
 
+// ---- deterministic mode: the vertex sums gathered in a fixed order instead of scattered with float atomics ---------------
+D3M_EXPORT int d3m_vertex_gather(const float* grad_faces_a, const float* grad_faces_b, const int32_t* adj_offsets,
+                                 const int32_t* adj_items, float* grad_vertices, int batch_size, int num_vertices,
+                                 int num_tri, int fill_back, d3m_stream_t stream) {
+    if ((!grad_faces_a && !grad_faces_b) || !adj_offsets || !adj_items || !grad_vertices || batch_size <= 0 ||
+        num_vertices <= 0 || num_tri <= 0)
+        return D3M_ERR_INVALID;
+    LAUNCH("k_vertex_gather", k_vertex_gather, dim3(blocks_for((long)batch_size * num_vertices, 256)), dim3(256),
+           (hipStream_t)stream, grad_faces_a, grad_faces_b, adj_offsets, adj_items, grad_vertices, batch_size, num_vertices,
+           num_tri, fill_back ? 1 : 0);
+    return check_launch();
+}
+D3M_EXPORT int d3m_face_light_backward_gather(const float* vertices, const int32_t* tri, const int32_t* adj_offsets,
+                                              const int32_t* adj_items, const float* grad_light, float* grad_vertices,
+                                              float intensity_ambient, float intensity_directional,
+                                              const float* color_ambient, const float* color_directional,
+                                              const float* direction, int num_vertices, int num_tri, int fill_back,
+                                              d3m_stream_t stream) {
+    if (!vertices || !tri || !adj_offsets || !adj_items || !grad_light || !grad_vertices || !color_ambient ||
+        !color_directional || !direction || num_vertices <= 0 || num_tri <= 0)
+        return D3M_ERR_INVALID;
+    IndexedFaces fs{vertices, tri, num_vertices, num_tri, 1, fill_back ? 1 : 0, 1, 0};
+    const LightParams lp = to_light(intensity_ambient, intensity_directional, color_ambient, color_directional, direction);
+    LAUNCH("k_face_light_backward_gather", k_face_light_backward_gather, dim3(blocks_for((long)num_vertices, 256)), dim3(256),
+           (hipStream_t)stream, fs, lp, grad_light, adj_offsets, adj_items, grad_vertices);
+    return check_launch();
+}
+
 // ---- the first launch of a lit render step: camera + per-face light + every clear (d3m_front.h) ------------------------
 D3M_EXPORT int d3m_lit_front(const float* vertices, int vertices_batch, const d3m_camera* cam, const d3m_basis* basis,
                              float* screen_out, int batch_size, int num_vertices, const int32_t* tri, int tri_batch,
@@ -1409,7 +1438,8 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
         if (!visibility)
             LAUNCH("k_mark_visible", k_mark_visible, dim3(blocks_for(n, 256)), dim3(256), st, face_index_map, flags, B, lt.Fp, S);
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
+                       grad_faces, vt, flags, use_mask ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large,
+                       deterministic_mode() ? INT_MAX : FM_MAX_BBOX_AREA};
         // (a coarse mesh -- more than 48 raster pixels per triangle -- gives a face a whole wave instead of eight lanes)
         const bool coarse = list && (double)S * S > 48.0 * (double)num_tri;
         const unsigned all_blocks = blocks_for(nf, coarse ? 4 : LIT_FACES_PER_BLOCK);
@@ -1428,7 +1458,8 @@ D3M_EXPORT int d3m_backward_textures_lit(const float* faces, const float* textur
     } else if (gathered_any) {
         // texture cubes of 3^3 / 4^3 texels over the visibility list: the same three launches as ts = 2, the face's sums in LDS
         LitFaceArgs fa{faces, lt, face_index_map, weight_map, depth_map, grad_rgb, gview, grad_light, grad_depth_map,
-                       grad_faces, vt, flags, skip_zero ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large};
+                       grad_faces, vt, flags, skip_zero ? view_mask : nullptr, list, n_list, B, S, eps, gs, W.n_large,
+                       deterministic_mode() ? INT_MAX : FM_MAX_BBOX_AREA};
         const bool coarse = (double)S * S > 48.0 * (double)num_tri;          // (a wave per face: as at ts = 2)
         const unsigned all_blocks = blocks_for(nf, coarse ? 4 : LIT_FACES_PER_BLOCK);
         const dim3 g_faces(all_blocks > 4096 ? 4096 : (all_blocks + 7) / 8 * 8);

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ._util import f32c
+from ._util import deterministic, f32c, vertex_adjacency
 
 
 class _GatherFaces(torch.autograd.Function):
@@ -30,6 +30,14 @@ class _GatherFaces(torch.autograd.Function):
         (tri,) = ctx.saved_tensors
         B, V, Ft, fill_back = ctx.dims
         g = f32c(grad_faces)
+        if deterministic() and tri.shape[0] == 1:
+            # d3m_set_deterministic: the same sums gathered per vertex in a fixed order (CSR adjacency of the index tensor)
+            # instead of scattered with float atomics in arrival order
+            off, items = vertex_adjacency(tri, V)
+            gv = torch.empty(B, V, 3, dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().d3m_vertex_gather(_lib.ptr(g), None, _lib.ptr(off), _lib.ptr(items), _lib.ptr(gv), B, V, Ft,
+                                                    int(fill_back), _lib.stream_ptr()), "d3m_vertex_gather")
+            return gv, None, None
         gv = torch.zeros(B, V, 3, dtype=torch.float32, device=g.device)
         rc = _lib.lib().d3m_scatter_face_grads(_lib.ptr(g), _lib.ptr(tri), tri.shape[0], _lib.ptr(gv), B, V, Ft,
                                                int(fill_back), _lib.stream_ptr())

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import _lib
 from . import rasterize_ops as ops
-from ._util import const_tensor, f32c
+from ._util import const_tensor, deterministic as _deterministic, f32c, vertex_adjacency
 
 DEFAULT_IMAGE_SIZE = 256
 DEFAULT_ANTI_ALIASING = True
@@ -498,7 +498,12 @@ class _RasterizeLit(torch.autograd.Function):
                           torch.empty(B, S, S, dtype=torch.float32, device=dev))           # grad_depth_map
             fit_state = (rgb_t, depth_t, alpha_t, mask, scratch, loss_g, g_maps, mask_sum, bool(anti_aliasing))
         cur = torch.cuda.current_stream()
-        serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
+        det = need_grad and _deterministic()
+        if det:
+            _RasterizeLit._deterministic_supported(G, tri, vertices, ts, idr, ctx.needs_input_grad[1])
+            if need_geom:
+                vertex_adjacency(tri, V)            # (built here, outside any capture of the backward pass)
+        serial = G == 1 and (det or getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         nz_own = None
@@ -538,7 +543,7 @@ class _RasterizeLit(torch.autograd.Function):
                 flags_fit = _lib.PRECLEARED
         if nz_own is not None:
             clears.append(_lib.tensor_range(nz_own))
-        step_mode = G == 1 and need_grad and (defer_plan_join or getattr(ctx, "force_serial", False)) and \
+        step_mode = G == 1 and need_grad and (defer_plan_join or getattr(ctx, "force_serial", False)) and not det and \
             os.environ.get("D3M_NO_PRECLEAR") != "1"
         if step_mode:
             pre = _RasterizeLit._backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera is not None,
@@ -655,6 +660,17 @@ class _RasterizeLit(torch.autograd.Function):
             return loss_g.sum() if G > 1 else loss_g.reshape(())
         empty = torch.tensor([])
         return (rgb, alpha if return_alpha else empty, depth if return_depth else empty)
+
+    @staticmethod
+    def _deterministic_supported(G, tri, vertices, ts, idr, vertices_need_grad):
+        """The deterministic backward pass covers one pipeline over ONE shared index tensor (and, for the light's adjoint,
+        one shared mesh) with gathered texture passes (texture_size 2, 3 or 4): anything else would silently fall back to
+        float atomics in arrival order, so it raises instead."""
+        if G != 1 or tri.shape[0] != 1 or ts not in (2, 3, 4) or (vertices_need_grad and idr != 0 and vertices.shape[0] != 1):
+            raise NotImplementedError(
+                "D3M_DETERMINISTIC / d3m_set_deterministic(1): the lit render node's reproducible backward pass needs "
+                "view_groups == 1, faces of batch 1 (one shared topology), texture_size 2..4 and, with directional light, "
+                "vertices of batch 1")
 
     @staticmethod
     def _backward_buffers(ctx, L, vertices, textures, light, grad_sink, camera_inside, B, V, Ft, ts, Bl, fill_back, idr,
@@ -808,8 +824,23 @@ class _RasterizeLit(torch.autograd.Function):
                     else:
                         grad_light = torch.empty_like(light)
                         gl_g = [grad_light[lo:hi] for lo, hi in groups]
+        # DETERMINISTIC (d3m_set_deterministic / D3M_DETERMINISTIC=1; one pipeline, one shared topology).  Everything the
+        # pass adds up with float atomics in arrival order is produced per (view, face) by the lanes that own it and then
+        # summed in a FIXED order instead:
+        #   K4 -> its own dense [B,F',3,3] array (k_edge_gather's plain stores: the reference's layout), K6 -> another one
+        #   (k_backward_textures_lit_faces with grad_faces and NO large-face fallback: a face's lanes own its sums whatever
+        #   its size), both gathered per vertex over a CSR adjacency of the index tensor (d3m_vertex_gather);
+        #   the light's gradient per VIEW ([B,F',3]: one contribution per entry), summed over the views by torch's ordered
+        #   reduction, its adjoint gathered per vertex (d3m_face_light_backward_gather);
+        #   the visibility list in ascending order (the library, same switch); every kernel on one stream.
+        # The camera's adjoint and the sum of the per-view texel gradients already add in view order.  What stays
+        # unordered: the plan's fallback for an undersized workspace (k_edge_overflow) -- see DESIGN.md section 6.
+        det = _deterministic()
+        if det:
+            _RasterizeLit._deterministic_supported(G, tri, vertices, ts, idr, ctx.needs_input_grad[1])
+            pre = None
         cur = torch.cuda.current_stream()
-        serial = G == 1 and (getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
+        serial = G == 1 and (det or getattr(ctx, "force_serial", False) or _serial_branches(B, Ft, S))
         mains = [cur] + [_side_stream(dev, k) for k in range(1, G)]
         auxs = [_side_stream(dev, G + k, serial) for k in range(G)]
         plan_ready = m["plan_ready"]
@@ -833,11 +864,25 @@ class _RasterizeLit(torch.autograd.Function):
             ranges = [_lib.tensor_range(grad_sv)] if grad_sv is not None else []
             if grad_vertices is not None:
                 ranges.append(_lib.tensor_range(grad_vertices))
+            det_light = det_gl = det_k4 = det_k6 = None
+            if det:
+                # per-VIEW light gradients (one contribution per entry), the two per-face arrays of K4 and K6
+                Fp_ = 2 * Ft if fill_back else Ft
+                if gathered and need_vert:
+                    det_light = light.expand(B, Fp_, 3).contiguous() if light_shared else light
+                    det_gl = torch.empty(B, Fp_, 3, dtype=torch.float32, device=dev)
+                if need_geom:
+                    det_k4 = torch.empty(B, Fp_, 3, 3, dtype=torch.float32, device=dev)
+                    ranges.append(_lib.tensor_range(det_k4))
+                    if rd:
+                        det_k6 = torch.empty(B, Fp_, 3, 3, dtype=torch.float32, device=dev)
+                        ranges.append(_lib.tensor_range(det_k6))
             if gathered and G == 1:
                 with torch.cuda.stream(s_gath[0]):     # (scratch is cached per stream: the stream the pass will run on)
                     ws1 = ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(B, Ft, int(fill_back), ts), dev)
                 ranges += _lit_clear_ranges(L, grad_textures if grad_textures is not None else gt_g[0], textures.shape[0],
-                                            gl_g[0] if gl_g is not None else None, light.shape[0], B, Ft, fill_back, ts, ws1)
+                                            det_gl if det_gl is not None else (gl_g[0] if gl_g is not None else None),
+                                            B if det_gl is not None else light.shape[0], B, Ft, fill_back, ts, ws1)
                 lit_ws, lit_flags = [ws1], _lib.PRECLEARED
             _lib.zero_raw(ranges)
         for k in range(G):
@@ -879,27 +924,52 @@ class _RasterizeLit(torch.autograd.Function):
                     ws = lit_ws[k] if lit_ws is not None else \
                         ops._workspace("lit", L.d3m_backward_textures_lit_workspace_bytes(Bg, Ft, int(fill_back), ts), dev)
                     # the depth gradient (K6, add) rides along in the same pass over the faces' pixels
-                    _lib.check(L.d3m_backward_textures_lit(
-                        _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
-                        _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(_bslice(g_rgb_map, lo, hi)), _lib.ptr(gt_g[k]),
-                        _lib.ptr(gl_g[k]) if gl_g is not None else None,
-                        _lib.ptr(g_depth_map[lo:hi]) if rd_geom else None, None, Bg, Ft, int(fill_back), S, ts, eps,
-                        _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd_geom else None, _lib.ptr(vis[k]),
-                        ctypes.byref(unscaled) if unscaled is not None else None, lit_flags, _lib.stream_ptr()),
-                        "d3m_backward_textures_lit")
+                    if det:     # per-view light gradient, K6 into its own per-face array: no vertex target (see DETERMINISTIC)
+                        light_d = det_light if det_light is not None else light_g
+                        _lib.check(L.d3m_backward_textures_lit(
+                            _lib.ptr(faces), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_d), light_d.shape[0],
+                            _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), None, _lib.ptr(gt_g[k]), _lib.ptr(det_gl),
+                            _lib.ptr(g_depth_map) if rd_geom else None, _lib.ptr(det_k6) if rd_geom else None, Bg, Ft,
+                            int(fill_back), S, ts, eps, _lib.ptr(ws), ws.numel(), None, _lib.ptr(vis[k]),
+                            ctypes.byref(unscaled) if unscaled is not None else None, lit_flags, _lib.stream_ptr()),
+                            "d3m_backward_textures_lit")
+                    else:
+                        _lib.check(L.d3m_backward_textures_lit(
+                            _lib.ptr(faces[lo:hi]), _lib.ptr(tex_g), tex_g.shape[0], _lib.ptr(light_g), light_g.shape[0],
+                            _lib.ptr(fi_g), _lib.ptr(wm_g), _lib.ptr(dm_g), _lib.ptr(_bslice(g_rgb_map, lo, hi)),
+                            _lib.ptr(gt_g[k]), _lib.ptr(gl_g[k]) if gl_g is not None else None,
+                            _lib.ptr(g_depth_map[lo:hi]) if rd_geom else None, None, Bg, Ft, int(fill_back), S, ts, eps,
+                            _lib.ptr(ws), ws.numel(), ctypes.byref(target) if rd_geom else None, _lib.ptr(vis[k]),
+                            ctypes.byref(unscaled) if unscaled is not None else None, lit_flags, _lib.stream_ptr()),
+                            "d3m_backward_textures_lit")
             if G == 1:
                 yield "textures"        # (one pipeline: the texture side is complete in the order of its stream)
             if need_geom:
                 with torch.cuda.stream(s_edges[k]):
                     ops.backward_pixel_map(faces[lo:hi], fi_g, m["rgb_map"][lo:hi], m["alpha_map"][lo:hi] if ra else None,
-                                           _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None, None, S,
-                                           eps, True, ra,
-                                           vertex_target=target, visibility=vis[k], unscaled=unscaled,
+                                           _bslice(g_rgb_map, lo, hi), _bslice(g_alpha_map, lo, hi) if ra else None,
+                                           det_k4 if det else None, S, eps, True, ra,
+                                           vertex_target=None if det else target, visibility=vis[k], unscaled=unscaled,
                                            edge_plan=m["edge_plan"][k])
+                    if det:     # K4's and K6's per-face arrays -> the screen-space gradient, per vertex in a fixed order
+                        adj_off, adj_items = vertex_adjacency(tri, V)
+                        _lib.check(L.d3m_vertex_gather(_lib.ptr(det_k4), _lib.ptr(det_k6), _lib.ptr(adj_off), _lib.ptr(adj_items),
+                                                       _lib.ptr(grad_sv), B, V, Ft, int(fill_back), _lib.stream_ptr()),
+                                   "d3m_vertex_gather")
         if G > 1:
             yield "textures"
         def light_to_vertices(grad_light):
             # the light gradient -> world-space vertices through the face normals
+            if det:     # the views' gradients summed in view order (torch's reduction), the adjoint gathered per vertex
+                total = det_gl.sum(0) if light_shared else None
+                if total is None:
+                    raise NotImplementedError("deterministic mode: one shared mesh")
+                adj_off, adj_items = vertex_adjacency(tri, V)
+                _lib.check(L.d3m_face_light_backward_gather(
+                    _lib.ptr(vertices), _lib.ptr(tri), _lib.ptr(adj_off), _lib.ptr(adj_items), _lib.ptr(total),
+                    _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), V, Ft,
+                    int(fill_back), _lib.stream_ptr()), "d3m_face_light_backward_gather")
+                return
             _lib.check(L.d3m_face_light_backward(
                 _lib.ptr(vertices), vertices.shape[0], _lib.ptr(tri), tri.shape[0], _lib.ptr(grad_light),
                 _lib.ptr(grad_vertices), ia, idr, _vec3_host(ca), _vec3_host(cd), _vec3_host(direction), Bl, V,
@@ -908,7 +978,7 @@ class _RasterizeLit(torch.autograd.Function):
         # One pipeline on one stream with the camera inside the node: the light's adjoint and the camera's are the step's last
         # two kernels -- ONE launch then (d3m_lit_back: both add into the zeroed grad_vertices with float atomics).  With
         # branches the light's adjoint runs beside the line walk instead (below), where it costs the step nothing.
-        fused_tail = serial and G == 1 and gathered and need_vert and ctx.camera is not None
+        fused_tail = serial and G == 1 and gathered and need_vert and ctx.camera is not None and not det
         light_done = fused_tail
         if gathered and need_vert and G == 1 and not fused_tail:
             # one pipeline: straight behind the gathered pass on its branch, beside the line walk, not behind the join

@@ -89,6 +89,22 @@ int d3m_get_coverage_form(void);
  * environment variable D3M_DETERMINISTIC=1 sets the initial value.  Returns D3M_ERR_INVALID for values other than 0 / 1. */
 int d3m_set_deterministic(int on);
 int d3m_get_deterministic(void);
+/* The per-vertex sums of the deterministic mode (deep3dmap_amd/neural_renderer/rasterize.py, "DETERMINISTIC"): the adjoint
+ * of vertices_to_faces + fill_back (NR/vertices_to_faces.py:16-22, NR/renderer.py:86) GATHERED per vertex in a fixed order
+ * instead of scattered with float atomics.  adj_offsets [V+1], adj_items [3 F]: CSR adjacency of ONE index tensor tri [F,3]
+ * -- item = 3 f + c for "corner c of triangle f", the items of a vertex in ascending order.
+ * d3m_vertex_gather: grad_vertices [B,V,3] (WRITTEN) = the sum over a vertex's items of grad_faces_a[b,f,c,:] +
+ * grad_faces_b[b,f,c,:] (either array may be NULL; both [B,F',3,3]) and, with fill_back, of the copy's [b,F+f,2-c,:].
+ * d3m_face_light_backward_gather: d3m_face_light_backward for ONE shared mesh (vertices [V,3], grad_light [F',3]), the same
+ * per-face terms gathered per vertex: grad_vertices [V,3] is WRITTEN. */
+int d3m_vertex_gather(const float* grad_faces_a, const float* grad_faces_b, const int32_t* adj_offsets,
+                      const int32_t* adj_items, float* grad_vertices, int batch_size, int num_vertices, int num_tri,
+                      int fill_back, d3m_stream_t stream);
+int d3m_face_light_backward_gather(const float* vertices, const int32_t* tri, const int32_t* adj_offsets,
+                                   const int32_t* adj_items, const float* grad_light, float* grad_vertices,
+                                   float intensity_ambient, float intensity_directional, const float* color_ambient,
+                                   const float* color_directional, const float* direction, int num_vertices, int num_tri,
+                                   int fill_back, d3m_stream_t stream);
 /* The form (0 | 1) a launch of d3m_forward_face_index_map_mesh on `batch_size` views of a mesh of `num_triangles` triangles
  * (before fill_back) at `image_size` takes with a workspace of d3m_forward_workspace_bytes(); -1 for invalid sizes.  The
  * automatic choice: bidding for sub-pixel triangles (more than two per three raster pixels) whatever the batch; per-tile

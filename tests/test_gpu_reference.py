@@ -428,3 +428,78 @@ def test_config4_mesh_path_and_lit_step_against_reference(views, form, ran):
     gt_fb = (gt_ref * light[None]).sum(0)
     gt_ref0 = gt_fb[:Ft] + gt_fb[Ft:].permute(0, 3, 2, 1, 4)
     assert _rel_max(texg.grad[0], gt_ref0) <= GRAD_RTOL, _rel_max(texg.grad[0], gt_ref0)
+
+
+def test_config4_pooled_objective_at_full_size_against_reference():
+    """the anti-aliased form of the fused objective (k_render_lit_fit_records_pooled: objective on the
+    2x2-pooled images, walk records per INTERNAL pixel) had only been checked at <= 64^2.  Here at the headline's size --
+    config 4's mesh, output 512^2 = internal 1024^2, three cameras -- against the reference's kernels: the pooled images the
+    same pass writes (images_out) equal the reference's maps flipped and pooled (NR/rasterize.py:305-326); the objective's
+    value equals the composition of deep3dmap's losses on them; and d(loss)/d(screen vertices), d(loss)/d(textures) equal
+    the reference's K4 + K5 + K6 fed with the objective's gradient images spread over the internal pixels (the pooling's
+    adjoint: a quarter each), pushed through the gather's adjoint."""
+    import torch.nn.functional as Fnn
+    from deep3dmap_amd import synthetic
+    from deep3dmap_amd.neural_renderer import mesh_ops
+    from deep3dmap_amd.neural_renderer.rasterize import rasterize_lit_fit
+    s_out = 512
+    eyes_np = synthetic.camera_ring(32)[[2, 13, 24]]
+    v, tri, sv, faces, S = _config_scene(225, eyes_np, s_out, True)
+    assert S == 1024
+    B = len(eyes_np)
+    tex0 = torch.from_numpy(synthetic.random_textures(tri.shape[0], 2)).cuda()
+    vt = torch.from_numpy(v).cuda()[None]
+    ft = torch.from_numpy(tri).cuda()[None]
+    light_cfg = (0.5, 0.5, [1, 1, 1], [1, 1, 1], [0, 1, 0])
+    tex_fb = torch.cat((tex0[None], tex0[None].permute(0, 1, 4, 3, 2, 5)), dim=1)
+    faces_world = mesh_ops.gather_faces(vt, ft, True)
+    tex_lit = mesh_ops.lighting(faces_world, tex_fb.clone(), *light_cfg).expand(B, -1, -1, -1, -1, -1).contiguous()
+    ref = RH.forward(faces, tex_lit, S, 0.1, 100.0, 1e-3, (0, 0, 0))
+    # the reference's output images: flip, CHW, 2x2 mean (NR/rasterize.py:305-326) -- leaves of a torch graph
+    pool = lambda x: Fnn.avg_pool2d(x, 2)
+    rgb_r = pool(ref["rgb_map"].permute(0, 3, 1, 2).flip(2)).requires_grad_(True)
+    alpha_r = pool(ref["alpha_map"].flip(1)[:, None])[:, 0].requires_grad_(True)
+    depth_r = pool(ref["depth_map"].flip(1)[:, None])[:, 0].requires_grad_(True)
+    gen = torch.Generator(device="cuda").manual_seed(45)
+    rgb_t = torch.rand(B, 3, s_out, s_out, device="cuda", generator=gen)
+    depth_t = (depth_r.detach() + 0.05 * torch.randn(B, s_out, s_out, device="cuda", generator=gen)).contiguous()
+    blobs = Fnn.avg_pool2d(torch.rand(B, 1, s_out, s_out, device="cuda", generator=gen), 31, stride=1, padding=15)[:, 0]
+    alpha_t = (blobs > blobs.median()).float().contiguous()
+    mask = alpha_t
+    # deep3dmap's objective on those images (utils.py:105-114 masked L1 means; examples/example2.py:46 squared error)
+    den = mask.sum()
+    loss_r = ((rgb_r - rgb_t).abs() * mask[:, None]).sum() / (3 * den) + ((alpha_r - alpha_t) ** 2).sum() / (s_out * s_out) + \
+        ((depth_r - depth_t).abs() * mask).sum() / den
+    loss_r.backward()
+    # the pooling's adjoint: every internal pixel of an output pixel gets a quarter of its gradient; un-flip, HWC
+    spread = lambda g: (g.repeat_interleave(2, -2).repeat_interleave(2, -1) * 0.25)
+    g_rgb = spread(rgb_r.grad).flip(2).permute(0, 2, 3, 1).contiguous()
+    g_alpha = spread(alpha_r.grad).flip(1).contiguous()
+    g_depth = spread(depth_r.grad).flip(1).contiguous()
+    gf_ref, gt_ref = RH.backward(ref, g_rgb, g_alpha, g_depth, True, True, True)
+    # product: the fused objective with anti-aliasing, images as a by-product
+    svg = sv.detach().clone().requires_grad_(True)
+    texg = tex0[None].clone().requires_grad_(True)
+    images = (torch.empty(B, 3, s_out, s_out, device="cuda"), torch.empty(B, s_out, s_out, device="cuda"),
+              torch.empty(B, s_out, s_out, device="cuda"))
+    with kernels_launched() as k:
+        loss = rasterize_lit_fit(svg, vt, ft, texg, light_cfg, True, (rgb_t, depth_t, alpha_t, mask), s_out, 0.1, 100.0, 1e-3,
+                                 (0, 0, 0), images_out=images, anti_aliasing=True)
+        loss.backward()
+    assert "k_render_lit_fit_records" in k.names and "k_pack_maps" not in k.names, sorted(k.names)
+    rgb_p, depth_p, alpha_p = images
+    assert torch.equal(alpha_p, alpha_r.detach())
+    assert float((rgb_p - rgb_r.detach()).abs().max()) <= 1e-6 and float((depth_p - depth_r.detach()).abs().max()) <= 1e-5
+    assert abs(float(loss) - float(loss_r)) <= 2e-6 * abs(float(loss_r)), (float(loss), float(loss_r))
+    Ft = tri.shape[0]
+    idx = torch.from_numpy(tri).cuda().long()
+    idx_fb = torch.cat((idx, idx.flip(-1)), 0).reshape(-1)
+    gsv_ref = torch.zeros_like(sv)
+    gsv_ref.index_add_(1, idx_fb, gf_ref.reshape(B, 2 * Ft * 3, 3))
+    light = (tex_lit[0] / tex_fb[0].clamp_min(1e-20))
+    gt_fb = (gt_ref * light[None]).sum(0)
+    gt_ref0 = gt_fb[:Ft] + gt_fb[Ft:].permute(0, 3, 2, 1, 4)
+    errs = {"grad_screen_vertices": _rel_max(svg.grad, gsv_ref), "grad_textures": _rel_max(texg.grad[0], gt_ref0),
+            "loss_rel": abs(float(loss) - float(loss_r)) / abs(float(loss_r))}
+    _record("config4_100352tri_512aa_3views_pooled_objective", {**errs, "pixels_internal": B * S * S, "views": B})
+    assert errs["grad_screen_vertices"] <= GRAD_RTOL and errs["grad_textures"] <= GRAD_RTOL, errs

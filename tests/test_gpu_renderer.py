@@ -1348,3 +1348,68 @@ def test_registered_objective_that_does_not_fit_the_call_is_ignored():
     assert abs(float(local) - float(ref_local)) <= 1e-6 * abs(float(ref_local))
     assert abs(float(glob) - float(ref_glob)) <= 1e-6 * abs(float(ref_glob))
     assert abs(float(ref_local) - float(ref_glob)) > 1e-3 * abs(float(ref_local))          # (the two really differ)
+
+
+@pytest.mark.parametrize("scene", ["fine_mesh_32_views_graph", "coarse_mesh_large_faces", "anti_aliased_dropin"])
+def test_deterministic_mode_is_bit_reproducible(scene):
+    """d3m_set_deterministic(1) / D3M_DETERMINISTIC=1.  The default backward pass adds its vertex gradients
+    with float atomics in arrival order: grad_vertices differs by ~1e-7 of its largest entry from run to run (an ascending
+    visibility list alone does not change that -- measured in round 6: 1 of 12 runs bit-identical either way).  In the
+    deterministic mode the lit render node produces every term per (view, face) and sums per vertex in a fixed order:
+    loss, grad_vertices and grad_textures are BIT-identical over repeated steps -- eager and replayed from a HIP graph --
+    and agree with the default mode to the order of its own spread."""
+    from deep3dmap_amd import _lib, synthetic
+    from deep3dmap_amd.core.losses import multiview_fit_loss
+    from deep3dmap_amd.multiview import MultiViewFit
+    if scene == "fine_mesh_32_views_graph":
+        n, views, size, aa = 120, 32, 256, False
+    elif scene == "coarse_mesh_large_faces":
+        n, views, size, aa = 4, 3, 256, False            # 18 triangles filling a 256^2 raster: boxes far beyond 4096 pixels
+    else:
+        n, views, size, aa = 40, 4, 96, True
+    v, tri = synthetic.grid_mesh(n)
+    tex = synthetic.random_textures(tri.shape[0], 2)
+    fit = MultiViewFit(v, tri, tex, synthetic.camera_ring(views), image_size=size, anti_aliasing=aa,
+                       objective_in_renderer=scene != "anti_aliased_dropin")
+    fit.set_targets_from(synthetic.perturb(v, 0.03))
+    ref = [t.clone() for t in fit.step()]                # default mode
+    runs = []
+    with _lib.deterministic():
+        assert _lib.lib().d3m_get_deterministic() == 1
+        for _ in range(3):
+            runs.append([t.clone() for t in fit.step()])
+        if scene == "fine_mesh_32_views_graph":
+            fit.capture_graph()
+            for _ in range(3):
+                runs.append([t.clone() for t in fit.step()])
+            fit.release_graph()
+    assert _lib.lib().d3m_get_deterministic() == 0
+    for r in runs[1:]:
+        for name, a, b in zip(("loss", "grad_vertices", "grad_textures"), r, runs[0]):
+            assert torch.equal(a, b), (scene, name, float((a - b).abs().max()))
+    assert float(runs[0][1].abs().max()) > 0 and float(runs[0][2].abs().max()) > 0
+    assert abs(float(runs[0][0]) - float(ref[0])) <= 1e-6 * abs(float(ref[0]))
+    assert _rel_max(runs[0][1], ref[1]) < 1e-5 and _rel_max(runs[0][2], ref[2]) < 1e-5
+
+
+def test_deterministic_mode_refuses_what_it_does_not_cover():
+    """... and the shapes its fixed-order sums do not cover (per-view index tensors, view groups) raise instead of silently
+    running the unordered pass; the reference-shaped gather's adjoint (vertices_to_faces) is gathered in order too."""
+    from deep3dmap_amd import _lib
+    from deep3dmap_amd.neural_renderer import mesh_ops
+    vs, tris, texs = (t.cuda() for t in _scene(B=2, n=10))          # faces of batch 2
+    vs.requires_grad_(True)
+    r = _nr().Renderer(camera_mode="look_at", image_size=32, anti_aliasing=False)
+    r.eye = [0.3, 0.4, -2.5]
+    with _lib.deterministic():
+        with pytest.raises(NotImplementedError):
+            r(vs, tris, texs)[0].sum().backward()
+        grads = []
+        for _ in range(3):
+            vv = vs.detach()[:1].clone().requires_grad_(True)
+            (mesh_ops.gather_faces(vv, tris[:1], True) * torch.linspace(0.5, 1.5, 9, device="cuda").view(3, 3)).sum().backward()
+            grads.append(vv.grad.clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    vv = vs.detach()[:1].clone().requires_grad_(True)
+    (mesh_ops.gather_faces(vv, tris[:1], True) * torch.linspace(0.5, 1.5, 9, device="cuda").view(3, 3)).sum().backward()
+    assert _rel_max(grads[0], vv.grad) < 1e-6

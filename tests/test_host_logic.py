@@ -116,6 +116,16 @@ def test_coverage_form_switch_is_host_state():
         assert L.d3m_get_coverage_form() == 0
     assert L.d3m_get_coverage_form() == -1
     L.d3m_set_coverage_form(start)
+    # the deterministic switch: 0 / 1 accepted and read back, anything else refused; the context manager restores
+    was = L.d3m_get_deterministic()
+    assert was in (0, 1)
+    assert L.d3m_set_deterministic(1) == 0 and L.d3m_get_deterministic() == 1
+    assert L.d3m_set_deterministic(2) == 1 and L.d3m_set_deterministic(-1) == 1 and L.d3m_get_deterministic() == 1
+    assert L.d3m_set_deterministic(0) == 0 and L.d3m_get_deterministic() == 0
+    with _lib.deterministic():
+        assert L.d3m_get_deterministic() == 1
+    assert L.d3m_get_deterministic() == 0
+    L.d3m_set_deterministic(was)
 
 
 def test_no_kernel_spills_to_scratch():
