@@ -71,7 +71,7 @@ _SIGNATURES = {
     "d3m_get_coverage_form": (_I, []),
     "d3m_set_deterministic": (_I, [_I]),
     "d3m_get_deterministic": (_I, []),
-    "d3m_vertex_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "d3m_vertex_gather": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "d3m_face_light_backward_gather": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _I, _P]),
     "d3m_forward_coverage_form": (_I, [_I, _I, _I]),
     "d3m_forward_big_batch": (_I, [_I, _I, _I]),

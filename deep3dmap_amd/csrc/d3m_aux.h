@@ -244,7 +244,9 @@ __global__ void __launch_bounds__(256) k_scatter_face_grads(IndexedFaces fs, con
 __global__ void __launch_bounds__(256) k_vertex_gather(const float* __restrict__ gf_a, const float* __restrict__ gf_b,
                                                       const int32_t* __restrict__ adj_offsets,
                                                       const int32_t* __restrict__ adj_items, float* __restrict__ grad_vertices,
-                                                      int B, int V, int Ft, int fill_back) {
+                                                      int B, int V, int Ft, int fill_back, const int* __restrict__ flags) {
+    // flags [B,F'] (optional: a d3m_visibility blob's): a face whose flag is 0 owns no pixel and its entries are zeros --
+    // nine tenths of a fill_back mesh's (view, face) pairs, skipped on a 4-byte look-up instead of two 12-byte reads
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * V) return;
     const int b = (int)(i / V), v = (int)(i % V);
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(256) k_vertex_gather(const float* __restrict__
 #pragma unroll
         for (int copy = 0; copy < 2; copy++) {
             if (copy == 1 && !fill_back) break;
+            if (flags && flags[(size_t)b * Fp + (copy ? Ft + f : f)] == 0) continue;
             const size_t at = view + (size_t)(copy ? Ft + f : f) * 9 + (size_t)(copy ? 2 - c : c) * 3;
 #pragma unroll
             for (int k = 0; k < 3; k++) {

@@ -17,7 +17,7 @@
 //                     line costs the workgroup one global atomic (k_edge_count: the by-key form, for S > 2048);
 //   2. k_scan_small / k_alloc_ranges   crossing base per workgroup, record slice per line (no same-address atomics);
 //   3. k_edge_scatter the lanes' crossings flattened over the threads (one crossing each per round): the geometry of a
-//                     crossing's two walks, computed once, as one 32-byte record written in LINE order; a crossing
+//                     crossing's two walks, computed once, as one 16-byte record written in LINE order; a crossing
 //                     whose walks cannot contribute gets none;
 //  THE GRADIENT (needs the gradient maps)
 //   4. k_pack_maps    what a walk reads per pixel -- (grad_alpha, grad_rgb), sum value*grad, owner -- plus each line's
@@ -153,9 +153,10 @@ __device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p
     g.in_from = g.in_to = 0;
     if (g.d1_in < 0 || is <= g.d1_in || d1_out < 0 || is <= d1_out) { g.d1_in = 0; return g; }   // KCU:325-328
     g.bits |= XG_ALIVE | (p10 != fd0 ? XG_F0 : 0u) | (p00 != fd0 ? XG_F1 : 0u);
-    // KCU:404 / :409: first factor of `dist` -- by v_rcp_f32, like every quotient of the walk that uses it
-    g.q0 = (p10 - p00) * __builtin_amdgcn_rcpf(p10 - fd0);
-    g.q1 = (p10 - p00) * __builtin_amdgcn_rcpf(fd0 - p00);
+    // KCU:404 / :409: first factors of `dist`, correctly rounded quotients (once per crossing; the record keeps ONE of them:
+    // geometry_to_record)
+    g.q0 = (p10 - p00) / (p10 - fd0);
+    g.q1 = (p10 - p00) / (fd0 - p00);
     if (owner(d0, g.d1_in) == fn) g.bits |= XG_OWNER;                                       // KCU:354
     // inward: in-pixel .. opposite edge (KCU:417-431)
     float d0_cross2;
@@ -177,19 +178,39 @@ __device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p
     return g;
 }
 
-// record <-> geometry (32 bytes per crossing)
-__device__ __forceinline__ void geometry_to_record(const XGeom& g, int fn, uint32_t crossing, uint32_t line, uint4& r0,
-                                                   uint4& r1) {
-    r0 = make_uint4(__float_as_uint(g.d1_cross), __float_as_uint(g.q0), __float_as_uint(g.q1), g.bits | ((uint32_t)g.d1_in << 8));
-    r1 = make_uint4((uint32_t)g.in_from | ((uint32_t)g.in_to << 16), (uint32_t)fn, crossing, line);
+// record <-> geometry: SIXTEEN bytes per crossing (round 6; 32 up to round 5, and the records are the K4 chain's largest
+// intermediate: written once by k_edge_scatter, read once or twice by k_edge_lines -- 8.3 M of them per headline step):
+//   x  d1_cross
+//   y  ONE of the two first factors: 1 / q0 + 1 / q1 = (p10 - d0 + d0 - p00) / (p10 - p00) = 1, so the other one is
+//      q / (q - 1).  Kept: the LARGER (>= 2, so q - 1 is exact and the quotient well conditioned: an error of the kept
+//      factor reaches the derived one divided by q - 1); when a term is not evaluated at all (KCU:403/:408: an edge end on
+//      this very line -- the other factor is then exactly 1) the one that is.  XR_QSEL says which.
+//   z  inward walk from | to << 16
+//   w  bits (XG_ALIVE .. XG_ORIENTED, XR_QSEL) | face << 7        (the in-pixel follows from d1_cross and the direction,
+//      the line is the reader's own, and nobody read the crossing's index)
+enum : uint32_t { XR_QSEL = 64 };       // (XG_IDLE's bit: an idle crossing has no record)
+__device__ __forceinline__ uint4 geometry_to_record(const XGeom& g, int fn) {
+    const bool f0 = (g.bits & XG_F0) != 0, f1 = (g.bits & XG_F1) != 0;
+    const bool keep1 = !f0 ? true : (!f1 ? false : g.q1 > g.q0);
+    return make_uint4(__float_as_uint(g.d1_cross), __float_as_uint(keep1 ? g.q1 : g.q0),
+                      (uint32_t)g.in_from | ((uint32_t)g.in_to << 16),
+                      (g.bits & 0x3Fu) | (keep1 ? XR_QSEL : 0u) | ((uint32_t)fn << 7));
 }
-__device__ __forceinline__ XGeom record_to_geometry(const uint4 r0, const uint4 r1) {
+__device__ __forceinline__ XGeom record_to_geometry(const uint4 r) {
     XGeom g;
-    g.d1_cross = __uint_as_float(r0.x); g.q0 = __uint_as_float(r0.y); g.q1 = __uint_as_float(r0.z);
-    g.bits = r0.w & 0xFFu; g.d1_in = (int)(r0.w >> 8);
-    g.in_from = (int)(r1.x & 0xFFFFu); g.in_to = (int)(r1.x >> 16);
+    g.d1_cross = __uint_as_float(r.x);
+    g.bits = r.w & 0x3Fu;
+    const float kept = __uint_as_float(r.y), d = kept - 1.0f;
+    // kept / (kept - 1): v_rcp_f32 and one Newton step (the derived factor then carries about the rounding the kept one has)
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float other = kept * __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    g.q0 = (r.w & XR_QSEL) ? other : kept;
+    g.q1 = (r.w & XR_QSEL) ? kept : other;
+    g.d1_in = (g.bits & XG_ALIVE) ? ((g.bits & XG_DIRPOS) ? f2i(floorf(g.d1_cross)) : f2i(ceilf(g.d1_cross))) : 0;
+    g.in_from = (int)(r.z & 0xFFFFu); g.in_to = (int)(r.z >> 16);
     return g;
 }
+__device__ __forceinline__ int record_face(const uint4 r) { return (int)(r.w >> 7); }
 
 // Walk `which` (0: outward, 1: inward) of a crossing, clipped to [nz_lo, nz_hi]: the line's pixels with a non-zero
 // gradient.  Outside it diff_grad is exactly 0 and KCU:401/:481 skip the pixel (with a masked loss the gradients vanish
@@ -557,9 +578,8 @@ __device__ __forceinline__ int crossing_lane(const LaneTable& t, int c) {
 // faces + face_index_map decide which faces are visible, where their edges cross the pixel grid, and therefore
 // which line every crossing belongs to.  None of that depends on the gradient maps, so the plan can be built as soon
 // as the forward pass has produced face_index_map (d3m_edge_plan: on a side stream, beside the sampling pass) and
-// the backward pass starts with the line kernel.  One record (32 bytes) per crossing, stored in LINE order:
-//   xrec[2*i]   = d1_cross, q0, q1, bits | in-pixel << 8            (struct XGeom)
-//   xrec[2*i+1] = inward walk from | to << 16, face index, crossing index, line
+// the backward pass starts with the line kernel.  One record (16 bytes: geometry_to_record) per crossing, stored in LINE
+// order:  xrec[i] = d1_cross, one first factor, inward walk from | to << 16, bits | face << 7
 // The results of record i live at results[2*i + {0: outward, 1: inward}] -- LINE order too, so that the line kernel's
 // stores are contiguous; xpos[crossing index] = i lets k_edge_gather find them (scattered READS of 16 bytes instead of
 // scattered 8-byte writes, which cost the line kernel 0.15 ms of partial-line write traffic).
@@ -573,7 +593,7 @@ struct EdgePlan {
     int* line_cursor;    // [B*2*S] records written so far under each line (zeroed per call)
     int2* line_slice;    // [B*2*S] (first record, number of records) of the line's slice of xrec
     int* alloc;          // [0] total crossings (written by the block scan), [1] slice cursor (zeroed per call)
-    uint4* xrec;         // [2 * cap]
+    uint4* xrec;         // [cap]
     float2* results;     // [2 * cap] written by the line kernel (record order) or the overflow kernel (crossing order)
     int* xpos;           // [cap]     record position of every crossing (plan complete only)
     int cap;             // crossings the record / result arrays can hold; the rest is walked by k_edge_overflow
@@ -820,8 +840,7 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
             if (wants && lane_id() == leader) cursor_base = atomicAdd(&w.line_cursor[line], n);
             const int in_line = __shfl(cursor_base, leader, 64) + mask_rank(same);
             if (wants) {
-                uint4* rec = w.xrec + 2 * ((size_t)slice.x + in_line);
-                geometry_to_record(g, t.fn[l], (uint32_t)(cbase + c), (uint32_t)line, rec[0], rec[1]);
+                w.xrec[(size_t)slice.x + in_line] = geometry_to_record(g, t.fn[l]);
                 w.xpos[cbase + c] = slice.x + in_line;
             }
         }
@@ -985,7 +1004,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     const size_t bn = line / ((size_t)2 * is);
     const size_t view_base = bn * is * is;
     const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
-    const uint4* xrec = w.xrec + 2 * (size_t)x_first;
+    const uint4* xrec = w.xrec + (size_t)x_first;
     const float two_over_is = 2.0f / (float)is;
     // only the line's non-zero-gradient extent is staged: every segment is clipped to it (geometry_segment)
     const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
@@ -996,18 +1015,13 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     // record loads) for a handful of crossings).  A thread decodes its record, takes the crossing's inward walk (mean
     // length 2 pixels: walked on the spot; the rare long one is queued) and classifies the outward one (96 % of the
     // records have one, nearly all of them long: queued).  Nothing but two wave masks stays live across the queue's
-    // barriers: the threads that queue a segment read their record AGAIN behind them (32 bytes from the L2) and build the
+    // barriers: the threads that queue a segment read their record AGAIN behind them (16 bytes from the L2) and build the
     // item there -- with the geometry of both walks carried across, the 64-register budget spilled 100 bytes per lane
     // (and with the first pass's record requested before the line image is staged, as the two-thread form did, 20: the
     // record's round trip now follows the staging's; still the faster form, 0.50 -> 0.48 ms on the headline step).
-    struct Record {
-        uint4 r0, r1;
-    };
     auto load_record = [&](int ci) {
-        Record r;
-        r.r0 = make_uint4(0, 0, 0, 0);      // bits 0: not alive -> neither walk exists
-        r.r1 = r.r0;
-        if (ci < n_x) { r.r0 = xrec[2u * (uint32_t)ci]; r.r1 = xrec[2u * (uint32_t)ci + 1u]; }     // (uniform base + 32-bit offset)
+        uint4 r = make_uint4(0, 0, 0, 0);   // bits 0: not alive -> neither walk exists
+        if (ci < n_x) r = xrec[(uint32_t)ci];                     // (uniform base + 32-bit offset)
         return r;
     };
     // LDS image of the line: per pixel the float4 of gradients (alpha, r, g, b) and the pair (T/2, owner) with
@@ -1282,12 +1296,13 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         // ---- both walks classified: empty ones store their zero, short ones are walked here, long ones only flagged ----
         unsigned long long qm[2];
         {
-            const Record rc = load_record(ci);
-            const XGeom geo = record_to_geometry(rc.r0, rc.r1);      // (bits 0 past the line's last record: no walk)
-            const int fn = (int)rc.r1.y;
+            const uint4 rc = load_record(ci);
+            const XGeom geo = record_to_geometry(rc);               // (bits 0 past the line's last record: no walk)
+            const int fn = record_face(rc);
             // the outward walk: queued whenever it exists -- nearly all of them are long, and the queued walk takes a
-            // segment of any length (outward walks are always oriented), so there is no in-thread form of it
-            {
+            // segment of any length (outward walks are always oriented), so there is no in-thread form of it (but the
+            // alpha-only mode's sparse one)
+            auto outward = [&]() {
                 bool queue_it = false;
                 if (ci < n_x) {
                     Segment q;
@@ -1307,16 +1322,16 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                                 const int d1 = (int)s_nz[i];
                                 if (d1 > q.to) break;
                                 visit_pixel_div(diff_of(s_grd[d1], s_df[d1], one_ar, none_gb), d1, q.d1_cross, qq0, qq1, q.f0 != 0,
-                                                q.f1 != 0, two_over_is, a.eps, g0, g1);
+                                                q.f1 != 0, 2.0f / (float)is, a.eps, g0, g1);
                             }
                         }
                     }
                     if (!queue_it) w.results[2u * (uint32_t)(x_first + ci)] = make_float2(g0, g1);
                 }
                 qm[0] = __builtin_amdgcn_ballot_w64(queue_it);
-            }
+            };
             // the inward walk: short ones (mean length 2 pixels) on the spot, the rare long one flagged for the queue
-            {
+            auto inward = [&]() {
                 bool queue_it = false;
                 if (ci < n_x) {
                     float g0 = 0, g1 = 0;
@@ -1328,7 +1343,10 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                     if (!queue_it) w.results[2u * (uint32_t)(x_first + ci) + 1u] = make_float2(g0, g1);
                 }
                 qm[1] = __builtin_amdgcn_ballot_w64(queue_it);
-            }
+            };
+            // (alpha only: the inward walk first -- what it needs of the record is dead before the sparse outward walk's loop
+            //  starts; in the other order the 64-register form of this instantiation spilled two registers)
+            if constexpr (USE_RGB) { outward(); inward(); } else { inward(); outward(); }
         }
         // the pass's long segments: if they do not fit behind what is queued already, that is walked first
         int n0 = __popcll(qm[0]), n1 = __popcll(qm[1]);
@@ -1348,9 +1366,9 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
             if ((int)threadIdx.x >= step) { qm[0] = 0; qm[1] = 0; n0 = 0; n1 = 0; }       // (whole waves)
         }
         if ((qm[0] | qm[1]) != 0) {                               // (wave-uniform) this wave queues: its records again
-            const Record rc = load_record(ci);
-            const XGeom geo = record_to_geometry(rc.r0, rc.r1);
-            const int fn = (int)rc.r1.y;
+            const uint4 rc = load_record(ci);
+            const XGeom geo = record_to_geometry(rc);
+            const int fn = record_face(rc);
             // queue positions: one LDS atomic per wave, ranks from the ballots (outward items first, then inward)
             int base = 0;
             const int lane = lane_here();
@@ -1604,7 +1622,7 @@ struct EdgePlanLayout {
     size_t off_lane_cross, off_lane_block, off_line_slice, off_xrec;   // xrec | results follow, sized by capacity
     size_t fixed_bytes;
 };
-constexpr size_t EG_BYTES_PER_CROSSING = 32 + 16 + 4;  // record + its two result slots + its position
+constexpr size_t EG_BYTES_PER_CROSSING = 16 + 16 + 4;  // record + its two result slots + its position
 // Default capacity of a plan, in crossings per view: two per face (visible or not) or three per raster pixel, whichever is
 // more.  A mesh that covers P pixels with triangles of A pixels each has about 6 P / sqrt(A) crossings (every triangle's
 // three edges, both axes, counted once per adjacent face): the 100 k-triangle mesh at 512^2 has 261 k per view of the 401 k
@@ -1656,8 +1674,8 @@ inline bool edge_plan_view(void* blob, size_t bytes, const VisibilityView& v, in
     w.lane_block = (int*)(p + L.off_lane_block);
     w.line_slice = (int2*)(p + L.off_line_slice);
     w.xrec = (uint4*)(p + L.off_xrec);
-    w.results = (float2*)(p + eg_align(L.off_xrec + cap * 32));
-    w.xpos = (int*)(p + eg_align(eg_align(L.off_xrec + cap * 32) + cap * 16));
+    w.results = (float2*)(p + eg_align(L.off_xrec + cap * 16));
+    w.xpos = (int*)(p + eg_align(eg_align(L.off_xrec + cap * 16) + cap * 16));
     w.cap = (int)cap;
     return true;
 }
@@ -1745,7 +1763,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
                   void* shared_plan, size_t shared_plan_bytes, EdgeRecords rec, GradScale gs, int B, float eps, void* ws,
                   size_t ws_bytes, hipStream_t st, int* last_err) {
     const int S = m.S, F = fs.num_faces();
-    if (S > 65535 || F > (1 << 26) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
+    if (S > 65535 || F > (1 << 25) || (long)B * 2 * S >= (1l << 31)) return 1;   // item packing / line key limits (D3M_ERR_INVALID)
     const size_t smem = edge_lines_lds(S);
     if (smem + EG_LINE_STATIC_LDS > 160 * 1024) return 1;                // a line does not fit LDS beside the item queue (S > ~5600)
     const EdgeLayout L = edge_layout(B, F, S);

@@ -573,7 +573,7 @@ D3M_EXPORT int d3m_edge_plan(const float* faces, const int32_t* face_index_map, 
                              size_t edge_plan_size, int batch_size, int num_faces, int image_size, int flags,
                              d3m_stream_t stream) {
     if (!faces || !face_index_map || !visibility || !edge_plan || batch_size <= 0 || num_faces <= 0 || image_size <= 0) return D3M_ERR_INVALID;
-    if (image_size > 65535 || num_faces > (1 << 26) || (long)batch_size * 2 * image_size >= (1l << 31)) return D3M_ERR_INVALID;
+    if (image_size > 65535 || num_faces > (1 << 25) || (long)batch_size * 2 * image_size >= (1l << 31)) return D3M_ERR_INVALID;
     const VisibilityView vis = visibility_view(visibility, (long)batch_size * num_faces);
     EdgePlan w;
     if (!edge_plan_view(edge_plan, edge_plan_size, vis, batch_size, num_faces, image_size, w)) return D3M_ERR_WORKSPACE;
@@ -1009,13 +1009,15 @@ D3M_EXPORT int d3m_face_light_backward(const float* vertices, int vertices_batch
 // ---- deterministic mode: the vertex sums gathered in a fixed order instead of scattered with float atomics ---------------
 D3M_EXPORT int d3m_vertex_gather(const float* grad_faces_a, const float* grad_faces_b, const int32_t* adj_offsets,
                                  const int32_t* adj_items, float* grad_vertices, int batch_size, int num_vertices,
-                                 int num_tri, int fill_back, d3m_stream_t stream) {
+                                 int num_tri, int fill_back, const void* visibility, d3m_stream_t stream) {
     if ((!grad_faces_a && !grad_faces_b) || !adj_offsets || !adj_items || !grad_vertices || batch_size <= 0 ||
         num_vertices <= 0 || num_tri <= 0)
         return D3M_ERR_INVALID;
     LAUNCH("k_vertex_gather", k_vertex_gather, dim3(blocks_for((long)batch_size * num_vertices, 256)), dim3(256),
            (hipStream_t)stream, grad_faces_a, grad_faces_b, adj_offsets, adj_items, grad_vertices, batch_size, num_vertices,
-           num_tri, fill_back ? 1 : 0);
+           num_tri, fill_back ? 1 : 0,
+           visibility ? (const int*)visibility_view(const_cast<void*>(visibility), (long)batch_size * (fill_back ? 2 : 1) * num_tri).flags
+                      : (const int*)nullptr);
     return check_launch();
 }
 D3M_EXPORT int d3m_face_light_backward_gather(const float* vertices, const int32_t* tri, const int32_t* adj_offsets,

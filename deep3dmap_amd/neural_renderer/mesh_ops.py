@@ -36,7 +36,7 @@ class _GatherFaces(torch.autograd.Function):
             off, items = vertex_adjacency(tri, V)
             gv = torch.empty(B, V, 3, dtype=torch.float32, device=g.device)
             _lib.check(_lib.lib().d3m_vertex_gather(_lib.ptr(g), None, _lib.ptr(off), _lib.ptr(items), _lib.ptr(gv), B, V, Ft,
-                                                    int(fill_back), _lib.stream_ptr()), "d3m_vertex_gather")
+                                                    int(fill_back), None, _lib.stream_ptr()), "d3m_vertex_gather")
             return gv, None, None
         gv = torch.zeros(B, V, 3, dtype=torch.float32, device=g.device)
         rc = _lib.lib().d3m_scatter_face_grads(_lib.ptr(g), _lib.ptr(tri), tri.shape[0], _lib.ptr(gv), B, V, Ft,

@@ -954,8 +954,8 @@ class _RasterizeLit(torch.autograd.Function):
                     if det:     # K4's and K6's per-face arrays -> the screen-space gradient, per vertex in a fixed order
                         adj_off, adj_items = vertex_adjacency(tri, V)
                         _lib.check(L.d3m_vertex_gather(_lib.ptr(det_k4), _lib.ptr(det_k6), _lib.ptr(adj_off), _lib.ptr(adj_items),
-                                                       _lib.ptr(grad_sv), B, V, Ft, int(fill_back), _lib.stream_ptr()),
-                                   "d3m_vertex_gather")
+                                                       _lib.ptr(grad_sv), B, V, Ft, int(fill_back), _lib.ptr(vis[k]),
+                                                       _lib.stream_ptr()), "d3m_vertex_gather")
         if G > 1:
             yield "textures"
         def light_to_vertices(grad_light):

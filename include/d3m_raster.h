@@ -94,12 +94,13 @@ int d3m_get_deterministic(void);
  * instead of scattered with float atomics.  adj_offsets [V+1], adj_items [3 F]: CSR adjacency of ONE index tensor tri [F,3]
  * -- item = 3 f + c for "corner c of triangle f", the items of a vertex in ascending order.
  * d3m_vertex_gather: grad_vertices [B,V,3] (WRITTEN) = the sum over a vertex's items of grad_faces_a[b,f,c,:] +
- * grad_faces_b[b,f,c,:] (either array may be NULL; both [B,F',3,3]) and, with fill_back, of the copy's [b,F+f,2-c,:].
+ * grad_faces_b[b,f,c,:] (either array may be NULL; both [B,F',3,3]) and, with fill_back, of the copy's [b,F+f,2-c,:];
+ * `visibility` (optional): the d3m_visibility blob of the forward result -- faces that own no pixel are skipped unread.
  * d3m_face_light_backward_gather: d3m_face_light_backward for ONE shared mesh (vertices [V,3], grad_light [F',3]), the same
  * per-face terms gathered per vertex: grad_vertices [V,3] is WRITTEN. */
 int d3m_vertex_gather(const float* grad_faces_a, const float* grad_faces_b, const int32_t* adj_offsets,
                       const int32_t* adj_items, float* grad_vertices, int batch_size, int num_vertices, int num_tri,
-                      int fill_back, d3m_stream_t stream);
+                      int fill_back, const void* visibility, d3m_stream_t stream);
 int d3m_face_light_backward_gather(const float* vertices, const int32_t* tri, const int32_t* adj_offsets,
                                    const int32_t* adj_items, const float* grad_light, float* grad_vertices,
                                    float intensity_ambient, float intensity_directional, const float* color_ambient,
