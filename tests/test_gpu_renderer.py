@@ -1413,3 +1413,21 @@ def test_deterministic_mode_refuses_what_it_does_not_cover():
     vv = vs.detach()[:1].clone().requires_grad_(True)
     (mesh_ops.gather_faces(vv, tris[:1], True) * torch.linspace(0.5, 1.5, 9, device="cuda").view(3, 3)).sum().backward()
     assert _rel_max(grads[0], vv.grad) < 1e-6
+
+
+def test_second_backward_over_one_forward_result():
+    """One render(), two backward passes (retain_graph): the plan built in forward is walked twice, so whatever the first walk
+    leaves in the plan's blob must not reach the second -- the lanes' sums (round 6: added with atomics by the line kernel) are
+    handed back zeroed by the gather pass that consumes them.  Both passes give the same gradients."""
+    vs, tris, texs = (t.cuda() for t in _scene(B=2, n=16))
+    r = _nr().Renderer(camera_mode="look_at", image_size=64, anti_aliasing=False)
+    r.eye = [0.3, 0.5, -2.6]
+    w = torch.randn(2, 3, 64, 64, device="cuda")
+    vv = vs.clone().requires_grad_(True)
+    tt = texs.clone().requires_grad_(True)
+    rgb, depth, alpha = r(vv, tris, tt)
+    loss = (rgb * w).sum() + (alpha * w[:, 0]).sum() + (depth.clamp(max=4) * w[:, 1]).sum()
+    first = torch.autograd.grad(loss, (vv, tt), retain_graph=True)
+    second = torch.autograd.grad(loss, (vv, tt))
+    for a, b in zip(first, second):
+        assert float(a.abs().max()) > 0 and _rel_max(b, a) < 1e-5
