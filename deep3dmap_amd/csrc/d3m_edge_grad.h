@@ -186,21 +186,20 @@ __device__ __forceinline__ XGeom crossing_geometry(float p00, float p01, float p
 //      factor reaches the derived one divided by q - 1); when a term is not evaluated at all (KCU:403/:408: an edge end on
 //      this very line -- the other factor is then exactly 1) the one that is.  XR_QSEL says which.
 //   z  inward walk from | to << 16
-//   w  XG_ALIVE | XG_DIRPOS | XG_F0 | XG_F1 | XG_OWNER | XR_QSEL | edge << 6 | face << 8
-// The in-pixel follows from d1_cross and the direction, XG_ORIENTED from the inward range and the in-pixel, the line and the
-// axis are the reader's own; (face, edge, axis) name the lane whose sum the crossing's walks belong to (EdgePlan::lane_sum).
-enum : uint32_t { XR_QSEL = 32 };       // (XG_ORIENTED's bit: derived on reading)
-__device__ __forceinline__ uint4 geometry_to_record(const XGeom& g, int fn, int edge) {
+//   w  bits (XG_ALIVE .. XG_ORIENTED, XR_QSEL) | face << 7        (the in-pixel follows from d1_cross and the direction,
+//      the line is the reader's own, and nobody read the crossing's index)
+enum : uint32_t { XR_QSEL = 64 };       // (XG_IDLE's bit: an idle crossing has no record)
+__device__ __forceinline__ uint4 geometry_to_record(const XGeom& g, int fn) {
     const bool f0 = (g.bits & XG_F0) != 0, f1 = (g.bits & XG_F1) != 0;
     const bool keep1 = !f0 ? true : (!f1 ? false : g.q1 > g.q0);
     return make_uint4(__float_as_uint(g.d1_cross), __float_as_uint(keep1 ? g.q1 : g.q0),
                       (uint32_t)g.in_from | ((uint32_t)g.in_to << 16),
-                      (g.bits & 0x1Fu) | (keep1 ? XR_QSEL : 0u) | ((uint32_t)edge << 6) | ((uint32_t)fn << 8));
+                      (g.bits & 0x3Fu) | (keep1 ? XR_QSEL : 0u) | ((uint32_t)fn << 7));
 }
 __device__ __forceinline__ XGeom record_to_geometry(const uint4 r) {
     XGeom g;
     g.d1_cross = __uint_as_float(r.x);
-    g.bits = r.w & 0x1Fu;
+    g.bits = r.w & 0x3Fu;
     const float kept = __uint_as_float(r.y), d = kept - 1.0f;
     // kept / (kept - 1): v_rcp_f32 and one Newton step (the derived factor then carries about the rounding the kept one has)
     const float r0 = __builtin_amdgcn_rcpf(d);
@@ -209,12 +208,9 @@ __device__ __forceinline__ XGeom record_to_geometry(const uint4 r) {
     g.q1 = (r.w & XR_QSEL) ? kept : other;
     g.d1_in = (g.bits & XG_ALIVE) ? ((g.bits & XG_DIRPOS) ? f2i(floorf(g.d1_cross)) : f2i(ceilf(g.d1_cross))) : 0;
     g.in_from = (int)(r.z & 0xFFFFu); g.in_to = (int)(r.z >> 16);
-    // every inward pixel on the expected side of the crossing (crossing_geometry decides it the same way, on these values)
-    if ((g.bits & XG_ALIVE) && ((g.bits & XG_DIRPOS) ? g.in_to == g.d1_in : g.in_from == g.d1_in)) g.bits |= XG_ORIENTED;
     return g;
 }
-__device__ __forceinline__ int record_face(const uint4 r) { return (int)(r.w >> 8); }
-__device__ __forceinline__ int record_edge(const uint4 r) { return (int)((r.w >> 6) & 3u); }
+__device__ __forceinline__ int record_face(const uint4 r) { return (int)(r.w >> 7); }
 
 // Walk `which` (0: outward, 1: inward) of a crossing, clipped to [nz_lo, nz_hi]: the line's pixels with a non-zero
 // gradient.  Outside it diff_grad is exactly 0 and KCU:401/:481 skip the pixel (with a masked loss the gradients vanish
@@ -601,21 +597,6 @@ struct EdgePlan {
     float2* results;     // [2 * cap] written by the line kernel (record order) or the overflow kernel (crossing order)
     int* xpos;           // [cap]     record position of every crossing (plan complete only)
     int cap;             // crossings the record / result arrays can hold; the rest is walked by k_edge_overflow
-    // LANE SUMS (round 6; `accum`): what the gather needs of a (face, edge, axis) lane is the SUM of its crossings' walks,
-    // and the per-crossing detour -- 16 bytes of results per crossing written in line order, their positions (xpos) written
-    // by the scatter pass and both read back, scattered, by the gather pass: 200 MB of the chain's traffic and most of
-    // k_edge_gather's 90 us -- exists only to keep that sum in a fixed order.  With accum != 0 every walk's sum is added
-    // straight into lane_sum[((view * F + face) * 3 + edge) * 2 + axis] (float atomics, ~3.5 per entry from neighbouring
-    // line workgroups; zeros are not sent), entries zeroed by the count pass and again by the gather pass that consumes
-    // them; results / xpos / lane_cross do not exist (lane_sum takes lane_cross's room, indexed by face instead of by list
-    // position) and a blob of the same size holds 2.25 x the crossings.  The order of a lane's handful of terms is then
-    // arrival order: the deterministic mode keeps the per-crossing form.
-    float2* lane_sum;    // [6*B*F]   (accum)
-    int accum;
-    int F;               // faces per view
-    __device__ __forceinline__ size_t lane_index(int bn, int fn, int edge, int axis) const {
-        return (((size_t)bn * F + fn) * 3 + edge) * 2 + axis;
-    }
 };
 
 // The records are written iff ALL the batch's crossings fit (uniform over a launch): they are then dense and complete,
@@ -682,11 +663,7 @@ __global__ void __launch_bounds__(256) k_edge_count_window(FS fs, int is, EdgePl
         // every lane of a listed face gets its record (n_cross is 0 for a lane that is not `on`)
         if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
             const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
-            if (w.accum)        // the lane's sum starts at zero (lane t of a listed face: edge t % 6 / 2, axis t % 2)
-                w.lane_sum[w.lane_index(t.bn_axis[threadIdx.x] >> 1, t.fn[threadIdx.x], ((int)threadIdx.x % 6) >> 1,
-                                        (int)threadIdx.x & 1)] = make_float2(0.0f, 0.0f);
-            else
-                w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
+            w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
         }
         if (threadIdx.x == 0) w.lane_block[blk] = total;
         const int view = t.bn_axis[0] >> 1;
@@ -730,11 +707,7 @@ __global__ void __launch_bounds__(256) k_edge_count(FS fs, int is, EdgePlan w) {
         // every lane of a listed face gets its record (n_cross is 0 for a lane that is not `on`)
         if (threadIdx.x < EG_FACES_PER_BLOCK * 6 && blk * EG_FACES_PER_BLOCK + (int)threadIdx.x / 6 < *w.n_visible) {
             const size_t lane6 = (size_t)blk * EG_FACES_PER_BLOCK * 6 + threadIdx.x;
-            if (w.accum)        // the lane's sum starts at zero (lane t of a listed face: edge t % 6 / 2, axis t % 2)
-                w.lane_sum[w.lane_index(t.bn_axis[threadIdx.x] >> 1, t.fn[threadIdx.x], ((int)threadIdx.x % 6) >> 1,
-                                        (int)threadIdx.x & 1)] = make_float2(0.0f, 0.0f);
-            else
-                w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
+            w.lane_cross[lane6] = make_int2(t.pre[threadIdx.x], n_cross);
         }
         if (threadIdx.x == 0) w.lane_block[blk] = total;
         for (int c0 = 0; c0 < total; c0 += 256) {
@@ -831,7 +804,7 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
-        const long cbase = w.accum ? 0 : w.lane_block[blk]; // scanned: first crossing of this workgroup (xpos's index)
+        const long cbase = w.lane_block[blk];               // scanned: first crossing of this workgroup
         {   // the lane's slopes, once (see EdgeSlopes)
             const int l = threadIdx.x;
             const EdgeSlopes sl = edge_slopes(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l]);
@@ -859,7 +832,7 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
                                       EdgeSlopes{s_slope[0][l], s_slope[1][l], s_slope[2][l]}, axis, t.fn[l], is, d0,
                                       [&](int e0, int e1) { return view[axis ? (size_t)e0 * is + e1 : (size_t)e1 * is + e0]; });
                 wants = (g.bits & XG_ALIVE) && !(g.bits & XG_IDLE);
-                if (!wants && !w.accum) w.xpos[cbase + c] = -1;
+                if (!wants) w.xpos[cbase + c] = -1;
             }
             const unsigned long long same = wave_match_any((uint32_t)line, wants);      // uniform call site
             const int leader = wants ? __builtin_ctzll(same) : 0, n = wants ? __popcll(same) : 0;
@@ -867,8 +840,8 @@ __global__ void __launch_bounds__(256) k_edge_scatter(FS fs, const int32_t* __re
             if (wants && lane_id() == leader) cursor_base = atomicAdd(&w.line_cursor[line], n);
             const int in_line = __shfl(cursor_base, leader, 64) + mask_rank(same);
             if (wants) {
-                w.xrec[(size_t)slice.x + in_line] = geometry_to_record(g, t.fn[l], (l % 6) >> 1);
-                if (!w.accum) w.xpos[cbase + c] = slice.x + in_line;
+                w.xrec[(size_t)slice.x + in_line] = geometry_to_record(g, t.fn[l]);
+                w.xpos[cbase + c] = slice.x + in_line;
             }
         }
         __syncthreads();
@@ -893,7 +866,7 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
         bool on;
         int pos = 0, ea = 0, n_cross = 0;
         const int total = publish_lanes(fs, w.visible_list, w.n_visible, blk, is, t, on, pos, ea, n_cross);
-        const long cbase = w.accum ? 0 : w.lane_block[blk];
+        const long cbase = w.lane_block[blk];
         for (int c = threadIdx.x; c < total; c += 256) {
             const int l = crossing_lane(t, c);
             const int d0 = t.d0_from[l] + (c - t.pre[l]);
@@ -912,13 +885,7 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
                     const SegRef ref = load_ref(a, axis, base, sg.d0, sg.ref_pos);
                     walk_inline(a, base, sg, sg.from, sg.to, ref, fn, two_over_is, g0, g1);
                 }
-                if (w.accum) {
-                    if (g0 != 0 || g1 != 0) {
-                        float2* sum = &w.lane_sum[w.lane_index(bn, fn, (l % 6) >> 1, axis)];
-                        atomicAdd(&sum->x, g0);
-                        atomicAdd(&sum->y, g1);
-                    }
-                } else if (cbase + c < (long)w.cap) {
+                if (cbase + c < (long)w.cap) {
                     w.results[2 * (cbase + c) + which] = make_float2(g0, g1);
                 } else if (g0 != 0 || g1 != 0) {
                     const size_t lane_id6 = ((size_t)blk * EG_FACES_PER_BLOCK) * 6 + l;
@@ -990,7 +957,6 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     constexpr int EG_LINE_THREADS = WAVES * 64, EG_QUEUE = EG_LINE_THREADS, EG_LINE_WAVES = WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_line[];
     if (!plan_complete(w)) {          // no records at all: k_edge_overflow walks every crossing; zero the sums it adds to
-        if (w.accum) return;          // (the lanes' sums: zeroed by the count pass)
         const long n = (long)*w.n_visible * 6;
         for (long i = (long)blockIdx.x * EG_LINE_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * EG_LINE_THREADS)
             lane_partial[i] = make_float2(0.0f, 0.0f);
@@ -1253,13 +1219,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                         if (ux * zinv0 < 0) s0 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(ux));
                         if (uy * zinv1 < 0) s1 -= 2.0f * (dpos * __builtin_amdgcn_rcpf(uy));
                     }
-                    const float o0 = (zbits & 2u) ? zinv0 * s0 : 0.0f, o1 = (zbits & 4u) ? zinv1 * s1 : 0.0f;
-                    if (!w.accum) {
-                        w.results[z0.w] = make_float2(o0, o1);
-                    } else if (o0 != 0 || o1 != 0) {          // (its lane's sum: EdgePlan::lane_sum; NaN != 0 is sent)
-                        atomicAdd(&w.lane_sum[z0.w].x, o0);
-                        atomicAdd(&w.lane_sum[z0.w].y, o1);
-                    }
+                    w.results[z0.w] = make_float2((zbits & 2u) ? zinv0 * s0 : 0.0f, (zbits & 4u) ? zinv1 * s1 : 0.0f);
                 }
             }
 
@@ -1335,15 +1295,10 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         const int ci = chunk0 + (int)threadIdx.x;
         // ---- both walks classified: empty ones store their zero, short ones are walked here, long ones only flagged ----
         unsigned long long qm[2];
-        // accum: what the record's walks summed to on the spot, and its lane -- sent behind the pass's decision below (a pass
-        // whose second half is taken again must not send that half's sums twice)
-        float e0 = 0.0f, e1 = 0.0f;
-        uint32_t e_lane = 0;
         {
             const uint4 rc = load_record(ci);
             const XGeom geo = record_to_geometry(rc);               // (bits 0 past the line's last record: no walk)
             const int fn = record_face(rc);
-            if (w.accum) e_lane = (uint32_t)w.lane_index((int)bn, fn, record_edge(rc), axis);
             // the outward walk: queued whenever it exists -- nearly all of them are long, and the queued walk takes a
             // segment of any length (outward walks are always oriented), so there is no in-thread form of it (but the
             // alpha-only mode's sparse one)
@@ -1371,10 +1326,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                             }
                         }
                     }
-                    if (!queue_it) {
-                        if (w.accum) { e0 += g0; e1 += g1; }
-                        else w.results[2u * (uint32_t)(x_first + ci)] = make_float2(g0, g1);
-                    }
+                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci)] = make_float2(g0, g1);
                 }
                 qm[0] = __builtin_amdgcn_ballot_w64(queue_it);
             };
@@ -1388,10 +1340,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                         if (segment_queueable(q)) queue_it = true;
                         else walk_short(q, fn, g0, g1);
                     }
-                    if (!queue_it) {
-                        if (w.accum) { e0 += g0; e1 += g1; }
-                        else w.results[2u * (uint32_t)(x_first + ci) + 1u] = make_float2(g0, g1);
-                    }
+                    if (!queue_it) w.results[2u * (uint32_t)(x_first + ci) + 1u] = make_float2(g0, g1);
                 }
                 qm[1] = __builtin_amdgcn_ballot_w64(queue_it);
             };
@@ -1414,11 +1363,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         // same values).
         if (pass_total > EG_QUEUE) {                              // uniform
             step = EG_LINE_THREADS / 2;
-            if ((int)threadIdx.x >= step) { qm[0] = 0; qm[1] = 0; n0 = 0; n1 = 0; e0 = 0.0f; e1 = 0.0f; }     // (whole waves)
-        }
-        if (w.accum && (e0 != 0 || e1 != 0)) {                    // (zero for a thread without a record; NaN != 0 is sent)
-            atomicAdd(&w.lane_sum[e_lane].x, e0);
-            atomicAdd(&w.lane_sum[e_lane].y, e1);
+            if ((int)threadIdx.x >= step) { qm[0] = 0; qm[1] = 0; n0 = 0; n1 = 0; }       // (whole waves)
         }
         if ((qm[0] | qm[1]) != 0) {                               // (wave-uniform) this wave queues: its records again
             const uint4 rc = load_record(ci);
@@ -1435,8 +1380,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
                     Segment q;
                     geometry_segment(geo, which, axis, d0, is, p_lo, p_hi, q);
                     uint4 rec0, rec1;
-                    make_item(q, fn, w.accum ? (uint32_t)w.lane_index((int)bn, fn, record_edge(rc), axis)
-                                             : 2u * (uint32_t)(x_first + ci) + which, rec0, rec1);
+                    make_item(q, fn, 2u * (uint32_t)(x_first + ci) + which, rec0, rec1);
                     uint4* it = (uint4*)(s_items + (size_t)(base + (which ? n0 : 0) + mask_rank(qm[which])) * EG_ITEM_DW);
                     it[0] = rec0; it[1] = rec1;
                 }
@@ -1470,15 +1414,7 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
         const int pos = blk * EG_FACES_PER_BLOCK + t / 6, ea = t % 6;
         const bool on = t < EG_FACES_PER_BLOCK * 6 && pos < n_vis;
         float2 g = make_float2(0.0f, 0.0f);
-        if (on && w.accum) {
-            // the lane's sum, and the entry back to zero for whoever walks this plan's lines again (a second backward pass
-            // over one forward result); `parts` deal nothing here: one 8-byte read per lane
-            if (part == 0) {
-                float2* sum = &w.lane_sum[(size_t)w.visible_list[pos] * 6 + ea];
-                g = *sum;
-                *sum = make_float2(0.0f, 0.0f);
-            }
-        } else if (on) {
+        if (on) {
             const int2 lc = w.lane_cross[(size_t)pos * 6 + ea];
             if (!complete && part == 0) g = lane_partial[(size_t)pos * 6 + ea];
             // slots (2c, 2c+1) of the lane's crossings c, contiguous and 16-byte aligned: one float4 per crossing, four
@@ -1686,13 +1622,7 @@ struct EdgePlanLayout {
     size_t off_lane_cross, off_lane_block, off_line_slice, off_xrec;   // xrec | results follow, sized by capacity
     size_t fixed_bytes;
 };
-constexpr size_t EG_BYTES_PER_CROSSING = 16 + 16 + 4;  // record + its two result slots + its position (the per-crossing form)
-constexpr size_t EG_BYTES_PER_CROSSING_ACCUM = 16;     // the record alone (lane sums: EdgePlan::accum)
-
-// Which form a plan takes (EdgePlan::accum): lane sums unless the deterministic mode is on -- or D3M_EG_ACCUM=0 in the
-// environment (measurements).  Decided when the plan is BUILT and again when it is walked: do not change the switches between a
-// forward pass and its backward pass.
-inline bool edge_accum_mode() { return !deterministic_mode() && d3m_env_int("D3M_EG_ACCUM", 1) != 0; }
+constexpr size_t EG_BYTES_PER_CROSSING = 16 + 16 + 4;  // record + its two result slots + its position
 // Default capacity of a plan, in crossings per view: two per face (visible or not) or three per raster pixel, whichever is
 // more.  A mesh that covers P pixels with triangles of A pixels each has about 6 P / sqrt(A) crossings (every triangle's
 // three edges, both axes, counted once per adjacent face): the 100 k-triangle mesh at 512^2 has 261 k per view of the 401 k
@@ -1733,8 +1663,7 @@ inline bool edge_plan_view(void* blob, size_t bytes, const VisibilityView& v, in
     const EdgePlanLayout L = edge_plan_layout(B, F, S);
     if (!blob || bytes < L.fixed_bytes + 1024) return false;
     char* p = (char*)blob;
-    const bool accum = edge_accum_mode() && (size_t)B * F * 6 < (1ull << 32);     // (an item names its lane in 32 bits)
-    size_t cap = (bytes - L.fixed_bytes - 512) / (accum ? EG_BYTES_PER_CROSSING_ACCUM : EG_BYTES_PER_CROSSING);
+    size_t cap = (bytes - L.fixed_bytes - 512) / EG_BYTES_PER_CROSSING;
     cap = cap > 64 ? cap - 32 : 0;                             // slack for the 256-byte alignments below
     if (cap > 0x3FFFFF00) cap = 0x3FFFFF00;                    // 2 * cap result slots are indexed with an int
     w.visible = v.flags; w.visible_list = v.list; w.n_visible = v.count;
@@ -1748,10 +1677,6 @@ inline bool edge_plan_view(void* blob, size_t bytes, const VisibilityView& v, in
     w.results = (float2*)(p + eg_align(L.off_xrec + cap * 16));
     w.xpos = (int*)(p + eg_align(eg_align(L.off_xrec + cap * 16) + cap * 16));
     w.cap = (int)cap;
-    w.lane_sum = (float2*)w.lane_cross;         // (the same room, indexed by face: see EdgePlan)
-    w.accum = accum ? 1 : 0;
-    w.F = F;
-    if (accum) { w.results = nullptr; w.xpos = nullptr; }
     return true;
 }
 

@@ -275,64 +275,6 @@ def test_alpha_only_edge_gradient_sparse_and_dense_walks(gradient, monkeypatch):
     assert np.abs(got["sparse"] - gf_ref).max() <= np.abs(got["dense"] - gf_ref).max() + 2e-6 * scale
 
 
-@pytest.mark.parametrize("scene", ["shingles_more_than_a_queue", "random_two_views", "undersized_plan"])
-def test_edge_gradient_lane_sums_equal_per_crossing_results(scene, monkeypatch):
-    """Round 6: the line kernel adds every walk's sum straight into its (face, edge, axis) lane's entry (EdgePlan::lane_sum,
-    float atomics) instead of leaving 16 bytes of results per crossing for the gather pass to collect through a position
-    table; the per-crossing form stays (the deterministic mode takes it; D3M_EG_ACCUM=0 forces it).  Both forms against the
-    oracle's per-face walk (KCU:245-503) and against each other: a scene whose rows hold more long segments than the
-    queue (the pass is re-taken by halves: the half taken again must not be added twice), random faces of all sizes in
-    two views with alpha-only and rgb + alpha gradients, and a plan too small for the scene's crossings (every crossing
-    walked by k_edge_overflow, which then feeds the lanes' sums too)."""
-    from deep3dmap_amd import _lib
-    from deep3dmap_amd.neural_renderer import rasterize_ops as ops
-    from oracle import nr_oracle as O
-    rng = np.random.default_rng(314)
-    if scene == "shingles_more_than_a_queue":
-        S, n, B = 512, 250, 1
-        px = 2.0 / S
-        x0 = -1.0 + 2.5 * px + 2 * px * np.arange(n)
-        z = 2.0 - 0.003 * np.arange(n)
-        tri = np.stack([np.stack([x0, np.full(n, -0.5)], -1), np.stack([x0 + 8.2 * px, np.full(n, -0.5 + 0.3 * px)], -1),
-                        np.stack([x0 + 4.1 * px, np.full(n, 0.62)], -1)], 1)
-        faces = np.concatenate([tri, np.broadcast_to(z[:, None, None], (n, 3, 1))], -1)[None].astype(np.float32)
-    else:
-        S, n, B = 160, 260, 2
-        xy = rng.uniform(-0.9, 0.9, (B, n, 1, 2)) + rng.uniform(-1, 1, (B, n, 3, 2)) * rng.choice([0.01, 0.06, 0.35], (B, n, 1, 1))
-        faces = np.concatenate([xy, rng.uniform(1.0, 2.0, (B, n, 3, 1))], -1).astype(np.float32)
-    faces = np.concatenate([faces, faces[:, :, ::-1]], 1).copy()
-    F2 = faces.shape[1]
-    tex = rng.uniform(0, 1, (B, F2, 2, 2, 2, 3)).astype(np.float32)
-    m = O.raster_forward(faces, tex, S, 0.1, 100.0, 1e-3, (0.1, 0.2, 0.3), True, True, False)
-    g_rgb = rng.normal(size=(B, S, S, 3)).astype(np.float32)
-    g_alpha = rng.normal(size=(B, S, S)).astype(np.float32)
-    fd, fi, rgb, al = _dev(faces), _dev(m["face_index_map"]), _dev(m["rgb_map"]), _dev(m["alpha_map"])
-    dummy = torch.zeros(1, device="cuda")
-    L = _lib.lib()
-    for use_rgb in (True, False):
-        gf_ref, _ = O.raster_backward(m, g_rgb if use_rgb else None, g_alpha, None, use_rgb, True, False)
-        got = {}
-        for form, env in (("lane_sums", "1"), ("per_crossing", "0")):
-            monkeypatch.setenv("D3M_EG_ACCUM", env)
-            gf = torch.zeros_like(fd)
-            if scene == "undersized_plan":       # the smallest workspace the operator accepts: no room for the records
-                ws = torch.empty(int(L.d3m_backward_pixel_map_workspace_min_bytes(B, F2, S)), dtype=torch.uint8, device="cuda")
-                rc = L.d3m_backward_pixel_map(_lib.ptr(fd), _lib.ptr(fi), _lib.ptr(rgb if use_rgb else None), _lib.ptr(al),
-                                              _lib.ptr(_dev(g_rgb) if use_rgb else None), _lib.ptr(_dev(g_alpha)), _lib.ptr(gf),
-                                              B, F2, S, 1e-3, int(use_rgb), 1, _lib.ptr(ws), ws.numel(), None, None, None, 0,
-                                              None, _lib.stream_ptr())
-                _lib.check(rc, "d3m_backward_pixel_map")
-            else:
-                ops.backward_pixel_map(fd, fi, rgb if use_rgb else dummy, al, _dev(g_rgb) if use_rgb else dummy, _dev(g_alpha),
-                                       gf, S, 1e-3, use_rgb, True)
-            got[form] = gf.cpu().numpy()
-        scale = np.abs(gf_ref).max()
-        assert scale > 0
-        for form, g in got.items():
-            assert _grad_close(g, gf_ref), (scene, use_rgb, form, np.abs(g - gf_ref).max() / scale)
-        assert np.abs(got["lane_sums"] - got["per_crossing"]).max() <= 2e-5 * scale, (scene, use_rgb)
-
-
 def test_edge_gradient_on_an_image_wider_than_the_line_window():
     """K4 at S = 2304: above 2048 pixels per line the plan's count pass merges its line counters by key instead of in
     the LDS line window, and the line kernel clamps instead of padding -- small and large faces, two views, against

@@ -1416,9 +1416,8 @@ def test_deterministic_mode_refuses_what_it_does_not_cover():
 
 
 def test_second_backward_over_one_forward_result():
-    """One render(), two backward passes (retain_graph): the plan built in forward is walked twice, so whatever the first walk
-    leaves in the plan's blob must not reach the second -- the lanes' sums (round 6: added with atomics by the line kernel) are
-    handed back zeroed by the gather pass that consumes them.  Both passes give the same gradients."""
+    """One render(), two backward passes (retain_graph): the plan built in forward is walked twice, and whatever the first
+    walk leaves in the plan's blob and the node's buffers must not reach the second.  Both passes give the same gradients."""
     vs, tris, texs = (t.cuda() for t in _scene(B=2, n=16))
     r = _nr().Renderer(camera_mode="look_at", image_size=64, anti_aliasing=False)
     r.eye = [0.3, 0.5, -2.6]
