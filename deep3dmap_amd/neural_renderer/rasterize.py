@@ -211,13 +211,28 @@ class _RasterizeImages(torch.autograd.Function):
         return (gf, gt) + (None,) * 9
 
 
+_vec3_cache = {}
+
+
 def _vec3_host(x):
-    if torch.is_tensor(x):
-        x = x.detach().cpu().numpy()
+    """A light colour / direction as three host floats (the C ABI takes them by value).  A device tensor costs a
+    device-to-host copy -- a synchronisation -- so its value is remembered per tensor OBJECT and version (a weak reference:
+    an address alone may be a new tensor in a freed one's place): the copy happens once per in-place change, not per call."""
+    import weakref
     import numpy as np
-    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+    cacheable = torch.is_tensor(x) and x.is_cuda
+    if cacheable:
+        hit = _vec3_cache.get(id(x))
+        if hit is not None and hit[0]() is x and hit[1] == x._version:
+            return np.ctypeslib.as_ctypes(hit[2])
+    a = x.detach().cpu().numpy() if torch.is_tensor(x) else x
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))
     if a.size != 3:
         raise NotImplementedError("lighting: per-batch colours / directions are not supported by the HIP path")
+    if cacheable:
+        if len(_vec3_cache) >= 64:
+            _vec3_cache.clear()
+        _vec3_cache[id(x)] = (weakref.ref(x), x._version, a)
     return np.ctypeslib.as_ctypes(a)
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # on the GPU box: bench lines of BASELINE.json's other configurations and the secondary workloads (one JSON line each)
-R=${R:-r05}
+R=${R:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 : > $O/${R}_bench_other_configs.jsonl
@@ -20,6 +20,10 @@ run "silhouettes mode (render_silhouettes + loss + backward), 32 views" --worklo
 run "depth mode (render_depth + masked L1 + backward), 32 views" --workload depth
 run "silhouettes mode with anti-aliasing (S = 1024), 32 views" --workload silhouettes --anti-aliasing
 run "config 4's mesh @1024x1024, 8 views" --image-size 1024 --views-per-gpu 8
+run "the headline with anti-aliasing (Renderer's default): 32 views, output 512x512, internal S = 1024" --anti-aliasing
+run "silhouettes mode, config 4's 4-view shard" --workload silhouettes --views-per-gpu 4
+run "the unmodified caller's step as the timed line: render() with nothing registered + loss operators (--materialise-images)" --materialise-images --no-dropin
+run "... with the losses in eager torch operators" --materialise-images --loss-form torch --no-dropin
 # the N > 1 step on ONE rank through RCCL (D3M_BENCH_FORCE_DIST: process group, the split exchange's two all-reduces per step)
 rccl() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; D3M_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --no-cpu-baseline --no-dropin "$@" 2>> $O/bench.err | grep "^{" | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
 rccl "one rank through RCCL, split exchange (two graphs, two all-reduces): 32 views"

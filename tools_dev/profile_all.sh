@@ -2,7 +2,7 @@
 # on the GPU box: the round's judged measurements in one call -- PMC passes and SQ counters first (bench.py reads their
 # folded summaries from profiles/), then the bench line, the drop-in (--materialise-images) line and the rocprofv3
 # kernel stats of the same command.  R = round tag (r02).
-R=${R:-r05}
+R=${R:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/final; mkdir -p $O
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --no-cpu-baseline --no-dropin --steps 3 --warmup 1 --no-graph > $O/pmc_fetch.log 2>&1

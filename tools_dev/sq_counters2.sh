@@ -2,7 +2,7 @@
 # on the GPU box: a second set of SQ counters per kernel -- lane utilisation of the VALU (SQ_THREAD_CYCLES_VALU), scalar-unit
 # time, LDS-side stalls, instruction fetch, the transcendental share; folded by tools_dev/fold_pmc.py into
 # gpurun_out/sq2/<R>_sq_counters2.csv
-R=${R:-r05}
+R=${R:-r06}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/sq2; rm -rf $O; mkdir -p $O
 i=0
