@@ -88,6 +88,9 @@ struct EdgeGradArgs {
     unsigned n_lines;   // B*2*S
     int sparse_max;     // alpha only: a line with at most this many pixels that can contribute to an OUTWARD walk takes the
                         // sparse form of those walks (k_edge_lines, "SPARSE OUTWARD WALKS"); 0 = always the dense walk
+    // alpha only: per line with records, written by k_edge_lines_alpha in front of k_edge_lines: 0 = that kernel has walked
+    // the line, 1 = left to k_edge_lines; NULL = no such pass ran
+    int* line_left;
 };
 
 struct SegRef {
@@ -995,6 +998,9 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
 #endif
     const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // crossing records under this line
     if (n_x <= 0) return;                                     // nothing to do (uniform exit)
+    if constexpr (!USE_RGB) {                                 // (walked by k_edge_lines_alpha already: uniform exit)
+        if (a.line_left && __builtin_amdgcn_readfirstlane(a.line_left[line]) == 0) return;
+    }
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the lane number where it is needed, from the thread index behind an opaque copy: a `lane` kept live through the set-up
     // passes is one of the registers those do not have
@@ -1391,6 +1397,112 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     walk_queue();
 }
 
+// ---- 5a. the alpha-only mode (render_silhouettes, every return_rgb == 0 call) on lines of few contributing pixels ----------
+// With alpha alone a walk's terms are  diff_grad(d) = (alpha(d) - alpha_ref) * grad_alpha(d)  (KCU:385-387 / :473-475), kept
+// where > 0 (KCU:401/:481), and alpha is 0 or 1: against alpha_ref = 1 (every outward walk: its in-pixel is the face's own)
+// only UNCOVERED pixels with a negative gradient count, against alpha_ref = 0 only COVERED pixels with a positive one --
+// the two thin bands where a silhouette should grow or shrink.  k_edge_lines stages 40 bytes per pixel of the line, builds
+// a queue, sorts it and walks four lanes per segment to find those few pixels (its sparse form of the outward walks took
+// the 32-view silhouette step from 1.24 to 1.09 ms; what was left were the fixed phases of a 512-thread workgroup per
+// line: 255 us).  Here a line is a workgroup of TWO waves holding 12 bytes per pixel (alpha, gradient, owner) and the two
+// bands as sorted position lists; a thread per crossing record adds its two walks' handful of terms itself -- the reference's
+// own expression, (alpha(d) - alpha_ref) first, correctly rounded quotients -- and stores the crossing's two result slots.
+// No queue, no 16-wave barriers, sixteen lines in flight per CU instead of four.  A line whose bands hold more than
+// EGA_LIST pixels each (a dense alpha gradient: every term counts) or whose alpha is not 0 / 1 somewhere (a caller's own
+// map) is LEFT to k_edge_lines, which is launched behind this kernel and leaves at once on every line walked here
+// (EdgeGradArgs::line_left).
+constexpr int EGA_THREADS = 128;
+constexpr int EGA_LIST = 128;
+inline size_t edge_lines_alpha_lds(int S) { return (size_t)S * 12; }
+__global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a, EdgePlan w) {
+    extern __shared__ __attribute__((aligned(16))) float s_aline[];
+    __shared__ unsigned short s_raw[2][EGA_LIST], s_pos[2][EGA_LIST];     // [0]: counts against alpha_ref = 1, [1]: against 0
+    __shared__ int s_n[2], s_odd;
+    if (!plan_complete(w)) return;                            // (k_edge_lines / k_edge_overflow handle that case)
+    const int is = a.S;
+    const XcdOrder xo((int)a.n_lines);
+    const size_t line = (size_t)xo.unit((int)blockIdx.x);     // (b*2 + axis)*S + d0
+    if (line >= a.n_lines) return;
+    const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);
+    if (n_x <= 0) return;
+    const int d0 = (int)(line % is), axis = (int)((line / is) & 1);
+    const size_t view_base = (line / ((size_t)2 * is)) * is * is;
+    const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
+    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
+    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    float* s_al = s_aline;                                    // [S] alpha of the whole line (a walk's reference pixel may lie
+    float* s_g = s_al + is;                                   //     outside the gradients' extent); [S] gradient; [S] owner
+    int* s_own = (int*)(s_g + is);
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    if (threadIdx.x == 2) s_odd = 0;
+    const float go_sign = a.go_sign();
+    bool odd = false;
+    for (int p = (int)threadIdx.x; p < is; p += EGA_THREADS) {
+        const size_t pi = a.pixel(axis, view_base, d0, p);
+        const float al = a.alpha_map[pi];
+        s_al[p] = al;
+        odd = odd || !(al == 0.0f || al == 1.0f);
+        if (p >= p_lo && p <= p_hi) {
+            s_g[p] = go_sign * a.grad[pi].x;
+            s_own[p] = __float_as_int(a.dot[pi].y);
+        }
+    }
+    __syncthreads();
+    if (odd) s_odd = 1;
+    for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EGA_THREADS) {
+        const float al = s_al[p], g = s_g[p];
+        if (!((al - 1.0f) * g <= 0)) {                        // (NaN stays, as in the walk)
+            const int k = atomicAdd(&s_n[0], 1);
+            if (k < EGA_LIST) s_raw[0][k] = (unsigned short)p;
+        }
+        if (!(al * g <= 0)) {
+            const int k = atomicAdd(&s_n[1], 1);
+            if (k < EGA_LIST) s_raw[1][k] = (unsigned short)p;
+        }
+    }
+    __syncthreads();
+    const int n_out = s_n[0], n_in = s_n[1];
+    const bool left = n_out > EGA_LIST || n_in > EGA_LIST || s_odd != 0 || a.sparse_max <= 0;      // (uniform)
+    if (threadIdx.x == 0) a.line_left[line] = left ? 1 : 0;
+    if (left) return;
+    // ascending order (the entries arrive in any order): rank = the number of smaller positions.  The walks then add their
+    // terms in pixel order -- the same sums in every run
+    for (int e = (int)threadIdx.x; e < n_out + n_in; e += EGA_THREADS) {
+        const int which = e < n_out ? 0 : 1, i = which ? e - n_out : e, n = which ? n_in : n_out;
+        const unsigned short mine = s_raw[which][i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += s_raw[which][j] < mine ? 1 : 0;
+        s_pos[which][rank] = mine;
+    }
+    __syncthreads();
+    const float two_over_is = 2.0f / (float)is;
+    const uint4* xrec = w.xrec + (size_t)x_first;
+    for (int ci = (int)threadIdx.x; ci < n_x; ci += EGA_THREADS) {
+        const uint4 rc = xrec[ci];
+        const XGeom geo = record_to_geometry(rc);
+        const int fn = record_face(rc);
+#pragma unroll
+        for (int which = 0; which < 2; which++) {             // 0: outward, 1: inward
+            float g0 = 0.0f, g1 = 0.0f;
+            Segment q;
+            if (geometry_segment(geo, which, axis, d0, is, p_lo, p_hi, q)) {
+                const float ref = s_al[q.ref_pos];            // (0 or 1: the line holds nothing else)
+                const int list = ref == 1.0f ? 0 : 1, n = list ? n_in : n_out;
+                const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
+                for (int i = 0; i < n; i++) {
+                    const int d1 = (int)s_pos[list][i];
+                    if (d1 < q.from) continue;
+                    if (d1 > q.to) break;
+                    if (which == 1 && s_own[d1] != fn) continue;                  // KCU:470: the face's own pixels only
+                    visit_pixel_div((s_al[d1] - ref) * s_g[d1], d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is,
+                                    a.eps, g0, g1);
+                }
+            }
+            w.results[2u * (uint32_t)(x_first + ci) + which] = make_float2(g0, g1);
+        }
+    }
+}
+
 // ---- 5. per visible face: the results of its six lanes' crossings, stored once ---------------------------
 // `parts` (> 1 only with a vertex target, whose sums are ADDED): a block's lanes are dealt to that many workgroups, each
 // taking every parts-th group of four crossings of every lane -- a coarse mesh's lane has hundreds of crossings to add up, one
@@ -1714,7 +1826,7 @@ inline hipError_t run_edge_plan(FS fs, const int32_t* face_index_map, const Edge
 struct EdgeLayout {
     size_t off_grad_row, off_dot_row;
     size_t off_nz_lo, off_nz_hi, nz_bytes;     // zeroed per call
-    size_t off_lane_partial, off_visibility, off_plan;
+    size_t off_lane_partial, off_line_left, off_visibility, off_plan;
     size_t fixed_bytes;                         // everything but the plan (sized by capacity)
 };
 
@@ -1728,6 +1840,7 @@ inline EdgeLayout edge_layout(int B, int F, int S) {
     L.off_nz_hi = o;    o += eg_align(nl * 4);
     L.nz_bytes = o - L.off_nz_lo;
     L.off_lane_partial = o; o += eg_align(nf * 6 * 8);
+    L.off_line_left = o;    o += eg_align(nl * 4);
     L.off_visibility = o;   o += eg_align(visibility_bytes((long)nf));
     L.off_plan = o;
     L.fixed_bytes = o;
@@ -1810,7 +1923,14 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     a.S = S; a.use_rgb = m.use_rgb; a.use_alpha = m.use_alpha; a.eps = eps; a.n_lines = (unsigned)nl;
     // (a quarter of the line: beyond that the list holds about as many entries as the dense walks would visit)
     a.sparse_max = m.use_rgb ? 0 : d3m_env_int("D3M_EG_SPARSE_MAX", S / 4);
+    a.line_left = nullptr;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
+    // alpha only: the lines of few contributing pixels first, two waves per line (k_edge_lines_alpha); k_edge_lines behind it
+    // takes what that pass leaves
+    if (!m.use_rgb && m.use_alpha && a.sparse_max > 0 && edge_lines_alpha_lds(S) <= 64 * 1024) {
+        a.line_left = (int*)(p + L.off_line_left);
+        LAUNCH_SMEM("k_edge_lines_alpha", k_edge_lines_alpha, glines, dim3(EGA_THREADS), edge_lines_alpha_lds(S), st, a, w);
+    }
 #define D3M_LINES(RGB, ALPHA, WV)                                                                                    \
     do {                                                                                                             \
         if (smem + eg_line_static_lds(WV) > 64 * 1024) {                                                             \
