@@ -1406,7 +1406,7 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
 // the 32-view silhouette step from 1.24 to 1.09 ms; what was left were the fixed phases of a 512-thread workgroup per
 // line: 255 us).  Here a line is a workgroup of TWO waves holding 12 bytes per pixel (alpha, gradient, owner) and the two
 // bands as sorted position lists; a thread per crossing record adds its two walks' handful of terms itself -- the reference's
-// own expression, (alpha(d) - alpha_ref) first, correctly rounded quotients -- and stores the crossing's two result slots.
+// own expression, (alpha(d) - alpha_ref) first -- and stores the crossing's two result slots.
 // No queue, no 16-wave barriers, sixteen lines in flight per CU instead of four.  A line whose bands hold more than
 // EGA_LIST pixels each (a dense alpha gradient: every term counts) or whose alpha is not 0 / 1 somewhere (a caller's own
 // map) is LEFT to k_edge_lines, which is launched behind this kernel and leaves at once on every line walked here
@@ -1489,13 +1489,19 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
                 const float ref = s_al[q.ref_pos];            // (0 or 1: the line holds nothing else)
                 const int list = ref == 1.0f ? 0 : 1, n = list ? n_in : n_out;
                 const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
-                for (int i = 0; i < n; i++) {
+                int lo = 0, hi = n;
+                while (lo < hi) {                             // first entry at or behind the segment's start
+                    const int mid = (lo + hi) >> 1;
+                    if ((int)s_pos[list][mid] < q.from) lo = mid + 1; else hi = mid;
+                }
+                // (v_rcp_f32 quotients, as in every other walk: with correctly rounded divisions this loop was the kernel --
+                //  82 M wave VALU instructions per 32-view launch, 133 us of issue)
+                for (int i = lo; i < n; i++) {
                     const int d1 = (int)s_pos[list][i];
-                    if (d1 < q.from) continue;
                     if (d1 > q.to) break;
                     if (which == 1 && s_own[d1] != fn) continue;                  // KCU:470: the face's own pixels only
-                    visit_pixel_div((s_al[d1] - ref) * s_g[d1], d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is,
-                                    a.eps, g0, g1);
+                    visit_pixel((s_al[d1] - ref) * s_g[d1], d1, q.d1_cross, qq0, qq1, q.f0 != 0, q.f1 != 0, two_over_is, a.eps,
+                                g0, g1);
                 }
             }
             w.results[2u * (uint32_t)(x_first + ci) + which] = make_float2(g0, g1);

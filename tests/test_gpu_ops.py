@@ -214,9 +214,10 @@ def test_edge_gradient_pass_with_more_long_segments_than_the_queue_holds():
 @pytest.mark.parametrize("gradient", ["grow_band", "dense", "single_pixels", "nan"])
 def test_alpha_only_edge_gradient_sparse_and_dense_walks(gradient, monkeypatch):
     """K4 with return_rgb == 0 (render_silhouettes): the outward walks' terms are (alpha(d) - 1) * grad_alpha(d), non-zero
-    only at uncovered pixels with a negative gradient, so k_edge_lines compacts those pixels per line and a crossing's
-    thread adds its few terms itself (SPARSE OUTWARD WALKS) -- unless the line holds more of them than D3M_EG_SPARSE_MAX
-    (default S / 4), which walks densely as the rgb modes do.  Both forms against the oracle's per-face walk
+    only at uncovered pixels with a negative gradient (and the inward walks' only at covered ones with a positive one), so
+    lines of few such pixels are walked by k_edge_lines_alpha (two waves per line over sorted lists of them) and, beyond its
+    lists, by k_edge_lines' own sparse form (SPARSE OUTWARD WALKS) -- unless the line holds more of them than
+    D3M_EG_SPARSE_MAX (default S / 4; 0 = neither), which walks densely as the rgb modes do.  Both forms against the oracle's per-face walk
     (KCU:245-503), and against each other far below the tolerance: a thin band of negative gradients outside the
     silhouette (the shape a silhouette fit produces), dense random gradients (every line over the limit at the default;
     forced sparse with the limit raised), isolated pixels, and a NaN gradient (kept by `diff_grad <= 0` being false,
@@ -271,8 +272,8 @@ def test_alpha_only_edge_gradient_sparse_and_dense_walks(gradient, monkeypatch):
         assert _grad_close(g, gf_ref), (form, np.abs(g - gf_ref).max() / np.abs(gf_ref).max())
     scale = np.abs(gf_ref).max()
     assert np.abs(got["sparse"] - got["dense"]).max() <= 1e-4 * scale
-    # the sparse form's terms carry correctly rounded quotients: no further from the reference than the dense walk
-    assert np.abs(got["sparse"] - gf_ref).max() <= np.abs(got["dense"] - gf_ref).max() + 2e-6 * scale
+    # ... and no further from the reference than the dense walk (the same v_rcp_f32 quotients, fewer terms)
+    assert np.abs(got["sparse"] - gf_ref).max() <= np.abs(got["dense"] - gf_ref).max() + 2e-5 * scale
 
 
 def test_edge_gradient_on_an_image_wider_than_the_line_window():
