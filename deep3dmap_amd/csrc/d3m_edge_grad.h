@@ -88,9 +88,11 @@ struct EdgeGradArgs {
     unsigned n_lines;   // B*2*S
     int sparse_max;     // alpha only: a line with at most this many pixels that can contribute to an OUTWARD walk takes the
                         // sparse form of those walks (k_edge_lines, "SPARSE OUTWARD WALKS"); 0 = always the dense walk
-    // alpha only: per line with records, written by k_edge_lines_alpha in front of k_edge_lines: 0 = that kernel has walked
-    // the line, 1 = left to k_edge_lines; NULL = no such pass ran
+    // alpha only: the lines k_edge_lines_alpha (in front of k_edge_lines) LEFT to it -- those of many contributing pixels --
+    // as a list and its length (EdgePlan::alloc[2]: zero when the plan is built, handed back zeroed by k_edge_gather); NULL =
+    // no such pass ran, k_edge_lines takes every line
     int* line_left;
+    int* n_left;
 };
 
 struct SegRef {
@@ -989,18 +991,9 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     // their pixels' cache lines (a 64-byte line holds the records of 4 neighbouring columns, the pairs of 8, the alphas
     // of 16) -- dealt to different XCDs every one of them is fetched into up to 8 L2s (1.74 GB of HBM-side traffic per
     // launch for 0.3 GB of maps).  XCD x takes the contiguous lines [x*per, (x+1)*per).
-#ifndef D3M_EG_LINES_PLAIN_ORDER
-    const XcdOrder xo((int)a.n_lines);
-    const size_t line = (size_t)xo.unit((int)blockIdx.x);     // (b*2 + axis)*S + d0
-    if (line >= a.n_lines) return;
-#else
-    const size_t line = blockIdx.x;
-#endif
+    auto do_line = [&](const size_t line) {                   // (b*2 + axis)*S + d0
     const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);      // crossing records under this line
     if (n_x <= 0) return;                                     // nothing to do (uniform exit)
-    if constexpr (!USE_RGB) {                                 // (walked by k_edge_lines_alpha already: uniform exit)
-        if (a.line_left && __builtin_amdgcn_readfirstlane(a.line_left[line]) == 0) return;
-    }
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the lane number where it is needed, from the thread index behind an opaque copy: a `lane` kept live through the set-up
     // passes is one of the registers those do not have
@@ -1395,6 +1388,27 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
         __syncthreads();
     }
     walk_queue();
+    };      // do_line
+    if constexpr (!USE_RGB) {
+        // behind k_edge_lines_alpha: only the lines that pass left, from its list -- a small grid strides over it (a workgroup
+        // per line of the image that leaves at once on nearly every one was 27 us of dispatch per 32-view launch)
+        if (a.line_left) {
+            const int n_left = __builtin_amdgcn_readfirstlane(*a.n_left);
+            for (int item = (int)blockIdx.x; item < n_left; item += (int)gridDim.x) {
+                do_line((size_t)a.line_left[item]);
+                __syncthreads();                              // (the next line's image takes this one's place)
+            }
+            return;
+        }
+    }
+#ifndef D3M_EG_LINES_PLAIN_ORDER
+    const XcdOrder xo((int)a.n_lines);
+    const size_t line = (size_t)xo.unit((int)blockIdx.x);
+    if (line >= a.n_lines) return;
+#else
+    const size_t line = blockIdx.x;
+#endif
+    do_line(line);
 }
 
 // ---- 5a. the alpha-only mode (render_silhouettes, every return_rgb == 0 call) on lines of few contributing pixels ----------
@@ -1463,8 +1477,10 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
     __syncthreads();
     const int n_out = s_n[0], n_in = s_n[1];
     const bool left = n_out > EGA_LIST || n_in > EGA_LIST || s_odd != 0 || a.sparse_max <= 0;      // (uniform)
-    if (threadIdx.x == 0) a.line_left[line] = left ? 1 : 0;
-    if (left) return;
+    if (left) {
+        if (threadIdx.x == 0) a.line_left[atomicAdd(a.n_left, 1)] = (int)line;
+        return;
+    }
     // ascending order (the entries arrive in any order): rank = the number of smaller positions.  The walks then add their
     // terms in pixel order -- the same sums in every run
     for (int e = (int)threadIdx.x; e < n_out + n_in; e += EGA_THREADS) {
@@ -1487,7 +1503,9 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
             Segment q;
             if (geometry_segment(geo, which, axis, d0, is, p_lo, p_hi, q)) {
                 const float ref = s_al[q.ref_pos];            // (0 or 1: the line holds nothing else)
-                const int list = ref == 1.0f ? 0 : 1, n = list ? n_in : n_out;
+                // (an inward walk against a COVERED out-pixel -- every interior edge -- has nothing to add: it counts the
+                //  face's own, covered pixels only, whose terms (1 - 1) * g vanish)
+                const int list = ref == 1.0f ? 0 : 1, n = (which == 1 && ref == 1.0f) ? 0 : (list ? n_in : n_out);
                 const float qq0 = q.f0 ? q.q0 : 1.0f, qq1 = q.f1 ? q.q1 : 1.0f;
                 int lo = 0, hi = n;
                 while (lo < hi) {                             // first entry at or behind the segment's start
@@ -1518,6 +1536,7 @@ __global__ void __launch_bounds__(256) k_edge_gather(FS fs, EdgePlan w, const fl
                                                     const float* __restrict__ go, float* __restrict__ grad_faces,
                                                     VertexTarget vt, int parts) {
     __shared__ float2 s_g[256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.alloc[2] = 0;    // (k_edge_lines_alpha's list of left lines: EdgeGradArgs::n_left)
     const int n_vis = *w.n_visible;
     const int n_blocks = (n_vis + EG_FACES_PER_BLOCK - 1) / EG_FACES_PER_BLOCK;
     const int n_units = n_blocks * parts;
@@ -1930,13 +1949,17 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     // (a quarter of the line: beyond that the list holds about as many entries as the dense walks would visit)
     a.sparse_max = m.use_rgb ? 0 : d3m_env_int("D3M_EG_SPARSE_MAX", S / 4);
     a.line_left = nullptr;
+    a.n_left = nullptr;
     const dim3 glines((unsigned)((nl + 7) / 8 * 8));            // a multiple of 8: see XcdOrder
     // alpha only: the lines of few contributing pixels first, two waves per line (k_edge_lines_alpha); k_edge_lines behind it
     // takes what that pass leaves
     if (!m.use_rgb && m.use_alpha && a.sparse_max > 0 && edge_lines_alpha_lds(S) <= 64 * 1024) {
         a.line_left = (int*)(p + L.off_line_left);
+        a.n_left = w.alloc + 2;
         LAUNCH_SMEM("k_edge_lines_alpha", k_edge_lines_alpha, glines, dim3(EGA_THREADS), edge_lines_alpha_lds(S), st, a, w);
     }
+    // (behind that pass k_edge_lines strides over its list of left lines with a small grid)
+    const dim3 glines_general(a.line_left ? std::min(glines.x, 2048u) : glines.x);
 #define D3M_LINES(RGB, ALPHA, WV)                                                                                    \
     do {                                                                                                             \
         if (smem + eg_line_static_lds(WV) > 64 * 1024) {                                                             \
@@ -1944,7 +1967,7 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                          \
             if (e != hipSuccess) { *last_err = (int)e; return 3; }                                                   \
         }                                                                                                            \
-        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, WV>), glines, dim3(WV * 64), smem, st, a, w,           \
+        LAUNCH_SMEM("k_edge_lines", (k_edge_lines<RGB, ALPHA, WV>), glines_general, dim3(WV * 64), smem, st, a, w,   \
                     lane_partial);                                                                                   \
     } while (0)
     // Waves per workgroup: the narrow form while its workgroups keep a CU at 24 waves or more (their phases -- stage, set

@@ -2,7 +2,7 @@
 # round 6, call 6: the two-wave alpha-only line kernel -- suite, silhouette-mode lines against round 5's tree
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 ROOT=$PWD
-O=gpurun_out/r6c8; rm -rf $O; mkdir -p $O
+O=gpurun_out/r6c9; rm -rf $O; mkdir -p $O
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 ) > $O/suite.txt
 line() { d=$1; shift; (cd $ROOT/$d && timeout 600 python bench.py --no-cpu-baseline --no-dropin "$@" 2>/dev/null | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); k=d.get('kernel_ms_per_step',{})
