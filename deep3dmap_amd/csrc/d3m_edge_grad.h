@@ -1451,14 +1451,28 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
     if (threadIdx.x == 2) s_odd = 0;
     const float go_sign = a.go_sign();
     bool odd = false;
-    for (int p = (int)threadIdx.x; p < is; p += EGA_THREADS) {
-        const size_t pi = a.pixel(axis, view_base, d0, p);
-        const float al = a.alpha_map[pi];
-        s_al[p] = al;
-        odd = odd || !(al == 0.0f || al == 1.0f);
-        if (p >= p_lo && p <= p_hi) {
-            s_g[p] = go_sign * a.grad[pi].x;
-            s_own[p] = __float_as_int(a.dot[pi].y);
+    // (four pixels per thread and round, every load of a round requested before any is used: a column line's pixels are a
+    //  raster row apart, one round trip to the L2 each -- four in flight instead of four in a row)
+    for (int p0 = (int)threadIdx.x; p0 < is; p0 += 4 * EGA_THREADS) {
+        float al[4], gx[4], ow[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = p0 + k * EGA_THREADS;
+            const size_t pi = a.pixel(axis, view_base, d0, min(p, is - 1));
+            al[k] = a.alpha_map[pi];
+            const bool in = p >= p_lo && p <= p_hi;
+            gx[k] = in ? a.grad[pi].x : 0.0f;
+            ow[k] = in ? a.dot[pi].y : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = p0 + k * EGA_THREADS;
+            if (p < is) {
+                s_al[p] = al[k];
+                odd = odd || !(al[k] == 0.0f || al[k] == 1.0f);
+                s_g[p] = go_sign * gx[k];
+                s_own[p] = __float_as_int(ow[k]);
+            }
         }
     }
     __syncthreads();
@@ -1493,8 +1507,11 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
     __syncthreads();
     const float two_over_is = 2.0f / (float)is;
     const uint4* xrec = w.xrec + (size_t)x_first;
+    uint4 rc_next = make_uint4(0, 0, 0, 0);
+    if ((int)threadIdx.x < n_x) rc_next = xrec[threadIdx.x];
     for (int ci = (int)threadIdx.x; ci < n_x; ci += EGA_THREADS) {
-        const uint4 rc = xrec[ci];
+        const uint4 rc = rc_next;                             // (the next round's record is requested before this one's walks)
+        if (ci + EGA_THREADS < n_x) rc_next = xrec[ci + EGA_THREADS];
         const XGeom geo = record_to_geometry(rc);
         const int fn = record_face(rc);
 #pragma unroll
