@@ -88,6 +88,32 @@ struct EdgeGradArgs {
     unsigned n_lines;   // B*2*S
     int sparse_max;     // alpha only: a line with at most this many pixels that can contribute to an OUTWARD walk takes the
                         // sparse form of those walks (k_edge_lines, "SPARSE OUTWARD WALKS"); 0 = always the dense walk
+    // DIRECT (alpha only, final gradients: round 6).  No per-pixel records at all: the alpha gradient is read where it already
+    // is -- an internal-layout map [B,S,S] (ga_map: the reference-shaped operator's grad_alpha_map) or the OUTPUT image's
+    // gradient [B,s,s] through the row flip and the 2x2 pooling's adjoint (ga_img: the silhouette node) --, the owner from
+    // face_index_map, T = alpha * gradient; the lines have no extents (nz_* NULL: the whole line).  k_pack_maps -- a pass
+    // over every pixel writing 24 bytes each, 55 us of a 32-view silhouette step -- does not run.
+    const float* ga_map;
+    const float* ga_img;
+    const int32_t* fi_direct;
+    int img_s, img_aa;
+    __device__ __forceinline__ bool direct() const { return ga_map != nullptr || ga_img != nullptr; }
+    __device__ __forceinline__ float direct_ga(size_t pi) const {       // pi = (b*S + y)*S + x
+        if (ga_map) return ga_map[pi];
+        const size_t plane = (size_t)S * S;
+        const int b = (int)(pi / plane), rem = (int)(pi - (size_t)b * plane), y = rem / S, x = rem - y * S;
+        const int yo = img_aa ? (S - 1 - y) >> 1 : S - 1 - y, xo = img_aa ? x >> 1 : x;
+        return ga_img[((size_t)b * img_s + yo) * img_s + xo] * (img_aa ? 0.25f : 1.0f);
+    }
+    __device__ __forceinline__ float4 rec_grad(size_t pi) const {
+        return direct() ? make_float4(direct_ga(pi), 0.0f, 0.0f, 0.0f) : grad[pi];
+    }
+    __device__ __forceinline__ float2 rec_dot(size_t pi) const {
+        if (!direct()) return dot[pi];
+        return make_float2(alpha_map[pi] * direct_ga(pi), __int_as_float(fi_direct[pi]));
+    }
+    __device__ __forceinline__ int extent_lo(size_t line) const { return nz_lo_inv ? S - nz_lo_inv[line] : 0; }
+    __device__ __forceinline__ int extent_hi(size_t line) const { return nz_hi1 ? nz_hi1[line] - 1 : S - 1; }
     // alpha only: the lines k_edge_lines_alpha (in front of k_edge_lines) LEFT to it -- those of many contributing pixels --
     // as a list and its length (EdgePlan::alloc[2]: zero when the plan is built, handed back zeroed by k_edge_gather); NULL =
     // no such pass ran, k_edge_lines takes every line
@@ -322,8 +348,8 @@ __device__ __forceinline__ void walk_inline(const EdgeGradArgs& a, size_t view_b
     for (int d1 = from; d1 <= to; d1 += 2) {
         const bool two = d1 + 1 <= to;
         const size_t ia = a.pixel(sg.axis, view_base, sg.d0, d1), ib = two ? a.pixel(sg.axis, view_base, sg.d0, d1 + 1) : ia;
-        float2 dta = a.dot[ia], dtb = a.dot[ib];
-        float4 ga = a.grad[ia], gb = a.grad[ib];
+        float2 dta = a.rec_dot(ia), dtb = a.rec_dot(ib);
+        float4 ga = a.rec_grad(ia), gb = a.rec_grad(ib);
         dta.x *= gs; dtb.x *= gs;
         ga.x *= gs; ga.y *= gs; ga.z *= gs; ga.w *= gs;
         gb.x *= gs; gb.y *= gs; gb.z *= gs; gb.w *= gs;
@@ -881,12 +907,12 @@ __global__ void __launch_bounds__(256) k_edge_overflow(FS fs, EdgeGradArgs a, Ed
             const XGeom xg = crossing_geometry(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l],
                                                edge_slopes(t.p[0][l], t.p[1][l], t.p[2][l], t.p[3][l], t.p[4][l], t.p[5][l]),
                                                axis, fn, is, d0,
-                                               [&](int e0, int e1) { return __float_as_int(a.dot[a.pixel(axis, base, e0, e1)].y); });
+                                               [&](int e0, int e1) { return __float_as_int(a.rec_dot(a.pixel(axis, base, e0, e1)).y); });
 #pragma unroll
             for (int which = 0; which < 2; which++) {
                 float g0 = 0, g1 = 0;
                 Segment sg;
-                if (geometry_segment(xg, which, axis, d0, is, is - a.nz_lo_inv[line], a.nz_hi1[line] - 1, sg)) {
+                if (geometry_segment(xg, which, axis, d0, is, a.extent_lo(line), a.extent_hi(line), sg)) {
                     const SegRef ref = load_ref(a, axis, base, sg.d0, sg.ref_pos);
                     walk_inline(a, base, sg, sg.from, sg.to, ref, fn, two_over_is, g0, g1);
                 }
@@ -1006,8 +1032,8 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     const uint4* xrec = w.xrec + (size_t)x_first;
     const float two_over_is = 2.0f / (float)is;
     // only the line's non-zero-gradient extent is staged: every segment is clipped to it (geometry_segment)
-    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
-    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    const int p_lo = __builtin_amdgcn_readfirstlane(a.extent_lo(line));
+    const int p_hi = __builtin_amdgcn_readfirstlane(a.extent_hi(line));
     // ONE THREAD PER RECORD (round 4; before: one per (record, outward | inward), i.e. every record decoded by two
     // threads and EG_LINE_THREADS / 2 records per pass -- and the headline mesh puts a median of 260 records on a line,
     // four more than a pass of the 8-wave form took, so half the lines paid a second pass (three barriers, a round of
@@ -1040,8 +1066,8 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     }
     for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_THREADS) {
         const size_t pi = a.pixel(axis, view_base, d0, p);
-        float4 g = a.grad[pi];
-        const float2 d = a.dot[pi];
+        float4 g = a.rec_grad(pi);
+        const float2 d = a.rec_dot(pi);
         g.x *= go_sign; g.y *= go_sign; g.z *= go_sign; g.w *= go_sign;
         s_grd[p] = g;
         s_df[p] = make_float2(0.5f * go_sign * d.x, d.y);
@@ -1442,8 +1468,8 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
     const int d0 = (int)(line % is), axis = (int)((line / is) & 1);
     const size_t view_base = (line / ((size_t)2 * is)) * is * is;
     const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
-    const int p_lo = __builtin_amdgcn_readfirstlane(is - a.nz_lo_inv[line]);
-    const int p_hi = __builtin_amdgcn_readfirstlane(a.nz_hi1[line] - 1);
+    const int p_lo = __builtin_amdgcn_readfirstlane(a.extent_lo(line));
+    const int p_hi = __builtin_amdgcn_readfirstlane(a.extent_hi(line));
     float* s_al = s_aline;                                    // [S] alpha of the whole line (a walk's reference pixel may lie
     float* s_g = s_al + is;                                   //     outside the gradients' extent); [S] gradient; [S] owner
     int* s_own = (int*)(s_g + is);
@@ -1461,8 +1487,8 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
             const size_t pi = a.pixel(axis, view_base, d0, min(p, is - 1));
             al[k] = a.alpha_map[pi];
             const bool in = p >= p_lo && p <= p_hi;
-            gx[k] = in ? a.grad[pi].x : 0.0f;
-            ow[k] = in ? a.dot[pi].y : 0.0f;
+            gx[k] = in ? (a.direct() ? a.direct_ga(pi) : a.grad[pi].x) : 0.0f;
+            ow[k] = in ? (a.direct() ? __int_as_float(a.fi_direct[pi]) : a.dot[pi].y) : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1903,6 +1929,9 @@ struct EdgeRecords {
     const int* nz_lo_inv;
     const int* nz_hi1;
     const float* go;       // the factor they still lack (device scalar; NULL = 1)
+    // alpha only, no records at all (EdgeGradArgs "DIRECT"): the OUTPUT image's alpha gradient [B,s,s], s = S or S/2 (aa)
+    const float* ga_img = nullptr;
+    int img_aa = 0;
 };
 
 // the lanes' overflow sums start at zero -- only ever used when the plan is incomplete (leaves at once otherwise)
@@ -1948,9 +1977,18 @@ int run_edge_grad(FS fs, PixelMaps m, float* grad_faces, VertexTarget vt, const 
     float2* dot_row = (float2*)(p + L.off_dot_row);
     float2* lane_partial = (float2*)(p + L.off_lane_partial);
     EdgeGradArgs a;
+    a.ga_map = a.ga_img = nullptr; a.fi_direct = m.face_index_map; a.img_s = S; a.img_aa = 0;
+    // DIRECT: final alpha gradients need no records (D3M_EG_DIRECT=0: pack an internal-layout map all the same, for A/B
+    // runs; the output image's gradient has no packed form)
+    const bool direct = !rec.grad && !m.use_rgb && m.use_alpha && !gs.totals &&
+                        (rec.ga_img || d3m_env_int("D3M_EG_DIRECT", 1) != 0);
     if (rec.grad) {
         a.grad = rec.grad; a.dot = rec.dot; a.go = rec.go;
         a.nz_lo_inv = rec.nz_lo_inv; a.nz_hi1 = rec.nz_hi1;
+    } else if (direct) {
+        a.grad = nullptr; a.dot = nullptr; a.go = nullptr; a.nz_lo_inv = a.nz_hi1 = nullptr;
+        if (rec.ga_img) { a.ga_img = rec.ga_img; a.img_aa = rec.img_aa; a.img_s = rec.img_aa ? S / 2 : S; }
+        else a.ga_map = m.grad_alpha_map;
     } else {
         e = zero_async(p + L.off_nz_lo, L.nz_bytes, st);
         if (e != hipSuccess) { *last_err = (int)e; return 3; }

@@ -523,7 +523,12 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
                                       const d3m_vertex_target* vertex_target, void* visibility, void* edge_plan,
                                       size_t edge_plan_size, const d3m_fit_targets* unscaled, d3m_stream_t stream) {
     if (edge_plan && !visibility) return D3M_ERR_INVALID;      // a plan indexes the list of its visibility blob
-    if (unscaled && !unscaled->scratch && !unscaled->edge_grad) return D3M_ERR_INVALID;    // (records without a scratch: final)
+    // alpha only, the OUTPUT image's gradient as it is (flags & D3M_GRAD_OF_OUTPUT_IMAGE; | D3M_FIT_POOLED: of the 2x2-pooled image)
+    const bool of_image = unscaled && !unscaled->scratch && !unscaled->edge_grad &&
+                          (unscaled->flags & D3M_GRAD_OF_OUTPUT_IMAGE) && unscaled->grad_alpha_map;
+    if (of_image && (return_rgb || !return_alpha || ((unscaled->flags & D3M_FIT_POOLED) && (image_size & 1))))
+        return D3M_ERR_INVALID;
+    if (unscaled && !unscaled->scratch && !unscaled->edge_grad && !of_image) return D3M_ERR_INVALID;    // (records without a scratch: final)
     if (!faces || !face_index_map || (!grad_faces && !vertex_target) || batch_size <= 0 || num_faces <= 0 ||
         image_size <= 0)
         return D3M_ERR_INVALID;
@@ -532,7 +537,7 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
     const bool records = unscaled && unscaled->edge_grad;      // the gradient maps arrive as per-pixel records
     if (records && !(unscaled->edge_dot && unscaled->edge_nz_lo_inv && unscaled->edge_nz_hi1)) return D3M_ERR_INVALID;
     if (return_rgb && (!rgb_map || (!grad_rgb_map && !records))) return D3M_ERR_INVALID;
-    if (return_alpha && (!alpha_map || (!grad_alpha_map && !records))) return D3M_ERR_INVALID;
+    if (return_alpha && (!alpha_map || (!grad_alpha_map && !records && !of_image))) return D3M_ERR_INVALID;
     if (!return_rgb && !return_alpha) return D3M_OK;    // rasterize.py:200-201
     DenseFaces fs{faces, num_faces};
     PixelMaps m{face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, image_size, return_rgb != 0,
@@ -543,8 +548,12 @@ D3M_EXPORT int d3m_backward_pixel_map(const float* faces, const int32_t* face_in
     if (records)
         rec = EdgeRecords{(const float4*)unscaled->edge_grad, (const float2*)unscaled->edge_dot, unscaled->edge_nz_lo_inv,
                           unscaled->edge_nz_hi1, unscaled->grad_loss};
+    if (of_image) {
+        rec.ga_img = unscaled->grad_alpha_map;
+        rec.img_aa = (unscaled->flags & D3M_FIT_POOLED) ? 1 : 0;
+    }
     return run_edge_grad(fs, m, grad_faces, vt, visibility ? &vis : nullptr, edge_plan, edge_plan_size, rec,
-                         to_grad_scale(unscaled, image_size), batch_size, eps, workspace, workspace_bytes,
+                         to_grad_scale(of_image ? nullptr : unscaled, image_size), batch_size, eps, workspace, workspace_bytes,
                          (hipStream_t)stream, &g_last_hip_error);
 }
 

@@ -1163,7 +1163,16 @@ class _RasterizeMeshModes(torch.autograd.Function):
         grad_sv, counter = acc[:B * V * 3].view(B, V, 3), acc[B * V * 3:]
         target = _lib.D3MVertexTarget(_lib.ptr(grad_sv), _lib.ptr(tri), V, Ft, tri.shape[0], int(fill_back))
         g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev) if (rd and (ra or aa)) else None
-        if ra:
+        if ra and not rd:
+            # silhouettes only: the edge gradient reads the image's gradient where it is -- through the row flip and the
+            # pooling's adjoint -- and the owners from face_index_map; no per-pixel records (d3m_edge_grad.h, "DIRECT")
+            g_img = f32c(g_alpha)
+            unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, _lib.ptr(g_img), None, None, None,
+                                          None, None, None, None,
+                                          _lib.GRAD_OF_OUTPUT_IMAGE | (_lib.FIT_POOLED if aa else 0))
+            ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
+                                   visibility=vis, unscaled=unscaled, edge_plan=plan)
+        elif ra:
             # the adjoint of the output epilogue writes the alpha gradient straight as the edge gradient's per-pixel records
             # (and the depth gradient as the map K6 reads)
             records = (torch.empty(B, S, S, 4, dtype=torch.float32, device=dev),

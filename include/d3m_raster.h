@@ -198,7 +198,12 @@ typedef struct {
 } d3m_vertex_target;
 /* `unscaled` (NULL = the gradient maps are final): the maps are the unscaled ones a fused fit objective left
  * (d3m_render_lit_epilogue with fit->grad_*_map, see struct d3m_fit_targets below); their scalar factors are applied
- * as the maps are read. */
+ * as the maps are read.
+ * Alpha only (return_alpha, not return_rgb) with FINAL gradients takes no pass over the pixels to pack them: the walks read
+ * grad_alpha_map and face_index_map as they are.  The same for the gradient of the OUTPUT image instead of the internal map:
+ * `unscaled` with only grad_alpha_map = that image's gradient [B,s,s] and flags = D3M_GRAD_OF_OUTPUT_IMAGE (s = image_size:
+ * the image is the alpha map with its rows reversed) or D3M_GRAD_OF_OUTPUT_IMAGE | D3M_FIT_POOLED (s = image_size / 2: its 2x2
+ * average); the argument grad_alpha_map is then not read (NULL).  Any other `unscaled` without scratch or records: D3M_ERR_INVALID. */
 typedef struct d3m_fit_targets d3m_fit_targets;
 int d3m_backward_pixel_map(const float* faces, const int32_t* face_index_map, const float* rgb_map,
                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,

@@ -251,7 +251,10 @@ def test_alpha_only_edge_gradient_sparse_and_dense_walks(gradient, monkeypatch):
     fd, fi, am, ga = _dev(faces), _dev(m["face_index_map"]), _dev(alpha), _dev(g_alpha)
     dummy = torch.zeros(1, device="cuda")
     got = {}
-    for form, limit in (("default", None), ("dense", "0"), ("sparse", str(S))):
+    for form, limit in (("default", None), ("dense", "0"), ("sparse", str(S)), ("packed", None)):
+        # ("packed": D3M_EG_DIRECT=0 -- the gradients as per-pixel records with line extents, the form the rgb modes and
+        # the fused objectives use; the default reads grad_alpha_map / face_index_map directly, d3m_edge_grad.h "DIRECT")
+        monkeypatch.setenv("D3M_EG_DIRECT", "0" if form == "packed" else "1")
         if limit is None:
             monkeypatch.delenv("D3M_EG_SPARSE_MAX", raising=False)
         else:

@@ -1053,6 +1053,8 @@ def test_silhouette_and_depth_modes_over_the_indexed_mesh(mode, aa, per_view_mes
     assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible", "k_output_epilogue_backward"} & out[True][2]) \
         or mode == "depth", sorted(out[True][2])
     assert not ({"k_gather_faces", "k_scatter_face_grads", "k_mark_visible"} & out[True][2]), sorted(out[True][2])
+    if mode == "silhouettes":      # round 6: the walks read the image's gradient where it is -- no pass packing records
+        assert "k_pack_maps" not in out[True][2] and "k_pack_maps" not in out[False][2], sorted(out[True][2])
 
 
 def _projection_camera(size, batch):
