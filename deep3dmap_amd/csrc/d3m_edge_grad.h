@@ -105,6 +105,13 @@ struct EdgeGradArgs {
         const int yo = img_aa ? (S - 1 - y) >> 1 : S - 1 - y, xo = img_aa ? x >> 1 : x;
         return ga_img[((size_t)b * img_s + yo) * img_s + xo] * (img_aa ? 0.25f : 1.0f);
     }
+    // the same for position d1 of line (view, axis, d0) at pi = pixel(axis, view * S * S, d0, d1) -- the staging loops' form (no divisions)
+    __device__ __forceinline__ float direct_ga_at(size_t view, int axis, int d0, int d1, size_t pi) const {
+        if (ga_map) return ga_map[pi];
+        const int y = axis ? d0 : d1, x = axis ? d1 : d0;
+        const int yo = img_aa ? (S - 1 - y) >> 1 : S - 1 - y, xo = img_aa ? x >> 1 : x;
+        return ga_img[(view * img_s + yo) * img_s + xo] * (img_aa ? 0.25f : 1.0f);
+    }
     __device__ __forceinline__ float4 rec_grad(size_t pi) const {
         return direct() ? make_float4(direct_ga(pi), 0.0f, 0.0f, 0.0f) : grad[pi];
     }
@@ -1066,8 +1073,16 @@ __global__ void __launch_bounds__(WAVES * 64, 8) k_edge_lines(EdgeGradArgs a, Ed
     }
     for (int p = p_lo + (int)threadIdx.x; p <= p_hi; p += EG_LINE_THREADS) {
         const size_t pi = a.pixel(axis, view_base, d0, p);
-        float4 g = a.rec_grad(pi);
-        const float2 d = a.rec_dot(pi);
+        float4 g;
+        float2 d;
+        if (!USE_RGB && a.direct()) {
+            const float ga = a.direct_ga_at(bn, axis, d0, p, pi);
+            g = make_float4(ga, 0.0f, 0.0f, 0.0f);
+            d = make_float2(a.alpha_map[pi] * ga, __int_as_float(a.fi_direct[pi]));
+        } else {
+            g = a.grad[pi];
+            d = a.dot[pi];
+        }
         g.x *= go_sign; g.y *= go_sign; g.z *= go_sign; g.w *= go_sign;
         s_grd[p] = g;
         s_df[p] = make_float2(0.5f * go_sign * d.x, d.y);
@@ -1466,7 +1481,7 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
     const int n_x = __builtin_amdgcn_readfirstlane(w.line_cursor[line]);
     if (n_x <= 0) return;
     const int d0 = (int)(line % is), axis = (int)((line / is) & 1);
-    const size_t view_base = (line / ((size_t)2 * is)) * is * is;
+    const size_t bn = line / ((size_t)2 * is), view_base = bn * is * is;
     const int x_first = __builtin_amdgcn_readfirstlane(w.line_slice[line].x);
     const int p_lo = __builtin_amdgcn_readfirstlane(a.extent_lo(line));
     const int p_hi = __builtin_amdgcn_readfirstlane(a.extent_hi(line));
@@ -1487,7 +1502,7 @@ __global__ void __launch_bounds__(EGA_THREADS) k_edge_lines_alpha(EdgeGradArgs a
             const size_t pi = a.pixel(axis, view_base, d0, min(p, is - 1));
             al[k] = a.alpha_map[pi];
             const bool in = p >= p_lo && p <= p_hi;
-            gx[k] = in ? (a.direct() ? a.direct_ga(pi) : a.grad[pi].x) : 0.0f;
+            gx[k] = in ? (a.direct() ? a.direct_ga_at(bn, axis, d0, min(p, is - 1), pi) : a.grad[pi].x) : 0.0f;
             ow[k] = in ? (a.direct() ? __int_as_float(a.fi_direct[pi]) : a.dot[pi].y) : 0.0f;
         }
 #pragma unroll
