@@ -136,6 +136,7 @@ def test_large_faces_and_small_workspace_against_oracle(S):
     g_alpha = rng.normal(size=(B, S, S)).astype(np.float32)
     g_depth = rng.normal(size=(B, S, S)).astype(np.float32)
     gf_ref, gt_ref = O.raster_backward(m, g_rgb, g_alpha, g_depth, True, True, True)
+    gf_alpha_ref, _ = O.raster_backward(m, None, g_alpha, None, False, True, False)
     L = _lib.lib()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     fd, td = dev(faces), dev(tex)
@@ -169,6 +170,13 @@ def test_large_faces_and_small_workspace_against_oracle(S):
         assert rc == 0
         torch.cuda.synchronize()
         grads.append(gf)
+        # ... and alpha only, where the walks read grad_alpha_map / face_index_map directly (no per-pixel records): the overflow
+        # kernel and the line kernels through that form too
+        ga = torch.zeros_like(fd)
+        assert L.d3m_backward_pixel_map(_lib.ptr(fd), _lib.ptr(fi), None, _lib.ptr(alpha_d), None, _lib.ptr(g_alpha_d),
+                                        _lib.ptr(ga), B, F2, S, 1e-3, 0, 1, _lib.ptr(ws2), ws2.numel(), None, None, None, 0,
+                                        None, _lib.stream_ptr()) == 0
+        assert np.abs(ga.cpu().numpy() - gf_alpha_ref).max() <= 1e-3 * max(1.0, float(np.abs(gf_alpha_ref).max())), room
     assert L.d3m_backward_pixel_map(_lib.ptr(fd), _lib.ptr(fi), _lib.ptr(rgb_d), _lib.ptr(alpha_d), _lib.ptr(g_rgb_d),
                                     _lib.ptr(g_alpha_d), _lib.ptr(grads[0]), B, F2, S, 1e-3, 1, 1, _lib.ptr(ws2), base - 1,
                                     None, None, None, 0, None, _lib.stream_ptr()) == 2
