@@ -275,8 +275,9 @@ static bool bidding_preferred(int B, long triangles, int S) {
     const double px_per_tri = (double)B * (double)triangles < 65536.0 ? 10.0 : std::min(10.0 + 2.0 * (B - 1), 32.0);
     return !big_batch(B, triangles, S) && (double)S * S <= px_per_tri * (double)triangles;
 }
-// Whether a launch is a "big batch" in that sense -- what the lit render node takes for "every kernel fills the chip by
-// itself: run on one stream" (rasterize._serial_branches), independent of the form of coverage a coarse mesh takes.
+// Whether a launch is a "big batch" in that sense ("every kernel fills the chip by itself"), independent of the form of
+// coverage a coarse mesh takes: what multiview.MultiViewFit keys its split exchange on (the lit render node took it for "run
+// on one stream" in rounds 4-5; since round 6 its branches run beside each other at every size, rasterize._serial_branches).
 D3M_EXPORT int d3m_forward_big_batch(int batch_size, int num_triangles, int image_size) {
     if (batch_size <= 0 || num_triangles <= 0 || image_size <= 0) return -1;
     return big_batch(batch_size, num_triangles, image_size) ? 1 : 0;

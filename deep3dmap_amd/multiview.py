@@ -13,7 +13,7 @@ import weakref
 import torch
 import torch.distributed as dist
 
-from . import neural_renderer as nr
+from . import _lib, neural_renderer as nr
 from .graph import CapturedStep
 from .core.losses import multiview_fit_loss, photometric_loss, silhouette_loss
 
@@ -152,19 +152,19 @@ class MultiViewFit:
         # communicator's stream | geometry side of backward beside it | all-reduce of [loss | vertex gradient].  The node's
         # two halves are called by hand (rasterize.LitFitManual: a capture cannot end on autograd's worker thread).
         # Default: on when gradients are exchanged, the fused objective runs (one pipeline, look_at cameras) AND the
-        # rank's batch is one whose step runs on one stream anyway (the lit node's choice, rasterize._serial_branches: the
-        # big batches of ordinary meshes).  Measured on one rank through RCCL (profiles/r04_bench_other_configs.jsonl): the
-        # split form costs a 32-view step 0.03 ms (two graph launches, two collectives) and hides a 9.6 MB all-reduce
-        # (0.07-0.17 ms over xGMI); an 8-view shard it costs 0.08 ms (0.04 of it the side branches it gives up), which is
-        # about what its collective takes -- no gain there, so the small shards keep the one-graph step.
+        # rank's batch is a big one (d3m_forward_big_batch: every kernel fills the chip by itself).  Measured on one rank
+        # through RCCL (profiles/r06_bench_other_configs.jsonl): the split form costs a 32-view step 0.03 ms of graph launches
+        # and collectives plus the 0.05 ms its side branches buy since round 6 (the two halves run on one stream each), and
+        # hides a 9.6 MB all-reduce (0.07-0.17 ms over xGMI); an 8-view shard it costs 0.08 ms, which is about what its
+        # collective takes -- no gain there, so the small shards keep the one-graph step.
         if split_exchange is None:
-            from .neural_renderer.rasterize import _serial_branches
             # (decided on the LARGEST shard, rank 0's: the ranks of one job must agree on the form of the exchange --
             #  with shards of unequal size a per-rank decision could pair one rank's two collectives with another's one)
             n_largest = shard_views(len(eyes), 0, world_size)[1]
             split_exchange = (os.environ.get("D3M_SPLIT_EXCHANGE", "1") != "0" and
                               (world_size > 1 or COLLECTIVES_WITH_ONE_RANK) and
-                              _serial_branches(n_largest, self.triangles.shape[0], image_size * (2 if anti_aliasing else 1)))
+                              _lib.lib().d3m_forward_big_batch(int(n_largest), int(self.triangles.shape[0]),
+                                                               int(image_size * (2 if anti_aliasing else 1))) == 1)
         self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
                                    and self.renderer._on_the_fly())
         self._manual = self._tex_work = None

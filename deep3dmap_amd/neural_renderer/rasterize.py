@@ -240,16 +240,17 @@ _side_streams = ops.StreamKeyedCache(max_per_kind=64)     # ((device index, whic
 
 
 def _serial_branches(batch, num_tri, image_size):
-    """Whether a lit render node runs its side branches (visibility list + edge plan beside the sampling pass; the
-    gathered texture / depth pass beside the line walk) on the forking stream instead.  Measured: once
-    every kernel of the step fills the chip by itself -- the big batches of ordinary meshes (d3m_forward_big_batch; a coarse
-    mesh's small batch also takes the per-tile lists since round 5, and keeps its branches) -- the cross-queue waits of the branches cost more than the tails they fill
-    (32 views of the headline mesh: -1.5 %), while small batches and dense meshes gain 3-6 % from them.
-    D3M_SERIAL_BRANCHES=1 / 0 forces / forbids (measurements)."""
+    """Whether a lit render node keeps its side branches (visibility list + edge plan beside the sampling pass; the
+    gathered texture / depth pass beside the line walk) on the forking stream.  Default: never -- the branches win at every
+    size measured in round 6 (32 views of the headline mesh 1.555-1.568 -> 1.506-1.522 ms on one box, 64 views -2.5 %, the
+    anti-aliased step -3 %, 8 views at 1024x1024 -4.5 %, config 5 -1 to -4 %: tools_dev/branches_ab.sh).
+    Rounds 4 and 5 ran the big batches (d3m_forward_big_batch) on one stream: with the kernels of that time the cross-queue
+    waits cost what the filled tails bought (-1.5 % to +0 %); every kernel that got shorter since left a longer tail to fill.
+    D3M_SERIAL_BRANCHES=1 / 0 forces / forbids (measurements); the deterministic mode and LitFitManual run on one stream."""
     env = os.environ.get("D3M_SERIAL_BRANCHES")
     if env is not None and env != "":
         return env != "0"
-    return _lib.lib().d3m_forward_big_batch(int(batch), int(num_tri), int(image_size)) == 1
+    return False
 
 
 def _side_stream(device, which=0, serial=False):

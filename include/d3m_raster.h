@@ -113,7 +113,8 @@ int d3m_face_light_backward_gather(const float* vertices, const int32_t* tri, co
  * least 65 536 (view, triangle) pairs in the batch more than 10 + 2 (views - 1), at most 32); bidding otherwise. */
 int d3m_forward_coverage_form(int batch_size, int num_triangles, int image_size);
 /* 1 when the launch is a BIG BATCH of an ordinary mesh (more than 65 536 blocks of 8 x 8 pixels, triangles not sub-pixel):
- * every kernel of a step fills the chip by itself, and a caller's side branches cost more than they hide. */
+ * every kernel of a step fills the chip by itself.  (Rounds 4-5 ran such a step's branches on one stream; since round 6
+ * they run beside each other at every size.  The camera-sharded fit still keys its split exchange on it.) */
 int d3m_forward_big_batch(int batch_size, int num_triangles, int image_size);
 
 /* Replaces forward_face_index_map (KCPP:70-95 -> KCU:24-169: kernels 1 and 2).
