@@ -161,10 +161,11 @@ class MultiViewFit:
             # (decided on the LARGEST shard, rank 0's: the ranks of one job must agree on the form of the exchange --
             #  with shards of unequal size a per-rank decision could pair one rank's two collectives with another's one)
             n_largest = shard_views(len(eyes), 0, world_size)[1]
-            split_exchange = (os.environ.get("D3M_SPLIT_EXCHANGE", "1") != "0" and
-                              (world_size > 1 or COLLECTIVES_WITH_ONE_RANK) and
-                              _lib.lib().d3m_forward_big_batch(int(n_largest), int(self.triangles.shape[0]),
-                                                               int(image_size * (2 if anti_aliasing else 1))) == 1)
+            env = os.environ.get("D3M_SPLIT_EXCHANGE", "1")          # "0": never, "force": whatever the batch (tests)
+            split_exchange = (env != "0" and (world_size > 1 or COLLECTIVES_WITH_ONE_RANK) and
+                              (env == "force" or
+                               _lib.lib().d3m_forward_big_batch(int(n_largest), int(self.triangles.shape[0]),
+                                                                int(image_size * (2 if anti_aliasing else 1))) == 1))
         self.split_exchange = bool(split_exchange and objective_in_renderer and optimise_textures and view_groups == 1
                                    and self.renderer._on_the_fly())
         self._manual = self._tex_work = None

@@ -159,13 +159,13 @@ def test_bench_eight_ranks_preflight():
     """the line the driver's SCALE run executes -- `bench.py --gpus 8`, weak scaling with the strong-scaling
     figures of BASELINE configs 4 (4 cameras per GPU) and 5 (32 per GPU) riding in it -- had never run anywhere beyond two
     ranks.  Here: eight ranks on this box's one GPU (gloo), meshes and rasters shrunk (--strong-shrink; camera counts and
-    therefore shard sizes as in the real run), the split exchange forced on (D3M_SERIAL_BRANCHES=1: two captured graphs and
+    therefore shard sizes as in the real run), the split exchange forced on (D3M_SPLIT_EXCHANGE=force: two captured graphs and
     two collectives per step on every rank), in the bare form (bench.py starts its ranks) and in the driver's form with an
     odd camera count (30 over 8: shards of 4 and 3).  No rate is checked -- eight processes share one device --: one JSON
     line, eight distinct ranks seen through the process group, finite figures, and the stages' wall times on stderr."""
     import math
     small = ("--mesh-n", "40", "--image-size", "128", "--views-per-gpu", "6", "--repeats", "2")
-    split_on = {"D3M_SERIAL_BRANCHES": "1"}
+    split_on = {"D3M_SPLIT_EXCHANGE": "force"}
     d = _bench(8, "weak", extra=small + ("--strong-shrink", "0.2"), bare=True, env_extra=split_on, steps=3)
     assert d["n_gpus"] == 8 and d["world_size_seen"] == 8 and len(d["ranks"]) == 8
     assert len({r["pid"] for r in d["ranks"]}) == 8 and sorted(r["rank"] for r in d["ranks"]) == list(range(8))

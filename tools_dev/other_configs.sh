@@ -27,7 +27,7 @@ run "... with the losses in eager torch operators" --materialise-images --loss-f
 # the N > 1 step on ONE rank through RCCL (D3M_BENCH_FORCE_DIST: process group, the split exchange's two all-reduces per step)
 rccl() { echo "# $1" >> $O/${R}_bench_other_configs.jsonl; shift; D3M_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --no-cpu-baseline --no-dropin "$@" 2>> $O/bench.err | grep "^{" | tail -1 >> $O/${R}_bench_other_configs.jsonl; }
 rccl "one rank through RCCL, split exchange (two graphs, two all-reduces): 32 views"
-rccl "one rank through RCCL, split exchange: config 4's 8-view shard" --views-per-gpu 8
+D3M_SPLIT_EXCHANGE=force rccl "one rank through RCCL, split exchange (forced: the default keeps the one-graph step at this size): config 4's 8-view shard" --views-per-gpu 8
 D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, one all-reduce behind the step: 32 views"
 D3M_SPLIT_EXCHANGE=0 rccl "one rank through RCCL, one all-reduce: config 4's 8-view shard" --views-per-gpu 8
 python3 - <<PY

@@ -21,10 +21,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_final.csv
 cp $O/${R}_kernel_stats_final.csv profiles/
 head -5 $O/${R}_kernel_stats_final.csv | cut -c1-150
+# ... and of the same command with the step's kernels on one stream: every kernel by itself (in the default step the render
+# node's branches share the chip; roofline.frac / frac_rocprof are the kernel's own, roofline.in_step the contended ones)
+D3M_SERIAL_BRANCHES=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -o stats -- python3 bench.py --no-cpu-baseline --no-dropin --steps 30 > $O/stats1.log 2>&1
+cp $(find $O/stats1 -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_one_stream.csv
+cp $O/${R}_kernel_stats_one_stream.csv profiles/
 timeout 600 python bench.py > $O/${R}_bench_final.json 2> $O/bench.err
 tail -c 400 $O/${R}_bench_final.json
 timeout 300 python bench.py --no-cpu-baseline --no-dropin --fit-with-images > $O/${R}_bench_fit_with_images.json 2>> $O/bench.err
-# the lit node's side branches forced off / on (since round 4 the node chooses by the form of coverage: off at 32 views)
+# the lit node's side branches forced off / on (round 6: on at every size by default)
 D3M_SERIAL_BRANCHES=1 timeout 300 python bench.py --no-cpu-baseline --no-dropin > $O/${R}_bench_serial_branches.json 2>> $O/bench.err
 D3M_SERIAL_BRANCHES=0 timeout 300 python bench.py --no-cpu-baseline --no-dropin > $O/${R}_bench_side_branches.json 2>> $O/bench.err
 # the gan2shape renderer block: bench line + kernel stats of the same command
