@@ -1143,6 +1143,39 @@ def test_mesh_modes_without_fill_back_and_without_gradients(mode):
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * float(res[1][1].abs().max()) > 0
 
 
+@pytest.mark.parametrize("size,aa,views", [(37, False, 1), (33, True, 2), (130, False, 3), (65, True, 1)])
+def test_silhouette_node_reads_the_image_gradient_in_place_at_odd_sizes(size, aa, views):
+    """Round 6: the silhouette node's edge gradient reads the OUTPUT image's gradient where it is -- through the row flip and,
+    with anti-aliasing, the 2x2 pooling's adjoint -- instead of packing per-pixel records (d3m_edge_grad.h "DIRECT";
+    d3m_fit_targets.flags = D3M_GRAD_OF_OUTPUT_IMAGE [| D3M_FIT_POOLED]).  Image sizes that are odd, not a multiple of the
+    staging loops' four pixels per thread, and above one round of the two-wave line kernel; a random (dense) gradient and a
+    band-shaped one: against the reference's operator sequence (mesh_modes off: rasterize_silhouettes' own flip / pooling
+    nodes in front of the reference-shaped K4)."""
+    from deep3dmap_amd import neural_renderer as nr, synthetic
+    v_np, tri_np = synthetic.grid_mesh(14)
+    eyes = torch.from_numpy(synthetic.camera_ring(max(views, 2))[:views]).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    gen = torch.Generator(device="cuda").manual_seed(size)
+    for kind in ("dense", "band"):
+        res = []
+        for on in (True, False):
+            r = nr.Renderer(image_size=size, anti_aliasing=aa, camera_mode="look_at", fill_back=True)
+            r.eye, r.mesh_modes = eyes, on
+            v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+            image = r.render_silhouettes(v, tri)
+            if on:
+                if kind == "dense":
+                    w = torch.rand(image.shape, device="cuda", generator=gen) - 0.4
+                else:       # the gradient of a squared error against a shifted silhouette: two thin bands
+                    w = 2.0 * (image.detach() - torch.roll(image.detach(), shifts=(2, -3), dims=(1, 2))) / image[0].numel()
+            (image * w).sum().backward()
+            res.append((image.detach(), v.grad.clone()))
+        assert res[0][0].shape == (views, size, size) and torch.equal(res[0][0], res[1][0])
+        assert 0.02 < float((res[0][0] > 0).float().mean()) < 0.98
+        scale = float(res[1][1].abs().max())
+        assert scale > 0 and float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale, (kind, scale)
+
+
 def test_mesh_depth_mode_with_large_faces():
     """Faces whose pixel box exceeds the gathered pass's limit are left to the per-pixel pass (counted, so that it leaves at
     once in the ordinary case): an 8-triangle mesh in a 384x384 image (boxes of ~7 000 pixels) takes that route in d3m_backward_depth_map_mesh --
