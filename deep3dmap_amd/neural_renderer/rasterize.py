@@ -1141,6 +1141,8 @@ class _RasterizeMeshModes(torch.autograd.Function):
             if plan is not None:
                 _lib.check(L.d3m_edge_plan(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(vis), _lib.ptr(plan), plan.numel(), B, Fp, S,
                                            flags_plan, _lib.stream_ptr()), "d3m_edge_plan")
+        if need_grad and return_alpha and not return_depth and tri.shape[0] == 1 and _deterministic():
+            vertex_adjacency(tri, V)            # (the deterministic backward pass's CSR adjacency: built outside any capture of it)
         ctx.cfg = (B, V, Ft, Fp, S, bool(anti_aliasing), float(eps), bool(fill_back), bool(return_alpha), bool(return_depth))
         ctx.camera, ctx.keep = camera, (cam_keep, basis_keep)
         ctx.maps = (faces, fi, wm, dm, alpha_map, vis, plan)
@@ -1171,8 +1173,20 @@ class _RasterizeMeshModes(torch.autograd.Function):
             unscaled = _lib.D3MFitTargets(None, None, None, None, None, None, None, _lib.ptr(g_img), None, None, None,
                                           None, None, None, None,
                                           _lib.GRAD_OF_OUTPUT_IMAGE | (_lib.FIT_POOLED if aa else 0))
-            ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
-                                   visibility=vis, unscaled=unscaled, edge_plan=plan)
+            if tri.shape[0] == 1 and _deterministic():
+                # DETERMINISTIC (as the lit node's): K4 into its own per-face array (plain stores), summed per vertex in a
+                # fixed order over the index tensor's CSR adjacency -- bit-identical runs.  (One shared topology; the depth
+                # mode and per-view topologies keep their float atomics: DESIGN.md section 6.)
+                det_k4 = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
+                _lib.zero_raw([_lib.tensor_range(det_k4)])
+                ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, det_k4, S, eps, False, True,
+                                       visibility=vis, unscaled=unscaled, edge_plan=plan)
+                adj_off, adj_items = vertex_adjacency(tri, V)
+                _lib.check(L.d3m_vertex_gather(_lib.ptr(det_k4), None, _lib.ptr(adj_off), _lib.ptr(adj_items), _lib.ptr(grad_sv),
+                                               B, V, Ft, int(fill_back), _lib.ptr(vis), _lib.stream_ptr()), "d3m_vertex_gather")
+            else:
+                ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
+                                       visibility=vis, unscaled=unscaled, edge_plan=plan)
         elif ra:
             # the adjoint of the output epilogue writes the alpha gradient straight as the edge gradient's per-pixel records
             # (and the depth gradient as the map K6 reads)

@@ -1427,6 +1427,42 @@ def test_deterministic_mode_is_bit_reproducible(scene):
     assert _rel_max(runs[0][1], ref[1]) < 1e-5 and _rel_max(runs[0][2], ref[2]) < 1e-5
 
 
+@pytest.mark.parametrize("aa", [False, True])
+def test_deterministic_mode_covers_the_silhouette_node(aa):
+    """... and the silhouette node (render_silhouettes over one shared topology): K4 into a per-face array, summed per vertex
+    over the index tensor's CSR adjacency -- bit-identical gradients over repeated backward passes, eager and replayed from
+    a HIP graph, and equal to the default mode's to the order of its float atomics."""
+    from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
+    from deep3dmap_amd.graph import CapturedStep
+    v_np, tri_np = synthetic.grid_mesh(60)
+    B = 6
+    r = nr.Renderer(image_size=128, anti_aliasing=aa, camera_mode="look_at", fill_back=True)
+    r.eye = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
+    tri = torch.from_numpy(tri_np).int().cuda()[None]
+    v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+    with torch.no_grad():
+        target = torch.roll(r.render_silhouettes(v, tri), shifts=(3, -2), dims=(1, 2))
+
+    def step():
+        v.grad = None
+        ((r.render_silhouettes(v, tri) - target) ** 2).sum().backward()
+        return v.grad
+
+    ref = step().clone()
+    default_runs = [step().clone() for _ in range(4)]
+    with _lib.deterministic():
+        runs = [step().clone() for _ in range(3)]
+        captured = CapturedStep(step).capture()
+        for _ in range(3):
+            runs.append(captured().clone())
+        torch.cuda.synchronize()
+        captured.release()
+    for g in runs[1:]:
+        assert torch.equal(g, runs[0]), float((g - runs[0]).abs().max())
+    assert float(ref.abs().max()) > 0 and _rel_max(runs[0], ref) < 1e-5
+    assert all(_rel_max(g, ref) < 1e-5 for g in default_runs)
+
+
 def test_deterministic_mode_refuses_what_it_does_not_cover():
     """... and the shapes its fixed-order sums do not cover (per-view index tensors, view groups) raise instead of silently
     running the unordered pass; the reference-shaped gather's adjoint (vertices_to_faces) is gathered in order too."""
