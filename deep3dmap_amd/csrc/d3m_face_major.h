@@ -68,14 +68,15 @@ __device__ __forceinline__ void backward_depth_face(FS fs, const float* __restri
                                                     const float* __restrict__ weight_map,
                                                     const float* __restrict__ grad_depth_map, float* __restrict__ grad_faces,
                                                     int* __restrict__ flags, int S, long gi, int sub, int F,
-                                                    const VertexTarget& vt, int* __restrict__ n_large, int flip_rows) {
+                                                    const VertexTarget& vt, int* __restrict__ n_large, int flip_rows,
+                                                    int max_area) {
     const int bn = (int)(gi / F), fn = (int)(gi % F);
     float face[9], finv[9];
     fs.load(bn, fn, face);
     int x0, x1, y0, y1;
     if (!pixel_bbox(face, S, x0, x1, y0, y1)) return;
     const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
-    if (area > FM_MAX_BBOX_AREA) {                      // left to the per-pixel pass (counted, so that it can leave at once)
+    if (area > max_area) {      // (FM_MAX_BBOX_AREA; INT_MAX in the deterministic mode: a face's lanes own its sums whatever its size)                      // left to the per-pixel pass (counted, so that it can leave at once)
         flags[gi] = FLAG_LARGE;
         if (n_large && sub == 0) atomicAdd(n_large, 1);
         return;
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
                                                              float* __restrict__ grad_faces, int* __restrict__ flags, int B,
                                                              int S, const int* __restrict__ list,
                                                              const int* __restrict__ n_list, VertexTarget vt,
-                                                             int* __restrict__ n_large, int flip_rows) {
+                                                             int* __restrict__ n_large, int flip_rows, int max_area) {
     static_assert(LANES == FM_LANES || LANES == 64, "eight lanes per face, or a wave");
     const int sub = threadIdx.x % LANES;
     const int F = fs.num_faces();
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(256) k_backward_depth_faces(FS fs, const float
         const long gi = list ? (long)list[u] : u;
         if (!list && flags[gi] == FLAG_HIDDEN) continue;
         backward_depth_face<FS, LANES>(fs, depth_map, face_index_map, weight_map, grad_depth_map, grad_faces, flags, S, gi, sub, F, vt,
-                            n_large, flip_rows);
+                            n_large, flip_rows, max_area);
     }
 }
 

@@ -634,7 +634,8 @@ static int run_backward_depth(FS fs, const float* depth_map, const int32_t* face
         }
         LAUNCH("k_backward_depth_faces", k_backward_depth_faces<FS>, dim3(blocks_for(nf, FM_FACES_PER_BLOCK)), dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, grad_faces, flags, B, S, (const int*)nullptr, (const int*)nullptr,
-               VertexTarget{nullptr, nullptr, 0, 0, 1}, (int*)nullptr, 0);
+               VertexTarget{nullptr, nullptr, 0, 0, 1}, (int*)nullptr, 0,
+               deterministic_mode() ? INT_MAX : FM_MAX_BBOX_AREA);      // (deterministic: no per-pixel atomic fallback)
     }
     LAUNCH("k_backward_depth_map", k_backward_depth_map<FS>, dim3(px_grid(n, false)), dim3(256), st, fs, depth_map,
            face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, S, (const int*)flags,
@@ -698,11 +699,11 @@ D3M_EXPORT int d3m_backward_depth_map_mesh(const float* faces, const float* dept
     if (coarse)
         LAUNCH("k_backward_depth_faces", (k_backward_depth_faces<DenseFaces, 64>), g_faces, dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S, (const int*)v.list,
-               (const int*)v.count, vt, (int*)large_counter, flip);
+               (const int*)v.count, vt, (int*)large_counter, flip, FM_MAX_BBOX_AREA);
     else
         LAUNCH("k_backward_depth_faces", (k_backward_depth_faces<DenseFaces>), g_faces, dim3(256), st, fs, depth_map,
                face_index_map, weight_map, grad_depth_map, (float*)nullptr, v.flags, B, S, (const int*)v.list,
-               (const int*)v.count, vt, (int*)large_counter, flip);
+               (const int*)v.count, vt, (int*)large_counter, flip, FM_MAX_BBOX_AREA);
     LAUNCH("k_backward_depth_map", k_backward_depth_map<DenseFaces>, dim3(px_grid(n, true)), dim3(256), st, fs, depth_map,
            face_index_map, (const float*)nullptr, weight_map, grad_depth_map, (float*)nullptr, B, S, (const int*)v.flags, vt,
            GradScale{nullptr, nullptr, 0.0f, 0, nullptr}, (const int*)large_counter, flip);

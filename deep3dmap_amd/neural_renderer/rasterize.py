@@ -1141,7 +1141,7 @@ class _RasterizeMeshModes(torch.autograd.Function):
             if plan is not None:
                 _lib.check(L.d3m_edge_plan(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(vis), _lib.ptr(plan), plan.numel(), B, Fp, S,
                                            flags_plan, _lib.stream_ptr()), "d3m_edge_plan")
-        if need_grad and return_alpha and not return_depth and tri.shape[0] == 1 and _deterministic():
+        if need_grad and (return_alpha != return_depth) and tri.shape[0] == 1 and _deterministic():
             vertex_adjacency(tri, V)            # (the deterministic backward pass's CSR adjacency: built outside any capture of it)
         ctx.cfg = (B, V, Ft, Fp, S, bool(anti_aliasing), float(eps), bool(fill_back), bool(return_alpha), bool(return_depth))
         ctx.camera, ctx.keep = camera, (cam_keep, basis_keep)
@@ -1175,8 +1175,8 @@ class _RasterizeMeshModes(torch.autograd.Function):
                                           _lib.GRAD_OF_OUTPUT_IMAGE | (_lib.FIT_POOLED if aa else 0))
             if tri.shape[0] == 1 and _deterministic():
                 # DETERMINISTIC (as the lit node's): K4 into its own per-face array (plain stores), summed per vertex in a
-                # fixed order over the index tensor's CSR adjacency -- bit-identical runs.  (One shared topology; the depth
-                # mode and per-view topologies keep their float atomics: DESIGN.md section 6.)
+                # fixed order over the index tensor's CSR adjacency -- bit-identical runs.  (One shared topology; per-view
+                # topologies keep their float atomics: DESIGN.md section 6.)
                 det_k4 = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
                 _lib.zero_raw([_lib.tensor_range(det_k4)])
                 ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, det_k4, S, eps, False, True,
@@ -1203,13 +1203,27 @@ class _RasterizeMeshModes(torch.autograd.Function):
             ops.backward_pixel_map(faces, fi, None, alpha_map, None, None, None, S, eps, False, True, vertex_target=target,
                                    visibility=vis, unscaled=unscaled, edge_plan=plan)
         k6_flags = _lib.PRECLEARED
-        if rd and not ra:
+        det_depth = rd and not ra and tri.shape[0] == 1 and _deterministic()
+        if det_depth:
+            # DETERMINISTIC, depth mode: the adjoint of the output epilogue as a map, K6 gathered per face into its own array by
+            # the reference-shaped operator (in this mode without its per-pixel fallback for large faces: d3m_backward_depth_map),
+            # summed per vertex over the CSR adjacency
+            g_depth_map = torch.empty(B, S, S, dtype=torch.float32, device=dev)
+            _lib.check(L.d3m_output_epilogue_backward(None, None, _lib.ptr(f32c(g_depth)), None, None, _lib.ptr(g_depth_map),
+                                                      B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward")
+            det_k6 = torch.empty(B, Fp, 3, 3, dtype=torch.float32, device=dev)
+            _lib.zero_raw([_lib.tensor_range(det_k6)])
+            ops.backward_depth_map(faces, dm, fi, const_tensor((0.0,), dev), wm, g_depth_map, det_k6, S)
+            adj_off, adj_items = vertex_adjacency(tri, V)
+            _lib.check(L.d3m_vertex_gather(_lib.ptr(det_k6), None, _lib.ptr(adj_off), _lib.ptr(adj_items), _lib.ptr(grad_sv),
+                                           B, V, Ft, int(fill_back), _lib.ptr(vis), _lib.stream_ptr()), "d3m_vertex_gather")
+        elif rd and not ra:
             if aa:
                 _lib.check(L.d3m_output_epilogue_backward(None, None, _lib.ptr(f32c(g_depth)), None, None, _lib.ptr(g_depth_map),
                                                           B, S, int(aa), _lib.stream_ptr()), "d3m_output_epilogue_backward")
             else:   # the output image is the depth map with its rows reversed: K6 reads the gradient through the flip
                 g_depth_map, k6_flags = f32c(g_depth), k6_flags | _lib.GRAD_OF_OUTPUT_IMAGE
-        if rd:
+        if rd and not det_depth:
             _lib.check(L.d3m_backward_depth_map_mesh(_lib.ptr(faces), _lib.ptr(dm), _lib.ptr(fi), _lib.ptr(wm),
                                                      _lib.ptr(g_depth_map), B, Fp, S, ctypes.byref(target), _lib.ptr(vis),
                                                      _lib.ptr(counter), k6_flags, _lib.stream_ptr()),

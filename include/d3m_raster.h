@@ -85,7 +85,9 @@ int d3m_get_coverage_form(void);
 /* Run-to-run reproducibility (no reference counterpart: the reference's float atomics, KCU:533-538,586-589, are unordered
  * too).  on = 1: d3m_visibility (and the list a forward launch leaves) is built in ASCENDING face order by three launches
  * -- count, scan, compact -- instead of one whose chunks land in arrival order, so that every pass over the list issues its
- * float atomics from the same workgroups, in the same list order, in every run.  Process-wide, read at every launch; the
+ * float atomics from the same workgroups, in the same list order, in every run; the gathered passes of
+ * d3m_backward_textures_lit and d3m_backward_depth_map take faces of ANY size (no per-pixel atomic fallback for boxes beyond
+ * 4096 pixels), so that a face's sums are its own lanes'.  Process-wide, read at every launch; the
  * environment variable D3M_DETERMINISTIC=1 sets the initial value.  Returns D3M_ERR_INVALID for values other than 0 / 1. */
 int d3m_set_deterministic(int on);
 int d3m_get_deterministic(void);

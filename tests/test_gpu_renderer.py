@@ -1428,24 +1428,27 @@ def test_deterministic_mode_is_bit_reproducible(scene):
 
 
 @pytest.mark.parametrize("aa", [False, True])
-def test_deterministic_mode_covers_the_silhouette_node(aa):
-    """... and the silhouette node (render_silhouettes over one shared topology): K4 into a per-face array, summed per vertex
-    over the index tensor's CSR adjacency -- bit-identical gradients over repeated backward passes, eager and replayed from
-    a HIP graph, and equal to the default mode's to the order of its float atomics."""
+@pytest.mark.parametrize("mode,n", [("silhouettes", 60), ("depth", 60), ("depth", 4)])
+def test_deterministic_mode_covers_the_silhouette_and_depth_nodes(mode, n, aa):
+    """... and the silhouette / depth node (render_silhouettes, render_depth over one shared topology): K4 -- or K6, gathered
+    per face whatever the face's size (n = 4: 18 triangles, boxes far beyond the gathered pass's usual limit) -- into a
+    per-face array, summed per vertex over the index tensor's CSR adjacency: bit-identical gradients over repeated backward
+    passes, eager and replayed from a HIP graph, and equal to the default mode's to the order of its float atomics."""
     from deep3dmap_amd import _lib, neural_renderer as nr, synthetic
     from deep3dmap_amd.graph import CapturedStep
-    v_np, tri_np = synthetic.grid_mesh(60)
+    v_np, tri_np = synthetic.grid_mesh(n)
     B = 6
     r = nr.Renderer(image_size=128, anti_aliasing=aa, camera_mode="look_at", fill_back=True)
     r.eye = torch.from_numpy(synthetic.camera_ring(B)).float().cuda()
     tri = torch.from_numpy(tri_np).int().cuda()[None]
     v = torch.from_numpy(v_np).float().cuda()[None].requires_grad_(True)
+    render = getattr(r, "render_" + mode)
     with torch.no_grad():
-        target = torch.roll(r.render_silhouettes(v, tri), shifts=(3, -2), dims=(1, 2))
+        target = torch.roll(render(v, tri), shifts=(3, -2), dims=(1, 2)).clamp(max=10.0)
 
     def step():
         v.grad = None
-        ((r.render_silhouettes(v, tri) - target) ** 2).sum().backward()
+        ((render(v, tri).clamp(max=10.0) - target) ** 2).sum().backward()
         return v.grad
 
     ref = step().clone()
